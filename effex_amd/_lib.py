@@ -1,0 +1,114 @@
+"""ctypes binding of libfxcorr.so (the C ABI in include/fxcorr.h).
+
+There is no fallback: if the shared library is missing or a symbol cannot be bound, ``load()``
+raises.  The library is built in-tree by ``__graft_entry__.build()`` /
+``python -m effex_amd.build``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfxcorr.so")
+
+FXC_OK = 0
+FXC_ERR_ARG = -1
+FXC_ERR_UNSUPPORTED = -2
+FXC_ERR_HIP = -3
+FXC_ERR_NOMEM = -4
+FXC_ERR_NODEVICE = -5
+FXC_ERR_STATE = -6
+
+FXC_MEM_HOST = 0
+FXC_MEM_DEVICE = 1
+FXC_MODE_SPECTRUM = 0
+FXC_MODE_CONTINUUM = 1
+FXC_PATH_GENERIC = 0
+FXC_PATH_FUSED = 1
+
+
+class FxcInfo(ctypes.Structure):
+    _fields_ = [("n_ant", ctypes.c_int32), ("n_baselines", ctypes.c_int32), ("nchan", ctypes.c_int32),
+                ("ntaps", ctypes.c_int32), ("num_samp", ctypes.c_int64), ("n_pts", ctypes.c_int64),
+                ("path", ctypes.c_int32), ("grid", ctypes.c_int32), ("block", ctypes.c_int32),
+                ("lds_bytes", ctypes.c_int32), ("device", ctypes.c_int32), ("cu_count", ctypes.c_int32),
+                ("workspace_bytes", ctypes.c_int64)]
+
+
+_c = ctypes
+_vp = ctypes.c_void_p
+# name -> (restype, argtypes); every symbol include/fxcorr.h declares
+SIGNATURES = {
+    "fxc_version": (_c.c_int, []),
+    "fxc_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
+    "fxc_status_string": (_c.c_char_p, [_c.c_int]),
+    "fxc_plan_create": (_c.c_int, [_c.POINTER(_vp), _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _vp, _vp,
+                                   _c.c_int]),
+    "fxc_plan_destroy": (_c.c_int, [_vp]),
+    "fxc_plan_get_info": (_c.c_int, [_vp, _c.POINTER(FxcInfo)]),
+    "fxc_last_error": (_c.c_char_p, [_vp]),
+    "fxc_set_rot": (_c.c_int, [_vp, _vp]),
+    "fxc_channelize": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int]),
+    "fxc_fx_accumulate": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int]),
+    "fxc_fx_rows": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double]),
+    "fxc_acc_reset": (_c.c_int, [_vp]),
+    "fxc_acc_export": (_c.c_int, [_vp, _vp]),
+    "fxc_finalize_sums": (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_double]),
+    "fxc_finalize": (_c.c_int, [_vp, _vp, _c.c_int, _c.c_double, _c.c_int]),
+    "fxc_sync": (_c.c_int, [_vp]),
+    "fxc_timer_start": (_c.c_int, [_vp]),
+    "fxc_timer_stop": (_c.c_int, [_vp, _c.POINTER(_c.c_double)]),
+    "fxc_kernel_profiling": (_c.c_int, [_vp, _c.c_int]),
+    "fxc_kernel_time": (_c.c_int, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.c_int]),
+    "fxc_synth_fill": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int64,
+                                  _vp, _vp, _c.c_int]),
+}
+
+_lib = None
+
+
+class FxcError(RuntimeError):
+    """A libfxcorr call failed; ``status`` is the negative fxc_status."""
+
+    def __init__(self, status, message):
+        super().__init__("libfxcorr: {} (status {})".format(message, status))
+        self.status = status
+        self.message = message
+
+
+def load():
+    """Load libfxcorr.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            "libfxcorr.so not found at {} — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "effex_amd has no CPU fallback".format(LIB_PATH))
+    # torch bundles its own libamdhip64 (same SONAME): load it first so the process has ONE HIP runtime
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, plan_handle=None):
+    """Map a non-zero status to the reference's exception types (SURVEY.md §8b 'Errors')."""
+    if status == FXC_OK:
+        return
+    lib = load()
+    msg = lib.fxc_last_error(plan_handle)
+    msg = msg.decode("utf-8", "replace") if msg else lib.fxc_status_string(status).decode()
+    if status == FXC_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)          # cusignal raises NotImplementedError for ntaps > 32
+    if status == FXC_ERR_ARG:
+        raise ValueError(msg)
+    if status == FXC_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise FxcError(status, msg)

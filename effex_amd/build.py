@@ -1,0 +1,42 @@
+"""Build libfxcorr.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libfxcorr.so")
+SOURCES = ["fxcorr.hip", "fx_math.h", "fx_fused4096.h", os.path.join("..", "..", "include", "fxcorr.h")]
+# -fno-slp-vectorize: packed f32 VALU runs at the scalar-f32 rate on gfx950 and the v_pk_* forms cost
+# operand-shuffling moves, so SLP packing of the butterflies is a net loss (MI355X_MICROARCH.md).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def up_to_date():
+    if not os.path.isfile(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(os.path.join(CSRC, s)) <= t for s in SOURCES)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    cmd = [hipcc_path()] + FLAGS + ["-o", LIB, "fxcorr.hip"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, cwd=CSRC, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

@@ -1,0 +1,351 @@
+"""Drop-in ``Correlator`` for effex's F/X hot path on MI355X.
+
+Keeps the call surface of ``/root/reference/effex/effex.py`` for the path (constructor keywords and
+defaults ``:45-53``, validated properties ``:199-320``, state names and legal transitions ``:210-224``,
+``_spectrometer_poly`` ``:530-555``, ``_pfb_xcorr`` / ``_run_task`` ``:490-527``, the ``.csv`` layout
+``:667-696``) and routes the arithmetic through libfxcorr (HIP).  What it does *not* reproduce is the
+reference's acquisition / threading / keyboard layer (SURVEY.md §8 scope): samples come from an
+``IQSource`` object instead of two RTL-SDR dongles (``:81-82``), and rows are written by the caller's
+thread instead of a writer thread fed through a ``multiprocessing.Queue`` (``:134,687-696``).
+
+There is no CPU arithmetic path here: every F/X result comes from the HIP library.
+"""
+import logging
+import time
+
+import numpy as np
+
+from . import synth
+from .plan import FxPlan, rot_table
+from .window import design_window
+
+
+class IQSource(object):
+    """What the correlator needs from a receiver pair: tuning attributes and chunk pairs."""
+    rs = None       # sample rate (Hz)      — RtlSdr.rs, effex.py:256-257
+    fc = None       # centre frequency (Hz) — RtlSdr.fc, effex.py:268-269
+    gain = None     # tuner gain            — RtlSdr.gain, effex.py:305-306
+
+    def read(self, num_samp):
+        """Return (iq_0, iq_1), each ``num_samp`` complex samples, or None when the stream ends."""
+        raise NotImplementedError
+
+    def close(self):
+        pass
+
+
+class SyntheticSource(IQSource):
+    """Counter-based synthetic sky (``effex_amd.synth``): a fixed number of chunk pairs."""
+
+    def __init__(self, seed=1234, n_chunks=4, delays=synth.DEFAULT_DELAYS):
+        self.seed, self.n_chunks, self.delays = seed, n_chunks, delays
+        self._next = 0
+        self.closed = False
+
+    def read(self, num_samp):
+        if self._next >= self.n_chunks:
+            return None
+        iq = synth.synth_iq(self.seed, 1, 2, int(num_samp), first_chunk=self._next, delays=self.delays)[0]
+        self._next += 1
+        return iq[0], iq[1]
+
+    def close(self):
+        self.closed = True
+
+
+class ArraySource(IQSource):
+    """Chunk pairs from an array [n_chunks, 2, num_samp]."""
+
+    def __init__(self, chunks):
+        self.chunks = np.asarray(chunks)
+        self._next = 0
+        self.closed = False
+
+    def read(self, num_samp):
+        if self._next >= len(self.chunks):
+            return None
+        pair = self.chunks[self._next]
+        self._next += 1
+        return pair[0][:num_samp], pair[1][:num_samp]
+
+    def close(self):
+        self.closed = True
+
+
+class Correlator(object):
+    # class constants — effex.py:34-35
+    _states = ('OFF', 'STARTUP', 'RUN', 'CALIBRATE', 'SHUTDOWN')
+    _modes = ('SPECTRUM', 'CONTINUUM', 'TEST')
+    # legal successors of each state — effex.py:210-224
+    _transitions = {'OFF': ('STARTUP',),
+                    'STARTUP': ('CALIBRATE', 'RUN', 'SHUTDOWN'),
+                    'RUN': ('CALIBRATE', 'SHUTDOWN'),
+                    'CALIBRATE': ('RUN', 'SHUTDOWN'),
+                    'SHUTDOWN': ('OFF',)}
+    _MAX_NUM_SAMP = 2 ** 18     # effex.py:282-283; lifted by max_num_samp= for the 2^20 continuum config
+
+    class StateTransitionError(Exception):
+        """effex.py:186-193."""
+
+        def __init__(self, prev, next):
+            self.prev = prev
+            self.next = next
+            self.message = 'Transition from {} to {} is not permitted.'.format(prev, next)
+
+        def __str__(self):
+            return repr(self.message)
+
+    def __init__(self, run_time=1, bandwidth=2.4e6, frequency=1.4204e9, num_samp=2 ** 18, nbins=2 ** 12,
+                 gain=49.6, mode='SPECTRUM', loglevel='INFO',
+                 source=None, device=0, max_num_samp=None, output_file=None, remove_dc=True):
+        self.logger = logging.getLogger(__name__)
+        self.logger.setLevel(getattr(logging, loglevel))
+        self._max_num_samp = int(max_num_samp) if max_num_samp else Correlator._MAX_NUM_SAMP
+        self.source = source if source is not None else SyntheticSource()
+        self.device = device
+        self.remove_dc = remove_dc
+        self._fx_plan = None
+        self._f_plans = {}
+        self._rot_key = None
+
+        self.run_time = run_time
+        self.bandwidth = bandwidth
+        self.frequency = frequency
+        self.num_samp = num_samp
+        self.nbins = nbins
+        self.gain = gain
+        self._state = 'OFF'
+        self.mode = mode
+        self.start_time = -1
+
+        # staging buffers the hot path reads — effex.py:109-110 (complex128 there; the HIP path
+        # computes in complex64)
+        self.gpu_iq_0 = np.zeros(int(self.num_samp), dtype=np.complex64)
+        self.gpu_iq_1 = np.zeros(int(self.num_samp), dtype=np.complex64)
+
+        self.ntaps = 4                                           # effex.py:115
+        n_int = len(self.gpu_iq_0) // self.ntaps // self.nbins   # effex.py:118-124
+        assert (n_int >= 1), ('Assertion failed: there must be at least 1 window of length n_branches*ntaps '
+                              'in each input timeseries.\ntimeseries len: {}\nn_branches: {}\nntaps: {}\n'
+                              'n_branches*ntaps: {}').format(len(self.gpu_iq_0), self.nbins, self.ntaps,
+                                                             self.nbins * self.ntaps)
+        self.window = design_window(self.ntaps, self.nbins)      # effex.py:126-127
+
+        self.calibrated_delay = 0                                # effex.py:132
+        self.output_file = output_file or (time.strftime('visibilities_%Y%m%d-%H%M%S') + '.csv')
+        crit_delay = 1 / self.frequency                          # effex.py:151-155
+        self.test_delay_sweep_step = crit_delay / 2
+        self.test_delay_offset = self.test_delay_sweep_step * 1600
+
+
+    # -- lifecycle --------------------------------------------------------------------------
+    def close(self):
+        """effex.py:176-180 — release the receivers (and the device plans)."""
+        self.source.close()
+        if self._fx_plan is not None:
+            self._fx_plan.close()
+            self._fx_plan = None
+        for p in self._f_plans.values():
+            p.close()
+        self._f_plans = {}
+
+    # -- properties (effex.py:199-320) ------------------------------------------------------
+    @property
+    def state(self):
+        return self._state
+
+    @state.setter
+    def state(self, input_state):
+        if input_state not in self._states:
+            self.close()
+            raise ValueError('State {} is not in known states: {}'.format(input_state, self._states))
+        if input_state not in self._transitions[self._state]:
+            self.close()
+            raise self.StateTransitionError(self._state, input_state)
+        self._state = input_state
+
+    @property
+    def run_time(self):
+        return self._run_time
+
+    @run_time.setter
+    def run_time(self, run_time):
+        if run_time < 1:
+            self.close()
+            raise ValueError('run time {} is not allowed; run times must be >= 1 second.'.format(run_time))
+        self._run_time = run_time
+
+    @property
+    def bandwidth(self):
+        return self._bandwidth
+
+    @bandwidth.setter
+    def bandwidth(self, value):
+        threshold = 2.8e6
+        if value > threshold:
+            self.logger.warning('Bandwidth value {} is greater than {}, and RtlSdrs may not be stable.'.format(
+                value, threshold))
+        self._bandwidth = value
+        self.source.rs = value
+
+    @property
+    def frequency(self):
+        return self._frequency
+
+    @frequency.setter
+    def frequency(self, value):
+        self._frequency = value
+        self.source.fc = value
+
+    @property
+    def num_samp(self):
+        return self._num_samp
+
+    @num_samp.setter
+    def num_samp(self, value):
+        int_val = int(round(value))
+        if int_val < 2 ** 8:
+            value = 2 ** 8
+        elif int_val > self._max_num_samp:
+            value = self._max_num_samp
+        self._num_samp = value           # clamped but not rounded, like the reference (:278-284)
+
+    @property
+    def nbins(self):
+        return self._nbins
+
+    @nbins.setter
+    def nbins(self, value):
+        self._nbins = value
+
+    @property
+    def gain(self):
+        return self._gain
+
+    @gain.setter
+    def gain(self, value):
+        self._gain = value
+        self.source.gain = value
+
+    @property
+    def mode(self):
+        return self._mode
+
+    @mode.setter
+    def mode(self, input_mode):
+        input_mode = input_mode.upper()
+        if input_mode not in self._modes:
+            raise ValueError('Mode input {} is not in known modes: {}'.format(input_mode, self._modes))
+        self._mode = input_mode
+
+    # -- hot path ---------------------------------------------------------------------------
+    def _spectrometer_poly(self, x, ntaps, n_branches, window):
+        """effex.py:530-555 — (len(x)//n_branches, n_branches) complex, natural bin order.
+
+        ``x`` may be a host array (result: numpy complex128 view of the complex64 device result) or a
+        CUDA complex64 tensor (result: tensor).  ``ntaps > 32`` raises NotImplementedError like cusignal.
+        """
+        n_branches = int(n_branches)
+        window = np.asarray(window, dtype=np.float64)
+        ntaps_w = int(len(window) / n_branches)      # what channelize_poly actually uses
+        is_tensor = type(x).__module__.startswith("torch")
+        length = int(x.shape[0])
+        key = (length, n_branches, ntaps_w, hash(window.tobytes()))
+        plan = self._f_plans.get(key)
+        if plan is None:
+            plan = FxPlan(1, n_branches, ntaps_w, length, window=window[:ntaps_w * n_branches], device=self.device)
+            self._f_plans[key] = plan
+        if is_tensor:
+            return plan.channelize(x)[0]
+        out = plan.channelize(np.asarray(x).astype(np.complex64))[0]
+        return out.astype(np.complex128)
+
+    def _plan(self):
+        n = int(self.num_samp)
+        if self._fx_plan is None or (self._fx_plan.num_samp, self._fx_plan.nchan) != (n, int(self.nbins)):
+            if self._fx_plan is not None:
+                self._fx_plan.close()
+            self._fx_plan = FxPlan(2, int(self.nbins), self.ntaps, n, window=self.window, device=self.device)
+            self._rot_key = None
+        key = (self.bandwidth, self.frequency, self.calibrated_delay)
+        if key != self._rot_key:      # rot only changes on calibration / TEST sweep
+            self._fx_plan.set_rot(rot_table(int(self.nbins), self.bandwidth, self.frequency, self.calibrated_delay))
+            self._rot_key = key
+        return self._fx_plan
+
+    def _pfb_xcorr(self):
+        """effex.py:497-527 — one visibility from the chunk pair in ``gpu_iq_0`` / ``gpu_iq_1``."""
+        plan = self._plan()
+        pair = np.stack([np.asarray(self.gpu_iq_0), np.asarray(self.gpu_iq_1)]).astype(np.complex64)[None]
+        if self.mode in ('CONTINUUM', 'TEST'):
+            return plan.fx_rows(pair, 'CONTINUUM', self.bandwidth)[0, 0]
+        return plan.fx_rows(pair, 'SPECTRUM')[0, 0].astype(np.complex128)
+
+    def _run_task(self):
+        """effex.py:490-494."""
+        return self._pfb_xcorr()
+
+    def integrate(self, chunks):
+        """Build extension: integrate a whole batch [n_chunks, 2, num_samp] (CUDA tensor
+        or host array) into one visibility spectrum / scalar — same definition as averaging the
+        reference's rows."""
+        plan = self._plan()
+        plan.acc_reset()
+        plan.fx_accumulate(chunks)
+        mode = 'CONTINUUM' if self.mode in ('CONTINUUM', 'TEST') else 'SPECTRUM'
+        out = plan.finalize(mode, self.bandwidth)
+        return out[0]
+
+    # -- output (effex.py:667-696) ----------------------------------------------------------
+    def _write_metadata(self):
+        fields = (('run_time', self.run_time), ('bandwidth', self.bandwidth), ('frequency', self.frequency),
+                  ('num_samp', self.num_samp), ('resolution', self.nbins), ('gain', self.gain), ('mode', self.mode))
+        with open(self.output_file, 'w') as fh:
+            fh.write(','.join('{}:{}'.format(k, v) for k, v in fields) + '\n')
+            if 'SPECTRUM' == self.mode:
+                freqs = np.fft.fftshift(np.fft.fftfreq(int(self.nbins), d=1 / self.bandwidth)) + self.frequency
+                np.savetxt(fh, [freqs], delimiter=',')
+
+    def _write_row(self, fh, vis):
+        np.savetxt(fh, [np.asarray(vis, dtype=np.complex128)], delimiter=',')
+
+    # -- control loop (host orchestration only; effex.py:326-417 without the hardware) ------
+    def _stage(self, pair):
+        iq_0, iq_1 = pair
+        self.gpu_iq_0 = np.asarray(iq_0)
+        self.gpu_iq_1 = np.asarray(iq_1)
+        if self.remove_dc:   # effex.py:394-395 (host numpy in the reference as well)
+            self.gpu_iq_0 = (self.gpu_iq_0.real - self.gpu_iq_0.real.mean()) + 1j * (self.gpu_iq_0.imag - self.gpu_iq_0.imag.mean())
+            self.gpu_iq_1 = (self.gpu_iq_1.real - self.gpu_iq_1.real.mean()) + 1j * (self.gpu_iq_1.imag - self.gpu_iq_1.imag.mean())
+
+    def run_state_machine(self):
+        """OFF -> STARTUP -> RUN ... -> SHUTDOWN -> OFF over the source's chunk pairs; one csv row each."""
+        rows = 0
+        fh = None
+        try:
+            while True:
+                if 'OFF' == self.state:
+                    self.state = 'STARTUP'
+                elif 'STARTUP' == self.state:
+                    self._write_metadata()
+                    fh = open(self.output_file, 'a')
+                    self.start_time = time.time()
+                    self.state = 'RUN'
+                elif 'RUN' == self.state:
+                    pair = self.source.read(int(self.num_samp))
+                    if pair is None:
+                        self.state = 'SHUTDOWN'
+                        continue
+                    self._stage(pair)
+                    if self.mode in ['TEST']:
+                        self.calibrated_delay += self.test_delay_sweep_step      # effex.py:403-404
+                    self._write_row(fh, self._run_task())
+                    rows += 1
+                elif 'SHUTDOWN' == self.state:
+                    self.close()
+                    self._state = 'OFF'
+                    break
+        finally:
+            if fh is not None:
+                fh.close()
+        return rows

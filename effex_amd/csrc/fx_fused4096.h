@@ -1,0 +1,172 @@
+// fx_fused4096.h — per-thread phases of the fused 2-antenna F+X kernel for nchan = 4096, ntaps = 4.
+//
+// One 512-thread workgroup (8 waves, one per CU) walks whole chunks; per spectrum i it
+//   phase 1  (thread = antenna h, branch set {j + 256 r}):  4-tap PFB FIR over a ring of four frames
+//            held in VGPRs (every IQ sample is fetched from HBM exactly once; the frame loop is
+//            unrolled by four so the ring rotates by renaming, not by moves),
+//            radix-16 over r, twiddle w4096^(j*k1), exchange 1 through LDS        [s_barrier]
+//   phase 2  (lane = antenna, k1, j0):  radix-16 over j1, twiddle w256^(j0*q1), exchange 2 —
+//            a 16x16 transpose that stays inside one wave (no s_barrier)
+//   phase 3  (lane = antenna, k1, q1):  radix-16 over j0 -> bins k = k1 + 16 q1 + 256 q2;
+//            v_permlane32_swap pairs antenna 0 (lanes 0-31) with antenna 1 (lanes 32-63) so every
+//            lane multiplies-and-accumulates 8 bins of  spec0 * conj(spec1).
+// FFT decomposition (kernel exp(+2 pi i m k / 4096)):
+//   m = j + 256 r,  j = j0 + 16 j1,  k = k1 + 16 q1 + 256 q2
+//   w^(mk) = w16^(r k1) * w4096^(j k1) * w16^(j1 q1) * w256^(j0 q1) * w16^(j0 q2)
+//
+// The same source is compiled by g++ in tests/emul (host emulation of the index logic; test
+// infrastructure only — the shipped library contains only the device build).
+#pragma once
+#include "fx_math.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FXC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FXC_SCHED_FENCE() ((void)0)
+#endif
+
+namespace fxc {
+namespace fused {
+
+constexpr int kN = 4096;
+constexpr int kT = 4;
+constexpr int kThreads = 512;
+constexpr int kRowPitch = 272;              // cf per k1 row; == 16 (mod 32) keeps ds_read_b64 conflict-free
+constexpr int kRegion = 16 * kRowPitch;     // cf per antenna
+constexpr int kAccPerThread = 8;
+
+// LDS carve (bytes); every offset is a multiple of 16
+constexpr int kLdsWin = 0;                                   // f4[4096]   window, [r*256 + j] = h[t*N + j + 256 r], t = x,y,z,w
+constexpr int kLdsRegion = kLdsWin + kN * 16;                // cf[2][kRegion]
+constexpr int kLdsTw2 = kLdsRegion + 2 * kRegion * 8;        // cf[256]    w256^(j0*q1) at [q1*16 + j0]
+constexpr int kLdsBytes = kLdsTw2 + 256 * 8;
+
+struct State {
+    // ring of four frames of this thread's 16 branch samples: slot PH holds the frame being
+    // channelised, the other three the PFB history (and, once dead, the prefetch of the next frame)
+    cf h[4][16];
+    cf tw1a[3], tw1b[3];         // w4096^(j*a), a = 1..3 and w4096^(j*4b), b = 1..3: w^(j*k1) for k1 = a + 4b
+    cf acc[kAccPerThread];       // sum_i spec0*conj(spec1) for this lane's 8 bins
+};
+
+// zero PFB history at the start of every chunk; the chunk's frame 0 sits in slot PH
+template <int PH>
+FXC_HD void state_reset_history(State& s) {
+#pragma unroll
+    for (int d = 1; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s.h[(PH + d) & 3][r] = mk(0.f, 0.f);
+}
+
+FXC_HD void state_reset_all(State& s) {
+    state_reset_history<0>(s);
+#pragma unroll
+    for (int q = 0; q < kAccPerThread; ++q) s.acc[q] = mk(0.f, 0.f);
+}
+
+// element offset (in cf) inside one frame of the sample this thread feeds to branch j + 256 r
+FXC_HD int sample_offset(int j, int r) { return (kN - 1) - j - 256 * r; }
+
+// phase 1a for a frame in ring slot PH: 4-tap FIR (taps t = 0..3 on frames i, i-1, i-2, i-3, summed
+// in that order), radix-16 over r, twiddle w4096^(j*k1); result left in v[k1]
+template <int PH>
+FXC_HD void phase1_compute(State& s, const f4* win, int tid, cf (&v)[16]) {
+    const int j = tid & 255;
+    const cf (&x0)[16] = s.h[PH];
+    const cf (&x1)[16] = s.h[(PH + 3) & 3];
+    const cf (&x2)[16] = s.h[(PH + 2) & 3];
+    const cf (&x3)[16] = s.h[(PH + 1) & 3];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const f4 w = win[r * 256 + j];
+        cf a = cscale(x0[r], w.x);
+        a = cfma(w.y, x1[r], a);
+        a = cfma(w.z, x2[r], a);
+        v[r] = cfma(w.w, x3[r], a);
+        if ((r & 3) == 3) FXC_SCHED_FENCE();   // keep at most four window quads live
+    }
+    dft16(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) {
+        // w4096^(j*k1) as a product of two stored powers: 12 twiddle VGPRs instead of 30
+        if (k1 & 3) v[k1] = cmul(v[k1], s.tw1a[(k1 & 3) - 1]);
+        if (k1 >> 2) v[k1] = cmul(v[k1], s.tw1b[(k1 >> 2) - 1]);
+    }
+}
+
+// load this thread's stored twiddle powers from the [16][256] table w4096^(j*k1)
+FXC_HD void state_load_twiddles(State& s, const cf* tw1_table, int tid) {
+    const int j = tid & 255;
+#pragma unroll
+    for (int a = 1; a < 4; ++a) {
+        s.tw1a[a - 1] = tw1_table[a * 256 + j];
+        s.tw1b[a - 1] = tw1_table[4 * a * 256 + j];
+    }
+}
+
+// phase 1b: exchange-1 store (after the barrier that retires the previous spectrum's reads)
+FXC_HD void phase1_store(const cf (&v)[16], cf* region, int tid) {
+    cf* mine = region + (tid >> 8) * kRegion + (tid & 255);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) mine[k1 * kRowPitch] = v[k1];
+}
+
+// this lane's row for phases 2 and 3
+FXC_HD cf* lane_row(cf* region, int tid) {
+    const int l = tid & 63, wave = tid >> 6;
+    const int ant = l >> 5, k1 = 2 * wave + ((l >> 4) & 1);
+    return region + ant * kRegion + k1 * kRowPitch;
+}
+
+FXC_HD void phase2_load(cf* region, int tid, cf (&v)[16]) {
+    const cf* row = lane_row(region, tid);
+    const int j0 = tid & 15;
+#pragma unroll
+    for (int j1 = 0; j1 < 16; ++j1) v[j1] = row[j0 + 16 * j1];
+}
+
+FXC_HD void phase2_compute(cf (&v)[16], const cf* tw2, int tid) {
+    const int j0 = tid & 15;
+    dft16(v);
+#pragma unroll
+    for (int q1 = 1; q1 < 16; ++q1) {
+        v[q1] = cmul(v[q1], tw2[q1 * 16 + j0]);
+        if ((q1 & 3) == 3) FXC_SCHED_FENCE();   // bound the live range of the twiddle reads
+    }
+}
+
+FXC_HD void phase2_store(const cf (&v)[16], cf* region, int tid) {
+    cf* row = lane_row(region, tid);
+    const int j0 = tid & 15;
+#pragma unroll
+    for (int q1 = 0; q1 < 16; ++q1) row[q1 * 17 + j0] = v[q1];
+}
+
+FXC_HD void phase3_load(cf* region, int tid, cf (&v)[16]) {
+    const cf* row = lane_row(region, tid);
+    const int q1 = tid & 15;
+#pragma unroll
+    for (int j0 = 0; j0 < 16; ++j0) v[j0] = row[q1 * 17 + j0];
+}
+
+// X-stage on paired data: a = antenna 0, b = antenna 1 for this lane's bin q (lanes 0-31) or
+// q + 8 (lanes 32-63) — effex/effex.py:520 without rot (applied once at finalize)
+FXC_HD void xacc(State& s, int q, cf a, cf b) { s.acc[q] = cadd(s.acc[q], cmulc(a, b)); }
+
+// natural bin index of accumulator q of thread tid
+FXC_HD int bin_of(int tid, int q) {
+    const int l = tid & 63, wave = tid >> 6;
+    const int k1 = 2 * wave + ((l >> 4) & 1), q1 = l & 15, q2 = q + 8 * (l >> 5);
+    return k1 + 16 * q1 + 256 * q2;
+}
+
+// inverse: where bin k lives in the [q*512 + tid] slot order the kernel stores partial sums in
+FXC_HD int slot_of_bin(int k) {
+    const int k1 = k & 15, q1 = (k >> 4) & 15, q2 = k >> 8;
+    const int l = (q2 >> 3) * 32 + (k1 & 1) * 16 + q1;
+    const int tid = (k1 >> 1) * 64 + l;
+    return (q2 & 7) * kThreads + tid;
+}
+
+}  // namespace fused
+}  // namespace fxc

@@ -1,0 +1,1221 @@
+// fxcorr.hip — MI355X (gfx950) F/X hot path: kernels + the C ABI of include/fxcorr.h.
+//
+// Replaces, for effex's hot path:
+//   cusignal.filtering.channelize_poly FIR half   effex/effex.py:553   -> pfb_fir_kernel / fused phase 1
+//   cusignal channelize_poly FFT half + conj      effex/effex.py:553   -> fft_pow2_kernel / dft_any_kernel / fused phases 1-3
+//   f0 * conj(f1 * rot), mean(axis=0), fftshift   effex/effex.py:516-521 -> xmul_kernel / fused X + finish kernels
+//   continuum tail mean_k / bandwidth             effex/effex.py:523-524 -> continuum kernels
+// Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fxcorr.h"
+#include "fx_fused4096.h"
+#include "fx_math.h"
+
+using fxc::cd;
+using fxc::cf;
+using fxc::f4;
+
+namespace {
+
+constexpr double kTwoPi = 6.283185307179586476925286766559;
+constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 channeliser kernels only
+constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
+constexpr int64_t kWorkspaceTarget = 1ll << 30;
+
+// ------------------------------------------------------------------------------------------
+// generic path kernels (any ntaps <= 32, any n_ant, any nchan <= 16384)
+// ------------------------------------------------------------------------------------------
+
+// v[s][i][m] = sum_{t<T, i-t>=0} x[s][(i-t)N + N-1-m] * h[tN+m]      
+__global__ void pfb_fir_kernel(const cf* __restrict__ x, const float* __restrict__ h, cf* __restrict__ v,
+                               int64_t num_samp, int nchan, int ntaps, int64_t n_pts, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int m = (int)(idx % nchan);
+        const int64_t si = idx / nchan;
+        const int64_t i = si % n_pts;
+        const int64_t s = si / n_pts;
+        const cf* xs = x + s * num_samp + (nchan - 1 - m);
+        float ar = 0.f, ai = 0.f;
+        const int tmax = (i + 1 < (int64_t)ntaps) ? (int)(i + 1) : ntaps;
+        for (int t = 0; t < tmax; ++t) {
+            const cf xv = xs[(i - t) * nchan];
+            const float w = h[(int64_t)t * nchan + m];
+            ar = fmaf(w, xv.x, ar);
+            ai = fmaf(w, xv.y, ai);
+        }
+        v[idx] = fxc::mk(ar, ai);
+    }
+}
+
+__device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
+
+// in-place spec[k] = sum_m v[m] exp(+2 pi i k m / N) for each row; N = 2^lg2n <= 16384; one WG per row
+__global__ __launch_bounds__(256) void fft_pow2_kernel(cf* __restrict__ data, const cf* __restrict__ tw /* [N/2] */,
+                                                      int nchan, int lg2n, int64_t n_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* buf = reinterpret_cast<cf*>(smem);
+    for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        cf* d = data + row * nchan;
+        for (int n = threadIdx.x; n < nchan; n += blockDim.x) buf[bitrev((unsigned)n, lg2n)] = d[n];
+        __syncthreads();
+        for (int s = 0; s < lg2n; ++s) {
+            const int half = 1 << s;
+            const int tstep = nchan >> (s + 1);
+            for (int b = threadIdx.x; b < (nchan >> 1); b += blockDim.x) {
+                const int pos = b & (half - 1);
+                const int i0 = ((b >> s) << (s + 1)) + pos;
+                const cf w = tw[pos * tstep];
+                const cf a = buf[i0];
+                const cf t = fxc::cmul(buf[i0 + half], w);
+                buf[i0] = fxc::cadd(a, t);
+                buf[i0 + half] = fxc::csub(a, t);
+            }
+            __syncthreads();
+        }
+        for (int n = threadIdx.x; n < nchan; n += blockDim.x) d[n] = buf[n];
+        __syncthreads();
+    }
+}
+
+// same transform for any nchan <= 16384 (O(N^2) per row); tw = [N] table, exact index arithmetic
+__global__ __launch_bounds__(256) void dft_any_kernel(cf* __restrict__ data, const cf* __restrict__ tw, int nchan,
+                                                     int64_t n_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* buf = reinterpret_cast<cf*>(smem);
+    for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        cf* d = data + row * nchan;
+        for (int n = threadIdx.x; n < nchan; n += blockDim.x) buf[n] = d[n];
+        __syncthreads();
+        for (int k = threadIdx.x; k < nchan; k += blockDim.x) {
+            float ar = 0.f, ai = 0.f;
+            int idx = 0;
+            for (int m = 0; m < nchan; ++m) {
+                const cf w = tw[idx];
+                const cf a = buf[m];
+                ar += a.x * w.x - a.y * w.y;
+                ai += a.x * w.y + a.y * w.x;
+                idx += k;
+                if (idx >= nchan) idx -= nchan;
+            }
+            d[k] = fxc::mk(ar, ai);
+        }
+        __syncthreads();
+    }
+}
+
+// raw[split][c][p][k] = sum_{i in split} spec[c][a][i][k] * conj(spec[c][b][i][k]); block = kx x iy threads
+__global__ __launch_bounds__(256) void xmul_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int n_ant,
+                                                  int n_base, int nchan, int64_t n_pts, int kx, int n_splits,
+                                                  int64_t n_chunks) {
+    __shared__ cf red[256];
+    const int iy = 256 / kx;
+    const int tk = threadIdx.x % kx, ti = threadIdx.x / kx;
+    const int kblocks = (nchan + kx - 1) / kx;
+    const int64_t total = n_chunks * n_base * kblocks * n_splits;
+    for (int64_t wid = blockIdx.x; wid < total; wid += gridDim.x) {
+        const int split = (int)(wid % n_splits);
+        int64_t rest = wid / n_splits;
+        const int kb = (int)(rest % kblocks);
+        rest /= kblocks;
+        const int p = (int)(rest % n_base);
+        const int64_t c = rest / n_base;
+        // baseline p -> (a, b), ordered (0,1),(0,2),...,(A-2,A-1)
+        int a = 0, q = p;
+        while (q >= n_ant - 1 - a) { q -= n_ant - 1 - a; ++a; }
+        const int b = a + 1 + q;
+        const int k = kb * kx + tk;
+        float ar = 0.f, ai = 0.f;
+        if (k < nchan) {
+            const cf* sa = spec + ((c * n_ant + a) * n_pts) * nchan + k;
+            const cf* sb = spec + ((c * n_ant + b) * n_pts) * nchan + k;
+            for (int64_t i = (int64_t)split * iy + ti; i < n_pts; i += (int64_t)iy * n_splits) {
+                const cf u = sa[i * nchan], w = sb[i * nchan];
+                ar += u.x * w.x + u.y * w.y;
+                ai += u.y * w.x - u.x * w.y;
+            }
+        }
+        red[threadIdx.x] = fxc::mk(ar, ai);
+        __syncthreads();
+        if (ti == 0 && k < nchan) {
+            for (int j = 1; j < iy; ++j) {
+                ar += red[j * kx + tk].x;
+                ai += red[j * kx + tk].y;
+            }
+            raw[(((int64_t)split * n_chunks + c) * n_base + p) * nchan + k] = fxc::mk(ar, ai);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// finishing kernels (shared by both paths); `slots` != 0: input is in the fused kernel's slot order
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t raw_index(int k, int slots) { return slots ? fxc::fused::slot_of_bin(k) : k; }
+
+// SPECTRUM rows: out[c][p][(k + N/2) % N] = (sum_split raw) * conj(rot[k]) / n_pts   (effex.py:520-521)
+__global__ void rows_spectrum_kernel(const cf* __restrict__ raw, cf* __restrict__ out, const cd* __restrict__ rot,
+                                     int nchan, int64_t rows, int n_splits, int64_t split_stride, float inv_pts,
+                                     int slots) {
+    const int64_t total = rows * nchan;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int k = (int)(idx % nchan);
+        const int64_t row = idx / nchan;
+        float ar = 0.f, ai = 0.f;
+        for (int s = 0; s < n_splits; ++s) {
+            const cf r = raw[s * split_stride + row * nchan + raw_index(k, slots)];
+            ar += r.x;
+            ai += r.y;
+        }
+        const float cr = (float)rot[k].x, ci = (float)rot[k].y;
+        // (ar + i ai) * (cr - i ci)
+        const float orr = (ar * cr + ai * ci) * inv_pts;
+        const float oi = (ai * cr - ar * ci) * inv_pts;
+        int ks = k + nchan / 2;
+        if (ks >= nchan) ks -= nchan;
+        out[row * nchan + ks] = fxc::mk(orr, oi);
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// CONTINUUM rows: out[row] = mean_k( raw * conj(rot) / n_pts ) / bandwidth   (effex.py:523-524); one WG per row
+__global__ __launch_bounds__(256) void rows_continuum_kernel(const cf* __restrict__ raw, cd* __restrict__ out,
+                                                            const cd* __restrict__ rot, int nchan, int64_t rows,
+                                                            int n_splits, int64_t split_stride, double scale,
+                                                            int slots) {
+    __shared__ double red[256];
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        double ar = 0.0, ai = 0.0;
+        for (int k = threadIdx.x; k < nchan; k += blockDim.x) {
+            double xr = 0.0, xi = 0.0;
+            for (int s = 0; s < n_splits; ++s) {
+                const cf r = raw[s * split_stride + row * nchan + raw_index(k, slots)];
+                xr += r.x;
+                xi += r.y;
+            }
+            const cd w = rot[k];
+            ar += xr * w.x + xi * w.y;
+            ai += xi * w.x - xr * w.y;
+        }
+        ar = block_sum(ar, red);
+        ai = block_sum(ai, red);
+        if (threadIdx.x == 0) {
+            cd o;
+            o.x = ar * scale;
+            o.y = ai * scale;
+            out[row] = o;
+        }
+    }
+}
+
+// generic accumulate: acc[p][k] += sum_split sum_c raw[split][c][p][k]   (fixed order -> reproducible)
+__global__ void acc_add_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, int64_t per_chunk /* n_base*nchan */,
+                               int64_t n_chunks, int n_splits) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per_chunk; idx += stride) {
+        double ar = 0.0, ai = 0.0;
+        for (int64_t sc = 0; sc < n_chunks * n_splits; ++sc) {
+            const cf r = raw[sc * per_chunk + idx];
+            ar += r.x;
+            ai += r.y;
+        }
+        cd a = acc[idx];
+        a.x += ar;
+        a.y += ai;
+        acc[idx] = a;
+    }
+}
+
+// fused accumulate: acc[k] += sum_wg partial[wg][slot(k)], and clear the partial rows
+__global__ void collapse_kernel(cd* __restrict__ partial, cd* __restrict__ acc, int n_rows) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= fxc::fused::kN) return;
+    const int slot = fxc::fused::slot_of_bin(k);
+    double ar = 0.0, ai = 0.0;
+    cd zero;
+    zero.x = zero.y = 0.0;
+    for (int w = 0; w < n_rows; ++w) {
+        const cd v = partial[(int64_t)w * fxc::fused::kN + slot];
+        ar += v.x;
+        ai += v.y;
+        partial[(int64_t)w * fxc::fused::kN + slot] = zero;
+    }
+    cd a = acc[k];
+    a.x += ar;
+    a.y += ai;
+    acc[k] = a;
+}
+
+// sums = [n_base*nchan] raw sums + [1] {count, 0}
+__global__ void export_kernel(const cd* __restrict__ acc, cd* __restrict__ sums, int64_t n, double count) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx <= n; idx += stride) {
+        cd v;
+        if (idx < n) {
+            v = acc[idx];
+        } else {
+            v.x = count;
+            v.y = 0.0;
+        }
+        sums[idx] = v;
+    }
+}
+
+// out[p][(k + N/2) % N] = sums[p][k] * conj(rot[k]) / count      (effex.py:520-521, integrated)
+__global__ void finalize_spectrum_kernel(const cd* __restrict__ sums, cd* __restrict__ out, const cd* __restrict__ rot,
+                                         int nchan, int n_base) {
+    const int64_t n = (int64_t)n_base * nchan;
+    const double inv = 1.0 / sums[n].x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        const int k = (int)(idx % nchan);
+        const int64_t p = idx / nchan;
+        const cd a = sums[idx], w = rot[k];
+        cd o;
+        o.x = (a.x * w.x + a.y * w.y) * inv;
+        o.y = (a.y * w.x - a.x * w.y) * inv;
+        int ks = k + nchan / 2;
+        if (ks >= nchan) ks -= nchan;
+        out[p * nchan + ks] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_continuum_kernel(const cd* __restrict__ sums, cd* __restrict__ out,
+                                                                const cd* __restrict__ rot, int nchan, int n_base,
+                                                                double inv_bw) {
+    __shared__ double red[256];
+    const int64_t n = (int64_t)n_base * nchan;
+    const double scale = inv_bw / (sums[n].x * (double)nchan);
+    for (int p = blockIdx.x; p < n_base; p += gridDim.x) {
+        double ar = 0.0, ai = 0.0;
+        for (int k = threadIdx.x; k < nchan; k += blockDim.x) {
+            const cd a = sums[(int64_t)p * nchan + k], w = rot[k];
+            ar += a.x * w.x + a.y * w.y;
+            ai += a.y * w.x - a.x * w.y;
+        }
+        ar = block_sum(ar, red);
+        ai = block_sum(ai, red);
+        if (threadIdx.x == 0) {
+            cd o;
+            o.x = ar * scale;
+            o.y = ai * scale;
+            out[p] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused 2-antenna, nchan = 4096, ntaps = 4 kernel (phases in fx_fused4096.h)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// vdst keeps its low half and receives src's low half in its high half; src gets the two high halves
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// one frame of this thread's 16 branch samples: element (255 - j) + 256 (15 - r) of frame i
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load_frame(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned voff,
+                                           int64_t i) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    const unsigned soff = (unsigned)(i * fxc::fused::kN * (int64_t)sizeof(cf));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff + (unsigned)(256 * (15 - r) * sizeof(cf)), 0);
+        xr[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+    }
+}
+
+// one spectrum of both antennas: frame i of chunk c sits in ring slot PH.  All control flow here is
+// wave-uniform and none of it guards a *definition* of ring registers (the prefetch is unconditional),
+// which keeps the register allocator from doubling live ranges at merge points.
+template <int PH, bool ROWS>
+__device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, cf* region, const cf* tw2, int tid,
+                                           const cf* x, int64_t num_samp, unsigned chunk_bytes, unsigned voff,
+                                           int64_t& c, int64_t& i, int64_t n_pts, int64_t n_chunks,
+                                           cd* partial_row, cf* rows_raw) {
+    using namespace fxc::fused;
+    if (i == 0) {   // zero PFB history at the start of every chunk
+        asm volatile("" ::: "memory");   // keep this a (rarely taken) uniform branch, not 96 v_cndmask per frame
+        state_reset_history<PH>(s);
+    }
+    cf v[16];
+    phase1_compute<PH>(s, win, tid, v);
+    // the oldest history slot is dead now: refill it with the next frame this workgroup will process
+    // (next frame of the chunk, or frame 0 of its next chunk; at the very end the current frame again,
+    // which is never used).  The loads stay in flight under phases 1b-3 and are first waited for by
+    // the next FIR.
+    int64_t ni = i + 1, nc = c;
+    if (ni == n_pts) {
+        ni = 0;
+        nc = c + gridDim.x;
+    }
+    const bool more = nc < n_chunks;
+    load_frame(s.h[(PH + 1) & 3], x + (more ? nc : c) * 2 * num_samp, chunk_bytes, voff, more ? ni : i);
+    __syncthreads();   // every wave has finished reading the previous spectrum's rows
+    phase1_store(v, region, tid);
+    __syncthreads();
+    phase2_load(region, tid, v);
+    phase2_compute(v, tw2, tid);
+    wave_sync();
+    phase2_store(v, region, tid);
+    wave_sync();
+    phase3_load(region, tid, v);
+    fxc::dft16(v);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        cf a = v[q], b = v[q + 8];
+        permlane32_swap(a.x, b.x);
+        permlane32_swap(a.y, b.y);
+        xacc(s, q, a, b);
+    }
+    if (i + 1 == n_pts) {   // chunk done: flush this lane's 8 bins
+        if (ROWS) {
+            cf* row = rows_raw + c * kN;
+#pragma unroll
+            for (int q = 0; q < kAccPerThread; ++q) row[q * kThreads + tid] = s.acc[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < kAccPerThread; ++q) {
+                cd t = partial_row[q * kThreads + tid];
+                t.x += (double)s.acc[q].x;
+                t.y += (double)s.acc[q].y;
+                partial_row[q * kThreads + tid] = t;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
+    }
+    c = nc;
+    i = ni;
+}
+
+template <bool ROWS>
+__global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
+    const cf* __restrict__ x, int64_t num_samp, int64_t n_pts, int64_t n_chunks, const f4* __restrict__ win_g,
+    const cf* __restrict__ tw1_g, const cf* __restrict__ tw2_g, cd* __restrict__ partial, cf* __restrict__ rows_raw) {
+    using namespace fxc::fused;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f4* win = reinterpret_cast<f4*>(smem + kLdsWin);
+    cf* region = reinterpret_cast<cf*>(smem + kLdsRegion);
+    cf* tw2 = reinterpret_cast<cf*>(smem + kLdsTw2);
+
+    const int tid = threadIdx.x;
+    const int ant = tid >> 8, j = tid & 255;
+    for (int idx = tid; idx < kN; idx += kThreads) win[idx] = win_g[idx];
+    if (tid < 256) tw2[tid] = tw2_g[tid];
+    State s;
+    state_load_twiddles(s, tw1_g, tid);
+#pragma unroll
+    for (int q = 0; q < kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
+    __syncthreads();
+
+    int64_t c = blockIdx.x, i = 0;
+    if (c >= n_chunks) return;
+    const int64_t my_chunks = (n_chunks - c + gridDim.x - 1) / gridDim.x;
+    const int64_t total = my_chunks * n_pts;
+    // IQ frames come in through buffer loads: one VGPR byte offset per thread (antenna stream +
+    // (255 - j)), everything that varies with chunk / frame / r is scalar
+    const unsigned voff = (unsigned)((ant * num_samp + (255 - j)) * (int64_t)sizeof(cf));
+    const unsigned chunk_bytes = (unsigned)(2 * num_samp * (int64_t)sizeof(cf));
+    cd* prow = partial + (int64_t)blockIdx.x * kN;
+    load_frame(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
+    // frame g of this workgroup's stream of frames sits in ring slot g & 3: unrolled by four so the
+    // ring rotates by register renaming
+    for (int64_t g = 0; g < total; g += 4) {
+        fused_step<0, ROWS>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, prow, rows_raw);
+        if (g + 1 < total)
+            fused_step<1, ROWS>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, prow, rows_raw);
+        if (g + 2 < total)
+            fused_step<2, ROWS>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, prow, rows_raw);
+        if (g + 3 < total)
+            fused_step<3, ROWS>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, prow, rows_raw);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic IQ (effex_amd/synth.py, bit for bit)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void synth_kernel(cf* __restrict__ x, uint64_t seed, int64_t first_chunk, int64_t n_chunks, int n_ant,
+                             int64_t num_samp, const int* __restrict__ delays, const cf* __restrict__ tone,
+                             int tone_period, const float* __restrict__ lut) {
+    const int64_t total = n_chunks * n_ant * num_samp;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint64_t key_seed = seed * 0x8CB92BA72F3D8DD7ull;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t n = idx % num_samp;
+        const int64_t ca = idx / num_samp;
+        const int a = (int)(ca % n_ant);
+        const int64_t c = ca / n_ant;
+        const uint64_t g = (uint64_t)(1 << 20) + (uint64_t)((first_chunk + c) * num_samp) + (uint64_t)n;
+        const uint64_t gd = g - (uint64_t)delays[a];
+        const uint64_t hs = mix64(key_seed + gd);   // stream 0 = sky
+        const uint64_t hr = mix64(key_seed + (uint64_t)(a + 1) * 0xD1B54A32D192ED03ull + g);
+        const cf t = tone[(int)(gd % (uint64_t)tone_period)];
+        const float s_re = lut[hs & 0xFF], s_im = lut[(hs >> 8) & 0xFF];
+        const float r_re = lut[hr & 0xFF], r_im = lut[(hr >> 8) & 0xFF];
+        // (s + 0.5 r) + t with one rounding per step; 0.5*r is exact
+        const float re = __fadd_rn(__fadd_rn(s_re, 0.5f * r_re), t.x);
+        const float im = __fadd_rn(__fadd_rn(s_im, 0.5f * r_im), t.y);
+        x[idx] = fxc::mk(re, im);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+thread_local std::string g_lib_error;
+
+}  // namespace
+
+struct fxc_plan {
+    int device = 0, cu_count = 0;
+    int n_ant = 0, n_base = 0, nchan = 0, ntaps = 0;
+    int64_t num_samp = 0, n_pts = 0;
+    int path = FXC_PATH_GENERIC;
+    bool pow2 = false;
+    int lg2n = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device tables
+    float* d_win = nullptr;        // [ntaps*nchan] float (generic)
+    cf* d_tw = nullptr;            // generic FFT twiddles
+    cd* d_rot = nullptr;           // [nchan]
+    f4* d_win4 = nullptr;          // fused
+    cf* d_tw1 = nullptr;
+    cf* d_tw2 = nullptr;
+    cd* d_partial = nullptr;       // fused: [fused_grid_max][4096]
+    int fused_grid_max = 0;
+    cd* d_acc = nullptr;           // [n_base*nchan]
+    cd* d_sums = nullptr;          // [n_base*nchan + 1]
+    cd* d_out = nullptr;           // finalize staging [n_base*nchan]
+    double spectra_count = 0.0;
+    bool partial_dirty = false;
+    // workspace (grown on demand)
+    void* d_ws = nullptr;
+    int64_t ws_bytes = 0;
+    // timing
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+    double kernel_ms = 0.0;
+    int64_t kernel_launches = 0;
+    mutable std::string error;
+};
+
+namespace {
+
+int fail(const fxc_plan* p, int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (p)
+        p->error = buf;
+    else
+        g_lib_error = buf;
+    return status;
+}
+
+#define FXC_HIP(p, call)                                                                                       \
+    do {                                                                                                       \
+        hipError_t e__ = (call);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return fail(p, e__ == hipErrorOutOfMemory ? FXC_ERR_NOMEM : FXC_ERR_HIP, "%s failed: %s", #call,   \
+                        hipGetErrorString(e__));                                                               \
+    } while (0)
+
+int grid_for(int64_t work_items, int block, int cu_count) {
+    int64_t g = (work_items + block - 1) / block;
+    const int64_t cap = (int64_t)cu_count * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int ensure_ws(fxc_plan* p, int64_t bytes) {
+    if (bytes <= p->ws_bytes) return FXC_OK;
+    if (p->d_ws) {
+        FXC_HIP(p, hipStreamSynchronize(p->stream));
+        FXC_HIP(p, hipFree(p->d_ws));
+        p->d_ws = nullptr;
+        p->ws_bytes = 0;
+    }
+    FXC_HIP(p, hipMalloc(&p->d_ws, (size_t)bytes));
+    p->ws_bytes = bytes;
+    return FXC_OK;
+}
+
+struct KernelTimer {
+    fxc_plan* p;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit KernelTimer(fxc_plan* plan) : p(plan) {
+        if (p->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+            (void)hipEventRecord(a, p->stream);
+        else
+            a = b = nullptr;
+    }
+    void stop() {
+        if (a) {
+            (void)hipEventRecord(b, p->stream);
+            p->kev.emplace_back(a, b);
+            a = b = nullptr;
+        }
+    }
+};
+
+int drain_kernel_events(fxc_plan* p) {
+    for (auto& e : p->kev) {
+        FXC_HIP(p, hipEventSynchronize(e.second));
+        float ms = 0.f;
+        FXC_HIP(p, hipEventElapsedTime(&ms, e.first, e.second));
+        p->kernel_ms += ms;
+        p->kernel_launches += 1;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    p->kev.clear();
+    return FXC_OK;
+}
+
+// F-stage of `n_streams` streams: x -> spec (both device), generic path
+int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
+    if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
+    const int64_t total = n_streams * p->n_pts * p->nchan;
+    hipLaunchKernelGGL(pfb_fir_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream, x, p->d_win,
+                       spec, p->num_samp, p->nchan, p->ntaps, p->n_pts, total);
+    const int64_t rows = n_streams * p->n_pts;
+    if (p->nchan > 1) {
+        const int grid = (int)std::min<int64_t>(rows, (int64_t)p->cu_count * 4);
+        const size_t lds = (size_t)p->nchan * sizeof(cf);
+        if (p->pow2)
+            hipLaunchKernelGGL(fft_pow2_kernel, dim3(grid), dim3(256), lds, p->stream, spec, p->d_tw, p->nchan,
+                               p->lg2n, rows);
+        else
+            hipLaunchKernelGGL(dft_any_kernel, dim3(grid), dim3(256), lds, p->stream, spec, p->d_tw, p->nchan, rows);
+    }
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+struct XGeom {
+    int kx, n_splits;
+};
+
+XGeom x_geometry(const fxc_plan* p) {
+    XGeom g;
+    g.kx = 1;
+    while (g.kx < 256 && g.kx < p->nchan) g.kx <<= 1;
+    const int iy = 256 / g.kx;
+    int64_t splits = (p->n_pts + (int64_t)iy * 64 - 1) / ((int64_t)iy * 64);
+    if (splits < 1) splits = 1;
+    if (splits > 256) splits = 256;
+    g.n_splits = (int)splits;
+    return g;
+}
+
+// chunks per pass on the generic path so that spectra + raw sums fit the workspace target
+int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom& g, int64_t* spec_bytes,
+                                int64_t* raw_bytes) {
+    const int64_t spec_per_chunk = (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
+    const int64_t raw_per_chunk = (int64_t)g.n_splits * p->n_base * p->nchan * (int64_t)sizeof(cf);
+    int64_t cb = kWorkspaceTarget / std::max<int64_t>(1, spec_per_chunk + raw_per_chunk);
+    if (cb < 1) cb = 1;
+    if (cb > n_chunks) cb = n_chunks;
+    *spec_bytes = (cb * spec_per_chunk + 255) / 256 * 256;
+    *raw_bytes = cb * raw_per_chunk;
+    return cb;
+}
+
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_chunks, bool rows, cf* rows_raw) {
+    using namespace fxc::fused;
+    const int grid = (int)std::min<int64_t>(n_chunks, p->fused_grid_max);
+    KernelTimer kt(p);
+    if (rows)
+        hipLaunchKernelGGL(fx_fused4096_kernel<true>, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x, p->num_samp,
+                           p->n_pts, n_chunks, p->d_win4, p->d_tw1, p->d_tw2, p->d_partial, rows_raw);
+    else
+        hipLaunchKernelGGL(fx_fused4096_kernel<false>, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
+                           p->num_samp, p->n_pts, n_chunks, p->d_win4, p->d_tw1, p->d_tw2, p->d_partial, rows_raw);
+    kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+int collapse_partials(fxc_plan* p) {
+    if (p->path == FXC_PATH_FUSED && p->partial_dirty) {
+        hipLaunchKernelGGL(collapse_kernel, dim3(fxc::fused::kN / 256), dim3(256), 0, p->stream, p->d_partial, p->d_acc,
+                           p->fused_grid_max);
+        FXC_HIP(p, hipGetLastError());
+        p->partial_dirty = false;
+    }
+    return FXC_OK;
+}
+
+// device-resident implementation of fx_accumulate
+int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
+    if (n_chunks == 0) return FXC_OK;
+    if (p->path == FXC_PATH_FUSED) {
+        int rc = launch_fused(p, x, n_chunks, false, nullptr);
+        if (rc) return rc;
+        p->partial_dirty = true;
+    } else {
+        const XGeom g = x_geometry(p);
+        int64_t spec_bytes, raw_bytes;
+        const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes);
+        int rc = ensure_ws(p, spec_bytes + raw_bytes);
+        if (rc) return rc;
+        cf* spec = reinterpret_cast<cf*>(p->d_ws);
+        cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            KernelTimer kt(p);
+            rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);
+            if (rc) return rc;
+            const int kblocks = (p->nchan + g.kx - 1) / g.kx;
+            const int64_t wgs = nc * p->n_base * kblocks * g.n_splits;
+            hipLaunchKernelGGL(xmul_kernel, dim3((int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8)), dim3(256), 0,
+                               p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
+            const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
+            hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream, raw,
+                               p->d_acc, per_chunk, nc, g.n_splits);
+            kt.stop();
+            FXC_HIP(p, hipGetLastError());
+        }
+    }
+    p->spectra_count += (double)n_chunks * (double)p->n_pts;
+    return FXC_OK;
+}
+
+// device-resident implementation of fx_rows; out = cf[n_chunks][n_base][nchan] or cd[n_chunks][n_base]
+int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode, double bandwidth) {
+    if (n_chunks == 0) return FXC_OK;
+    const float inv_pts = (float)(1.0 / (double)p->n_pts);
+    const double cscale = 1.0 / ((double)p->n_pts * (double)p->nchan * bandwidth);
+    if (p->path == FXC_PATH_FUSED) {
+        const int64_t raw_bytes = n_chunks * fxc::fused::kN * (int64_t)sizeof(cf);
+        int rc = ensure_ws(p, raw_bytes);
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        rc = launch_fused(p, x, n_chunks, true, raw);
+        if (rc) return rc;
+        if (mode == FXC_MODE_SPECTRUM)
+            hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(n_chunks * p->nchan, 256, p->cu_count)), dim3(256),
+                               0, p->stream, raw, static_cast<cf*>(out), p->d_rot, p->nchan, n_chunks, 1,
+                               (int64_t)0, inv_pts, 1);
+        else
+            hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(n_chunks, (int64_t)p->cu_count * 8)),
+                               dim3(256), 0, p->stream, raw, static_cast<cd*>(out), p->d_rot, p->nchan, n_chunks, 1,
+                               (int64_t)0, cscale, 1);
+        FXC_HIP(p, hipGetLastError());
+        return FXC_OK;
+    }
+    const XGeom g = x_geometry(p);
+    int64_t spec_bytes, raw_bytes;
+    const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes);
+    int rc = ensure_ws(p, spec_bytes + raw_bytes);
+    if (rc) return rc;
+    cf* spec = reinterpret_cast<cf*>(p->d_ws);
+    cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+        const int64_t nc = std::min(cb, n_chunks - c0);
+        KernelTimer kt(p);
+        rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);
+        if (rc) return rc;
+        const int kblocks = (p->nchan + g.kx - 1) / g.kx;
+        const int64_t wgs = nc * p->n_base * kblocks * g.n_splits;
+        hipLaunchKernelGGL(xmul_kernel, dim3((int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8)), dim3(256), 0,
+                           p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
+        kt.stop();
+        const int64_t rows = nc * p->n_base;
+        const int64_t split_stride = rows * p->nchan;
+        if (mode == FXC_MODE_SPECTRUM)
+            hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(rows * p->nchan, 256, p->cu_count)), dim3(256), 0,
+                               p->stream, raw, static_cast<cf*>(out) + c0 * p->n_base * p->nchan, p->d_rot, p->nchan,
+                               rows, g.n_splits, split_stride, inv_pts, 0);
+        else
+            hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
+                               dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot, p->nchan,
+                               rows, g.n_splits, split_stride, cscale, 0);
+        FXC_HIP(p, hipGetLastError());
+    }
+    return FXC_OK;
+}
+
+// host-buffer helper: stage in, run, stage out (synchronous)
+template <class Fn>
+int with_host_staging(fxc_plan* p, const void* x, size_t x_bytes, void* out, size_t out_bytes, Fn fn) {
+    void *dx = nullptr, *dout = nullptr;
+    int rc = FXC_OK;
+    hipError_t e = hipMalloc(&dx, x_bytes ? x_bytes : 1);
+    if (e == hipSuccess && out_bytes) e = hipMalloc(&dout, out_bytes);
+    if (e != hipSuccess) {
+        if (dx) (void)hipFree(dx);
+        return fail(p, FXC_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
+    }
+    e = hipMemcpyAsync(dx, x, x_bytes, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) rc = fn(static_cast<const cf*>(dx), dout);
+    if (e == hipSuccess && rc == FXC_OK && out_bytes)
+        e = hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, p->stream);
+    hipError_t e2 = hipStreamSynchronize(p->stream);
+    (void)hipFree(dx);
+    if (dout) (void)hipFree(dout);
+    if (rc != FXC_OK) return rc;
+    if (e != hipSuccess) return fail(p, FXC_ERR_HIP, "host staging copy failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(p, FXC_ERR_HIP, "stream sync failed: %s", hipGetErrorString(e2));
+    return FXC_OK;
+}
+
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI (include/fxcorr.h)
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int fxc_version(void) { return FXC_VERSION; }
+
+const char* fxc_status_string(int status) {
+    switch (status) {
+        case FXC_OK: return "ok";
+        case FXC_ERR_ARG: return "invalid argument";
+        case FXC_ERR_UNSUPPORTED: return "unsupported configuration";
+        case FXC_ERR_HIP: return "HIP runtime error";
+        case FXC_ERR_NOMEM: return "out of device memory";
+        case FXC_ERR_NODEVICE: return "no HIP device";
+        case FXC_ERR_STATE: return "invalid call sequence";
+        default: return "unknown status";
+    }
+}
+
+int fxc_device_count(int* count) {
+    if (!count) return fail(nullptr, FXC_ERR_ARG, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return FXC_OK;
+}
+
+const char* fxc_last_error(const fxc_plan* plan) { return plan ? plan->error.c_str() : g_lib_error.c_str(); }
+
+int fxc_plan_destroy(fxc_plan* p) {
+    if (!p) return FXC_OK;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (auto& e : p->kev) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_partial,
+                    p->d_acc, p->d_sums, p->d_out, p->d_ws};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
+    if (p->ev_t1) (void)hipEventDestroy(p->ev_t1);
+    if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return FXC_OK;
+}
+
+static int plan_build(fxc_plan* p, const double* window, int force_path) {
+    hipDeviceProp_t prop;
+    FXC_HIP(p, hipGetDeviceProperties(&prop, p->device));
+    p->cu_count = prop.multiProcessorCount;
+    if (!p->stream) {
+        FXC_HIP(p, hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        p->own_stream = true;
+    }
+    FXC_HIP(p, hipEventCreate(&p->ev_t0));
+    FXC_HIP(p, hipEventCreate(&p->ev_t1));
+
+    const int N = p->nchan, T = p->ntaps;
+    const bool fused_shape = (p->n_ant == 2 && N == fxc::fused::kN && T == fxc::fused::kT);
+    if (force_path == FXC_PATH_FUSED && !fused_shape)
+        return fail(p, FXC_ERR_UNSUPPORTED, "no fused kernel for n_ant=%d nchan=%d ntaps=%d", p->n_ant, N, T);
+    p->path = (fused_shape && force_path != FXC_PATH_GENERIC) ? FXC_PATH_FUSED : FXC_PATH_GENERIC;
+
+    // window: float32 copy of the float64 design (both layouts)
+    std::vector<float> wf((size_t)T * N);
+    for (size_t n = 0; n < wf.size(); ++n) wf[n] = (float)window[n];
+    FXC_HIP(p, hipMalloc(&p->d_win, wf.size() * sizeof(float)));
+    FXC_HIP(p, hipMemcpy(p->d_win, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
+
+    // generic FFT twiddles exp(+2 pi i j / N): [N/2] for the radix-2 kernel, [N] for the direct DFT
+    if (N > 1) {
+        const int cnt = p->pow2 ? N / 2 : N;
+        std::vector<cf> tw((size_t)cnt);
+        for (int jx = 0; jx < cnt; ++jx) {
+            const double ph = kTwoPi * (double)jx / (double)N;
+            tw[jx] = fxc::mk((float)std::cos(ph), (float)std::sin(ph));
+        }
+        FXC_HIP(p, hipMalloc(&p->d_tw, tw.size() * sizeof(cf)));
+        FXC_HIP(p, hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+    }
+
+    std::vector<cd> rot((size_t)N);
+    for (auto& r : rot) {
+        r.x = 1.0;
+        r.y = 0.0;
+    }
+    FXC_HIP(p, hipMalloc(&p->d_rot, rot.size() * sizeof(cd)));
+    FXC_HIP(p, hipMemcpy(p->d_rot, rot.data(), rot.size() * sizeof(cd), hipMemcpyHostToDevice));
+
+    const size_t acc_n = (size_t)p->n_base * N;
+    FXC_HIP(p, hipMalloc(&p->d_acc, acc_n * sizeof(cd)));
+    FXC_HIP(p, hipMemset(p->d_acc, 0, acc_n * sizeof(cd)));
+    FXC_HIP(p, hipMalloc(&p->d_sums, (acc_n + 1) * sizeof(cd)));
+    FXC_HIP(p, hipMalloc(&p->d_out, acc_n * sizeof(cd)));
+
+    if (p->path == FXC_PATH_FUSED) {
+        using namespace fxc::fused;
+        std::vector<f4> w4((size_t)kN);
+        for (int r = 0; r < 16; ++r)
+            for (int jx = 0; jx < 256; ++jx) {
+                const int m = jx + 256 * r;
+                f4 w;
+                w.x = wf[0 * kN + m];
+                w.y = wf[1 * kN + m];
+                w.z = wf[2 * kN + m];
+                w.w = wf[3 * kN + m];
+                w4[r * 256 + jx] = w;
+            }
+        std::vector<cf> tw1((size_t)16 * 256), tw2((size_t)256);
+        for (int k1 = 0; k1 < 16; ++k1)
+            for (int jx = 0; jx < 256; ++jx) {
+                const double ph = kTwoPi * (double)((jx * k1) % kN) / (double)kN;
+                tw1[k1 * 256 + jx] = fxc::mk((float)std::cos(ph), (float)std::sin(ph));
+            }
+        for (int q1 = 0; q1 < 16; ++q1)
+            for (int j0 = 0; j0 < 16; ++j0) {
+                const double ph = kTwoPi * (double)(j0 * q1) / 256.0;
+                tw2[q1 * 16 + j0] = fxc::mk((float)std::cos(ph), (float)std::sin(ph));
+            }
+        FXC_HIP(p, hipMalloc(&p->d_win4, w4.size() * sizeof(f4)));
+        FXC_HIP(p, hipMemcpy(p->d_win4, w4.data(), w4.size() * sizeof(f4), hipMemcpyHostToDevice));
+        FXC_HIP(p, hipMalloc(&p->d_tw1, tw1.size() * sizeof(cf)));
+        FXC_HIP(p, hipMemcpy(p->d_tw1, tw1.data(), tw1.size() * sizeof(cf), hipMemcpyHostToDevice));
+        FXC_HIP(p, hipMalloc(&p->d_tw2, tw2.size() * sizeof(cf)));
+        FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
+        p->fused_grid_max = p->cu_count;   // one 512-thread workgroup (136 KiB LDS) per CU
+        const size_t pbytes = (size_t)p->fused_grid_max * kN * sizeof(cd);
+        FXC_HIP(p, hipMalloc(&p->d_partial, pbytes));
+        FXC_HIP(p, hipMemset(p->d_partial, 0, pbytes));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    }
+    if (N > 1) {
+        const int lds = N * (int)sizeof(cf);
+        if (p->pow2)
+            FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_pow2_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        else
+            FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&dft_any_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    return FXC_OK;
+}
+
+int fxc_plan_create(fxc_plan** out, int device, int n_ant, int nchan, int ntaps, int64_t num_samp,
+                    const double* window, void* stream, int force_path) {
+    if (!out) return fail(nullptr, FXC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!window) return fail(nullptr, FXC_ERR_ARG, "window is NULL");
+    if (n_ant < 1 || n_ant > 64) return fail(nullptr, FXC_ERR_ARG, "n_ant=%d out of range [1,64]", n_ant);
+    if (nchan < 1) return fail(nullptr, FXC_ERR_ARG, "nchan=%d must be >= 1", nchan);
+    if (ntaps < 1) return fail(nullptr, FXC_ERR_ARG, "ntaps=%d must be >= 1", ntaps);
+    if (ntaps > kMaxTaps)
+        return fail(nullptr, FXC_ERR_UNSUPPORTED, "Number of taps (%d) must be less than (32).", ntaps);
+    if (nchan > kMaxLdsFftN)
+        return fail(nullptr, FXC_ERR_UNSUPPORTED, "nchan=%d exceeds the in-LDS FFT limit %d", nchan, kMaxLdsFftN);
+    if (num_samp < nchan)
+        return fail(nullptr, FXC_ERR_ARG, "num_samp=%lld shorter than one frame of nchan=%d", (long long)num_samp,
+                    nchan);
+    if (force_path < -1 || force_path > FXC_PATH_FUSED) return fail(nullptr, FXC_ERR_ARG, "bad force_path");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device available (this library has no CPU backend)");
+    if (device < 0 || device >= ndev) return fail(nullptr, FXC_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, FXC_ERR_HIP, "hipSetDevice(%d) failed", device);
+
+    fxc_plan* p = new (std::nothrow) fxc_plan();
+    if (!p) return fail(nullptr, FXC_ERR_NOMEM, "host allocation failed");
+    p->device = device;
+    p->n_ant = n_ant;
+    p->n_base = n_ant * (n_ant - 1) / 2;
+    p->nchan = nchan;
+    p->ntaps = ntaps;
+    p->num_samp = num_samp;
+    p->n_pts = num_samp / nchan;
+    p->pow2 = (nchan & (nchan - 1)) == 0;
+    p->lg2n = 0;
+    while ((1 << p->lg2n) < nchan) ++p->lg2n;
+    p->stream = static_cast<hipStream_t>(stream);
+    const int rc = plan_build(p, window, force_path);
+    if (rc != FXC_OK) {
+        g_lib_error = p->error;
+        fxc_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return FXC_OK;
+}
+
+int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
+    if (!p || !info) return fail(p, FXC_ERR_ARG, "NULL argument");
+    std::memset(info, 0, sizeof *info);
+    info->n_ant = p->n_ant;
+    info->n_baselines = p->n_base;
+    info->nchan = p->nchan;
+    info->ntaps = p->ntaps;
+    info->num_samp = p->num_samp;
+    info->n_pts = p->n_pts;
+    info->path = p->path;
+    if (p->path == FXC_PATH_FUSED) {
+        info->grid = p->fused_grid_max;
+        info->block = fxc::fused::kThreads;
+        info->lds_bytes = fxc::fused::kLdsBytes;
+    } else {
+        info->grid = p->cu_count * 4;
+        info->block = 256;
+        info->lds_bytes = p->nchan > 1 ? p->nchan * (int)sizeof(cf) : 0;
+    }
+    info->device = p->device;
+    info->cu_count = p->cu_count;
+    info->workspace_bytes = p->ws_bytes;
+    return FXC_OK;
+}
+
+int fxc_set_rot(fxc_plan* p, const double* rot_re_im) {
+    if (!p || !rot_re_im) return fail(p, FXC_ERR_ARG, "NULL argument");
+    FXC_HIP(p, hipSetDevice(p->device));
+    // ordered after any queued finish kernel that still reads the old table
+    FXC_HIP(p, hipStreamSynchronize(p->stream));
+    FXC_HIP(p, hipMemcpy(p->d_rot, rot_re_im, (size_t)p->nchan * sizeof(cd), hipMemcpyHostToDevice));
+    return FXC_OK;
+}
+
+int fxc_sync(fxc_plan* p) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_HIP(p, hipStreamSynchronize(p->stream));
+    return FXC_OK;
+}
+
+int fxc_channelize(fxc_plan* p, const void* x, void* out, int64_t n_streams, int mem_kind) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    if (n_streams < 0) return fail(p, FXC_ERR_ARG, "n_streams < 0");
+    if (n_streams == 0) return FXC_OK;
+    if (!x || !out) return fail(p, FXC_ERR_ARG, "NULL buffer");
+    FXC_HIP(p, hipSetDevice(p->device));
+    if (mem_kind == FXC_MEM_DEVICE) return run_channelize(p, static_cast<const cf*>(x), static_cast<cf*>(out), n_streams);
+    if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
+    const size_t xb = (size_t)n_streams * p->num_samp * sizeof(cf);
+    const size_t ob = (size_t)n_streams * p->n_pts * p->nchan * sizeof(cf);
+    return with_host_staging(p, x, xb, out, ob, [&](const cf* dx, void* dout) {
+        return run_channelize(p, dx, static_cast<cf*>(dout), n_streams);
+    });
+}
+
+int fxc_fx_accumulate(fxc_plan* p, const void* x, int64_t n_chunks, int mem_kind) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    if (n_chunks < 0) return fail(p, FXC_ERR_ARG, "n_chunks < 0");
+    if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
+    if (n_chunks == 0) return FXC_OK;
+    if (!x) return fail(p, FXC_ERR_ARG, "NULL buffer");
+    FXC_HIP(p, hipSetDevice(p->device));
+    if (mem_kind == FXC_MEM_DEVICE) return fx_accumulate_dev(p, static_cast<const cf*>(x), n_chunks);
+    if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
+    const size_t xb = (size_t)n_chunks * p->n_ant * p->num_samp * sizeof(cf);
+    return with_host_staging(p, x, xb, nullptr, 0,
+                             [&](const cf* dx, void*) { return fx_accumulate_dev(p, dx, n_chunks); });
+}
+
+int fxc_fx_rows(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mem_kind, int mode, double bandwidth) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    if (n_chunks < 0) return fail(p, FXC_ERR_ARG, "n_chunks < 0");
+    if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
+    if (mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
+    if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
+    if (n_chunks == 0) return FXC_OK;
+    if (!x || !out) return fail(p, FXC_ERR_ARG, "NULL buffer");
+    FXC_HIP(p, hipSetDevice(p->device));
+    if (mem_kind == FXC_MEM_DEVICE) return fx_rows_dev(p, static_cast<const cf*>(x), out, n_chunks, mode, bandwidth);
+    if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
+    const size_t xb = (size_t)n_chunks * p->n_ant * p->num_samp * sizeof(cf);
+    const size_t ob = mode == FXC_MODE_SPECTRUM ? (size_t)n_chunks * p->n_base * p->nchan * sizeof(cf)
+                                                : (size_t)n_chunks * p->n_base * sizeof(cd);
+    return with_host_staging(p, x, xb, out, ob, [&](const cf* dx, void* dout) {
+        return fx_rows_dev(p, dx, dout, n_chunks, mode, bandwidth);
+    });
+}
+
+int fxc_acc_reset(fxc_plan* p) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_HIP(p, hipMemsetAsync(p->d_acc, 0, (size_t)p->n_base * p->nchan * sizeof(cd), p->stream));
+    if (p->d_partial)
+        FXC_HIP(p, hipMemsetAsync(p->d_partial, 0, (size_t)p->fused_grid_max * fxc::fused::kN * sizeof(cd), p->stream));
+    p->partial_dirty = false;
+    p->spectra_count = 0.0;
+    return FXC_OK;
+}
+
+int fxc_acc_export(fxc_plan* p, void* sums_dev) {
+    if (!p || !sums_dev) return fail(p, FXC_ERR_ARG, "NULL argument");
+    FXC_HIP(p, hipSetDevice(p->device));
+    int rc = collapse_partials(p);
+    if (rc) return rc;
+    const int64_t n = (int64_t)p->n_base * p->nchan;
+    hipLaunchKernelGGL(export_kernel, dim3(grid_for(n + 1, 256, p->cu_count)), dim3(256), 0, p->stream, p->d_acc,
+                       static_cast<cd*>(sums_dev), n, p->spectra_count);
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+int fxc_finalize_sums(fxc_plan* p, const void* sums_dev, void* out_host, int mode, double bandwidth) {
+    if (!p || !sums_dev || !out_host) return fail(p, FXC_ERR_ARG, "NULL argument");
+    if (mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
+    if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
+    FXC_HIP(p, hipSetDevice(p->device));
+    const cd* sums = static_cast<const cd*>(sums_dev);
+    size_t out_bytes;
+    if (mode == FXC_MODE_SPECTRUM) {
+        const int64_t n = (int64_t)p->n_base * p->nchan;
+        hipLaunchKernelGGL(finalize_spectrum_kernel, dim3(grid_for(n, 256, p->cu_count)), dim3(256), 0, p->stream, sums,
+                           p->d_out, p->d_rot, p->nchan, p->n_base);
+        out_bytes = (size_t)n * sizeof(cd);
+    } else {
+        hipLaunchKernelGGL(finalize_continuum_kernel, dim3(p->n_base), dim3(256), 0, p->stream, sums, p->d_out,
+                           p->d_rot, p->nchan, p->n_base, 1.0 / bandwidth);
+        out_bytes = (size_t)p->n_base * sizeof(cd);
+    }
+    FXC_HIP(p, hipGetLastError());
+    FXC_HIP(p, hipMemcpyAsync(out_host, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    FXC_HIP(p, hipStreamSynchronize(p->stream));
+    return FXC_OK;
+}
+
+int fxc_finalize(fxc_plan* p, void* out_host, int mode, double bandwidth, int reset) {
+    if (!p || !out_host) return fail(p, FXC_ERR_ARG, "NULL argument");
+    if (!(p->spectra_count > 0.0)) return fail(p, FXC_ERR_STATE, "nothing accumulated");
+    int rc = fxc_acc_export(p, p->d_sums);
+    if (rc) return rc;
+    rc = fxc_finalize_sums(p, p->d_sums, out_host, mode, bandwidth);
+    if (rc) return rc;
+    if (reset) return fxc_acc_reset(p);
+    return FXC_OK;
+}
+
+int fxc_timer_start(fxc_plan* p) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_HIP(p, hipEventRecord(p->ev_t0, p->stream));
+    return FXC_OK;
+}
+
+int fxc_timer_stop(fxc_plan* p, double* elapsed_ms) {
+    if (!p || !elapsed_ms) return fail(p, FXC_ERR_ARG, "NULL argument");
+    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_HIP(p, hipEventRecord(p->ev_t1, p->stream));
+    FXC_HIP(p, hipEventSynchronize(p->ev_t1));
+    float ms = 0.f;
+    FXC_HIP(p, hipEventElapsedTime(&ms, p->ev_t0, p->ev_t1));
+    *elapsed_ms = ms;
+    return FXC_OK;
+}
+
+int fxc_kernel_profiling(fxc_plan* p, int enable) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    p->profiling = enable != 0;
+    return FXC_OK;
+}
+
+int fxc_kernel_time(fxc_plan* p, double* total_ms, int64_t* launches, int reset) {
+    if (!p || !total_ms || !launches) return fail(p, FXC_ERR_ARG, "NULL argument");
+    FXC_HIP(p, hipSetDevice(p->device));
+    int rc = drain_kernel_events(p);
+    if (rc) return rc;
+    *total_ms = p->kernel_ms;
+    *launches = p->kernel_launches;
+    if (reset) {
+        p->kernel_ms = 0.0;
+        p->kernel_launches = 0;
+    }
+    return FXC_OK;
+}
+
+int fxc_synth_fill(int device, void* stream, void* x_dev, uint64_t seed, int64_t first_chunk, int64_t n_chunks,
+                   int n_ant, int64_t num_samp, const int32_t* delays, const float* tone_re_im, int tone_period) {
+    if (!x_dev || !delays || !tone_re_im) return fail(nullptr, FXC_ERR_ARG, "NULL argument");
+    if (n_chunks < 0 || n_ant < 1 || num_samp < 1 || tone_period < 1) return fail(nullptr, FXC_ERR_ARG, "bad size");
+    if (n_chunks == 0) return FXC_OK;
+    const fxc_plan* p = nullptr;
+    FXC_HIP(p, hipSetDevice(device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float lut[256];
+    for (int b = 0; b < 256; ++b) lut[b] = ((float)b - 127.5f) / 127.5f;
+    int* d_delays = nullptr;
+    cf* d_tone = nullptr;
+    float* d_lut = nullptr;
+    FXC_HIP(p, hipMalloc(&d_delays, (size_t)n_ant * sizeof(int)));
+    FXC_HIP(p, hipMalloc(&d_tone, (size_t)tone_period * sizeof(cf)));
+    FXC_HIP(p, hipMalloc(&d_lut, sizeof lut));
+    FXC_HIP(p, hipMemcpy(d_delays, delays, (size_t)n_ant * sizeof(int), hipMemcpyHostToDevice));
+    FXC_HIP(p, hipMemcpy(d_tone, tone_re_im, (size_t)tone_period * sizeof(cf), hipMemcpyHostToDevice));
+    FXC_HIP(p, hipMemcpy(d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    const int64_t total = n_chunks * n_ant * num_samp;
+    int64_t grid = (total + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(synth_kernel, dim3((int)grid), dim3(256), 0, st, static_cast<cf*>(x_dev), seed, first_chunk,
+                       n_chunks, n_ant, num_samp, d_delays, d_tone, tone_period, d_lut);
+    hipError_t e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_delays);
+    (void)hipFree(d_tone);
+    (void)hipFree(d_lut);
+    if (e != hipSuccess) return fail(nullptr, FXC_ERR_HIP, "synth launch failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(nullptr, FXC_ERR_HIP, "synth sync failed: %s", hipGetErrorString(e2));
+    return FXC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,221 @@
+"""FxPlan — thin Python handle on an ``fxc_plan`` (include/fxcorr.h).
+
+Buffers are either device-resident ``torch`` complex64 tensors (passed by ``data_ptr()``; PyTorch is
+only the allocator / stream / collective plumbing) or host numpy complex64 arrays (the library stages
+them itself).  Outputs come back in the same kind as the input.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .window import design_window
+
+MODES = {"SPECTRUM": _lib.FXC_MODE_SPECTRUM, "CONTINUUM": _lib.FXC_MODE_CONTINUUM, "TEST": _lib.FXC_MODE_CONTINUUM}
+PATHS = {None: -1, "auto": -1, "generic": _lib.FXC_PATH_GENERIC, "fused": _lib.FXC_PATH_FUSED}
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def rot_table(nbins, bandwidth, frequency, calibrated_delay):
+    """rot[k] = exp(+2 pi i f_k tau), natural bin order, complex128 — effex/effex.py:516,519.
+
+    Formed in float64 on the host: the phase is ~9e3 rad for tau = 1 us.
+    """
+    freqs = np.fft.fftfreq(nbins, d=1.0 / bandwidth) + frequency
+    return np.exp(2j * np.pi * freqs * calibrated_delay)
+
+
+class FxPlan(object):
+    def __init__(self, n_ant, nchan, ntaps, num_samp, window=None, device=0, stream=None, path=None):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        if window is None:
+            window = design_window(ntaps, nchan)
+        window = np.ascontiguousarray(window, dtype=np.float64)
+        if window.shape != (int(ntaps) * int(nchan),):
+            raise ValueError("window must have ntaps*nchan = {} taps, got {}".format(ntaps * nchan, window.shape))
+        self.window = window
+        stream_ptr = ctypes.c_void_p(int(stream)) if stream else None
+        rc = self._lib.fxc_plan_create(ctypes.byref(self._h), int(device), int(n_ant), int(nchan), int(ntaps),
+                                       int(num_samp), window.ctypes.data, stream_ptr, PATHS[path])
+        _lib.check(rc, None)
+        info = _lib.FxcInfo()
+        self._check(self._lib.fxc_plan_get_info(self._h, ctypes.byref(info)))
+        self.n_ant, self.n_baselines, self.nchan, self.ntaps = info.n_ant, info.n_baselines, info.nchan, info.ntaps
+        self.num_samp, self.n_pts = info.num_samp, info.n_pts
+        self.device = info.device
+        self.path = "fused" if info.path == _lib.FXC_PATH_FUSED else "generic"
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc):
+        _lib.check(rc, self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.fxc_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def info(self):
+        info = _lib.FxcInfo()
+        self._check(self._lib.fxc_plan_get_info(self._h, ctypes.byref(info)))
+        return {name: getattr(info, name) for name, _ in _lib.FxcInfo._fields_}
+
+    def _in(self, x, shape_tail):
+        """-> (pointer, mem_kind, leading count, keepalive)."""
+        if _is_torch(x):
+            import torch
+            if x.dtype != torch.complex64 or not x.is_cuda or not x.is_contiguous():
+                raise ValueError("device input must be a contiguous complex64 CUDA tensor")
+            if x.device.index != self.device:
+                raise ValueError("tensor is on device {} but the plan is on {}".format(x.device.index, self.device))
+            shape = tuple(x.shape)
+            ptr, kind, keep = x.data_ptr(), _lib.FXC_MEM_DEVICE, x
+        else:
+            keep = np.ascontiguousarray(x, dtype=np.complex64)
+            shape = keep.shape
+            ptr, kind = keep.ctypes.data, _lib.FXC_MEM_HOST
+        if len(shape) == len(shape_tail):
+            shape = (1,) + shape
+        if len(shape) != len(shape_tail) + 1 or tuple(shape[1:]) != tuple(shape_tail):
+            raise ValueError("expected shape [n, {}], got {}".format(", ".join(map(str, shape_tail)), shape))
+        return ptr, kind, shape[0], keep
+
+    def _out(self, like, shape, dtype):
+        if _is_torch(like):
+            import torch
+            tdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+            out = torch.empty(shape, dtype=tdt, device=like.device)
+            return out, out.data_ptr()
+        out = np.empty(shape, dtype=dtype)
+        return out, out.ctypes.data
+
+    # -- configuration ----------------------------------------------------------------------
+    def set_rot(self, rot):
+        rot = np.ascontiguousarray(rot, dtype=np.complex128)
+        if rot.shape != (self.nchan,):
+            raise ValueError("rot must have shape ({},)".format(self.nchan))
+        self._check(self._lib.fxc_set_rot(self._h, rot.ctypes.data))
+
+    def set_delay(self, bandwidth, frequency, calibrated_delay):
+        self.set_rot(rot_table(self.nchan, bandwidth, frequency, calibrated_delay))
+
+    # -- F stage ----------------------------------------------------------------------------
+    def channelize(self, x):
+        """x: [n_streams, num_samp] (or [num_samp]) complex64 -> [n_streams, n_pts, nchan] complex64."""
+        ptr, kind, n, keep = self._in(x, (self.num_samp,))
+        out, optr = self._out(x, (n, self.n_pts, self.nchan), np.complex64)
+        self._check(self._lib.fxc_channelize(self._h, ptr, optr, n, kind))
+        return out
+
+    # -- F + X ------------------------------------------------------------------------------
+    def fx_accumulate(self, x):
+        """x: [n_chunks, n_ant, num_samp] complex64; adds into the plan's accumulator (async)."""
+        ptr, kind, n, keep = self._in(x, (self.n_ant, self.num_samp))
+        self._check(self._lib.fxc_fx_accumulate(self._h, ptr, n, kind))
+        return n
+
+    def fx_rows(self, x, mode="SPECTRUM", bandwidth=1.0):
+        """One visibility row per chunk (the reference's ``_run_task`` result, effex.py:490-527).
+
+        SPECTRUM -> [n_chunks, n_baselines, nchan] complex64; CONTINUUM/TEST -> [n_chunks, n_baselines]
+        complex128.
+        """
+        m = MODES[mode.upper()]
+        ptr, kind, n, keep = self._in(x, (self.n_ant, self.num_samp))
+        if m == _lib.FXC_MODE_SPECTRUM:
+            out, optr = self._out(x, (n, self.n_baselines, self.nchan), np.complex64)
+        else:
+            out, optr = self._out(x, (n, self.n_baselines), np.complex128)
+        self._check(self._lib.fxc_fx_rows(self._h, ptr, optr, n, kind, m, float(bandwidth)))
+        return out
+
+    def acc_reset(self):
+        self._check(self._lib.fxc_acc_reset(self._h))
+
+    def acc_export(self, sums):
+        """sums: CUDA complex128 tensor [n_baselines*nchan + 1] (raw sums + {spectra count})."""
+        import torch
+        if sums.dtype != torch.complex128 or sums.numel() != self.n_baselines * self.nchan + 1 \
+                or not sums.is_contiguous() or not sums.is_cuda:
+            raise ValueError("sums must be a contiguous CUDA complex128 tensor of n_baselines*nchan + 1 elements")
+        self._check(self._lib.fxc_acc_export(self._h, sums.data_ptr()))
+        return sums
+
+    def new_sums(self):
+        import torch
+        return torch.empty(self.n_baselines * self.nchan + 1, dtype=torch.complex128,
+                           device=torch.device("cuda", self.device))
+
+    def finalize_sums(self, sums, mode="SPECTRUM", bandwidth=1.0):
+        m = MODES[mode.upper()]
+        shape = (self.n_baselines, self.nchan) if m == _lib.FXC_MODE_SPECTRUM else (self.n_baselines,)
+        out = np.empty(shape, dtype=np.complex128)
+        self._check(self._lib.fxc_finalize_sums(self._h, sums.data_ptr(), out.ctypes.data, m, float(bandwidth)))
+        return out
+
+    def finalize(self, mode="SPECTRUM", bandwidth=1.0, reset=True):
+        """Mean over everything accumulated, times conj(rot), fft-shifted -> numpy complex128."""
+        m = MODES[mode.upper()]
+        shape = (self.n_baselines, self.nchan) if m == _lib.FXC_MODE_SPECTRUM else (self.n_baselines,)
+        out = np.empty(shape, dtype=np.complex128)
+        self._check(self._lib.fxc_finalize(self._h, out.ctypes.data, m, float(bandwidth), int(bool(reset))))
+        return out
+
+    def sync(self):
+        self._check(self._lib.fxc_sync(self._h))
+
+    # -- measurement ------------------------------------------------------------------------
+    def timer_start(self):
+        self._check(self._lib.fxc_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = ctypes.c_double()
+        self._check(self._lib.fxc_timer_stop(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def kernel_profiling(self, enable):
+        self._check(self._lib.fxc_kernel_profiling(self._h, int(bool(enable))))
+
+    def kernel_time(self, reset=True):
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        self._check(self._lib.fxc_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n), int(bool(reset))))
+        return ms.value, n.value
+
+
+def synth_fill(x, seed, first_chunk=0, delays=None, stream=None):
+    """Fill a CUDA complex64 tensor [n_chunks, n_ant, num_samp] with the synthetic stream of
+    ``effex_amd.synth`` (bit-identical), generated on the device."""
+    import torch
+    from . import synth
+    lib = _lib.load()
+    if x.dtype != torch.complex64 or not x.is_cuda or not x.is_contiguous() or x.dim() != 3:
+        raise ValueError("x must be a contiguous CUDA complex64 tensor [n_chunks, n_ant, num_samp]")
+    n_chunks, n_ant, num_samp = x.shape
+    if delays is None:
+        delays = synth.DEFAULT_DELAYS
+    d = np.ascontiguousarray(delays[:n_ant], dtype=np.int32)
+    if len(d) < n_ant:
+        raise ValueError("not enough delays for n_ant")
+    tone = synth.tone_table()
+    if stream is None:
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+    rc = lib.fxc_synth_fill(x.device.index, ctypes.c_void_p(int(stream)), x.data_ptr(), int(seed), int(first_chunk),
+                            n_chunks, n_ant, num_samp, d.ctypes.data, tone.ctypes.data, len(tone))
+    _lib.check(rc, None)
+    return x

@@ -1,0 +1,129 @@
+/*
+ * fxcorr.h — C ABI of the MI355X-native F/X hot path (libfxcorr.so).
+ *
+ * The reference (evanmayer/effex) is pure Python and has no FFI of its own; its seam is the
+ * method surface of `Correlator` (effex/effex.py).  This ABI sits *underneath* that surface and
+ * replaces the third-party GPU calls the reference makes on its hot path.  Each entry point
+ * names the reference lines it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns FXC_OK (0) or a negative fxc_status; no exception crosses the ABI;
+ *     fxc_last_error(plan) returns a NUL-terminated message owned by the plan (or by the library
+ *     for plan == NULL), valid until the next failing call on that plan.
+ *   - "complex64" = interleaved float re,im (8 B); "complex128" = interleaved double (16 B).
+ *   - all device work is issued asynchronously on the plan's HIP stream; the caller owns every
+ *     x/out buffer and keeps it alive until fxc_sync() / a finalize call returns.
+ *   - a plan is thread-compatible, not thread-safe (one caller thread per plan — the reference
+ *     drives the path from one thread, effex/effex.py:326-417).
+ *   - there is NO CPU backend: without a HIP device fxc_plan_create fails with FXC_ERR_NODEVICE.
+ */
+#ifndef FXCORR_H
+#define FXCORR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FXC_VERSION 100 /* 0.1.0 */
+
+typedef struct fxc_plan fxc_plan; /* opaque; one per (device, configuration) */
+
+enum fxc_status {
+    FXC_OK = 0,
+    FXC_ERR_ARG = -1,         /* bad argument (NULL, non-positive size, ...)                     */
+    FXC_ERR_UNSUPPORTED = -2, /* ntaps > 32 (cusignal raises NotImplementedError), nchan too big */
+    FXC_ERR_HIP = -3,         /* a HIP runtime call failed; message has hipGetErrorString        */
+    FXC_ERR_NOMEM = -4,
+    FXC_ERR_NODEVICE = -5,
+    FXC_ERR_STATE = -6        /* call sequence error (e.g. finalize with nothing accumulated)    */
+};
+
+enum fxc_mem_kind { FXC_MEM_HOST = 0, FXC_MEM_DEVICE = 1 };
+enum fxc_mode { FXC_MODE_SPECTRUM = 0, FXC_MODE_CONTINUUM = 1 }; /* TEST == CONTINUUM arithmetic */
+enum fxc_path { FXC_PATH_GENERIC = 0, FXC_PATH_FUSED = 1 };
+
+typedef struct fxc_info {
+    int32_t n_ant, n_baselines, nchan, ntaps;
+    int64_t num_samp, n_pts;   /* n_pts = num_samp / nchan spectra per chunk (effex.py:553)     */
+    int32_t path;              /* fxc_path actually used by fxc_fx_* for this configuration      */
+    int32_t grid, block;       /* launch geometry of the dominant kernel                         */
+    int32_t lds_bytes;         /* dynamic LDS of the dominant kernel                             */
+    int32_t device, cu_count;
+    int64_t workspace_bytes;
+} fxc_info;
+
+int         fxc_version(void);
+int         fxc_device_count(int* count);
+const char* fxc_status_string(int status);
+
+/* Plan = the configuration Correlator.__init__ fixes once (effex.py:109-127): antenna count,
+ * nbins, ntaps, num_samp and the PFB window (float64 design, used as float32 on the device).
+ * `window` is host memory, [ntaps*nchan] doubles, copied.  `stream` is a hipStream_t to issue
+ * work on (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a plan-owned stream.
+ * force_path: -1 = choose automatically, else an fxc_path (FUSED fails if the shape has none). */
+int fxc_plan_create(fxc_plan** out, int device, int n_ant, int nchan, int ntaps, int64_t num_samp,
+                    const double* window, void* stream, int force_path);
+int fxc_plan_destroy(fxc_plan* plan);
+int fxc_plan_get_info(const fxc_plan* plan, fxc_info* info);
+const char* fxc_last_error(const fxc_plan* plan);
+
+/* rot[k] = exp(+2*pi*i*f_k*tau), natural bin order — effex.py:516,519.  Formed by the caller in
+ * float64 (phase ~ 9e3 rad), complex128[nchan] host memory, copied.  Default: all ones. */
+int fxc_set_rot(fxc_plan* plan, const double* rot_re_im);
+
+/* F-stage only — replaces cusignal.filtering.channelize_poly + .T at effex.py:553 (and the
+ * complex128 copy at :551).  x = [n_streams][num_samp] complex64, out = [n_streams][n_pts][nchan]
+ * complex64, natural (un-shifted) bin order; trailing num_samp mod nchan samples ignored; zero
+ * PFB history at the start of every stream. */
+int fxc_channelize(fxc_plan* plan, const void* x, void* out, int64_t n_streams, int mem_kind);
+
+/* F+X, integrate — replaces effex.py:508-521 for a batch of chunks: x = [n_chunks][n_ant][num_samp]
+ * complex64.  Adds sum_chunks sum_i spec_a[i,k]*conj(spec_b[i,k]) (natural bin order, no rot, no
+ * scale) into the plan's float64 accumulator [n_baselines][nchan], baselines ordered
+ * (0,1),(0,2)..(A-2,A-1), and n_chunks*n_pts into its spectra counter. */
+int fxc_fx_accumulate(fxc_plan* plan, const void* x, int64_t n_chunks, int mem_kind);
+
+/* F+X, one visibility row per chunk — the reference's literal _run_task() output (effex.py:490-527):
+ *   SPECTRUM : out = [n_chunks][n_baselines][nchan] complex64 = fftshift(mean_i(f_a*conj(f_b*rot)))
+ *   CONTINUUM: out = [n_chunks][n_baselines] complex128      = mean_k(that) / bandwidth  (:523-524)
+ * `out` has the same mem_kind as `x`. */
+int fxc_fx_rows(fxc_plan* plan, const void* x, void* out, int64_t n_chunks, int mem_kind, int mode,
+                double bandwidth);
+
+/* Accumulator access for the multi-GPU reduce.  fxc_acc_export writes
+ * [n_baselines*nchan] complex128 raw sums followed by one complex128 whose real part is the
+ * spectra count into device memory `sums_dev` (n_baselines*nchan + 1 complex128); the host sums
+ * those buffers across ranks (torch.distributed / RCCL all-reduce) and hands the result to
+ * fxc_finalize_sums on the root. */
+int fxc_acc_reset(fxc_plan* plan);
+int fxc_acc_export(fxc_plan* plan, void* sums_dev);
+int fxc_finalize_sums(fxc_plan* plan, const void* sums_dev, void* out_host, int mode, double bandwidth);
+
+/* Single-GPU finalize: mean over everything accumulated, times conj(rot), fftshift; D2H.
+ *   SPECTRUM : out_host = [n_baselines][nchan] complex128;  CONTINUUM: [n_baselines] complex128.
+ * Synchronises the plan's stream.  reset != 0 clears the accumulator afterwards. */
+int fxc_finalize(fxc_plan* plan, void* out_host, int mode, double bandwidth, int reset);
+
+int fxc_sync(fxc_plan* plan);
+
+/* Measurement hooks (bench.py): HIP events on the plan's stream.  fxc_timer_* bracket a region;
+ * with kernel profiling on, every launch of the dominant kernel is bracketed by its own event
+ * pair and fxc_kernel_time returns the summed duration and launch count since the last reset. */
+int fxc_timer_start(fxc_plan* plan);
+int fxc_timer_stop(fxc_plan* plan, double* elapsed_ms);
+int fxc_kernel_profiling(fxc_plan* plan, int enable);
+int fxc_kernel_time(fxc_plan* plan, double* total_ms, int64_t* launches, int reset);
+
+/* Deterministic synthetic IQ straight into HBM (same arithmetic as effex_amd/synth.py, bit for
+ * bit): x_dev = [n_chunks][n_ant][num_samp] complex64.  delays = n_ant ints (host), tone =
+ * complex64[tone_period] (host). */
+int fxc_synth_fill(int device, void* stream, void* x_dev, uint64_t seed, int64_t first_chunk,
+                   int64_t n_chunks, int n_ant, int64_t num_samp, const int32_t* delays,
+                   const float* tone_re_im, int tone_period);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FXCORR_H */

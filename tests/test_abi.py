@@ -1,0 +1,73 @@
+"""The C-ABI library loads and exports every symbol include/fxcorr.h declares (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from effex_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from effex_amd import build
+    build.build()           # cross-compiles for gfx950 here; on the GPU box the prebuilt .so is current
+    return _lib.load()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "fxcorr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fxc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = header_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), name
+        assert name in _lib.SIGNATURES, "no ctypes signature for " + name
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_version_and_status_strings(lib):
+    assert lib.fxc_version() == 100
+    assert lib.fxc_status_string(0) == b"ok"
+    assert b"unsupported" in lib.fxc_status_string(_lib.FXC_ERR_UNSUPPORTED)
+
+
+def test_argument_validation_needs_no_device(lib):
+    h = ctypes.c_void_p()
+    win = (ctypes.c_double * (64 * 33))()
+    # ntaps > 32: cusignal raises NotImplementedError (SURVEY.md §8b Errors)
+    rc = lib.fxc_plan_create(ctypes.byref(h), 0, 2, 64, 33, 64 * 64, win, None, -1)
+    assert rc == _lib.FXC_ERR_UNSUPPORTED
+    with pytest.raises(NotImplementedError):
+        _lib.check(rc, None)
+    rc = lib.fxc_plan_create(ctypes.byref(h), 0, 2, 64, 4, 32, win, None, -1)     # shorter than one frame
+    assert rc == _lib.FXC_ERR_ARG
+    with pytest.raises(ValueError):
+        _lib.check(rc, None)
+    assert lib.fxc_plan_create(ctypes.byref(h), 0, 0, 64, 4, 4096, win, None, -1) == _lib.FXC_ERR_ARG
+    assert lib.fxc_plan_create(ctypes.byref(h), 0, 2, 64, 4, 4096, None, None, -1) == _lib.FXC_ERR_ARG
+    assert lib.fxc_plan_create(None, 0, 2, 64, 4, 4096, win, None, -1) == _lib.FXC_ERR_ARG
+    assert lib.fxc_sync(None) == _lib.FXC_ERR_ARG
+    assert lib.fxc_plan_destroy(None) == _lib.FXC_OK
+
+
+def test_no_cpu_backend(lib):
+    """Without a HIP device the product path fails loudly instead of computing on the CPU."""
+    n = ctypes.c_int(-1)
+    assert lib.fxc_device_count(ctypes.byref(n)) == 0
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    win = (ctypes.c_double * (64 * 4))()
+    rc = lib.fxc_plan_create(ctypes.byref(h), 0, 2, 64, 4, 4096, win, None, -1)
+    assert rc == _lib.FXC_ERR_NODEVICE
+    assert b"no CPU backend" in lib.fxc_last_error(None)
+    from effex_amd.plan import FxPlan
+    with pytest.raises(_lib.FxcError):
+        FxPlan(2, 64, 4, 4096)

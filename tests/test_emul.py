@@ -1,0 +1,49 @@
+"""Host emulation of the fused kernel's phases (tests/emul/emul_fused.cpp compiles the kernel's own
+header with g++) against the oracle: validates the FFT decomposition, LDS layouts, ring rotation and
+permlane pairing on a machine without a GPU.  Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fx_oracle
+from effex_amd import synth
+from effex_amd.window import design_window
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emul():
+    src = os.path.join(HERE, "emul", "emul_fused.cpp")
+    lib = os.path.join(HERE, "emul", "libemul_fused.so")
+    deps = [src, os.path.join(HERE, "..", "effex_amd", "csrc", "fx_fused4096.h"),
+            os.path.join(HERE, "..", "effex_amd", "csrc", "fx_math.h")]
+    if not os.path.isfile(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", lib, src], check=True)
+    return ctypes.CDLL(lib)
+
+
+def test_dft16_sign_and_order(emul):
+    rng = np.random.default_rng(0)
+    a = (rng.standard_normal(16) + 1j * rng.standard_normal(16)).astype(np.complex64)
+    out = np.zeros(16, np.complex64)
+    emul.emul_dft16(a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    ref = np.fft.ifft(a.astype(np.complex128)) * 16          # kernel exp(+2 pi i n k / 16)
+    assert np.abs(out - ref).max() < 2e-6
+
+
+@pytest.mark.parametrize("num_samp", [4096, 4096 * 3 + 17, 4096 * 9])
+def test_fused_phases_match_oracle(emul, num_samp):
+    x = synth.synth_iq(1234, 1, 2, num_samp)[0]
+    w = design_window(4, 4096)
+    out = np.zeros(4096, np.complex128)
+    rc = emul.emul_fused4096(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(num_samp),
+                             w.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    f0 = fx_oracle.spectrometer_poly(x[0], 4, 4096, w)
+    f1 = fx_oracle.spectrometer_poly(x[1], 4, 4096, w)
+    ref = (f0 * np.conj(f1)).sum(axis=0)
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-6

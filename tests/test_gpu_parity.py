@@ -1,0 +1,330 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference-derived goldens.
+
+Tolerances (float32 pipeline vs the float64 oracle on identical complex64 input):
+  * F-stage spectra:      max|d| <= 2e-6 * max|spec|   (observed ~3e-7)
+  * per-chunk visibility: max|d| <= 1e-5 * max|vis|    (numpy c64-vs-c128 alone is 2.7e-7)
+  * integrations:         max|d| <= 1e-5 * max|vis|    (per-chunk float32 sums, float64 across chunks)
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import fx_oracle
+import golden_inputs as gi
+from effex_amd import synth
+from effex_amd.window import design_window
+
+pytestmark = pytest.mark.gpu
+
+TOL_SPEC = 2e-6
+TOL_VIS = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def plan_mod(torch):
+    from effex_amd import plan
+    return plan
+
+
+def rel_err(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
+
+
+# --------------------------------------------------------------------------------------------
+# F-stage: _spectrometer_poly (effex.py:530-555)
+# --------------------------------------------------------------------------------------------
+def test_kat_n4_t2(plan_mod, golden):
+    _, arrays = golden
+    x, h = gi.kat_input()
+    with plan_mod.FxPlan(1, 4, 2, len(x), window=h) as p:
+        spec = p.channelize(x.astype(np.complex64))[0]
+    assert spec.shape == (3, 4)
+    assert rel_err(spec, arrays["kat_spec"]) < TOL_SPEC
+
+
+def test_reference_tone_cases(plan_mod, torch, golden):
+    """The reference's 32 spectrometer cases (tests/test_effex.py:62-89) through the drop-in method."""
+    from effex_amd.correlator import Correlator, SyntheticSource
+    meta, arrays = golden
+    cor = Correlator(source=SyntheticSource())
+    try:
+        for idx, (num_samp, rate, freq, taps, branches) in enumerate(gi.tone_cases()):
+            iq = gi.tone_iq(num_samp, rate, freq)
+            window = design_window(taps, branches)
+            spec = cor._spectrometer_poly(iq, taps, branches, window)
+            g = meta["tones"][idx]
+            assert list(spec.shape) == g["shape"]
+            psd = np.fft.fftshift(np.real(spec * np.conj(spec)).mean(axis=0))
+            freqs = np.fft.fftshift(np.fft.fftfreq(len(psd), d=1 / rate))
+            assert 100. * abs(freqs[np.argmax(psd)] - freq) / freq < 1.          # the reference's criterion
+            assert int(np.argmax(psd)) == g["peak_shifted_bin"]
+            rows, cols = gi.spec_sample_indices(spec.shape)
+            ref = arrays["tone_samples"][idx]
+            scale = np.abs(fx_oracle.spectrometer_poly(iq.astype(np.complex64), taps, branches, window)).max()
+            assert np.abs(spec[rows, cols] - ref).max() < 5e-6 * scale, (idx, g["case"])
+    finally:
+        cor.close()
+
+
+@pytest.mark.parametrize("nchan,ntaps,num_samp", [(4096, 4, 4096 * 6 + 5), (2048, 32, 2048 * 40), (512, 4, 8192),
+                                                  (1, 4, 3000), (2, 3, 101), (96, 5, 96 * 20 + 7), (8192, 2, 8192 * 3),
+                                                  (16384, 1, 16384 * 2)])
+def test_channelize_matches_oracle(plan_mod, torch, nchan, ntaps, num_samp):
+    rng = np.random.default_rng(nchan + ntaps)
+    x = synth.synth_iq(11, 2, 1, num_samp)[:, 0]
+    h = design_window(ntaps, nchan) if nchan > 1 else rng.standard_normal(ntaps)
+    with plan_mod.FxPlan(1, nchan, ntaps, num_samp, window=h) as p:
+        host = p.channelize(x)
+        dev = p.channelize(torch.from_numpy(x).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(host, dev)
+    for s in range(2):
+        ref = fx_oracle.spectrometer_poly(x[s], ntaps, nchan, h)
+        assert host[s].shape == ref.shape
+        assert rel_err(host[s], ref) < (2e-5 if (nchan & (nchan - 1)) else TOL_SPEC)
+
+
+def test_more_than_32_taps_raises(plan_mod):
+    with pytest.raises(NotImplementedError):
+        plan_mod.FxPlan(1, 64, 33, 64 * 64, window=np.zeros(64 * 33))
+
+
+# --------------------------------------------------------------------------------------------
+# F+X: _pfb_xcorr / _run_task (effex.py:490-527)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["fused", "generic"])
+def test_pfb_xcorr_against_reference_goldens(plan_mod, torch, golden, path):
+    meta, arrays = golden
+    iq = gi.xcorr_input()
+    xd = torch.from_numpy(iq[None]).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, 2 ** 18, path=path) as p:
+        assert p.path == path
+        for item in meta["xcorr"]:
+            p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, item["delay"])
+            ref = arrays[item["key"]]
+            if item["mode"] == "SPECTRUM":
+                vis = p.fx_rows(xd, "SPECTRUM").cpu().numpy()[0, 0]
+                assert rel_err(vis, ref) < TOL_VIS, item
+                # single-chunk integration == the row
+                p.acc_reset()
+                p.fx_accumulate(xd)
+                assert rel_err(p.finalize("SPECTRUM")[0], ref) < TOL_VIS
+            else:
+                vis = p.fx_rows(xd, item["mode"], gi.BANDWIDTH).cpu().numpy()[0, 0]
+                assert abs(vis - ref) < TOL_VIS * abs(ref) + 1e-3 * TOL_VIS * np.abs(arrays["xcorr_SPECTRUM_0"]).max() / gi.BANDWIDTH
+                p.acc_reset()
+                p.fx_accumulate(xd)
+                integ = p.finalize(item["mode"], gi.BANDWIDTH)[0]
+                assert abs(integ - ref) < TOL_VIS * abs(ref) + 1e-3 * TOL_VIS * np.abs(arrays["xcorr_SPECTRUM_0"]).max() / gi.BANDWIDTH
+
+
+def test_drop_in_run_task(torch, golden):
+    """Correlator._run_task() on staged buffers == the reference's _run_task() (all three modes)."""
+    from effex_amd.correlator import Correlator, SyntheticSource
+    meta, arrays = golden
+    iq = gi.xcorr_input()
+    cor = Correlator(source=SyntheticSource())
+    try:
+        for item in meta["xcorr"]:
+            cor.mode = item["mode"]
+            cor.calibrated_delay = item["delay"]
+            cor.gpu_iq_0, cor.gpu_iq_1 = iq[0], iq[1]
+            vis = cor._run_task()
+            ref = arrays[item["key"]]
+            if item["mode"] == "SPECTRUM":
+                assert vis.shape == (4096,) and vis.dtype == np.complex128
+                assert rel_err(vis, ref) < TOL_VIS
+            else:
+                assert np.ndim(vis) == 0
+                assert abs(vis - ref) < 1e-4 * abs(ref)
+    finally:
+        cor.close()
+
+
+def test_small_multichunk_rows(plan_mod, torch, golden):
+    _, arrays = golden
+    x = gi.small_input()
+    with plan_mod.FxPlan(2, gi.SMALL_N, 4, gi.SMALL_S) as p:
+        assert p.path == "generic"
+        rows = p.fx_rows(x, "SPECTRUM")                      # host buffers in, host rows out
+        assert rows.shape == (gi.SMALL_CHUNKS, 1, gi.SMALL_N)
+        assert rel_err(rows[:, 0], arrays["small_rows"]) < TOL_VIS
+        p.fx_accumulate(x)
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ[0], arrays["small_rows"].mean(axis=0)) < TOL_VIS
+
+
+def test_state_machine_writes_reference_csv(tmp_path, torch, golden):
+    """End to end: source -> staging (DC removal) -> HIP path -> csv readable by the reference's reader."""
+    from effex_amd.correlator import ArraySource, Correlator
+    x = gi.small_input()
+    path = str(tmp_path / "vis.csv")
+    cor = Correlator(num_samp=gi.SMALL_S, nbins=gi.SMALL_N, source=ArraySource(x), output_file=path)
+    assert cor.run_state_machine() == gi.SMALL_CHUNKS
+    assert cor.state == 'OFF'
+    lines = open(path).read().split('\n')
+    assert lines[0] == fx_oracle.metadata_header(1, 2.4e6, 1.4204e9, gi.SMALL_S, gi.SMALL_N, 49.6, 'SPECTRUM').strip()
+    data = np.loadtxt(path, dtype=np.complex128, delimiter=',', skiprows=2)      # post_process.py:219
+    assert data.shape == (gi.SMALL_CHUNKS, gi.SMALL_N)
+    window = design_window(4, gi.SMALL_N)
+    for c in range(gi.SMALL_CHUNKS):
+        a = x[c, 0].astype(np.complex128)
+        b = x[c, 1].astype(np.complex128)
+        a = (a.real - a.real.mean()) + 1j * (a.imag - a.imag.mean())            # effex.py:394-395
+        b = (b.real - b.real.mean()) + 1j * (b.imag - b.imag.mean())
+        ref = fx_oracle.pfb_xcorr(a.astype(np.complex64), b.astype(np.complex64), 4, gi.SMALL_N, window, 2.4e6,
+                                  1.4204e9, 0, 'SPECTRUM')
+        assert rel_err(data[c], ref) < TOL_VIS
+
+
+# --------------------------------------------------------------------------------------------
+# batches, ragged sizes, multi-antenna, continuum streaming limit
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path,n_chunks,num_samp", [("fused", 5, 4096 * 7 + 123), ("fused", 300, 4096 * 4),
+                                                    ("fused", 3, 4096), ("generic", 5, 4096 * 7 + 123)])
+def test_batched_integration_matches_oracle(plan_mod, torch, path, n_chunks, num_samp):
+    x = synth.synth_iq(99, n_chunks, 2, num_samp)
+    window = design_window(4, 4096)
+    rot = plan_mod.rot_table(4096, gi.BANDWIDTH, gi.FREQUENCY, 3e-7)
+    ref_chunks = min(n_chunks, 12)            # oracle on a prefix for the rows; integration by property below
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp, path=path) as p:
+        p.set_rot(rot)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        for c in range(ref_chunks):
+            ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, 4096, window, gi.BANDWIDTH, gi.FREQUENCY, 3e-7, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        # integrate in two uneven calls; must equal the mean of the rows (same n_pts per chunk)
+        p.fx_accumulate(xd[: n_chunks // 3 + 1])
+        p.fx_accumulate(xd[n_chunks // 3 + 1:])
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ[0], rows[:, 0].astype(np.complex128).mean(axis=0)) < 2e-6
+        cont_rows = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
+        np.testing.assert_allclose(cont_rows[:, 0], rows[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH,
+                                   rtol=2e-5, atol=1e-7 * np.abs(cont_rows).max())
+
+
+def test_fused_and_generic_agree(plan_mod, torch):
+    x = torch.from_numpy(synth.synth_iq(5, 7, 2, 4096 * 10)).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, 4096 * 10, path="fused") as a, \
+            plan_mod.FxPlan(2, 4096, 4, 4096 * 10, path="generic") as b:
+        ra = a.fx_rows(x).cpu().numpy()
+        rb = b.fx_rows(x).cpu().numpy()
+    assert rel_err(ra, rb) < 2e-6
+
+
+def test_eight_antennas_28_baselines(plan_mod, torch):
+    n_ant, nchan, num_samp, n_chunks = 8, 1024, 1024 * 12, 3
+    x = synth.synth_iq(21, n_chunks, n_ant, num_samp)
+    window = design_window(4, nchan)
+    with plan_mod.FxPlan(n_ant, nchan, 4, num_samp) as p:
+        assert p.n_baselines == 28
+        p.fx_accumulate(torch.from_numpy(x).cuda())
+        integ = p.finalize("SPECTRUM")
+        rows = p.fx_rows(x)
+    ref = fx_oracle.fx_integrate(x, nchan, window)
+    assert integ.shape == (28, nchan)
+    assert rel_err(integ, ref) < TOL_VIS
+    assert rel_err(rows.astype(np.complex128).mean(axis=0), ref) < TOL_VIS
+
+
+def test_continuum_streaming_limit_nchan1(plan_mod, torch):
+    """BASELINE config 3(i): nchan = 1, the PFB degenerates to a 4-tap FIR and X to sum y0*conj(y1)."""
+    num_samp = 2 ** 16 + 3
+    x = synth.synth_iq(31, 2, 2, num_samp)
+    h = np.array([0.4, 0.3, 0.2, 0.1])
+    with plan_mod.FxPlan(2, 1, 4, num_samp, window=h) as p:
+        cont = p.fx_rows(x, "CONTINUUM", gi.BANDWIDTH)
+        p.fx_accumulate(x)
+        integ = p.finalize("CONTINUUM", gi.BANDWIDTH)
+    for c in range(2):
+        ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, 1, h, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "CONTINUUM")
+        assert abs(cont[c, 0] - ref) < 1e-5 * abs(ref)
+    ref_all = np.mean([fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, 1, h, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "CONTINUUM")
+                       for c in range(2)])
+    assert abs(integ[0] - ref_all) < 1e-5 * abs(ref_all)
+
+
+def test_empty_batches_and_errors(plan_mod, torch):
+    with plan_mod.FxPlan(2, 256, 4, 4096) as p:
+        empty = torch.empty((0, 2, 4096), dtype=torch.complex64, device="cuda")
+        assert p.fx_accumulate(empty) == 0
+        assert p.fx_rows(empty).shape == (0, 1, 256)
+        from effex_amd import _lib
+        with pytest.raises(_lib.FxcError):
+            p.finalize("SPECTRUM")                 # nothing accumulated
+        with pytest.raises(ValueError):
+            p.fx_accumulate(torch.empty((1, 2, 100), dtype=torch.complex64, device="cuda"))
+        with pytest.raises(ValueError):
+            p.fx_rows(torch.empty((1, 2, 4096), dtype=torch.complex64, device="cuda"), "CONTINUUM", 0.0)
+
+
+# --------------------------------------------------------------------------------------------
+# size-independent properties at the BASELINE size
+# --------------------------------------------------------------------------------------------
+def test_linearity_and_conjugate_symmetry_full_size(plan_mod, torch):
+    num_samp, n_chunks = 2 ** 18, 4
+    x = torch.from_numpy(synth.synth_iq(77777, n_chunks, 2, num_samp)).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        assert p.path == "fused"
+        base = p.fx_rows(x).cpu().numpy().astype(np.complex128)
+        scaled = p.fx_rows(x * 2.0).cpu().numpy().astype(np.complex128)          # exact: power of two
+        np.testing.assert_array_equal(scaled, 4.0 * base)
+        swapped = p.fx_rows(x.flip(1).contiguous()).cpu().numpy().astype(np.complex128)
+        # V_10 = conj(V_01) bin for bin (rot = 1)
+        assert rel_err(swapped, np.conj(base)) < 1e-6
+        # auto-correlation is real and non-negative
+        auto = p.fx_rows(torch.stack([x[:, 0], x[:, 0]], dim=1).contiguous()).cpu().numpy()
+        assert np.abs(auto.imag).max() <= 1e-6 * np.abs(auto.real).max()
+        assert auto.real.min() >= 0.0
+
+
+def test_sharded_integration_equals_single_rank(plan_mod, torch):
+    """SURVEY.md §8e on one GPU: two 'ranks' integrate disjoint chunk ranges, their exported sums are
+    added (what the RCCL all-reduce does) and finalised once."""
+    from effex_amd import sharding
+    num_samp, n_chunks = 4096 * 8, 21
+    x = torch.from_numpy(synth.synth_iq(3, n_chunks, 2, num_samp)).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as whole:
+        whole.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-6)
+        whole.fx_accumulate(x)
+        ref = whole.finalize("SPECTRUM")
+        total = None
+        for rank in range(2):
+            lo, hi = sharding.chunk_range(rank, 2, n_chunks)
+            with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+                p.fx_accumulate(x[lo:hi])
+                sums = p.acc_export(p.new_sums()).clone()
+                torch.cuda.synchronize()
+            total = sums if total is None else total + sums
+        out = whole.finalize_sums(total, "SPECTRUM")
+    assert rel_err(out, ref) < 1e-12
+
+
+def test_device_synth_is_bit_identical(plan_mod, torch):
+    n_chunks, n_ant, num_samp = 3, 3, 5000
+    x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")
+    plan_mod.synth_fill(x, 424242, first_chunk=5)
+    torch.cuda.synchronize()
+    ref = synth.synth_iq(424242, n_chunks, n_ant, num_samp, first_chunk=5)
+    np.testing.assert_array_equal(x.cpu().numpy(), ref)
+
+
+def test_timers_and_kernel_profiling(plan_mod, torch):
+    x = torch.from_numpy(synth.synth_iq(1, 4, 2, 4096 * 4)).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, 4096 * 4) as p:
+        p.kernel_profiling(True)
+        p.timer_start()
+        p.fx_accumulate(x)
+        p.fx_accumulate(x)
+        ms = p.timer_stop()
+        kms, n = p.kernel_time()
+        assert n == 2 and 0 < kms <= ms * 1.05
+        p.finalize("SPECTRUM")

@@ -1,0 +1,165 @@
+"""Host-side logic: window design, synthetic source, the Correlator shell (properties, state machine,
+csv bytes).  Mirrors the reference's system-level tests (tests/test_effex.py:127-248) with a fake IQ
+source instead of two RTL-SDRs.  No GPU compute is invoked."""
+import hashlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from effex_amd import synth
+from effex_amd.correlator import ArraySource, Correlator, SyntheticSource
+from effex_amd.window import design_window
+
+
+def test_window_sha256_matches_reference(golden):
+    meta, _ = golden
+    w = design_window(4, 4096)
+    sha = hashlib.sha256(np.ascontiguousarray(w, dtype="<f8").tobytes()).hexdigest()
+    # the closed form reproduces scipy to the last bit on this platform; tolerate a last-ulp platform
+    # difference by falling back to a value check
+    if sha != meta["window"]["4096_4"]["sha256"]:
+        np.testing.assert_allclose(w[meta["window"]["4096_4"]["sample_idx"]], meta["window"]["4096_4"]["samples"],
+                                   rtol=1e-12, atol=1e-24)
+
+
+def test_synth_is_deterministic_and_sharded():
+    a = synth.synth_iq(7, 3, 2, 1000)
+    b = synth.synth_iq(7, 3, 2, 1000)
+    np.testing.assert_array_equal(a, b)
+    # a rank generating only its shard gets the same samples
+    c = synth.synth_iq(7, 1, 2, 1000, first_chunk=2)
+    np.testing.assert_array_equal(a[2:3], c)
+    assert a.dtype == np.complex64 and np.abs(a).max() < 2.5
+    # antenna streams share the delayed sky signal: correlation at lag d1 - d0 = 3
+    x0, x1 = a[0, 0].astype(np.complex128), a[0, 1].astype(np.complex128)
+    lag3 = np.abs(np.vdot(x0[:-3], x1[3:]))
+    lag0 = np.abs(np.vdot(x0, x1))
+    assert lag3 > 5 * lag0
+
+
+# --- system-level (tests/test_effex.py:127-154) ------------------------------------------------
+@pytest.fixture()
+def cor(tmp_path):
+    c = Correlator(source=SyntheticSource(n_chunks=2), output_file=str(tmp_path / "vis.csv"))
+    yield c
+    c.close()
+
+
+def test_correlator_init_defaults(cor, golden):
+    d = golden[0]["defaults"]
+    assert cor.state == d["state"] == 'OFF'
+    assert cor.mode == d["mode"] == 'SPECTRUM'
+    assert cor.bandwidth == d["bandwidth"]
+    assert cor.nbins == d["nbins"]
+    assert cor.frequency == d["frequency"]
+    assert cor.gain == d["gain"]
+    assert cor.num_samp == d["num_samp"]
+    assert cor.run_time == d["run_time"]
+    assert cor.ntaps == d["ntaps"]
+    assert list(Correlator._states) == d["states"]
+    assert list(Correlator._modes) == d["modes"]
+    np.testing.assert_allclose(cor.window, design_window(4, 4096))
+
+
+def test_change_properties_reach_the_source(cor):
+    cor.bandwidth = 1.2e6
+    assert cor.bandwidth == 1.2e6 and cor.source.rs == 1.2e6
+    cor.nbins = 2 ** 11
+    assert cor.nbins == 2 ** 11
+    cor.frequency = 1.3e9
+    assert cor.frequency == 1.3e9 and cor.source.fc == 1.3e9
+    cor.gain = 9.9
+    assert cor.gain == 9.9 and cor.source.gain == 9.9
+
+
+def test_num_samp_clamp(tmp_path):
+    c = Correlator(num_samp=2 ** 20, source=SyntheticSource())
+    assert c.num_samp == 2 ** 18                     # effex.py:282-283
+    c2 = Correlator(num_samp=2 ** 20, max_num_samp=2 ** 20, source=SyntheticSource())
+    assert c2.num_samp == 2 ** 20                    # documented deviation for the continuum config
+    c3 = Correlator(num_samp=10, nbins=16, source=SyntheticSource())
+    assert c3.num_samp == 2 ** 8
+
+
+# --- state machine (tests/test_effex.py:157-219) -----------------------------------------------
+def step_and_assert(cor, sequence):
+    for state in sequence:
+        cor.state = state
+        assert state == cor.state
+
+
+def test_nominal_state_transitions(cor):
+    step_and_assert(cor, ['STARTUP', 'CALIBRATE', 'RUN', 'CALIBRATE', 'RUN', 'SHUTDOWN', 'OFF'])
+
+
+def test_early_aborts(cor):
+    step_and_assert(cor, ['STARTUP', 'SHUTDOWN', 'OFF', 'STARTUP', 'CALIBRATE', 'SHUTDOWN', 'OFF'])
+
+
+@pytest.mark.parametrize("path,bad", [
+    ([], 'RUN'), ([], 'CALIBRATE'), ([], 'SHUTDOWN'), ([], 'OFF'),
+    (['STARTUP'], 'OFF'), (['STARTUP'], 'STARTUP'),
+    (['STARTUP', 'RUN'], 'OFF'), (['STARTUP', 'RUN'], 'STARTUP'), (['STARTUP', 'RUN'], 'RUN'),
+    (['STARTUP', 'CALIBRATE'], 'OFF'), (['STARTUP', 'CALIBRATE'], 'STARTUP'), (['STARTUP', 'CALIBRATE'], 'CALIBRATE'),
+    (['STARTUP', 'SHUTDOWN'], 'RUN'),
+])
+def test_bad_transitions(cor, path, bad):
+    step_and_assert(cor, path)
+    with pytest.raises(Correlator.StateTransitionError):
+        cor.state = bad
+    assert cor.source.closed           # the reference closes the SDRs before raising (effex.py:210-228)
+
+
+def test_unknown_state(cor):
+    with pytest.raises(ValueError):
+        cor.state = 'BOGUS'
+
+
+# --- off-nominal init (tests/test_effex.py:225-248) --------------------------------------------
+def test_bad_run_time_init():
+    with pytest.raises(ValueError):
+        Correlator(run_time=0, source=SyntheticSource())
+
+
+def test_bad_bandwidth_init_only_warns(caplog):
+    c = Correlator(bandwidth=3e6, source=SyntheticSource())
+    assert c.bandwidth == 3e6
+    assert any("greater than" in r.message for r in caplog.records)
+
+
+def test_bad_mode_init():
+    with pytest.raises(ValueError):
+        Correlator(mode='nonsense', source=SyntheticSource())
+
+
+def test_alt_mode_init():
+    for mode in ('continuum', 'Spectrum', 'TEST'):
+        assert Correlator(mode=mode, source=SyntheticSource()).mode == mode.upper()
+
+
+def test_too_short_chunk_asserts():
+    with pytest.raises(AssertionError):
+        Correlator(num_samp=2 ** 12, nbins=2 ** 12, source=SyntheticSource())     # n_int = S//4//N < 1
+
+
+# --- csv header bytes (effex.py:667-684) -------------------------------------------------------
+@pytest.mark.parametrize("mode", ["SPECTRUM", "CONTINUUM"])
+def test_csv_bytes_match_reference(tmp_path, golden, mode):
+    meta, _ = golden
+    path = str(tmp_path / "vis.csv")
+    c = Correlator(mode=mode, nbins=gi.CSV_NBINS, num_samp=gi.CSV_S, source=SyntheticSource(), output_file=path)
+    c._write_metadata()
+    with open(path, 'a') as fh:
+        c._write_row(fh, gi.csv_row(mode))
+    assert open(path).read() == meta["csv"][mode]
+    skip = 2 if mode == "SPECTRUM" else 1                 # post_process.py:206-209
+    back = np.loadtxt(path, dtype=np.complex128, delimiter=',', skiprows=skip)
+    np.testing.assert_allclose(np.atleast_1d(back), gi.csv_row(mode), rtol=1e-15)
+
+
+def test_default_output_name():
+    c = Correlator(source=SyntheticSource())
+    assert c.output_file.startswith('visibilities_') and c.output_file.endswith('.csv')
