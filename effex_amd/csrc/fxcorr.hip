@@ -839,7 +839,7 @@ const char* fxc_last_error(const fxc_plan* plan) { return plan ? plan->error.c_s
 int fxc_plan_destroy(fxc_plan* p) {
     if (!p) return FXC_OK;
     (void)hipSetDevice(p->device);
-    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    (void)hipStreamSynchronize(p->stream);
     for (auto& e : p->kev) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -859,10 +859,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     hipDeviceProp_t prop;
     FXC_HIP(p, hipGetDeviceProperties(&prop, p->device));
     p->cu_count = prop.multiProcessorCount;
-    if (!p->stream) {
-        FXC_HIP(p, hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-        p->own_stream = true;
-    }
+    if (p->own_stream) FXC_HIP(p, hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     FXC_HIP(p, hipEventCreate(&p->ev_t0));
     FXC_HIP(p, hipEventCreate(&p->ev_t1));
 
@@ -989,7 +986,8 @@ int fxc_plan_create(fxc_plan** out, int device, int n_ant, int nchan, int ntaps,
     p->pow2 = (nchan & (nchan - 1)) == 0;
     p->lg2n = 0;
     while ((1 << p->lg2n) < nchan) ++p->lg2n;
-    p->stream = static_cast<hipStream_t>(stream);
+    p->own_stream = (stream == FXC_STREAM_OWNED);
+    p->stream = p->own_stream ? nullptr : static_cast<hipStream_t>(stream);
     const int rc = plan_build(p, window, force_path);
     if (rc != FXC_OK) {
         g_lib_error = p->error;

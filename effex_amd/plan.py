@@ -15,6 +15,17 @@ MODES = {"SPECTRUM": _lib.FXC_MODE_SPECTRUM, "CONTINUUM": _lib.FXC_MODE_CONTINUU
 PATHS = {None: -1, "auto": -1, "generic": _lib.FXC_PATH_GENERIC, "fused": _lib.FXC_PATH_FUSED}
 
 
+def _current_torch_stream(device):
+    """torch's current HIP stream on ``device`` (0 = the default stream) or 0 without torch/GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return int(torch.cuda.current_stream(device).cuda_stream)
+    except ImportError:
+        pass
+    return 0
+
+
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
@@ -38,7 +49,12 @@ class FxPlan(object):
         if window.shape != (int(ntaps) * int(nchan),):
             raise ValueError("window must have ntaps*nchan = {} taps, got {}".format(ntaps * nchan, window.shape))
         self.window = window
-        stream_ptr = ctypes.c_void_p(int(stream)) if stream else None
+        # work is issued on the caller's stream so it is ordered with torch's own copies / kernels
+        if stream is None:
+            stream = _current_torch_stream(int(device))
+        elif stream == "owned":
+            stream = -1                                   # FXC_STREAM_OWNED
+        stream_ptr = ctypes.c_void_p(int(stream) & 0xFFFFFFFFFFFFFFFF) if stream else None
         rc = self._lib.fxc_plan_create(ctypes.byref(self._h), int(device), int(n_ant), int(nchan), int(ntaps),
                                        int(num_samp), window.ctypes.data, stream_ptr, PATHS[path])
         _lib.check(rc, None)

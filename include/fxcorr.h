@@ -30,6 +30,8 @@ extern "C" {
 
 typedef struct fxc_plan fxc_plan; /* opaque; one per (device, configuration) */
 
+#define FXC_STREAM_OWNED ((void*)(intptr_t)-1)
+
 enum fxc_status {
     FXC_OK = 0,
     FXC_ERR_ARG = -1,         /* bad argument (NULL, non-positive size, ...)                     */
@@ -60,8 +62,10 @@ const char* fxc_status_string(int status);
 
 /* Plan = the configuration Correlator.__init__ fixes once (effex.py:109-127): antenna count,
  * nbins, ntaps, num_samp and the PFB window (float64 design, used as float32 on the device).
- * `window` is host memory, [ntaps*nchan] doubles, copied.  `stream` is a hipStream_t to issue
- * work on (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a plan-owned stream.
+ * `window` is host memory, [ntaps*nchan] doubles, copied.  `stream` is the hipStream_t to issue
+ * work on: the caller's stream (e.g. torch.cuda.current_stream().cuda_stream, so the plan's kernels
+ * are ordered with the caller's own work on that stream), NULL for HIP's default (null) stream, or
+ * FXC_STREAM_OWNED for a private non-blocking stream the caller then orders against with fxc_sync().
  * force_path: -1 = choose automatically, else an fxc_path (FUSED fails if the shape has none). */
 int fxc_plan_create(fxc_plan** out, int device, int n_ant, int nchan, int ntaps, int64_t num_samp,
                     const double* window, void* stream, int force_path);
