@@ -83,6 +83,21 @@ def cpu_baseline(seconds=8.0):
                                                                              workers, seconds)}
 
 
+def pmc_traffic_per_frame():
+    """HBM bytes per frame from the newest committed PMC summary (profiles/*/pmc_hbm_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic.json"))):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+            best = (d["hbm_traffic_bytes_per_launch"] / d["frames_per_launch"], os.path.relpath(path, ROOT))
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +188,7 @@ def main():
         algo_bytes = frames_per_launch * BYTES_PER_FRAME + NCHAN * 16        # + one cross-spectrum per integration
         avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = algo_bytes / avg_kernel_s / 1e9
+        pmc = pmc_traffic_per_frame()
         line = {
             "metric": "2-ant FX correlator throughput (PFB+FFT+X, integrated)",
             "value": round(value, 1),
@@ -198,7 +214,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),
                          "bytes_per_launch": int(algo_bytes), "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
-                         "launches": int(launches), "traffic": None},
+                         "launches": int(launches),
+                         "traffic": None if pmc is None else int(pmc[0] * frames_per_launch),
+                         "traffic_source": None if pmc is None else pmc[1]},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
