@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfxcorr.so")
+# FXCORR_LIB: developer override to A/B kernel variants built elsewhere; the default is the in-tree build
+LIB_PATH = os.environ.get("FXCORR_LIB") or os.path.join(_HERE, "csrc", "libfxcorr.so")
 
 FXC_OK = 0
 FXC_ERR_ARG = -1

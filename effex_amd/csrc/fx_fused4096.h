@@ -28,6 +28,24 @@
 namespace fxc {
 namespace fused {
 
+// One 8-byte LDS read that the compiler will not pair into ds_read2_b64 (half the LDS rate of
+// ds_read_b64 on gfx950, MI355X_MICROARCH.md §LDS).  FXC_LDS_READ2 != 0 restores plain loads.
+#ifndef FXC_LDS_READ2
+#define FXC_LDS_READ2 0
+#endif
+FXC_HD cf lds_load(const cf* p) {
+#if defined(__HIP_DEVICE_COMPILE__) && !FXC_LDS_READ2
+    typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_u64_ptr;
+    const unsigned long long u = *(lds_u64_ptr)(p);
+    cf r;
+    r.x = __uint_as_float((unsigned)(u & 0xffffffffull));
+    r.y = __uint_as_float((unsigned)(u >> 32));
+    return r;
+#else
+    return *p;
+#endif
+}
+
 constexpr int kN = 4096;
 constexpr int kT = 4;
 constexpr int kThreads = 512;
@@ -68,9 +86,9 @@ FXC_HD void state_reset_all(State& s) {
 FXC_HD int sample_offset(int j, int r) { return (kN - 1) - j - 256 * r; }
 
 // phase 1a for a frame in ring slot PH: 4-tap FIR (taps t = 0..3 on frames i, i-1, i-2, i-3, summed
-// in that order), radix-16 over r, twiddle w4096^(j*k1); result left in v[k1]
+// in that order); result left in v[r]
 template <int PH>
-FXC_HD void phase1_compute(State& s, const f4* win, int tid, cf (&v)[16]) {
+FXC_HD void phase1_fir(const State& s, const f4* win, int tid, cf (&v)[16]) {
     const int j = tid & 255;
     const cf (&x0)[16] = s.h[PH];
     const cf (&x1)[16] = s.h[(PH + 3) & 3];
@@ -85,13 +103,36 @@ FXC_HD void phase1_compute(State& s, const f4* win, int tid, cf (&v)[16]) {
         v[r] = cfma(w.w, x3[r], a);
         if ((r & 3) == 3) FXC_SCHED_FENCE();   // keep at most four window quads live
     }
-    dft16(v);
+}
+
+// phase 1a, second half: twiddle w4096^(j*k1) on the radix-16 outputs
+FXC_HD void phase1_twiddle(const State& s, cf (&v)[16]) {
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
         // w4096^(j*k1) as a product of two stored powers: 12 twiddle VGPRs instead of 30
         if (k1 & 3) v[k1] = cmul(v[k1], s.tw1a[(k1 & 3) - 1]);
         if (k1 >> 2) v[k1] = cmul(v[k1], s.tw1b[(k1 >> 2) - 1]);
     }
+}
+
+// twiddle and exchange-1 store fused per k1 (the stores trickle out between the multiplies instead
+// of a burst of sixteen after them)
+FXC_HD void phase1_twiddle_store(const State& s, cf (&v)[16], cf* region, int tid) {
+    cf* mine = region + (tid >> 8) * kRegion + (tid & 255);
+    mine[0] = v[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) {
+        if (k1 & 3) v[k1] = cmul(v[k1], s.tw1a[(k1 & 3) - 1]);
+        if (k1 >> 2) v[k1] = cmul(v[k1], s.tw1b[(k1 >> 2) - 1]);
+        mine[k1 * kRowPitch] = v[k1];
+    }
+}
+
+template <int PH>
+FXC_HD void phase1_compute(State& s, const f4* win, int tid, cf (&v)[16]) {
+    phase1_fir<PH>(s, win, tid, v);
+    dft16(v);
+    phase1_twiddle(s, v);
 }
 
 // load this thread's stored twiddle powers from the [16][256] table w4096^(j*k1)
@@ -122,17 +163,21 @@ FXC_HD void phase2_load(cf* region, int tid, cf (&v)[16]) {
     const cf* row = lane_row(region, tid);
     const int j0 = tid & 15;
 #pragma unroll
-    for (int j1 = 0; j1 < 16; ++j1) v[j1] = row[j0 + 16 * j1];
+    for (int j1 = 0; j1 < 16; ++j1) v[j1] = lds_load(row + j0 + 16 * j1);
+}
+
+FXC_HD void phase2_twiddle(cf (&v)[16], const cf* tw2, int tid) {
+    const int j0 = tid & 15;
+#pragma unroll
+    for (int q1 = 1; q1 < 16; ++q1) {
+        v[q1] = cmul(v[q1], lds_load(tw2 + q1 * 16 + j0));
+        if ((q1 & 3) == 3) FXC_SCHED_FENCE();   // bound the live range of the twiddle reads
+    }
 }
 
 FXC_HD void phase2_compute(cf (&v)[16], const cf* tw2, int tid) {
-    const int j0 = tid & 15;
     dft16(v);
-#pragma unroll
-    for (int q1 = 1; q1 < 16; ++q1) {
-        v[q1] = cmul(v[q1], tw2[q1 * 16 + j0]);
-        if ((q1 & 3) == 3) FXC_SCHED_FENCE();   // bound the live range of the twiddle reads
-    }
+    phase2_twiddle(v, tw2, tid);
 }
 
 FXC_HD void phase2_store(const cf (&v)[16], cf* region, int tid) {
@@ -146,7 +191,7 @@ FXC_HD void phase3_load(cf* region, int tid, cf (&v)[16]) {
     const cf* row = lane_row(region, tid);
     const int q1 = tid & 15;
 #pragma unroll
-    for (int j0 = 0; j0 < 16; ++j0) v[j0] = row[q1 * 17 + j0];
+    for (int j0 = 0; j0 < 16; ++j0) v[j0] = lds_load(row + q1 * 17 + j0);
 }
 
 // X-stage on paired data: a = antenna 0, b = antenna 1 for this lane's bin q (lanes 0-31) or

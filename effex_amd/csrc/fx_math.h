@@ -49,7 +49,8 @@ FXC_HD void dft4(cf& a, cf& b, cf& c, cf& d) {
 
 // 16-point DFT, kernel exp(+2*pi*i*n*k/16), natural order in and out:
 //   n = 4*n1 + n0, k = c + 4*d:  w16^(nk) = w4^(n1 c) * w16^(n0 c) * w4^(n0 d)
-FXC_HD void dft16(cf (&v)[16]) {
+// stage A: four DFT4 over n1 and the internal twiddles; stage B: four DFT4 over n0 + reorder
+FXC_HD void dft16_a(cf (&v)[16]) {
     const float C1 = 0.92387953251128673848f;  // cos(pi/8)
     const float S1 = 0.38268343236508978178f;  // sin(pi/8)
     const float R2 = 0.70710678118654752440f;  // sqrt(1/2)
@@ -65,6 +66,9 @@ FXC_HD void dft16(cf (&v)[16]) {
     v[13] = cmul(v[13], mk(S1, C1));                    // e = 3
     v[14] = mk((-v[14].x - v[14].y) * R2, (v[14].x - v[14].y) * R2);  // e = 6
     v[15] = cmul(v[15], mk(-C1, -S1));                  // e = 9
+}
+
+FXC_HD void dft16_b(cf (&v)[16]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
     // now v[4*c + d] = Y[c + 4*d]; transpose the 4x4 index to natural order
@@ -76,6 +80,11 @@ FXC_HD void dft16(cf (&v)[16]) {
             v[4 * c + d] = v[4 * d + c];
             v[4 * d + c] = t;
         }
+}
+
+FXC_HD void dft16(cf (&v)[16]) {
+    dft16_a(v);
+    dft16_b(v);
 }
 
 }  // namespace fxc

@@ -341,19 +341,59 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
     b = __uint_as_float(r[1]);
 }
 
-// one frame of this thread's 16 branch samples: element (255 - j) + 256 (15 - r) of frame i
+// this thread's 16 branch samples of frame i: element (255 - j) + 256 (15 - r); loads r = R0 .. R0+CNT-1
 typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void load_frame(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned voff,
-                                           int64_t i) {
+template <int R0, int CNT>
+__device__ __forceinline__ void load_frame_part(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned voff,
+                                                int64_t i) {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
                                                                    0x00020000);
     const unsigned soff = (unsigned)(i * fxc::fused::kN * (int64_t)sizeof(cf));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = R0; r < R0 + CNT; ++r) {
         const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff + (unsigned)(256 * (15 - r) * sizeof(cf)), 0);
         xr[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
     }
 }
+
+// timing ablation only (FXC_ABL & 32): the same 16 loads issued into a dummy register pair that the
+// compiler never waits for (inline-asm loads are invisible to its vmcnt bookkeeping)
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+template <int R0, int CNT>
+__device__ __forceinline__ void load_frame_part_nowait(const cf* chunk_base, unsigned chunk_bytes, unsigned voff, int64_t i) {
+    const unsigned long long b = (unsigned long long)chunk_base;
+    v4i32 rs;
+    rs[0] = (int)(unsigned)(b & 0xffffffffull);
+    rs[1] = (int)(unsigned)((b >> 32) & 0xffffull);
+    rs[2] = (int)chunk_bytes;
+    rs[3] = 0x00020000;
+    rs[0] = __builtin_amdgcn_readfirstlane(rs[0]);
+    rs[1] = __builtin_amdgcn_readfirstlane(rs[1]);
+    rs[2] = __builtin_amdgcn_readfirstlane(rs[2]);
+    const unsigned soff = (unsigned)(i * fxc::fused::kN * (int64_t)sizeof(cf));
+#pragma unroll
+    for (int r = R0; r < R0 + CNT; ++r) {
+        v2u32 d;
+        unsigned so = __builtin_amdgcn_readfirstlane(soff + (unsigned)(256 * (15 - r) * sizeof(cf)));
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rs), "s"(so) : "memory");
+    }
+}
+
+__device__ __forceinline__ void load_frame(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned voff,
+                                           int64_t i) {
+    load_frame_part<0, 16>(xr, chunk_base, chunk_bytes, voff, i);
+}
+
+// FXC_ABL: developer-only timing ablations (wrong results by design); the shipped build has FXC_ABL == 0
+#ifndef FXC_ABL
+#define FXC_ABL 0
+#endif
+#ifndef FXC_LOAD_SPREAD
+#define FXC_LOAD_SPREAD 1
+#endif
+#ifndef FXC_STORE_EARLY
+#define FXC_STORE_EARLY 0
+#endif
 
 // one spectrum of both antennas: frame i of chunk c sits in ring slot PH.  All control flow here is
 // wave-uniform and none of it guards a *definition* of ring registers (the prefetch is unconditional),
@@ -369,28 +409,106 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
         state_reset_history<PH>(s);
     }
     cf v[16];
-    phase1_compute<PH>(s, win, tid, v);
+    phase1_fir<PH>(s, win, tid, v);
     // the oldest history slot is dead now: refill it with the next frame this workgroup will process
     // (next frame of the chunk, or frame 0 of its next chunk; at the very end the current frame again,
-    // which is never used).  The loads stay in flight under phases 1b-3 and are first waited for by
-    // the next FIR.
+    // which is never used).  The loads are issued in four groups spread over the rest of the step —
+    // eight waves bursting 16 loads each at the same point stall in the (in-order) vector-memory
+    // issue — and are first waited for by the next FIR.
     int64_t ni = i + 1, nc = c;
     if (ni == n_pts) {
         ni = 0;
         nc = c + gridDim.x;
     }
     const bool more = nc < n_chunks;
-    load_frame(s.h[(PH + 1) & 3], x + (more ? nc : c) * 2 * num_samp, chunk_bytes, voff, more ? ni : i);
+    const cf* nbase = x + (more ? nc : c) * 2 * num_samp;
+    const int64_t nframe = more ? ni : i;
+    cf (&nx)[16] = s.h[(PH + 1) & 3];
+    // FXC_LOAD_SPREAD: 0 = one burst of 16 after the FIR; 1 = four groups over the whole step;
+    // 2 = four groups inside phase 1 (longest time in flight, still not a burst)
+#if (FXC_ABL & 32)
+#define FXC_LOADS(R0, CNT)                                                       \
+    do {                                                                         \
+        FXC_SCHED_FENCE();                                                       \
+        load_frame_part_nowait<R0, CNT>(nbase, chunk_bytes, voff, nframe);       \
+        FXC_SCHED_FENCE();                                                       \
+    } while (0)
+#else
+#define FXC_LOADS(R0, CNT)                                                  \
+    do {                                                                    \
+        FXC_SCHED_FENCE();                                                  \
+        load_frame_part<R0, CNT>(nx, nbase, chunk_bytes, voff, nframe);     \
+        FXC_SCHED_FENCE();                                                  \
+    } while (0)
+#endif
+#if (FXC_ABL & 16)
+#define FXC_LOADS_IF(mode, R0, CNT)
+#else
+#define FXC_LOADS_IF(mode, R0, CNT) if (FXC_LOAD_SPREAD == mode) FXC_LOADS(R0, CNT)
+#endif
+    FXC_LOADS_IF(0, 0, 16);
+    FXC_LOADS_IF(1, 0, 4);
+    FXC_LOADS_IF(2, 0, 4);
+    FXC_LOADS_IF(3, 0, 2);
+    FXC_LOADS_IF(4, 0, 1);
+    fxc::dft16_a(v);
+    FXC_LOADS_IF(2, 4, 4);
+    FXC_LOADS_IF(3, 2, 2);
+    FXC_LOADS_IF(4, 1, 2);
+    fxc::dft16_b(v);
+    FXC_LOADS_IF(1, 4, 4);
+    FXC_LOADS_IF(2, 8, 4);
+    FXC_LOADS_IF(3, 4, 2);
+    FXC_LOADS_IF(4, 3, 1);
+#if FXC_STORE_EARLY
     __syncthreads();   // every wave has finished reading the previous spectrum's rows
+    phase1_twiddle_store(s, v, region, tid);
+    FXC_LOADS_IF(2, 12, 4);
+    FXC_LOADS_IF(4, 4, 2);
+#else
+    phase1_twiddle(s, v);
+    FXC_LOADS_IF(2, 12, 4);
+    FXC_LOADS_IF(4, 4, 2);
+#if !(FXC_ABL & 1)
+    __syncthreads();   // every wave has finished reading the previous spectrum's rows
+#endif
+#if !(FXC_ABL & 4)
     phase1_store(v, region, tid);
+#endif
+#endif
+#if !(FXC_ABL & 2)
     __syncthreads();
+#endif
+#if !(FXC_ABL & 4)
     phase2_load(region, tid, v);
-    phase2_compute(v, tw2, tid);
+#endif
+    FXC_LOADS_IF(1, 8, 4);
+    FXC_LOADS_IF(3, 6, 2);
+    FXC_LOADS_IF(4, 6, 1);
+    fxc::dft16_a(v);
+    FXC_LOADS_IF(3, 8, 2);
+    FXC_LOADS_IF(4, 7, 2);
+    fxc::dft16_b(v);
+    FXC_LOADS_IF(3, 10, 2);
+    FXC_LOADS_IF(4, 9, 1);
+    phase2_twiddle(v, tw2, tid);
+    FXC_LOADS_IF(4, 10, 2);
+#if !(FXC_ABL & 8)
     wave_sync();
     phase2_store(v, region, tid);
     wave_sync();
+#endif
+    FXC_LOADS_IF(1, 12, 4);
+    FXC_LOADS_IF(3, 12, 2);
+    FXC_LOADS_IF(4, 12, 1);
+#if !(FXC_ABL & 8)
     phase3_load(region, tid, v);
-    fxc::dft16(v);
+#endif
+    fxc::dft16_a(v);
+    FXC_LOADS_IF(3, 14, 2);
+    FXC_LOADS_IF(4, 13, 2);
+    fxc::dft16_b(v);
+    FXC_LOADS_IF(4, 15, 1);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         cf a = v[q], b = v[q + 8];
