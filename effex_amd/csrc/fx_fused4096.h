@@ -49,15 +49,74 @@ FXC_HD cf lds_load(const cf* p) {
 constexpr int kN = 4096;
 constexpr int kT = 4;
 constexpr int kThreads = 512;
+// Exchange layout (cf units inside one k1 row).  FXC_XCHG128 == 1: element (j0, j1) of exchange 1 sits at
+// j0*18 + j1 and element (q1, j0) of exchange 2 at q1*18 + j0, so BOTH read sides are 16 contiguous
+// samples = eight ds_read_b128 (144-byte lane stride: conflict-free), the write sides stay 8-byte.
+// FXC_XCHG128 == 0: the 8-byte layout (column j / q1*17 + j0, sixteen ds_read_b64 per side).
+#ifndef FXC_XCHG128
+#define FXC_XCHG128 0
+#endif
+#if FXC_XCHG128
+constexpr int kRowPitch = 288;
+#else
 constexpr int kRowPitch = 272;              // cf per k1 row; == 16 (mod 32) keeps ds_read_b64 conflict-free
+#endif
 constexpr int kRegion = 16 * kRowPitch;     // cf per antenna
 constexpr int kAccPerThread = 8;
 
 // LDS carve (bytes); every offset is a multiple of 16
-constexpr int kLdsWin = 0;                                   // f4[4096]   window, [r*256 + j] = h[t*N + j + 256 r], t = x,y,z,w
+constexpr int kLdsWin = 0;                                   // f4[4096]   window, [r*256 + win_slot(j)] = h[t*N + j + 256 r], t = x,y,z,w
 constexpr int kLdsRegion = kLdsWin + kN * 16;                // cf[2][kRegion]
 constexpr int kLdsTw2 = kLdsRegion + 2 * kRegion * 8;        // cf[256]    w256^(j0*q1) at [q1*16 + j0]
 constexpr int kLdsBytes = kLdsTw2 + 256 * 8;
+
+// ---- phase-1 thread <-> branch map and the 16-byte IQ load scheme --------------------------------
+// A 16-byte load returns two adjacent samples = branches (j+1 | j) of one row r.  Lanes 0-31 of a
+// wave own the even branch j = 2p and load the even rows, lanes 32-63 own j + 1 and load the odd
+// rows; one v_permlane32_swap per register then leaves rows 2k in one register and rows 2k+1 in the
+// other for BOTH halves (the swap exchanges exactly the halves that belong to the other lane), so no
+// per-lane select is needed and every load instruction moves 1 KiB.  FXC_LOAD16 == 0 keeps the
+// 8-byte scheme (thread j owns branch j) for A/B runs.
+#ifndef FXC_LOAD16
+#define FXC_LOAD16 0
+#endif
+
+// branch (0..255) this thread channelises in phase 1
+FXC_HD int branch_of(int tid) {
+#if FXC_LOAD16
+    const int l = tid & 63, w = (tid >> 6) & 3;
+    return 2 * (32 * w + (l & 31)) + (l >> 5);
+#else
+    return tid & 255;
+#endif
+}
+
+// column of branch j inside an exchange-1 row / slot inside a window row: even branches first, so the
+// 32 lanes of a half-wave touch consecutive addresses; 136 == 8 (mod 32) keeps phase-2 reads conflict-free
+FXC_HD int col_of(int j) {
+#if FXC_XCHG128
+    return (j & 15) * 18 + (j >> 4);
+#elif FXC_LOAD16
+    return (j >> 1) + 136 * (j & 1);
+#else
+    return j;
+#endif
+}
+FXC_HD int win_slot(int j) {
+#if FXC_LOAD16
+    return (j >> 1) + 128 * (j & 1);
+#else
+    return j;
+#endif
+}
+
+// 16-byte scheme: element offset inside a frame of the LOW sample of the pair this lane loads for
+// row pair k (lane class cl = lane >> 5 loads row 2k + cl); the high sample is the next element
+FXC_HD int load16_offset(int tid, int k) {
+    const int l = tid & 63, w = (tid >> 6) & 3;
+    const int p = 32 * w + (l & 31), cl = l >> 5;
+    return (kN - 2) - 2 * p - 256 * (2 * k + cl);
+}
 
 struct State {
     // ring of four frames of this thread's 16 branch samples: slot PH holds the frame being
@@ -89,19 +148,33 @@ FXC_HD int sample_offset(int j, int r) { return (kN - 1) - j - 256 * r; }
 // in that order); result left in v[r]
 template <int PH>
 FXC_HD void phase1_fir(const State& s, const f4* win, int tid, cf (&v)[16]) {
-    const int j = tid & 255;
+    const int j = win_slot(branch_of(tid));
     const cf (&x0)[16] = s.h[PH];
     const cf (&x1)[16] = s.h[(PH + 3) & 3];
     const cf (&x2)[16] = s.h[(PH + 2) & 3];
     const cf (&x3)[16] = s.h[(PH + 1) & 3];
+    // software-pipelined in groups of four branches: the window quads of group g + 1 are requested
+    // from LDS before group g is computed, so only the first ds_read latency is exposed
+    f4 w[2][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const f4 w = win[r * 256 + j];
-        cf a = cscale(x0[r], w.x);
-        a = cfma(w.y, x1[r], a);
-        a = cfma(w.z, x2[r], a);
-        v[r] = cfma(w.w, x3[r], a);
-        if ((r & 3) == 3) FXC_SCHED_FENCE();   // keep at most four window quads live
+    for (int q = 0; q < 4; ++q) w[0][q] = win[q * 256 + j];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[(g + 1) & 1][q] = win[(4 * (g + 1) + q) * 256 + j];
+        }
+        FXC_SCHED_FENCE();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * g + q;
+            const f4 t = w[g & 1][q];
+            cf a = cscale(x0[r], t.x);
+            a = cfma(t.y, x1[r], a);
+            a = cfma(t.z, x2[r], a);
+            v[r] = cfma(t.w, x3[r], a);
+        }
+        FXC_SCHED_FENCE();
     }
 }
 
@@ -118,7 +191,7 @@ FXC_HD void phase1_twiddle(const State& s, cf (&v)[16]) {
 // twiddle and exchange-1 store fused per k1 (the stores trickle out between the multiplies instead
 // of a burst of sixteen after them)
 FXC_HD void phase1_twiddle_store(const State& s, cf (&v)[16], cf* region, int tid) {
-    cf* mine = region + (tid >> 8) * kRegion + (tid & 255);
+    cf* mine = region + (tid >> 8) * kRegion + col_of(branch_of(tid));
     mine[0] = v[0];
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
@@ -137,7 +210,7 @@ FXC_HD void phase1_compute(State& s, const f4* win, int tid, cf (&v)[16]) {
 
 // load this thread's stored twiddle powers from the [16][256] table w4096^(j*k1)
 FXC_HD void state_load_twiddles(State& s, const cf* tw1_table, int tid) {
-    const int j = tid & 255;
+    const int j = branch_of(tid);
 #pragma unroll
     for (int a = 1; a < 4; ++a) {
         s.tw1a[a - 1] = tw1_table[a * 256 + j];
@@ -147,7 +220,7 @@ FXC_HD void state_load_twiddles(State& s, const cf* tw1_table, int tid) {
 
 // phase 1b: exchange-1 store (after the barrier that retires the previous spectrum's reads)
 FXC_HD void phase1_store(const cf (&v)[16], cf* region, int tid) {
-    cf* mine = region + (tid >> 8) * kRegion + (tid & 255);
+    cf* mine = region + (tid >> 8) * kRegion + col_of(branch_of(tid));
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) mine[k1 * kRowPitch] = v[k1];
 }
@@ -159,19 +232,46 @@ FXC_HD cf* lane_row(cf* region, int tid) {
     return region + ant * kRegion + k1 * kRowPitch;
 }
 
+// 16 contiguous samples as eight 16-byte LDS reads
+FXC_HD void lds_load16(const cf* p, cf (&v)[16]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const f4 t = *reinterpret_cast<const f4*>(p + 2 * m);
+        v[2 * m] = mk(t.x, t.y);
+        v[2 * m + 1] = mk(t.z, t.w);
+    }
+}
+
 FXC_HD void phase2_load(cf* region, int tid, cf (&v)[16]) {
     const cf* row = lane_row(region, tid);
     const int j0 = tid & 15;
+#if FXC_XCHG128
+    lds_load16(row + j0 * 18, v);
+#else
 #pragma unroll
-    for (int j1 = 0; j1 < 16; ++j1) v[j1] = lds_load(row + j0 + 16 * j1);
+    for (int j1 = 0; j1 < 16; ++j1) v[j1] = lds_load(row + col_of(j0 + 16 * j1));
+#endif
 }
 
 FXC_HD void phase2_twiddle(cf (&v)[16], const cf* tw2, int tid) {
     const int j0 = tid & 15;
+    // same pipelining for the w256^(j0*q1) table: group g + 1 is in flight while group g multiplies
+    cf t[2][4];
 #pragma unroll
-    for (int q1 = 1; q1 < 16; ++q1) {
-        v[q1] = cmul(v[q1], lds_load(tw2 + q1 * 16 + j0));
-        if ((q1 & 3) == 3) FXC_SCHED_FENCE();   // bound the live range of the twiddle reads
+    for (int q = 1; q < 4; ++q) t[0][q] = lds_load(tw2 + q * 16 + j0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[(g + 1) & 1][q] = lds_load(tw2 + (4 * (g + 1) + q) * 16 + j0);
+        }
+        FXC_SCHED_FENCE();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int q1 = 4 * g + q;
+            if (q1 > 0) v[q1] = cmul(v[q1], t[g & 1][q]);
+        }
+        FXC_SCHED_FENCE();
     }
 }
 
@@ -184,14 +284,18 @@ FXC_HD void phase2_store(const cf (&v)[16], cf* region, int tid) {
     cf* row = lane_row(region, tid);
     const int j0 = tid & 15;
 #pragma unroll
-    for (int q1 = 0; q1 < 16; ++q1) row[q1 * 17 + j0] = v[q1];
+    for (int q1 = 0; q1 < 16; ++q1) row[q1 * (FXC_XCHG128 ? 18 : 17) + j0] = v[q1];
 }
 
 FXC_HD void phase3_load(cf* region, int tid, cf (&v)[16]) {
     const cf* row = lane_row(region, tid);
     const int q1 = tid & 15;
+#if FXC_XCHG128
+    lds_load16(row + q1 * 18, v);
+#else
 #pragma unroll
     for (int j0 = 0; j0 < 16; ++j0) v[j0] = lds_load(row + q1 * 17 + j0);
+#endif
 }
 
 // X-stage on paired data: a = antenna 0, b = antenna 1 for this lane's bin q (lanes 0-31) or

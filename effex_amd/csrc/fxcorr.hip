@@ -247,19 +247,34 @@ __global__ void acc_add_kernel(const cf* __restrict__ raw, cd* __restrict__ acc,
     }
 }
 
-// fused accumulate: acc[k] += sum_wg partial[wg][slot(k)], and clear the partial rows
-__global__ void collapse_kernel(cd* __restrict__ partial, cd* __restrict__ acc, int n_rows) {
+// fused accumulate, stage 1: part[split][slot] = sum over this split's chunks of the kernel's raw float32
+// rows (slot order, coalesced); fixed order -> bit-reproducible
+__global__ __launch_bounds__(256) void fused_reduce1_kernel(const cf* __restrict__ raw, cd* __restrict__ part,
+                                                           int64_t n_chunks, int n_splits) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int split = blockIdx.y;
+    double ar = 0.0, ai = 0.0;
+    for (int64_t c = split; c < n_chunks; c += n_splits) {
+        const cf r = raw[c * fxc::fused::kN + slot];
+        ar += r.x;
+        ai += r.y;
+    }
+    cd o;
+    o.x = ar;
+    o.y = ai;
+    part[(int64_t)split * fxc::fused::kN + slot] = o;
+}
+
+// stage 2: acc[k] += sum_split part[split][slot(k)]
+__global__ void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict__ acc, int n_splits) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= fxc::fused::kN) return;
     const int slot = fxc::fused::slot_of_bin(k);
     double ar = 0.0, ai = 0.0;
-    cd zero;
-    zero.x = zero.y = 0.0;
-    for (int w = 0; w < n_rows; ++w) {
-        const cd v = partial[(int64_t)w * fxc::fused::kN + slot];
+    for (int s = 0; s < n_splits; ++s) {
+        const cd v = part[(int64_t)s * fxc::fused::kN + slot];
         ar += v.x;
         ai += v.y;
-        partial[(int64_t)w * fxc::fused::kN + slot] = zero;
     }
     cd a = acc[k];
     a.x += ar;
@@ -356,6 +371,24 @@ __device__ __forceinline__ void load_frame_part(cf (&xr)[16], const cf* chunk_ba
     }
 }
 
+// 16-byte scheme (fx_fused4096.h): rows r = R0 .. R0+CNT-1 as CNT/2 loads of a sample pair; voff is
+// the lane's byte offset of (antenna stream + 254 - 2p + 256 (1 - class))
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+template <int R0, int CNT>
+__device__ __forceinline__ void load_frame16_part(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes,
+                                                  unsigned voff, int64_t i) {
+    static_assert((R0 & 1) == 0 && (CNT & 1) == 0, "16-byte loads move row pairs");
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    const unsigned soff = (unsigned)(i * fxc::fused::kN * (int64_t)sizeof(cf));
+#pragma unroll
+    for (int k = R0 / 2; k < (R0 + CNT) / 2; ++k) {
+        const v4u32 d = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + (unsigned)(256 * (14 - 2 * k) * sizeof(cf)), 0);
+        xr[2 * k + 1] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));   // low address: branch 2p + 1
+        xr[2 * k] = fxc::mk(__uint_as_float(d[2]), __uint_as_float(d[3]));       // high address: branch 2p
+    }
+}
+
 // timing ablation only (FXC_ABL & 32): the same 16 loads issued into a dummy register pair that the
 // compiler never waits for (inline-asm loads are invisible to its vmcnt bookkeeping)
 typedef int v4i32 __attribute__((ext_vector_type(4)));
@@ -392,24 +425,59 @@ __device__ __forceinline__ void load_frame(cf (&xr)[16], const cf* chunk_base, u
 #define FXC_LOAD_SPREAD 1
 #endif
 #ifndef FXC_STORE_EARLY
-#define FXC_STORE_EARLY 0
+#define FXC_STORE_EARLY 1
+#endif
+#ifndef FXC_SETPRIO
+#define FXC_SETPRIO 0
+#endif
+
+// FXC_STAMPS: diagnostic build only — s_memtime stamps between the phases of a step, summed per wave in
+// scalar registers and dumped by fxc_kernel_time(); never enabled in the shipped library.
+#ifndef FXC_STAMPS
+#define FXC_STAMPS 0
+#endif
+constexpr int kStampSegs = 12;
+#if FXC_STAMPS
+#define FXC_STAMP(k)                                                              \
+    do {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        const unsigned long long t_now__ = __builtin_amdgcn_s_memtime();          \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                       \
+        seg[k] += t_now__ - t_prev;                                               \
+        t_prev = t_now__;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+    } while (0)
+#else
+#define FXC_STAMP(k)
 #endif
 
 // one spectrum of both antennas: frame i of chunk c sits in ring slot PH.  All control flow here is
 // wave-uniform and none of it guards a *definition* of ring registers (the prefetch is unconditional),
 // which keeps the register allocator from doubling live ranges at merge points.
-template <int PH, bool ROWS>
+template <int PH>
 __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, cf* region, const cf* tw2, int tid,
                                            const cf* x, int64_t num_samp, unsigned chunk_bytes, unsigned voff,
                                            int64_t& c, int64_t& i, int64_t n_pts, int64_t n_chunks,
-                                           cd* partial_row, cf* rows_raw) {
+                                           cf* rows_raw, unsigned long long (&seg)[kStampSegs],
+                                           unsigned long long& t_prev) {
     using namespace fxc::fused;
+    FXC_STAMP(0);    // everything since the previous step's last stamp (loop overhead, epilogue)
     if (i == 0) {   // zero PFB history at the start of every chunk
         asm volatile("" ::: "memory");   // keep this a (rarely taken) uniform branch, not 96 v_cndmask per frame
         state_reset_history<PH>(s);
     }
+#if FXC_LOAD16
+    // this frame arrived as sample pairs: one swap per register hands every lane the 16 rows of its own branch
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        permlane32_swap(s.h[PH][2 * k].x, s.h[PH][2 * k + 1].x);
+        permlane32_swap(s.h[PH][2 * k].y, s.h[PH][2 * k + 1].y);
+    }
+#endif
+    FXC_STAMP(1);    // vmcnt wait + permlane fix-up
     cf v[16];
     phase1_fir<PH>(s, win, tid, v);
+    FXC_STAMP(2);    // FIR
     // the oldest history slot is dead now: refill it with the next frame this workgroup will process
     // (next frame of the chunk, or frame 0 of its next chunk; at the very end the current frame again,
     // which is never used).  The loads are issued in four groups spread over the rest of the step —
@@ -433,6 +501,13 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
         load_frame_part_nowait<R0, CNT>(nbase, chunk_bytes, voff, nframe);       \
         FXC_SCHED_FENCE();                                                       \
     } while (0)
+#elif FXC_LOAD16
+#define FXC_LOADS(R0, CNT)                                                  \
+    do {                                                                    \
+        FXC_SCHED_FENCE();                                                  \
+        load_frame16_part<R0, CNT>(nx, nbase, chunk_bytes, voff, nframe);   \
+        FXC_SCHED_FENCE();                                                  \
+    } while (0)
 #else
 #define FXC_LOADS(R0, CNT)                                                  \
     do {                                                                    \
@@ -446,29 +521,37 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
 #else
 #define FXC_LOADS_IF(mode, R0, CNT) if (FXC_LOAD_SPREAD == mode) FXC_LOADS(R0, CNT)
 #endif
+#if FXC_LOAD16 || (FXC_ABL & 16)
+#define FXC_LOADS_IF4(R0, CNT)      /* single-row groups exist only in the 8-byte scheme */
+#else
+#define FXC_LOADS_IF4(R0, CNT) FXC_LOADS_IF(4, R0, CNT)
+#endif
     FXC_LOADS_IF(0, 0, 16);
     FXC_LOADS_IF(1, 0, 4);
     FXC_LOADS_IF(2, 0, 4);
     FXC_LOADS_IF(3, 0, 2);
-    FXC_LOADS_IF(4, 0, 1);
+    FXC_LOADS_IF4(0, 1);
     fxc::dft16_a(v);
     FXC_LOADS_IF(2, 4, 4);
     FXC_LOADS_IF(3, 2, 2);
-    FXC_LOADS_IF(4, 1, 2);
+    FXC_LOADS_IF4(1, 2);
     fxc::dft16_b(v);
     FXC_LOADS_IF(1, 4, 4);
     FXC_LOADS_IF(2, 8, 4);
     FXC_LOADS_IF(3, 4, 2);
-    FXC_LOADS_IF(4, 3, 1);
+    FXC_LOADS_IF4(3, 1);
+    FXC_STAMP(3);    // radix-16 #1 (+ load issue)
 #if FXC_STORE_EARLY
     __syncthreads();   // every wave has finished reading the previous spectrum's rows
+    FXC_STAMP(4);    // barrier B0
     phase1_twiddle_store(s, v, region, tid);
+    FXC_STAMP(5);    // twiddle + exchange-1 stores
     FXC_LOADS_IF(2, 12, 4);
-    FXC_LOADS_IF(4, 4, 2);
+    FXC_LOADS_IF4(4, 2);
 #else
     phase1_twiddle(s, v);
     FXC_LOADS_IF(2, 12, 4);
-    FXC_LOADS_IF(4, 4, 2);
+    FXC_LOADS_IF4(4, 2);
 #if !(FXC_ABL & 1)
     __syncthreads();   // every wave has finished reading the previous spectrum's rows
 #endif
@@ -479,20 +562,23 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
 #if !(FXC_ABL & 2)
     __syncthreads();
 #endif
+    FXC_STAMP(6);    // barrier B1 (incl. lgkmcnt(0) for the stores)
 #if !(FXC_ABL & 4)
     phase2_load(region, tid, v);
 #endif
     FXC_LOADS_IF(1, 8, 4);
     FXC_LOADS_IF(3, 6, 2);
-    FXC_LOADS_IF(4, 6, 1);
+    FXC_LOADS_IF4(6, 1);
     fxc::dft16_a(v);
     FXC_LOADS_IF(3, 8, 2);
-    FXC_LOADS_IF(4, 7, 2);
+    FXC_LOADS_IF4(7, 2);
     fxc::dft16_b(v);
     FXC_LOADS_IF(3, 10, 2);
-    FXC_LOADS_IF(4, 9, 1);
+    FXC_LOADS_IF4(9, 1);
+    FXC_STAMP(7);    // exchange-1 reads + radix-16 #2
     phase2_twiddle(v, tw2, tid);
-    FXC_LOADS_IF(4, 10, 2);
+    FXC_STAMP(8);    // twiddle #2 (LDS table)
+    FXC_LOADS_IF4(10, 2);
 #if !(FXC_ABL & 8)
     wave_sync();
     phase2_store(v, region, tid);
@@ -500,15 +586,16 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
 #endif
     FXC_LOADS_IF(1, 12, 4);
     FXC_LOADS_IF(3, 12, 2);
-    FXC_LOADS_IF(4, 12, 1);
+    FXC_LOADS_IF4(12, 1);
 #if !(FXC_ABL & 8)
     phase3_load(region, tid, v);
 #endif
+    FXC_STAMP(9);    // exchange 2 (intra-wave): stores + reads issued
     fxc::dft16_a(v);
     FXC_LOADS_IF(3, 14, 2);
-    FXC_LOADS_IF(4, 13, 2);
+    FXC_LOADS_IF4(13, 2);
     fxc::dft16_b(v);
-    FXC_LOADS_IF(4, 15, 1);
+    FXC_LOADS_IF4(15, 1);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         cf a = v[q], b = v[q + 8];
@@ -516,31 +603,25 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
         permlane32_swap(a.y, b.y);
         xacc(s, q, a, b);
     }
-    if (i + 1 == n_pts) {   // chunk done: flush this lane's 8 bins
-        if (ROWS) {
-            cf* row = rows_raw + c * kN;
+    FXC_STAMP(10);   // radix-16 #3 + X
+    if (i + 1 == n_pts) {   // chunk done: store this lane's 8 bins of the chunk's raw sum (fire and forget)
+        cf* row = rows_raw + c * kN;
 #pragma unroll
-            for (int q = 0; q < kAccPerThread; ++q) row[q * kThreads + tid] = s.acc[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < kAccPerThread; ++q) {
-                cd t = partial_row[q * kThreads + tid];
-                t.x += (double)s.acc[q].x;
-                t.y += (double)s.acc[q].y;
-                partial_row[q * kThreads + tid] = t;
-            }
+        for (int q = 0; q < kAccPerThread; ++q) {
+            row[q * kThreads + tid] = s.acc[q];
+            s.acc[q] = fxc::mk(0.f, 0.f);
         }
-#pragma unroll
-        for (int q = 0; q < kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
     }
     c = nc;
     i = ni;
 }
 
-template <bool ROWS>
+// rows_raw[c][slot] = sum_i spec0[i,k] * conj(spec1[i,k]) of chunk c in float32, k = bin of slot
+// (fx_fused4096.h::slot_of_bin); stamps: diagnostic builds only
 __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     const cf* __restrict__ x, int64_t num_samp, int64_t n_pts, int64_t n_chunks, const f4* __restrict__ win_g,
-    const cf* __restrict__ tw1_g, const cf* __restrict__ tw2_g, cd* __restrict__ partial, cf* __restrict__ rows_raw) {
+    const cf* __restrict__ tw1_g, const cf* __restrict__ tw2_g, cf* __restrict__ rows_raw,
+    unsigned long long* __restrict__ stamps) {
     using namespace fxc::fused;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f4* win = reinterpret_cast<f4*>(smem + kLdsWin);
@@ -557,27 +638,51 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     for (int q = 0; q < kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
     __syncthreads();
 
+#if FXC_SETPRIO
+    // the second-dispatched half of an 8-wave workgroup loses VALU arbitration to its older SIMD partner
+    // (MI355X_MICROARCH.md, "Static priority for the younger half"): one static raise evens the pair
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int64_t c = blockIdx.x, i = 0;
     if (c >= n_chunks) return;
     const int64_t my_chunks = (n_chunks - c + gridDim.x - 1) / gridDim.x;
     const int64_t total = my_chunks * n_pts;
     // IQ frames come in through buffer loads: one VGPR byte offset per thread (antenna stream +
     // (255 - j)), everything that varies with chunk / frame / r is scalar
+#if FXC_LOAD16
+    const unsigned voff = (unsigned)((ant * num_samp + load16_offset(tid, 7)) * (int64_t)sizeof(cf));
+#else
     const unsigned voff = (unsigned)((ant * num_samp + (255 - j)) * (int64_t)sizeof(cf));
+#endif
     const unsigned chunk_bytes = (unsigned)(2 * num_samp * (int64_t)sizeof(cf));
-    cd* prow = partial + (int64_t)blockIdx.x * kN;
+#if FXC_LOAD16
+    load_frame16_part<0, 16>(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
+#else
     load_frame(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
+#endif
+    unsigned long long seg[kStampSegs] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0;
+#if FXC_STAMPS
+    t_prev = __builtin_amdgcn_s_memtime();
+#endif
     // frame g of this workgroup's stream of frames sits in ring slot g & 3: unrolled by four so the
     // ring rotates by register renaming
     for (int64_t g = 0; g < total; g += 4) {
-        fused_step<0, ROWS>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, prow, rows_raw);
+        fused_step<0>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
         if (g + 1 < total)
-            fused_step<1, ROWS>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, prow, rows_raw);
+            fused_step<1>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
         if (g + 2 < total)
-            fused_step<2, ROWS>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, prow, rows_raw);
+            fused_step<2>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
         if (g + 3 < total)
-            fused_step<3, ROWS>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, prow, rows_raw);
+            fused_step<3>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
     }
+#if FXC_STAMPS
+    if (stamps && (tid & 63) == 0) {
+        unsigned long long* dst = stamps + ((int64_t)blockIdx.x * (kThreads / 64) + (tid >> 6)) * kStampSegs;
+        for (int k = 0; k < kStampSegs; ++k) dst[k] = seg[k];
+        dst[kStampSegs - 1] = (unsigned long long)total;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -638,13 +743,12 @@ struct fxc_plan {
     f4* d_win4 = nullptr;          // fused
     cf* d_tw1 = nullptr;
     cf* d_tw2 = nullptr;
-    cd* d_partial = nullptr;       // fused: [fused_grid_max][4096]
+    unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int fused_grid_max = 0;
     cd* d_acc = nullptr;           // [n_base*nchan]
     cd* d_sums = nullptr;          // [n_base*nchan + 1]
     cd* d_out = nullptr;           // finalize staging [n_base*nchan]
     double spectra_count = 0.0;
-    bool partial_dirty = false;
     // workspace (grown on demand)
     void* d_ws = nullptr;
     int64_t ws_bytes = 0;
@@ -654,6 +758,7 @@ struct fxc_plan {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
     double kernel_ms = 0.0;
     int64_t kernel_launches = 0;
+    int stamp_grid = 0;
     mutable std::string error;
 };
 
@@ -782,28 +887,24 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
     return cb;
 }
 
-int launch_fused(fxc_plan* p, const cf* x, int64_t n_chunks, bool rows, cf* rows_raw) {
+constexpr int kFusedReduceSplits = 64;
+constexpr int64_t kFusedMaxChunksPerLaunch = 16384;   // 512 MiB of raw rows
+
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_chunks, cf* rows_raw) {
     using namespace fxc::fused;
     const int grid = (int)std::min<int64_t>(n_chunks, p->fused_grid_max);
+    unsigned long long* stamps = nullptr;
+#if FXC_STAMPS
+    if (!p->d_stamps) FXC_HIP(p, hipMalloc(&p->d_stamps, (size_t)p->fused_grid_max * 8 * kStampSegs * 8));
+    FXC_HIP(p, hipMemsetAsync(p->d_stamps, 0, (size_t)p->fused_grid_max * 8 * kStampSegs * 8, p->stream));
+    stamps = p->d_stamps;
+    p->stamp_grid = grid;
+#endif
     KernelTimer kt(p);
-    if (rows)
-        hipLaunchKernelGGL(fx_fused4096_kernel<true>, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x, p->num_samp,
-                           p->n_pts, n_chunks, p->d_win4, p->d_tw1, p->d_tw2, p->d_partial, rows_raw);
-    else
-        hipLaunchKernelGGL(fx_fused4096_kernel<false>, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           p->num_samp, p->n_pts, n_chunks, p->d_win4, p->d_tw1, p->d_tw2, p->d_partial, rows_raw);
+    hipLaunchKernelGGL(fx_fused4096_kernel, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x, p->num_samp, p->n_pts,
+                       n_chunks, p->d_win4, p->d_tw1, p->d_tw2, rows_raw, stamps);
     kt.stop();
     FXC_HIP(p, hipGetLastError());
-    return FXC_OK;
-}
-
-int collapse_partials(fxc_plan* p) {
-    if (p->path == FXC_PATH_FUSED && p->partial_dirty) {
-        hipLaunchKernelGGL(collapse_kernel, dim3(fxc::fused::kN / 256), dim3(256), 0, p->stream, p->d_partial, p->d_acc,
-                           p->fused_grid_max);
-        FXC_HIP(p, hipGetLastError());
-        p->partial_dirty = false;
-    }
     return FXC_OK;
 }
 
@@ -811,9 +912,23 @@ int collapse_partials(fxc_plan* p) {
 int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
     if (n_chunks == 0) return FXC_OK;
     if (p->path == FXC_PATH_FUSED) {
-        int rc = launch_fused(p, x, n_chunks, false, nullptr);
-        if (rc) return rc;
-        p->partial_dirty = true;
+        using namespace fxc::fused;
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += kFusedMaxChunksPerLaunch) {
+            const int64_t nc = std::min(kFusedMaxChunksPerLaunch, n_chunks - c0);
+            const int64_t raw_bytes = (nc * kN * (int64_t)sizeof(cf) + 255) / 256 * 256;
+            const int64_t part_bytes = (int64_t)kFusedReduceSplits * kN * (int64_t)sizeof(cd);
+            int rc = ensure_ws(p, raw_bytes + part_bytes);
+            if (rc) return rc;
+            cf* raw = reinterpret_cast<cf*>(p->d_ws);
+            cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + raw_bytes);
+            rc = launch_fused(p, x + c0 * 2 * p->num_samp, nc, raw);
+            if (rc) return rc;
+            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, kFusedReduceSplits), dim3(256), 0, p->stream, raw, part,
+                               nc, kFusedReduceSplits);
+            hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 256), dim3(256), 0, p->stream, part, p->d_acc,
+                               kFusedReduceSplits);
+            FXC_HIP(p, hipGetLastError());
+        }
     } else {
         const XGeom g = x_geometry(p);
         int64_t spec_bytes, raw_bytes;
@@ -852,7 +967,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         int rc = ensure_ws(p, raw_bytes);
         if (rc) return rc;
         cf* raw = reinterpret_cast<cf*>(p->d_ws);
-        rc = launch_fused(p, x, n_chunks, true, raw);
+        rc = launch_fused(p, x, n_chunks, raw);
         if (rc) return rc;
         if (mode == FXC_MODE_SPECTRUM)
             hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(n_chunks * p->nchan, 256, p->cu_count)), dim3(256),
@@ -962,7 +1077,7 @@ int fxc_plan_destroy(fxc_plan* p) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_partial,
+    void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_stamps,
                     p->d_acc, p->d_sums, p->d_out, p->d_ws};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -1030,7 +1145,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                 w.y = wf[1 * kN + m];
                 w.z = wf[2 * kN + m];
                 w.w = wf[3 * kN + m];
-                w4[r * 256 + jx] = w;
+                w4[r * 256 + fxc::fused::win_slot(jx)] = w;
             }
         std::vector<cf> tw1((size_t)16 * 256), tw2((size_t)256);
         for (int k1 = 0; k1 < 16; ++k1)
@@ -1050,12 +1165,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipMalloc(&p->d_tw2, tw2.size() * sizeof(cf)));
         FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
         p->fused_grid_max = p->cu_count;   // one 512-thread workgroup (136 KiB LDS) per CU
-        const size_t pbytes = (size_t)p->fused_grid_max * kN * sizeof(cd);
-        FXC_HIP(p, hipMalloc(&p->d_partial, pbytes));
-        FXC_HIP(p, hipMemset(p->d_partial, 0, pbytes));
-        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false>),
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
     if (N > 1) {
@@ -1209,9 +1319,6 @@ int fxc_acc_reset(fxc_plan* p) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     FXC_HIP(p, hipSetDevice(p->device));
     FXC_HIP(p, hipMemsetAsync(p->d_acc, 0, (size_t)p->n_base * p->nchan * sizeof(cd), p->stream));
-    if (p->d_partial)
-        FXC_HIP(p, hipMemsetAsync(p->d_partial, 0, (size_t)p->fused_grid_max * fxc::fused::kN * sizeof(cd), p->stream));
-    p->partial_dirty = false;
     p->spectra_count = 0.0;
     return FXC_OK;
 }
@@ -1219,8 +1326,6 @@ int fxc_acc_reset(fxc_plan* p) {
 int fxc_acc_export(fxc_plan* p, void* sums_dev) {
     if (!p || !sums_dev) return fail(p, FXC_ERR_ARG, "NULL argument");
     FXC_HIP(p, hipSetDevice(p->device));
-    int rc = collapse_partials(p);
-    if (rc) return rc;
     const int64_t n = (int64_t)p->n_base * p->nchan;
     hipLaunchKernelGGL(export_kernel, dim3(grid_for(n + 1, 256, p->cu_count)), dim3(256), 0, p->stream, p->d_acc,
                        static_cast<cd*>(sums_dev), n, p->spectra_count);
@@ -1291,6 +1396,25 @@ int fxc_kernel_time(fxc_plan* p, double* total_ms, int64_t* launches, int reset)
     FXC_HIP(p, hipSetDevice(p->device));
     int rc = drain_kernel_events(p);
     if (rc) return rc;
+#if FXC_STAMPS
+    if (p->stamp_grid > 0 && p->d_stamps) {
+        const int nw = p->stamp_grid * 8;
+        std::vector<unsigned long long> h((size_t)nw * kStampSegs);
+        FXC_HIP(p, hipStreamSynchronize(p->stream));
+        FXC_HIP(p, hipMemcpy(h.data(), p->d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum[kStampSegs] = {0};
+        double steps = 0;
+        for (int w = 0; w < nw; ++w) {
+            for (int k = 0; k < kStampSegs - 1; ++k) sum[k] += (double)h[(size_t)w * kStampSegs + k];
+            steps += (double)h[(size_t)w * kStampSegs + kStampSegs - 1];
+        }
+        double tot = 0;
+        for (int k = 0; k < kStampSegs - 1; ++k) tot += sum[k];
+        fprintf(stderr, "[fxc stamps] cycles per step per wave (s_memtime ticks), total %.0f:", tot / steps);
+        for (int k = 0; k < kStampSegs - 1; ++k) fprintf(stderr, " s%d=%.0f", k, sum[k] / steps);
+        fprintf(stderr, "\n");
+    }
+#endif
     *total_ms = p->kernel_ms;
     *launches = p->kernel_launches;
     if (reset) {
