@@ -29,12 +29,9 @@ namespace fxc {
 namespace fused {
 
 // One 8-byte LDS read that the compiler will not pair into ds_read2_b64 (half the LDS rate of
-// ds_read_b64 on gfx950, MI355X_MICROARCH.md §LDS).  FXC_LDS_READ2 != 0 restores plain loads.
-#ifndef FXC_LDS_READ2
-#define FXC_LDS_READ2 0
-#endif
+// ds_read_b64 on gfx950, MI355X_MICROARCH.md §LDS).
 FXC_HD cf lds_load(const cf* p) {
-#if defined(__HIP_DEVICE_COMPILE__) && !FXC_LDS_READ2
+#if defined(__HIP_DEVICE_COMPILE__)
     typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_u64_ptr;
     const unsigned long long u = *(lds_u64_ptr)(p);
     cf r;
@@ -49,74 +46,15 @@ FXC_HD cf lds_load(const cf* p) {
 constexpr int kN = 4096;
 constexpr int kT = 4;
 constexpr int kThreads = 512;
-// Exchange layout (cf units inside one k1 row).  FXC_XCHG128 == 1: element (j0, j1) of exchange 1 sits at
-// j0*18 + j1 and element (q1, j0) of exchange 2 at q1*18 + j0, so BOTH read sides are 16 contiguous
-// samples = eight ds_read_b128 (144-byte lane stride: conflict-free), the write sides stay 8-byte.
-// FXC_XCHG128 == 0: the 8-byte layout (column j / q1*17 + j0, sixteen ds_read_b64 per side).
-#ifndef FXC_XCHG128
-#define FXC_XCHG128 0
-#endif
-#if FXC_XCHG128
-constexpr int kRowPitch = 288;
-#else
 constexpr int kRowPitch = 272;              // cf per k1 row; == 16 (mod 32) keeps ds_read_b64 conflict-free
-#endif
 constexpr int kRegion = 16 * kRowPitch;     // cf per antenna
 constexpr int kAccPerThread = 8;
 
 // LDS carve (bytes); every offset is a multiple of 16
-constexpr int kLdsWin = 0;                                   // f4[4096]   window, [r*256 + win_slot(j)] = h[t*N + j + 256 r], t = x,y,z,w
+constexpr int kLdsWin = 0;                                   // f4[4096]   window, [r*256 + j] = h[t*N + j + 256 r], t = x,y,z,w
 constexpr int kLdsRegion = kLdsWin + kN * 16;                // cf[2][kRegion]
 constexpr int kLdsTw2 = kLdsRegion + 2 * kRegion * 8;        // cf[256]    w256^(j0*q1) at [q1*16 + j0]
 constexpr int kLdsBytes = kLdsTw2 + 256 * 8;
-
-// ---- phase-1 thread <-> branch map and the 16-byte IQ load scheme --------------------------------
-// A 16-byte load returns two adjacent samples = branches (j+1 | j) of one row r.  Lanes 0-31 of a
-// wave own the even branch j = 2p and load the even rows, lanes 32-63 own j + 1 and load the odd
-// rows; one v_permlane32_swap per register then leaves rows 2k in one register and rows 2k+1 in the
-// other for BOTH halves (the swap exchanges exactly the halves that belong to the other lane), so no
-// per-lane select is needed and every load instruction moves 1 KiB.  FXC_LOAD16 == 0 keeps the
-// 8-byte scheme (thread j owns branch j) for A/B runs.
-#ifndef FXC_LOAD16
-#define FXC_LOAD16 0
-#endif
-
-// branch (0..255) this thread channelises in phase 1
-FXC_HD int branch_of(int tid) {
-#if FXC_LOAD16
-    const int l = tid & 63, w = (tid >> 6) & 3;
-    return 2 * (32 * w + (l & 31)) + (l >> 5);
-#else
-    return tid & 255;
-#endif
-}
-
-// column of branch j inside an exchange-1 row / slot inside a window row: even branches first, so the
-// 32 lanes of a half-wave touch consecutive addresses; 136 == 8 (mod 32) keeps phase-2 reads conflict-free
-FXC_HD int col_of(int j) {
-#if FXC_XCHG128
-    return (j & 15) * 18 + (j >> 4);
-#elif FXC_LOAD16
-    return (j >> 1) + 136 * (j & 1);
-#else
-    return j;
-#endif
-}
-FXC_HD int win_slot(int j) {
-#if FXC_LOAD16
-    return (j >> 1) + 128 * (j & 1);
-#else
-    return j;
-#endif
-}
-
-// 16-byte scheme: element offset inside a frame of the LOW sample of the pair this lane loads for
-// row pair k (lane class cl = lane >> 5 loads row 2k + cl); the high sample is the next element
-FXC_HD int load16_offset(int tid, int k) {
-    const int l = tid & 63, w = (tid >> 6) & 3;
-    const int p = 32 * w + (l & 31), cl = l >> 5;
-    return (kN - 2) - 2 * p - 256 * (2 * k + cl);
-}
 
 struct State {
     // ring of four frames of this thread's 16 branch samples: slot PH holds the frame being
@@ -148,7 +86,7 @@ FXC_HD int sample_offset(int j, int r) { return (kN - 1) - j - 256 * r; }
 // in that order); result left in v[r]
 template <int PH>
 FXC_HD void phase1_fir(const State& s, const f4* win, int tid, cf (&v)[16]) {
-    const int j = win_slot(branch_of(tid));
+    const int j = tid & 255;
     const cf (&x0)[16] = s.h[PH];
     const cf (&x1)[16] = s.h[(PH + 3) & 3];
     const cf (&x2)[16] = s.h[(PH + 2) & 3];
@@ -178,20 +116,10 @@ FXC_HD void phase1_fir(const State& s, const f4* win, int tid, cf (&v)[16]) {
     }
 }
 
-// phase 1a, second half: twiddle w4096^(j*k1) on the radix-16 outputs
-FXC_HD void phase1_twiddle(const State& s, cf (&v)[16]) {
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) {
-        // w4096^(j*k1) as a product of two stored powers: 12 twiddle VGPRs instead of 30
-        if (k1 & 3) v[k1] = cmul(v[k1], s.tw1a[(k1 & 3) - 1]);
-        if (k1 >> 2) v[k1] = cmul(v[k1], s.tw1b[(k1 >> 2) - 1]);
-    }
-}
-
-// twiddle and exchange-1 store fused per k1 (the stores trickle out between the multiplies instead
-// of a burst of sixteen after them)
+// phase 1b: twiddle w4096^(j*k1) as a product of two stored powers (12 twiddle VGPRs instead of 30), fused
+// per k1 with the exchange-1 store so the stores trickle out between the multiplies instead of a burst
 FXC_HD void phase1_twiddle_store(const State& s, cf (&v)[16], cf* region, int tid) {
-    cf* mine = region + (tid >> 8) * kRegion + col_of(branch_of(tid));
+    cf* mine = region + (tid >> 8) * kRegion + (tid & 255);
     mine[0] = v[0];
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
@@ -201,28 +129,14 @@ FXC_HD void phase1_twiddle_store(const State& s, cf (&v)[16], cf* region, int ti
     }
 }
 
-template <int PH>
-FXC_HD void phase1_compute(State& s, const f4* win, int tid, cf (&v)[16]) {
-    phase1_fir<PH>(s, win, tid, v);
-    dft16(v);
-    phase1_twiddle(s, v);
-}
-
 // load this thread's stored twiddle powers from the [16][256] table w4096^(j*k1)
 FXC_HD void state_load_twiddles(State& s, const cf* tw1_table, int tid) {
-    const int j = branch_of(tid);
+    const int j = tid & 255;
 #pragma unroll
     for (int a = 1; a < 4; ++a) {
         s.tw1a[a - 1] = tw1_table[a * 256 + j];
         s.tw1b[a - 1] = tw1_table[4 * a * 256 + j];
     }
-}
-
-// phase 1b: exchange-1 store (after the barrier that retires the previous spectrum's reads)
-FXC_HD void phase1_store(const cf (&v)[16], cf* region, int tid) {
-    cf* mine = region + (tid >> 8) * kRegion + col_of(branch_of(tid));
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) mine[k1 * kRowPitch] = v[k1];
 }
 
 // this lane's row for phases 2 and 3
@@ -232,25 +146,11 @@ FXC_HD cf* lane_row(cf* region, int tid) {
     return region + ant * kRegion + k1 * kRowPitch;
 }
 
-// 16 contiguous samples as eight 16-byte LDS reads
-FXC_HD void lds_load16(const cf* p, cf (&v)[16]) {
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const f4 t = *reinterpret_cast<const f4*>(p + 2 * m);
-        v[2 * m] = mk(t.x, t.y);
-        v[2 * m + 1] = mk(t.z, t.w);
-    }
-}
-
 FXC_HD void phase2_load(cf* region, int tid, cf (&v)[16]) {
     const cf* row = lane_row(region, tid);
     const int j0 = tid & 15;
-#if FXC_XCHG128
-    lds_load16(row + j0 * 18, v);
-#else
 #pragma unroll
-    for (int j1 = 0; j1 < 16; ++j1) v[j1] = lds_load(row + col_of(j0 + 16 * j1));
-#endif
+    for (int j1 = 0; j1 < 16; ++j1) v[j1] = lds_load(row + j0 + 16 * j1);
 }
 
 FXC_HD void phase2_twiddle(cf (&v)[16], const cf* tw2, int tid) {
@@ -275,27 +175,18 @@ FXC_HD void phase2_twiddle(cf (&v)[16], const cf* tw2, int tid) {
     }
 }
 
-FXC_HD void phase2_compute(cf (&v)[16], const cf* tw2, int tid) {
-    dft16(v);
-    phase2_twiddle(v, tw2, tid);
-}
-
 FXC_HD void phase2_store(const cf (&v)[16], cf* region, int tid) {
     cf* row = lane_row(region, tid);
     const int j0 = tid & 15;
 #pragma unroll
-    for (int q1 = 0; q1 < 16; ++q1) row[q1 * (FXC_XCHG128 ? 18 : 17) + j0] = v[q1];
+    for (int q1 = 0; q1 < 16; ++q1) row[q1 * 17 + j0] = v[q1];
 }
 
 FXC_HD void phase3_load(cf* region, int tid, cf (&v)[16]) {
     const cf* row = lane_row(region, tid);
     const int q1 = tid & 15;
-#if FXC_XCHG128
-    lds_load16(row + q1 * 18, v);
-#else
 #pragma unroll
     for (int j0 = 0; j0 < 16; ++j0) v[j0] = lds_load(row + q1 * 17 + j0);
-#endif
 }
 
 // X-stage on paired data: a = antenna 0, b = antenna 1 for this lane's bin q (lanes 0-31) or

@@ -356,7 +356,8 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
     b = __uint_as_float(r[1]);
 }
 
-// this thread's 16 branch samples of frame i: element (255 - j) + 256 (15 - r); loads r = R0 .. R0+CNT-1
+// this thread's 16 branch samples of frame i: element (255 - j) + 256 (15 - r); loads r = R0 .. R0+CNT-1.
+// Buffer loads: one VGPR byte offset per thread, everything that varies with chunk / frame / r is scalar.
 typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
 template <int R0, int CNT>
 __device__ __forceinline__ void load_frame_part(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned voff,
@@ -371,68 +372,13 @@ __device__ __forceinline__ void load_frame_part(cf (&xr)[16], const cf* chunk_ba
     }
 }
 
-// 16-byte scheme (fx_fused4096.h): rows r = R0 .. R0+CNT-1 as CNT/2 loads of a sample pair; voff is
-// the lane's byte offset of (antenna stream + 254 - 2p + 256 (1 - class))
-typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
-template <int R0, int CNT>
-__device__ __forceinline__ void load_frame16_part(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes,
-                                                  unsigned voff, int64_t i) {
-    static_assert((R0 & 1) == 0 && (CNT & 1) == 0, "16-byte loads move row pairs");
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
-                                                                   0x00020000);
-    const unsigned soff = (unsigned)(i * fxc::fused::kN * (int64_t)sizeof(cf));
-#pragma unroll
-    for (int k = R0 / 2; k < (R0 + CNT) / 2; ++k) {
-        const v4u32 d = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + (unsigned)(256 * (14 - 2 * k) * sizeof(cf)), 0);
-        xr[2 * k + 1] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));   // low address: branch 2p + 1
-        xr[2 * k] = fxc::mk(__uint_as_float(d[2]), __uint_as_float(d[3]));       // high address: branch 2p
-    }
-}
-
-// timing ablation only (FXC_ABL & 32): the same 16 loads issued into a dummy register pair that the
-// compiler never waits for (inline-asm loads are invisible to its vmcnt bookkeeping)
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-template <int R0, int CNT>
-__device__ __forceinline__ void load_frame_part_nowait(const cf* chunk_base, unsigned chunk_bytes, unsigned voff, int64_t i) {
-    const unsigned long long b = (unsigned long long)chunk_base;
-    v4i32 rs;
-    rs[0] = (int)(unsigned)(b & 0xffffffffull);
-    rs[1] = (int)(unsigned)((b >> 32) & 0xffffull);
-    rs[2] = (int)chunk_bytes;
-    rs[3] = 0x00020000;
-    rs[0] = __builtin_amdgcn_readfirstlane(rs[0]);
-    rs[1] = __builtin_amdgcn_readfirstlane(rs[1]);
-    rs[2] = __builtin_amdgcn_readfirstlane(rs[2]);
-    const unsigned soff = (unsigned)(i * fxc::fused::kN * (int64_t)sizeof(cf));
-#pragma unroll
-    for (int r = R0; r < R0 + CNT; ++r) {
-        v2u32 d;
-        unsigned so = __builtin_amdgcn_readfirstlane(soff + (unsigned)(256 * (15 - r) * sizeof(cf)));
-        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rs), "s"(so) : "memory");
-    }
-}
-
-__device__ __forceinline__ void load_frame(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned voff,
-                                           int64_t i) {
-    load_frame_part<0, 16>(xr, chunk_base, chunk_bytes, voff, i);
-}
-
-// FXC_ABL: developer-only timing ablations (wrong results by design); the shipped build has FXC_ABL == 0
+// FXC_ABL: developer-only timing ablations (wrong results by design; the shipped build has FXC_ABL == 0):
+//   1 no barrier B0, 2 no barrier B1, 4 no exchange-1 LDS traffic, 8 no exchange-2 LDS traffic, 16 no IQ loads.
+// FXC_STAMPS: diagnostic build with s_memtime stamps between the phases, summed per wave in scalar
+// registers and printed by fxc_kernel_time().  profiles/r01/ablation_and_stamps.md has the readings.
 #ifndef FXC_ABL
 #define FXC_ABL 0
 #endif
-#ifndef FXC_LOAD_SPREAD
-#define FXC_LOAD_SPREAD 1
-#endif
-#ifndef FXC_STORE_EARLY
-#define FXC_STORE_EARLY 1
-#endif
-#ifndef FXC_SETPRIO
-#define FXC_SETPRIO 0
-#endif
-
-// FXC_STAMPS: diagnostic build only — s_memtime stamps between the phases of a step, summed per wave in
-// scalar registers and dumped by fxc_kernel_time(); never enabled in the shipped library.
 #ifndef FXC_STAMPS
 #define FXC_STAMPS 0
 #endif
@@ -450,8 +396,18 @@ constexpr int kStampSegs = 12;
 #else
 #define FXC_STAMP(k)
 #endif
+#if (FXC_ABL & 16)
+#define FXC_PREFETCH(R0) ((void)0)
+#else
+#define FXC_PREFETCH(R0)                                                    \
+    do {                                                                    \
+        FXC_SCHED_FENCE();                                                  \
+        load_frame_part<R0, 4>(nx, nbase, chunk_bytes, voff, nframe);       \
+        FXC_SCHED_FENCE();                                                  \
+    } while (0)
+#endif
 
-// one spectrum of both antennas: frame i of chunk c sits in ring slot PH.  All control flow here is
+// One spectrum of both antennas: frame i of chunk c sits in ring slot PH.  All control flow is
 // wave-uniform and none of it guards a *definition* of ring registers (the prefetch is unconditional),
 // which keeps the register allocator from doubling live ranges at merge points.
 template <int PH>
@@ -461,28 +417,18 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
                                            cf* rows_raw, unsigned long long (&seg)[kStampSegs],
                                            unsigned long long& t_prev) {
     using namespace fxc::fused;
-    FXC_STAMP(0);    // everything since the previous step's last stamp (loop overhead, epilogue)
-    if (i == 0) {   // zero PFB history at the start of every chunk
+    FXC_STAMP(0);    // loop overhead and the (rare) chunk-end store since the previous step's last stamp
+    if (i == 0) {    // zero PFB history at the start of every chunk
         asm volatile("" ::: "memory");   // keep this a (rarely taken) uniform branch, not 96 v_cndmask per frame
         state_reset_history<PH>(s);
     }
-#if FXC_LOAD16
-    // this frame arrived as sample pairs: one swap per register hands every lane the 16 rows of its own branch
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        permlane32_swap(s.h[PH][2 * k].x, s.h[PH][2 * k + 1].x);
-        permlane32_swap(s.h[PH][2 * k].y, s.h[PH][2 * k + 1].y);
-    }
-#endif
-    FXC_STAMP(1);    // vmcnt wait + permlane fix-up
     cf v[16];
-    phase1_fir<PH>(s, win, tid, v);
-    FXC_STAMP(2);    // FIR
-    // the oldest history slot is dead now: refill it with the next frame this workgroup will process
-    // (next frame of the chunk, or frame 0 of its next chunk; at the very end the current frame again,
-    // which is never used).  The loads are issued in four groups spread over the rest of the step —
-    // eight waves bursting 16 loads each at the same point stall in the (in-order) vector-memory
-    // issue — and are first waited for by the next FIR.
+    phase1_fir<PH>(s, win, tid, v);      // first use of this frame: waits for its loads (issued a step ago)
+    FXC_STAMP(2);
+    // The oldest ring slot is dead now: refill it with the next frame this workgroup will process (next
+    // frame of the chunk, or frame 0 of its next chunk; at the very end the current frame again, never
+    // used).  The 16 loads go out in four groups spread over the step: eight waves bursting 16 loads
+    // each at the same point stall in the in-order vector-memory issue (measured -7 %).
     int64_t ni = i + 1, nc = c;
     if (ni == n_pts) {
         ni = 0;
@@ -492,110 +438,43 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
     const cf* nbase = x + (more ? nc : c) * 2 * num_samp;
     const int64_t nframe = more ? ni : i;
     cf (&nx)[16] = s.h[(PH + 1) & 3];
-    // FXC_LOAD_SPREAD: 0 = one burst of 16 after the FIR; 1 = four groups over the whole step;
-    // 2 = four groups inside phase 1 (longest time in flight, still not a burst)
-#if (FXC_ABL & 32)
-#define FXC_LOADS(R0, CNT)                                                       \
-    do {                                                                         \
-        FXC_SCHED_FENCE();                                                       \
-        load_frame_part_nowait<R0, CNT>(nbase, chunk_bytes, voff, nframe);       \
-        FXC_SCHED_FENCE();                                                       \
-    } while (0)
-#elif FXC_LOAD16
-#define FXC_LOADS(R0, CNT)                                                  \
-    do {                                                                    \
-        FXC_SCHED_FENCE();                                                  \
-        load_frame16_part<R0, CNT>(nx, nbase, chunk_bytes, voff, nframe);   \
-        FXC_SCHED_FENCE();                                                  \
-    } while (0)
-#else
-#define FXC_LOADS(R0, CNT)                                                  \
-    do {                                                                    \
-        FXC_SCHED_FENCE();                                                  \
-        load_frame_part<R0, CNT>(nx, nbase, chunk_bytes, voff, nframe);     \
-        FXC_SCHED_FENCE();                                                  \
-    } while (0)
-#endif
-#if (FXC_ABL & 16)
-#define FXC_LOADS_IF(mode, R0, CNT)
-#else
-#define FXC_LOADS_IF(mode, R0, CNT) if (FXC_LOAD_SPREAD == mode) FXC_LOADS(R0, CNT)
-#endif
-#if FXC_LOAD16 || (FXC_ABL & 16)
-#define FXC_LOADS_IF4(R0, CNT)      /* single-row groups exist only in the 8-byte scheme */
-#else
-#define FXC_LOADS_IF4(R0, CNT) FXC_LOADS_IF(4, R0, CNT)
-#endif
-    FXC_LOADS_IF(0, 0, 16);
-    FXC_LOADS_IF(1, 0, 4);
-    FXC_LOADS_IF(2, 0, 4);
-    FXC_LOADS_IF(3, 0, 2);
-    FXC_LOADS_IF4(0, 1);
-    fxc::dft16_a(v);
-    FXC_LOADS_IF(2, 4, 4);
-    FXC_LOADS_IF(3, 2, 2);
-    FXC_LOADS_IF4(1, 2);
-    fxc::dft16_b(v);
-    FXC_LOADS_IF(1, 4, 4);
-    FXC_LOADS_IF(2, 8, 4);
-    FXC_LOADS_IF(3, 4, 2);
-    FXC_LOADS_IF4(3, 1);
-    FXC_STAMP(3);    // radix-16 #1 (+ load issue)
-#if FXC_STORE_EARLY
-    __syncthreads();   // every wave has finished reading the previous spectrum's rows
-    FXC_STAMP(4);    // barrier B0
-    phase1_twiddle_store(s, v, region, tid);
-    FXC_STAMP(5);    // twiddle + exchange-1 stores
-    FXC_LOADS_IF(2, 12, 4);
-    FXC_LOADS_IF4(4, 2);
-#else
-    phase1_twiddle(s, v);
-    FXC_LOADS_IF(2, 12, 4);
-    FXC_LOADS_IF4(4, 2);
+    FXC_PREFETCH(0);
+    fxc::dft16(v);
+    FXC_PREFETCH(4);
+    FXC_STAMP(3);
 #if !(FXC_ABL & 1)
-    __syncthreads();   // every wave has finished reading the previous spectrum's rows
+    __syncthreads();   // B0: every wave has finished reading the previous spectrum's exchange rows
 #endif
+    FXC_STAMP(4);
 #if !(FXC_ABL & 4)
-    phase1_store(v, region, tid);
+    phase1_twiddle_store(s, v, region, tid);   // twiddle w4096^(j k1) fused with the exchange-1 stores
 #endif
-#endif
+    FXC_STAMP(5);
 #if !(FXC_ABL & 2)
-    __syncthreads();
+    __syncthreads();   // B1: exchange-1 rows complete
 #endif
-    FXC_STAMP(6);    // barrier B1 (incl. lgkmcnt(0) for the stores)
+    FXC_STAMP(6);
 #if !(FXC_ABL & 4)
     phase2_load(region, tid, v);
 #endif
-    FXC_LOADS_IF(1, 8, 4);
-    FXC_LOADS_IF(3, 6, 2);
-    FXC_LOADS_IF4(6, 1);
-    fxc::dft16_a(v);
-    FXC_LOADS_IF(3, 8, 2);
-    FXC_LOADS_IF4(7, 2);
-    fxc::dft16_b(v);
-    FXC_LOADS_IF(3, 10, 2);
-    FXC_LOADS_IF4(9, 1);
-    FXC_STAMP(7);    // exchange-1 reads + radix-16 #2
+    FXC_PREFETCH(8);
+    fxc::dft16(v);
+    FXC_STAMP(7);
     phase2_twiddle(v, tw2, tid);
-    FXC_STAMP(8);    // twiddle #2 (LDS table)
-    FXC_LOADS_IF4(10, 2);
+    FXC_STAMP(8);
 #if !(FXC_ABL & 8)
-    wave_sync();
+    wave_sync();       // exchange 2 is a 16x16 transpose inside each 16-lane group: no s_barrier
     phase2_store(v, region, tid);
     wave_sync();
 #endif
-    FXC_LOADS_IF(1, 12, 4);
-    FXC_LOADS_IF(3, 12, 2);
-    FXC_LOADS_IF4(12, 1);
+    FXC_PREFETCH(12);
 #if !(FXC_ABL & 8)
     phase3_load(region, tid, v);
 #endif
-    FXC_STAMP(9);    // exchange 2 (intra-wave): stores + reads issued
-    fxc::dft16_a(v);
-    FXC_LOADS_IF(3, 14, 2);
-    FXC_LOADS_IF4(13, 2);
-    fxc::dft16_b(v);
-    FXC_LOADS_IF4(15, 1);
+    FXC_STAMP(9);
+    fxc::dft16(v);
+    // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins: after the swap each lane has both
+    // antennas for 8 of them (lanes 0-31: q2 = 0..7, lanes 32-63: q2 = 8..15) -- effex.py:520 without rot
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         cf a = v[q], b = v[q + 8];
@@ -603,7 +482,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
         permlane32_swap(a.y, b.y);
         xacc(s, q, a, b);
     }
-    FXC_STAMP(10);   // radix-16 #3 + X
+    FXC_STAMP(10);
     if (i + 1 == n_pts) {   // chunk done: store this lane's 8 bins of the chunk's raw sum (fire and forget)
         cf* row = rows_raw + c * kN;
 #pragma unroll
@@ -638,28 +517,13 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     for (int q = 0; q < kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
     __syncthreads();
 
-#if FXC_SETPRIO
-    // the second-dispatched half of an 8-wave workgroup loses VALU arbitration to its older SIMD partner
-    // (MI355X_MICROARCH.md, "Static priority for the younger half"): one static raise evens the pair
-    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     int64_t c = blockIdx.x, i = 0;
     if (c >= n_chunks) return;
     const int64_t my_chunks = (n_chunks - c + gridDim.x - 1) / gridDim.x;
     const int64_t total = my_chunks * n_pts;
-    // IQ frames come in through buffer loads: one VGPR byte offset per thread (antenna stream +
-    // (255 - j)), everything that varies with chunk / frame / r is scalar
-#if FXC_LOAD16
-    const unsigned voff = (unsigned)((ant * num_samp + load16_offset(tid, 7)) * (int64_t)sizeof(cf));
-#else
     const unsigned voff = (unsigned)((ant * num_samp + (255 - j)) * (int64_t)sizeof(cf));
-#endif
     const unsigned chunk_bytes = (unsigned)(2 * num_samp * (int64_t)sizeof(cf));
-#if FXC_LOAD16
-    load_frame16_part<0, 16>(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
-#else
-    load_frame(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
-#endif
+    load_frame_part<0, 16>(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
     unsigned long long seg[kStampSegs] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
 #if FXC_STAMPS
@@ -682,6 +546,8 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
         for (int k = 0; k < kStampSegs; ++k) dst[k] = seg[k];
         dst[kStampSegs - 1] = (unsigned long long)total;
     }
+#else
+    (void)stamps;
 #endif
 }
 
@@ -1145,7 +1011,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                 w.y = wf[1 * kN + m];
                 w.z = wf[2 * kN + m];
                 w.w = wf[3 * kN + m];
-                w4[r * 256 + fxc::fused::win_slot(jx)] = w;
+                w4[r * 256 + jx] = w;
             }
         std::vector<cf> tw1((size_t)16 * 256), tw2((size_t)256);
         for (int k1 = 0; k1 < 16; ++k1)

@@ -27,7 +27,7 @@ extern "C" int emul_fused4096(const float* x, int64_t num_samp, const double* wi
             w.y = (float)window[1 * kN + m];
             w.z = (float)window[2 * kN + m];
             w.w = (float)window[3 * kN + m];
-            win[r * 256 + win_slot(j)] = w;
+            win[r * 256 + j] = w;
         }
     const double two_pi = 6.283185307179586476925286766559;
     for (int q1 = 0; q1 < 16; ++q1)
@@ -49,52 +49,30 @@ extern "C" int emul_fused4096(const float* x, int64_t num_samp, const double* wi
     }
     const cf* xc = reinterpret_cast<const cf*>(x);
     for (int64_t i = 0; i < P; ++i) {
-        // phase 1: frame i goes to ring slot i & 3 exactly as the kernel's buffer loads put it there
-#if FXC_LOAD16
+        // phase 1: frame i goes to ring slot i & 3 (the kernel's buffer loads), then FIR + radix-16 + twiddle
         for (int tid = 0; tid < kThreads; ++tid) {
-            const int ant = tid >> 8;
-            for (int k = 0; k < 8; ++k) {
-                const int off = load16_offset(tid, k);
-                st[tid].h[i & 3][2 * k + 1] = xc[ant * num_samp + i * kN + off];       // low address
-                st[tid].h[i & 3][2 * k] = xc[ant * num_samp + i * kN + off + 1];       // high address
-            }
-        }
-        // v_permlane32_swap(a = h[2k], b = h[2k+1]): a' = [a.lo | b.lo], b' = [a.hi | b.hi]
-        for (int wave = 0; wave < kThreads / 64; ++wave)
-            for (int l = 0; l < 32; ++l) {
-                State& lo = st[wave * 64 + l];
-                State& hi = st[wave * 64 + l + 32];
-                for (int k = 0; k < 8; ++k) {
-                    const cf a_lo = lo.h[i & 3][2 * k], b_lo = lo.h[i & 3][2 * k + 1];
-                    const cf a_hi = hi.h[i & 3][2 * k], b_hi = hi.h[i & 3][2 * k + 1];
-                    lo.h[i & 3][2 * k] = a_lo;      lo.h[i & 3][2 * k + 1] = a_hi;
-                    hi.h[i & 3][2 * k] = b_lo;      hi.h[i & 3][2 * k + 1] = b_hi;
-                }
-            }
-#endif
-        for (int tid = 0; tid < kThreads; ++tid) {
-#if !FXC_LOAD16
             const int ant = tid >> 8, j = tid & 255;
             for (int r = 0; r < 16; ++r)
                 st[tid].h[i & 3][r] = xc[ant * num_samp + i * kN + sample_offset(j, r)];
-#endif
             cf(&v)[16] = *reinterpret_cast<cf(*)[16]>(&vbuf[tid * 16]);
             switch (i & 3) {
-                case 0: phase1_compute<0>(st[tid], win, tid, v); break;
-                case 1: phase1_compute<1>(st[tid], win, tid, v); break;
-                case 2: phase1_compute<2>(st[tid], win, tid, v); break;
-                default: phase1_compute<3>(st[tid], win, tid, v); break;
+                case 0: phase1_fir<0>(st[tid], win, tid, v); break;
+                case 1: phase1_fir<1>(st[tid], win, tid, v); break;
+                case 2: phase1_fir<2>(st[tid], win, tid, v); break;
+                default: phase1_fir<3>(st[tid], win, tid, v); break;
             }
+            dft16(v);
         }
         for (int tid = 0; tid < kThreads; ++tid)
-            phase1_store(*reinterpret_cast<cf(*)[16]>(&vbuf[tid * 16]), region, tid);
+            phase1_twiddle_store(st[tid], *reinterpret_cast<cf(*)[16]>(&vbuf[tid * 16]), region, tid);
         // barrier; phase 2 (reads complete for a whole wave before its stores: emulate per wave)
         for (int wave = 0; wave < kThreads / 64; ++wave) {
             for (int l = 0; l < 64; ++l) {
                 const int tid = wave * 64 + l;
                 cf(&v)[16] = *reinterpret_cast<cf(*)[16]>(&vbuf[tid * 16]);
                 phase2_load(region, tid, v);
-                phase2_compute(v, tw2, tid);
+                dft16(v);
+                phase2_twiddle(v, tw2, tid);
             }
             for (int l = 0; l < 64; ++l) {
                 const int tid = wave * 64 + l;
