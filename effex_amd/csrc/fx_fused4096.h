@@ -208,5 +208,15 @@ FXC_HD int slot_of_bin(int k) {
     return (q2 & 7) * kThreads + tid;
 }
 
+// position of bin k inside a spectrum row written by the F-only variant of the kernel (multi-antenna path):
+// for a fixed q2 the 32 (k1, q1) lanes of the eight waves fill 256 consecutive samples
+FXC_HD int specpos_of_bin(int k) { return (k >> 8) * 256 + (k & 15) * 16 + ((k >> 4) & 15); }
+
+// this lane's position base for phase 3 (add q2 * 256)
+FXC_HD int lane_specpos(int tid) {
+    const int l = tid & 63, wave = tid >> 6;
+    return (2 * wave + ((l >> 4) & 1)) * 16 + (l & 15);
+}
+
 }  // namespace fused
 }  // namespace fxc

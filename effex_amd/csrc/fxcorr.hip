@@ -158,9 +158,12 @@ __global__ __launch_bounds__(256) void xmul_kernel(const cf* __restrict__ spec, 
 }
 
 // ------------------------------------------------------------------------------------------
-// finishing kernels (shared by both paths); `slots` != 0: input is in the fused kernel's slot order
+// finishing kernels (shared by all paths); `slots` = layout of the raw sums inside a row:
+//   0 natural bin order, 1 the 2-antenna fused kernel's slot order, 2 the F-only kernel's spectrum order
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t raw_index(int k, int slots) { return slots ? fxc::fused::slot_of_bin(k) : k; }
+__device__ __forceinline__ int64_t raw_index(int k, int slots) {
+    return slots == 1 ? fxc::fused::slot_of_bin(k) : (slots == 2 ? fxc::fused::specpos_of_bin(k) : k);
+}
 
 // SPECTRUM rows: out[c][p][(k + N/2) % N] = (sum_split raw) * conj(rot[k]) / n_pts   (effex.py:520-521)
 __global__ void rows_spectrum_kernel(const cf* __restrict__ raw, cf* __restrict__ out, const cd* __restrict__ rot,
@@ -229,14 +232,17 @@ __global__ __launch_bounds__(256) void rows_continuum_kernel(const cf* __restric
     }
 }
 
-// generic accumulate: acc[p][k] += sum_split sum_c raw[split][c][p][k]   (fixed order -> reproducible)
-__global__ void acc_add_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, int64_t per_chunk /* n_base*nchan */,
-                               int64_t n_chunks, int n_splits) {
+// accumulate: acc[p][k] += sum_split sum_c raw[split][c][p][raw_index(k)]   (fixed order -> reproducible)
+__global__ void acc_add_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, int nchan, int n_base,
+                               int64_t n_chunks, int n_splits, int slots) {
+    const int64_t per_chunk = (int64_t)n_base * nchan;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per_chunk; idx += stride) {
+        const int k = (int)(idx % nchan);
+        const int64_t src = (idx / nchan) * nchan + raw_index(k, slots);
         double ar = 0.0, ai = 0.0;
         for (int64_t sc = 0; sc < n_chunks * n_splits; ++sc) {
-            const cf r = raw[sc * per_chunk + idx];
+            const cf r = raw[sc * per_chunk + src];
             ar += r.x;
             ai += r.y;
         }
@@ -280,6 +286,36 @@ __global__ void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict
     a.x += ar;
     a.y += ai;
     acc[k] = a;
+}
+
+// multi-antenna X-engine on the F-only kernel's spectra: spec[(c*A + a)*P + i][pos]; one thread per (chunk,
+// pos) keeps all A(A-1)/2 accumulators in registers over the chunk's P spectra and reads every spectrum
+// sample exactly once; raw[c][p][pos], baselines ordered (0,1),(0,2)..(A-2,A-1) -- effex.py:520 for A > 2
+template <int A>
+__global__ __launch_bounds__(256) void xengine4096_kernel(const cf* __restrict__ spec, cf* __restrict__ raw,
+                                                         int64_t n_pts) {
+    constexpr int NB = A * (A - 1) / 2;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    float ar[NB], ai[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) ar[p] = ai[p] = 0.f;
+    const cf* base = spec + (c * A * n_pts) * fxc::fused::kN + pos;
+    for (int64_t i = 0; i < n_pts; ++i) {
+        cf z[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * n_pts + i) * fxc::fused::kN];
+        int p = 0;
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int b = a + 1; b < A; ++b, ++p) {
+                ar[p] += z[a].x * z[b].x + z[a].y * z[b].y;
+                ai[p] += z[a].y * z[b].x - z[a].x * z[b].y;
+            }
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) raw[(c * NB + p) * fxc::fused::kN + pos] = fxc::mk(ar[p], ai[p]);
 }
 
 // sums = [n_base*nchan] raw sums + [1] {count, 0}
@@ -410,7 +446,9 @@ constexpr int kStampSegs = 12;
 // One spectrum of both antennas: frame i of chunk c sits in ring slot PH.  All control flow is
 // wave-uniform and none of it guards a *definition* of ring registers (the prefetch is unconditional),
 // which keeps the register allocator from doubling live ranges at merge points.
-template <int PH>
+// SPEC_OUT: the multi-antenna variant -- the pair of streams is only channelised and both spectra go to
+// HBM for xengine4096_kernel (rows_raw then is the spectra buffer [stream][i][specpos]).
+template <int PH, bool SPEC_OUT>
 __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, cf* region, const cf* tw2, int tid,
                                            const cf* x, int64_t num_samp, unsigned chunk_bytes, unsigned voff,
                                            int64_t& c, int64_t& i, int64_t n_pts, int64_t n_chunks,
@@ -473,30 +511,40 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
 #endif
     FXC_STAMP(9);
     fxc::dft16(v);
-    // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins: after the swap each lane has both
-    // antennas for 8 of them (lanes 0-31: q2 = 0..7, lanes 32-63: q2 = 8..15) -- effex.py:520 without rot
+    if (SPEC_OUT) {
+        // stream = 2 * (virtual chunk) + antenna; for a fixed q2 a half-wave stores 256 contiguous bytes
+        cf* dst = rows_raw + (((c * 2 + ((tid >> 5) & 1)) * n_pts + i) * kN + lane_specpos(tid));
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        cf a = v[q], b = v[q + 8];
-        permlane32_swap(a.x, b.x);
-        permlane32_swap(a.y, b.y);
-        xacc(s, q, a, b);
-    }
-    FXC_STAMP(10);
-    if (i + 1 == n_pts) {   // chunk done: store this lane's 8 bins of the chunk's raw sum (fire and forget)
-        cf* row = rows_raw + c * kN;
+        for (int q2 = 0; q2 < 16; ++q2) dst[q2 * 256] = v[q2];
+    } else {
+        // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins: after the swap each lane has both
+        // antennas for 8 of them (lanes 0-31: q2 = 0..7, lanes 32-63: q2 = 8..15) -- effex.py:520 without rot
 #pragma unroll
-        for (int q = 0; q < kAccPerThread; ++q) {
-            row[q * kThreads + tid] = s.acc[q];
-            s.acc[q] = fxc::mk(0.f, 0.f);
+        for (int q = 0; q < 8; ++q) {
+            cf a = v[q], b = v[q + 8];
+            permlane32_swap(a.x, b.x);
+            permlane32_swap(a.y, b.y);
+            xacc(s, q, a, b);
+        }
+        FXC_STAMP(10);
+        if (i + 1 == n_pts) {   // chunk done: store this lane's 8 bins of the chunk's raw sum (fire and forget)
+            cf* row = rows_raw + c * kN;
+#pragma unroll
+            for (int q = 0; q < kAccPerThread; ++q) {
+                row[q * kThreads + tid] = s.acc[q];
+                s.acc[q] = fxc::mk(0.f, 0.f);
+            }
         }
     }
     c = nc;
     i = ni;
 }
 
-// rows_raw[c][slot] = sum_i spec0[i,k] * conj(spec1[i,k]) of chunk c in float32, k = bin of slot
-// (fx_fused4096.h::slot_of_bin); stamps: diagnostic builds only
+// SPEC_OUT == false: rows_raw[c][slot] = sum_i spec0[i,k] * conj(spec1[i,k]) of chunk c in float32, k = bin
+// of slot (fx_fused4096.h::slot_of_bin).  SPEC_OUT == true: rows_raw[(2c + ant) * n_pts + i][specpos] = the
+// spectra themselves.  A "chunk" here is a pair of consecutive antenna streams, so an even number of
+// antennas [n_chunks][A][S] is simply n_chunks * A/2 pairs.  stamps: diagnostic builds only.
+template <bool SPEC_OUT>
 __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     const cf* __restrict__ x, int64_t num_samp, int64_t n_pts, int64_t n_chunks, const f4* __restrict__ win_g,
     const cf* __restrict__ tw1_g, const cf* __restrict__ tw2_g, cf* __restrict__ rows_raw,
@@ -532,13 +580,13 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     // frame g of this workgroup's stream of frames sits in ring slot g & 3: unrolled by four so the
     // ring rotates by register renaming
     for (int64_t g = 0; g < total; g += 4) {
-        fused_step<0>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+        fused_step<0, SPEC_OUT>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
         if (g + 1 < total)
-            fused_step<1>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+            fused_step<1, SPEC_OUT>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
         if (g + 2 < total)
-            fused_step<2>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+            fused_step<2, SPEC_OUT>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
         if (g + 3 < total)
-            fused_step<3>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+            fused_step<3, SPEC_OUT>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
     }
 #if FXC_STAMPS
     if (stamps && (tid & 63) == 0) {
@@ -754,11 +802,11 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
 }
 
 constexpr int kFusedReduceSplits = 64;
-constexpr int64_t kFusedMaxChunksPerLaunch = 16384;   // 512 MiB of raw rows
 
-int launch_fused(fxc_plan* p, const cf* x, int64_t n_chunks, cf* rows_raw) {
+// n_pairs = pairs of consecutive antenna streams to channelise; spec_out: write spectra instead of X sums
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out) {
     using namespace fxc::fused;
-    const int grid = (int)std::min<int64_t>(n_chunks, p->fused_grid_max);
+    const int grid = (int)std::min<int64_t>(n_pairs, p->fused_grid_max);
     unsigned long long* stamps = nullptr;
 #if FXC_STAMPS
     if (!p->d_stamps) FXC_HIP(p, hipMalloc(&p->d_stamps, (size_t)p->fused_grid_max * 8 * kStampSegs * 8));
@@ -767,9 +815,46 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_chunks, cf* rows_raw) {
     p->stamp_grid = grid;
 #endif
     KernelTimer kt(p);
-    hipLaunchKernelGGL(fx_fused4096_kernel, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x, p->num_samp, p->n_pts,
-                       n_chunks, p->d_win4, p->d_tw1, p->d_tw2, rows_raw, stamps);
+    if (spec_out)
+        hipLaunchKernelGGL(fx_fused4096_kernel<true>, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x, p->num_samp,
+                           p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps);
+    else
+        hipLaunchKernelGGL(fx_fused4096_kernel<false>, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x, p->num_samp,
+                           p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps);
     kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+// layout of the raw per-chunk sums the fused paths produce (see raw_index)
+int fused_layout(const fxc_plan* p) { return p->n_ant == 2 ? 1 : 2; }
+
+// chunks per pass on the fused paths: 2 antennas only need the raw rows; more antennas also the spectra
+int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec_bytes, int64_t* raw_bytes) {
+    using namespace fxc::fused;
+    const int64_t raw_per_chunk = (int64_t)p->n_base * kN * (int64_t)sizeof(cf);
+    const int64_t spec_per_chunk = p->n_ant == 2 ? 0 : (int64_t)p->n_ant * p->n_pts * kN * (int64_t)sizeof(cf);
+    int64_t cb = kWorkspaceTarget / (raw_per_chunk + spec_per_chunk);
+    if (cb < 1) cb = 1;
+    if (cb > n_chunks) cb = n_chunks;
+    *spec_bytes = (cb * spec_per_chunk + 255) / 256 * 256;
+    *raw_bytes = (cb * raw_per_chunk + 255) / 256 * 256;
+    return cb;
+}
+
+// raw[c][p][layout] for nc chunks starting at x; spec = scratch for the multi-antenna path
+int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw) {
+    using namespace fxc::fused;
+    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false);
+    int rc = launch_fused(p, x, nc * (p->n_ant / 2), spec, true);
+    if (rc) return rc;
+    const dim3 grid(kN / 256, (unsigned)nc);
+    switch (p->n_ant) {
+        case 4: hipLaunchKernelGGL(xengine4096_kernel<4>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts); break;
+        case 6: hipLaunchKernelGGL(xengine4096_kernel<6>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts); break;
+        case 8: hipLaunchKernelGGL(xengine4096_kernel<8>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts); break;
+        default: return fail(p, FXC_ERR_UNSUPPORTED, "no X-engine instantiation for n_ant=%d", p->n_ant);
+    }
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
 }
@@ -779,20 +864,28 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
     if (n_chunks == 0) return FXC_OK;
     if (p->path == FXC_PATH_FUSED) {
         using namespace fxc::fused;
-        for (int64_t c0 = 0; c0 < n_chunks; c0 += kFusedMaxChunksPerLaunch) {
-            const int64_t nc = std::min(kFusedMaxChunksPerLaunch, n_chunks - c0);
-            const int64_t raw_bytes = (nc * kN * (int64_t)sizeof(cf) + 255) / 256 * 256;
-            const int64_t part_bytes = (int64_t)kFusedReduceSplits * kN * (int64_t)sizeof(cd);
-            int rc = ensure_ws(p, raw_bytes + part_bytes);
+        int64_t spec_bytes, raw_bytes;
+        const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
+        const int64_t part_bytes = (int64_t)kFusedReduceSplits * kN * (int64_t)sizeof(cd);
+        int rc = ensure_ws(p, spec_bytes + raw_bytes + part_bytes);
+        if (rc) return rc;
+        cf* spec = reinterpret_cast<cf*>(p->d_ws);
+        cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
+        cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + spec_bytes + raw_bytes);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = fused_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, spec, raw);
             if (rc) return rc;
-            cf* raw = reinterpret_cast<cf*>(p->d_ws);
-            cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + raw_bytes);
-            rc = launch_fused(p, x + c0 * 2 * p->num_samp, nc, raw);
-            if (rc) return rc;
-            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, kFusedReduceSplits), dim3(256), 0, p->stream, raw, part,
-                               nc, kFusedReduceSplits);
-            hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 256), dim3(256), 0, p->stream, part, p->d_acc,
-                               kFusedReduceSplits);
+            if (p->n_ant == 2) {   // many chunks, one baseline: two-stage reduce over chunks
+                hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, kFusedReduceSplits), dim3(256), 0, p->stream, raw,
+                                   part, nc, kFusedReduceSplits);
+                hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 256), dim3(256), 0, p->stream, part, p->d_acc,
+                                   kFusedReduceSplits);
+            } else {
+                const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
+                hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream,
+                                   raw, p->d_acc, p->nchan, p->n_base, nc, 1, fused_layout(p));
+            }
             FXC_HIP(p, hipGetLastError());
         }
     } else {
@@ -814,7 +907,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
                                p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
             const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
             hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream, raw,
-                               p->d_acc, per_chunk, nc, g.n_splits);
+                               p->d_acc, p->nchan, p->n_base, nc, g.n_splits, 0);
             kt.stop();
             FXC_HIP(p, hipGetLastError());
         }
@@ -829,21 +922,27 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
     const float inv_pts = (float)(1.0 / (double)p->n_pts);
     const double cscale = 1.0 / ((double)p->n_pts * (double)p->nchan * bandwidth);
     if (p->path == FXC_PATH_FUSED) {
-        const int64_t raw_bytes = n_chunks * fxc::fused::kN * (int64_t)sizeof(cf);
-        int rc = ensure_ws(p, raw_bytes);
+        int64_t spec_bytes, raw_bytes;
+        const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
+        int rc = ensure_ws(p, spec_bytes + raw_bytes);
         if (rc) return rc;
-        cf* raw = reinterpret_cast<cf*>(p->d_ws);
-        rc = launch_fused(p, x, n_chunks, raw);
-        if (rc) return rc;
-        if (mode == FXC_MODE_SPECTRUM)
-            hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(n_chunks * p->nchan, 256, p->cu_count)), dim3(256),
-                               0, p->stream, raw, static_cast<cf*>(out), p->d_rot, p->nchan, n_chunks, 1,
-                               (int64_t)0, inv_pts, 1);
-        else
-            hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(n_chunks, (int64_t)p->cu_count * 8)),
-                               dim3(256), 0, p->stream, raw, static_cast<cd*>(out), p->d_rot, p->nchan, n_chunks, 1,
-                               (int64_t)0, cscale, 1);
-        FXC_HIP(p, hipGetLastError());
+        cf* spec = reinterpret_cast<cf*>(p->d_ws);
+        cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = fused_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, spec, raw);
+            if (rc) return rc;
+            const int64_t rows = nc * p->n_base;
+            if (mode == FXC_MODE_SPECTRUM)
+                hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(rows * p->nchan, 256, p->cu_count)), dim3(256), 0,
+                                   p->stream, raw, static_cast<cf*>(out) + c0 * p->n_base * p->nchan, p->d_rot, p->nchan,
+                                   rows, 1, (int64_t)0, inv_pts, fused_layout(p));
+            else
+                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
+                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot,
+                                   p->nchan, rows, 1, (int64_t)0, cscale, fused_layout(p));
+            FXC_HIP(p, hipGetLastError());
+        }
         return FXC_OK;
     }
     const XGeom g = x_geometry(p);
@@ -963,7 +1062,10 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     FXC_HIP(p, hipEventCreate(&p->ev_t1));
 
     const int N = p->nchan, T = p->ntaps;
-    const bool fused_shape = (p->n_ant == 2 && N == fxc::fused::kN && T == fxc::fused::kT);
+    // the fused kernel channelises pairs of antenna streams: 2 antennas (X fused in) or 4 / 6 / 8 (F-only +
+    // xengine4096_kernel); num_samp is bounded by the 32-bit buffer-descriptor range of one stream pair
+    const bool fused_shape = ((p->n_ant == 2 || p->n_ant == 4 || p->n_ant == 6 || p->n_ant == 8) && N == fxc::fused::kN &&
+                              T == fxc::fused::kT && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_FUSED && !fused_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "no fused kernel for n_ant=%d nchan=%d ntaps=%d", p->n_ant, N, T);
     p->path = (fused_shape && force_path != FXC_PATH_GENERIC) ? FXC_PATH_FUSED : FXC_PATH_GENERIC;
@@ -1031,7 +1133,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipMalloc(&p->d_tw2, tw2.size() * sizeof(cf)));
         FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
         p->fused_grid_max = p->cu_count;   // one 512-thread workgroup (136 KiB LDS) per CU
-        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel),
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
     if (N > 1) {

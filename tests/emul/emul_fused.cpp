@@ -106,6 +106,21 @@ extern "C" int emul_fused4096(const float* x, int64_t num_samp, const double* wi
     return 0;
 }
 
+// layout self-checks: the slot order of the raw sums and the spectrum order of the F-only variant
+extern "C" int emul_layout_check(void) {
+    for (int tid = 0; tid < kThreads; ++tid) {
+        const int l = tid & 63, wave = tid >> 6;
+        const int k1 = 2 * wave + ((l >> 4) & 1), q1 = l & 15;
+        for (int q2 = 0; q2 < 16; ++q2) {
+            const int k = k1 + 16 * q1 + 256 * q2;
+            if (specpos_of_bin(k) != q2 * 256 + lane_specpos(tid)) return -1;
+        }
+        for (int q = 0; q < kAccPerThread; ++q)
+            if (slot_of_bin(bin_of(tid, q)) != q * kThreads + tid) return -2;
+    }
+    return 0;
+}
+
 // 16-point DFT self-check hook
 extern "C" void emul_dft16(const float* in, float* out) {
     cf v[16];

@@ -35,6 +35,10 @@ def test_dft16_sign_and_order(emul):
     assert np.abs(out - ref).max() < 2e-6
 
 
+def test_output_layouts_are_consistent(emul):
+    assert emul.emul_layout_check() == 0
+
+
 @pytest.mark.parametrize("num_samp", [4096, 4096 * 3 + 17, 4096 * 9])
 def test_fused_phases_match_oracle(emul, num_samp):
     x = synth.synth_iq(1234, 1, 2, num_samp)[0]

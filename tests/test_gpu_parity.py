@@ -235,6 +235,32 @@ def test_eight_antennas_28_baselines(plan_mod, torch):
     assert rel_err(rows.astype(np.complex128).mean(axis=0), ref) < TOL_VIS
 
 
+@pytest.mark.parametrize("n_ant", [4, 6, 8])
+def test_multi_antenna_fused_path(plan_mod, torch, n_ant):
+    """BASELINE config 5 shape: even antenna counts at nchan 4096 run the F-only fused kernel + X-engine."""
+    nchan, num_samp, n_chunks = 4096, 4096 * 6 + 11, 3
+    x = synth.synth_iq(23, n_chunks, n_ant, num_samp)
+    window = design_window(4, nchan)
+    rot = plan_mod.rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, 2e-7)
+    with plan_mod.FxPlan(n_ant, nchan, 4, num_samp) as p, plan_mod.FxPlan(n_ant, nchan, 4, num_samp, path="generic") as g:
+        assert p.path == "fused" and g.path == "generic"
+        assert p.n_baselines == n_ant * (n_ant - 1) // 2
+        p.set_rot(rot)
+        g.set_rot(rot)
+        xd = torch.from_numpy(x).cuda()
+        p.fx_accumulate(xd)
+        integ = p.finalize("SPECTRUM")
+        rows = p.fx_rows(xd).cpu().numpy()
+        rows_g = g.fx_rows(xd).cpu().numpy()
+        cont = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
+    ref = fx_oracle.fx_integrate(x, nchan, window, rot=rot)
+    assert rel_err(integ, ref) < TOL_VIS
+    assert rel_err(rows.astype(np.complex128).mean(axis=0), ref) < TOL_VIS
+    assert rel_err(rows, rows_g) < 2e-6
+    np.testing.assert_allclose(cont, rows.astype(np.complex128).mean(axis=2) / gi.BANDWIDTH, rtol=2e-5,
+                               atol=1e-7 * np.abs(cont).max())
+
+
 def test_continuum_streaming_limit_nchan1(plan_mod, torch):
     """BASELINE config 3(i): nchan = 1, the PFB degenerates to a 4-tap FIR and X to sum y0*conj(y1)."""
     num_samp = 2 ** 16 + 3

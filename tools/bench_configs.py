@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Measure the other BASELINE.json configs on one MI355X: continuum (nchan = 1 streaming
+limit and reference CONTINUUM semantics at N = 4096, S = 2^20), 8-antenna / 28-baseline, and the
+per-chunk rows (time-series) variant of the headline config.  One JSON line per config.
+
+    python tools/bench_configs.py [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def timed(plan, fn, reps):
+    fn()
+    plan.sync()
+    best = []
+    for _ in range(reps):
+        plan.timer_start()
+        fn()
+        best.append(plan.timer_stop())
+    best.sort()
+    return best[len(best) // 2], best[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from effex_amd.plan import FxPlan, synth_fill
+    from effex_amd.window import design_window
+    bw = 2.4e6
+    out = []
+
+    def report(name, n_ant, nchan, ntaps, num_samp, n_chunks, mode, window=None, rows=False):
+        x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")
+        synth_fill(x, 1234)
+        plan = FxPlan(n_ant, nchan, ntaps, num_samp, window=window)
+        if rows:
+            fn = lambda: plan.fx_rows(x, mode, bw)
+        else:
+            def fn():
+                plan.acc_reset()
+                plan.fx_accumulate(x)
+                plan.finalize(mode, bw)
+        med, best = timed(plan, fn, args.reps)
+        samples = n_chunks * num_samp
+        algo = n_chunks * n_ant * num_samp * 8
+        line = {"config": name, "path": plan.path, "n_ant": n_ant, "nchan": nchan, "ntaps": ntaps, "num_samp": num_samp,
+                "n_chunks": n_chunks, "mode": mode, "rows": rows, "median_ms": round(med, 3),
+                "Msamples_per_s": round(samples / med / 1e3, 1), "algorithmic_GBps": round(algo / med / 1e6, 1),
+                "frac_of_8TBs": round(algo / med / 1e6 / 8000, 4)}
+        print(json.dumps(line), flush=True)
+        out.append(line)
+        plan.close()
+        del x
+        torch.cuda.empty_cache()
+
+    report("configs[1] headline, integrate", 2, 4096, 4, 2 ** 18, 4096, "SPECTRUM")
+    report("configs[1] headline, one row per frame (reference time series)", 2, 4096, 4, 2 ** 18, 4096, "SPECTRUM", rows=True)
+    report("configs[2](ii) continuum, reference semantics N=4096, S=2^20", 2, 4096, 4, 2 ** 20, 1024, "CONTINUUM", rows=True)
+    report("configs[2](i) continuum streaming limit nchan=1, S=2^20", 2, 1, 4, 2 ** 20, 256, "CONTINUUM",
+           window=np.array([0.4, 0.3, 0.2, 0.1]), rows=True)
+    report("configs[4] 8 antennas, 28 baselines, N=4096", 8, 4096, 4, 2 ** 18, 128, "SPECTRUM")
+    report("N=2048 T=32 (reference test shape), 2 antennas", 2, 2048, 32, 2 ** 18, 256, "SPECTRUM")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "configs.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
