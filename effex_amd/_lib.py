@@ -25,6 +25,7 @@ FXC_MODE_SPECTRUM = 0
 FXC_MODE_CONTINUUM = 1
 FXC_PATH_GENERIC = 0
 FXC_PATH_FUSED = 1
+FXC_PATH_STREAM = 2
 
 
 class FxcInfo(ctypes.Structure):

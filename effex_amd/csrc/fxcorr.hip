@@ -600,6 +600,121 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// continuum streaming limit: nchan == 1, 2 antennas (BASELINE config 3(i))
+// The PFB degenerates to a T-tap FIR y_a[n] = sum_t h[t] x_a[n - t] (zero history per chunk), the FFT is
+// the identity and X is sum_n y_0[n] conj(y_1[n]).  One workgroup takes kStreamBlock consecutive
+// samples of both streams (+ T-1 of halo) through LDS; raw[block][chunk] = its partial sum (float32),
+// summed over blocks in float64 by the finishing kernels.  16 B of HBM per sample, ~40 flop.
+// ------------------------------------------------------------------------------------------
+constexpr int kStreamBlock = 2048;
+struct StreamTaps {
+    float h[kMaxTaps];
+};
+
+__global__ __launch_bounds__(256) void stream1_kernel(const cf* __restrict__ x, cf* __restrict__ raw, int64_t num_samp,
+                                                     int ntaps, StreamTaps taps, int64_t n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* buf = reinterpret_cast<cf*>(smem);            // [2][kStreamBlock + ntaps - 1]
+    __shared__ cf red[256];
+    const int span = kStreamBlock + ntaps - 1;
+    const int64_t blk = blockIdx.x, c = blockIdx.y;
+    const int64_t n0 = blk * kStreamBlock;
+    for (int a = 0; a < 2; ++a) {
+        const cf* xs = x + (c * 2 + a) * num_samp;
+        for (int idx = threadIdx.x; idx < span; idx += blockDim.x) {
+            const int64_t n = n0 - (ntaps - 1) + idx;
+            buf[a * span + idx] = (n >= 0 && n < num_samp) ? xs[n] : fxc::mk(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    float ar = 0.f, ai = 0.f;
+    for (int q = 0; q < kStreamBlock / 256; ++q) {
+        const int m = q * 256 + threadIdx.x;          // output n0 + m sits at buf[m + ntaps - 1]
+        if (n0 + m < num_samp) {
+            float y0r = 0.f, y0i = 0.f, y1r = 0.f, y1i = 0.f;
+            for (int t = 0; t < ntaps; ++t) {
+                const float w = taps.h[t];
+                const cf u = buf[m + ntaps - 1 - t], z = buf[span + m + ntaps - 1 - t];
+                y0r = fmaf(w, u.x, y0r);
+                y0i = fmaf(w, u.y, y0i);
+                y1r = fmaf(w, z.x, y1r);
+                y1i = fmaf(w, z.y, y1i);
+            }
+            ar += y0r * y1r + y0i * y1i;
+            ai += y0i * y1r - y0r * y1i;
+        }
+    }
+    red[threadIdx.x] = fxc::mk(ar, ai);
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] = fxc::cadd(red[threadIdx.x], red[threadIdx.x + sft]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) raw[blk * n_chunks + c] = red[0];
+}
+
+// ntaps <= 4, even num_samp: no LDS.  A thread takes sample pairs (2m, 2m+1) of both streams with three
+// aligned 16-byte loads each ([2m-4, 2m-3], [2m-2, 2m-1], [2m, 2m+1]; the two halo loads hit L1 / the
+// neighbouring lanes' lines, HBM sees every sample once) and walks its workgroup's contiguous slice of the
+// chunk with a stride of 256 pairs.  raw[block][chunk] = partial sum.
+constexpr int kStream4Blocks = 16;   // workgroups per chunk
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void stream1_t4_kernel(const cf* __restrict__ x, cf* __restrict__ raw, int64_t num_samp,
+                                                        float h0, float h1, float h2, float h3, int64_t n_chunks) {
+    __shared__ cf red[256];
+    const int64_t c = blockIdx.y;
+    const int64_t pairs = num_samp / 2;
+    const int64_t per_blk = (pairs + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * per_blk;
+    const int64_t p1 = (p0 + per_blk < pairs) ? p0 + per_blk : pairs;
+    const v4f32* s0 = reinterpret_cast<const v4f32*>(x + (c * 2 + 0) * num_samp);
+    const v4f32* s1 = reinterpret_cast<const v4f32*>(x + (c * 2 + 1) * num_samp);
+    const v4f32 zero = {0.f, 0.f, 0.f, 0.f};
+    float ar = 0.f, ai = 0.f;
+    for (int64_t m = p0 + threadIdx.x; m < p1; m += 256) {
+        // q[a][0..2] = samples (2m-4, 2m-3), (2m-2, 2m-1), (2m, 2m+1) as (re, im, re, im)
+        const v4f32 a2 = s0[m], b2 = s1[m];
+        const v4f32 a1 = m >= 1 ? s0[m - 1] : zero, b1 = m >= 1 ? s1[m - 1] : zero;
+        const v4f32 a0 = m >= 2 ? s0[m - 2] : zero, b0 = m >= 2 ? s1[m - 2] : zero;
+        // y[2m] = h0 x[2m] + h1 x[2m-1] + h2 x[2m-2] + h3 x[2m-3];  y[2m+1] = h0 x[2m+1] + h1 x[2m] + h2 x[2m-1] + h3 x[2m-2]
+        const float y0er = h0 * a2[0] + h1 * a1[2] + h2 * a1[0] + h3 * a0[2];
+        const float y0ei = h0 * a2[1] + h1 * a1[3] + h2 * a1[1] + h3 * a0[3];
+        const float y0or = h0 * a2[2] + h1 * a2[0] + h2 * a1[2] + h3 * a1[0];
+        const float y0oi = h0 * a2[3] + h1 * a2[1] + h2 * a1[3] + h3 * a1[1];
+        const float y1er = h0 * b2[0] + h1 * b1[2] + h2 * b1[0] + h3 * b0[2];
+        const float y1ei = h0 * b2[1] + h1 * b1[3] + h2 * b1[1] + h3 * b0[3];
+        const float y1or = h0 * b2[2] + h1 * b2[0] + h2 * b1[2] + h3 * b1[0];
+        const float y1oi = h0 * b2[3] + h1 * b2[1] + h2 * b1[3] + h3 * b1[1];
+        ar += y0er * y1er + y0ei * y1ei + y0or * y1or + y0oi * y1oi;
+        ai += y0ei * y1er - y0er * y1ei + y0oi * y1or - y0or * y1oi;
+    }
+    red[threadIdx.x] = fxc::mk(ar, ai);
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] = fxc::cadd(red[threadIdx.x], red[threadIdx.x + sft]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) raw[(int64_t)blockIdx.x * n_chunks + c] = red[0];
+}
+
+// acc[0] += sum of all partials (float64, fixed order)
+__global__ __launch_bounds__(256) void stream1_acc_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, int64_t n) {
+    __shared__ double red[256];
+    double ar = 0.0, ai = 0.0;
+    for (int64_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        ar += raw[idx].x;
+        ai += raw[idx].y;
+    }
+    ar = block_sum(ar, red);
+    ai = block_sum(ai, red);
+    if (threadIdx.x == 0) {
+        acc[0].x += ar;
+        acc[0].y += ai;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // synthetic IQ (effex_amd/synth.py, bit for bit)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -673,6 +788,7 @@ struct fxc_plan {
     double kernel_ms = 0.0;
     int64_t kernel_launches = 0;
     int stamp_grid = 0;
+    StreamTaps taps;               // nchan == 1: the FIR taps by value
     mutable std::string error;
 };
 
@@ -859,10 +975,47 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw) {
     return FXC_OK;
 }
 
+// nchan == 1 streaming path: raw[block][chunk] partial sums for nc chunks
+bool stream_is_t4(const fxc_plan* p) { return p->ntaps <= 4 && (p->num_samp % 2) == 0; }
+
+int64_t stream_blocks(const fxc_plan* p) {
+    return stream_is_t4(p) ? kStream4Blocks : (p->num_samp + kStreamBlock - 1) / kStreamBlock;
+}
+
+int stream_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* raw) {
+    const int blocks = (int)stream_blocks(p);
+    KernelTimer kt(p);
+    if (stream_is_t4(p)) {
+        // 16-byte loads need 16-byte aligned streams: x from hipMalloc / torch is, and num_samp is even
+        hipLaunchKernelGGL(stream1_t4_kernel, dim3(blocks, (unsigned)nc), dim3(256), 0, p->stream, x, raw, p->num_samp,
+                           p->taps.h[0], p->taps.h[1], p->taps.h[2], p->taps.h[3], nc);
+    } else {
+        const size_t lds = (size_t)2 * (kStreamBlock + p->ntaps - 1) * sizeof(cf);
+        hipLaunchKernelGGL(stream1_kernel, dim3(blocks, (unsigned)nc), dim3(256), lds, p->stream, x, raw, p->num_samp,
+                           p->ntaps, p->taps, nc);
+    }
+    kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
 // device-resident implementation of fx_accumulate
 int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
     if (n_chunks == 0) return FXC_OK;
-    if (p->path == FXC_PATH_FUSED) {
+    if (p->path == FXC_PATH_STREAM) {
+        const int64_t blocks = stream_blocks(p);
+        const int64_t cb = std::min<int64_t>(n_chunks, 65535);
+        int rc = ensure_ws(p, cb * blocks * (int64_t)sizeof(cf));
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = stream_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
+            if (rc) return rc;
+            hipLaunchKernelGGL(stream1_acc_kernel, dim3(1), dim3(256), 0, p->stream, raw, p->d_acc, nc * blocks);
+            FXC_HIP(p, hipGetLastError());
+        }
+    } else if (p->path == FXC_PATH_FUSED) {
         using namespace fxc::fused;
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
@@ -921,6 +1074,28 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
     if (n_chunks == 0) return FXC_OK;
     const float inv_pts = (float)(1.0 / (double)p->n_pts);
     const double cscale = 1.0 / ((double)p->n_pts * (double)p->nchan * bandwidth);
+    if (p->path == FXC_PATH_STREAM) {
+        const int nb = (int)stream_blocks(p);
+        const int64_t cb = std::min<int64_t>(n_chunks, 65535);
+        int rc = ensure_ws(p, cb * nb * (int64_t)sizeof(cf));
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = stream_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
+            if (rc) return rc;
+            // raw[block][chunk]: the blocks play the role of the generic path's splits (nchan = n_base = 1)
+            if (mode == FXC_MODE_SPECTRUM)
+                hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc, 256, p->cu_count)), dim3(256), 0, p->stream, raw,
+                                   static_cast<cf*>(out) + c0, p->d_rot, 1, nc, nb, nc, inv_pts, 0);
+            else
+                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
+                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, 1, nc, nb, nc,
+                                   cscale, 0);
+            FXC_HIP(p, hipGetLastError());
+        }
+        return FXC_OK;
+    }
     if (p->path == FXC_PATH_FUSED) {
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
@@ -1068,7 +1243,13 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                               T == fxc::fused::kT && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_FUSED && !fused_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "no fused kernel for n_ant=%d nchan=%d ntaps=%d", p->n_ant, N, T);
-    p->path = (fused_shape && force_path != FXC_PATH_GENERIC) ? FXC_PATH_FUSED : FXC_PATH_GENERIC;
+    const bool stream_shape = (p->n_ant == 2 && N == 1);
+    if (force_path == FXC_PATH_STREAM && !stream_shape)
+        return fail(p, FXC_ERR_UNSUPPORTED, "the streaming kernel needs n_ant=2, nchan=1");
+    p->path = FXC_PATH_GENERIC;
+    if (fused_shape && (force_path == -1 || force_path == FXC_PATH_FUSED)) p->path = FXC_PATH_FUSED;
+    if (stream_shape && (force_path == -1 || force_path == FXC_PATH_STREAM)) p->path = FXC_PATH_STREAM;
+    for (int t = 0; t < kMaxTaps; ++t) p->taps.h[t] = t < T ? (float)window[t] : 0.f;
 
     // window: float32 copy of the float64 design (both layouts)
     std::vector<float> wf((size_t)T * N);
@@ -1165,7 +1346,7 @@ int fxc_plan_create(fxc_plan** out, int device, int n_ant, int nchan, int ntaps,
     if (num_samp < nchan)
         return fail(nullptr, FXC_ERR_ARG, "num_samp=%lld shorter than one frame of nchan=%d", (long long)num_samp,
                     nchan);
-    if (force_path < -1 || force_path > FXC_PATH_FUSED) return fail(nullptr, FXC_ERR_ARG, "bad force_path");
+    if (force_path < -1 || force_path > FXC_PATH_STREAM) return fail(nullptr, FXC_ERR_ARG, "bad force_path");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device available (this library has no CPU backend)");
@@ -1210,6 +1391,10 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
         info->grid = p->fused_grid_max;
         info->block = fxc::fused::kThreads;
         info->lds_bytes = fxc::fused::kLdsBytes;
+    } else if (p->path == FXC_PATH_STREAM) {
+        info->grid = (int)stream_blocks(p);
+        info->block = 256;
+        info->lds_bytes = 2 * (kStreamBlock + p->ntaps - 1) * (int)sizeof(cf);
     } else {
         info->grid = p->cu_count * 4;
         info->block = 256;

@@ -12,7 +12,9 @@ from . import _lib
 from .window import design_window
 
 MODES = {"SPECTRUM": _lib.FXC_MODE_SPECTRUM, "CONTINUUM": _lib.FXC_MODE_CONTINUUM, "TEST": _lib.FXC_MODE_CONTINUUM}
-PATHS = {None: -1, "auto": -1, "generic": _lib.FXC_PATH_GENERIC, "fused": _lib.FXC_PATH_FUSED}
+PATHS = {None: -1, "auto": -1, "generic": _lib.FXC_PATH_GENERIC, "fused": _lib.FXC_PATH_FUSED,
+         "stream": _lib.FXC_PATH_STREAM}
+PATH_NAMES = {_lib.FXC_PATH_GENERIC: "generic", _lib.FXC_PATH_FUSED: "fused", _lib.FXC_PATH_STREAM: "stream"}
 
 
 def _current_torch_stream(device):
@@ -63,7 +65,7 @@ class FxPlan(object):
         self.n_ant, self.n_baselines, self.nchan, self.ntaps = info.n_ant, info.n_baselines, info.nchan, info.ntaps
         self.num_samp, self.n_pts = info.num_samp, info.n_pts
         self.device = info.device
-        self.path = "fused" if info.path == _lib.FXC_PATH_FUSED else "generic"
+        self.path = PATH_NAMES[info.path]
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, rc):

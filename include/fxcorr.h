@@ -44,7 +44,11 @@ enum fxc_status {
 
 enum fxc_mem_kind { FXC_MEM_HOST = 0, FXC_MEM_DEVICE = 1 };
 enum fxc_mode { FXC_MODE_SPECTRUM = 0, FXC_MODE_CONTINUUM = 1 }; /* TEST == CONTINUUM arithmetic */
-enum fxc_path { FXC_PATH_GENERIC = 0, FXC_PATH_FUSED = 1 };
+enum fxc_path {
+    FXC_PATH_GENERIC = 0, /* any shape: FIR / FFT / X kernels through a workspace                          */
+    FXC_PATH_FUSED = 1,   /* nchan 4096, ntaps 4, 2 antennas (one kernel) or 4/6/8 (F-only kernel + X-engine) */
+    FXC_PATH_STREAM = 2   /* nchan 1, 2 antennas: the continuum streaming limit                             */
+};
 
 typedef struct fxc_info {
     int32_t n_ant, n_baselines, nchan, ntaps;

@@ -261,21 +261,26 @@ def test_multi_antenna_fused_path(plan_mod, torch, n_ant):
                                atol=1e-7 * np.abs(cont).max())
 
 
-def test_continuum_streaming_limit_nchan1(plan_mod, torch):
-    """BASELINE config 3(i): nchan = 1, the PFB degenerates to a 4-tap FIR and X to sum y0*conj(y1)."""
-    num_samp = 2 ** 16 + 3
-    x = synth.synth_iq(31, 2, 2, num_samp)
-    h = np.array([0.4, 0.3, 0.2, 0.1])
-    with plan_mod.FxPlan(2, 1, 4, num_samp, window=h) as p:
+@pytest.mark.parametrize("ntaps,num_samp", [(4, 2 ** 16 + 3), (4, 2 ** 16), (3, 4098), (32, 5000), (1, 2048), (4, 100)])
+def test_continuum_streaming_limit_nchan1(plan_mod, torch, ntaps, num_samp):
+    """BASELINE config 3(i): nchan = 1, the PFB degenerates to a T-tap FIR and X to sum y0*conj(y1)."""
+    x = synth.synth_iq(31, 3, 2, num_samp)
+    h = np.linspace(0.4, 0.1, ntaps)
+    with plan_mod.FxPlan(2, 1, ntaps, num_samp, window=h) as p, \
+            plan_mod.FxPlan(2, 1, ntaps, num_samp, window=h, path="generic") as g:
+        assert p.path == "stream" and g.path == "generic"
         cont = p.fx_rows(x, "CONTINUUM", gi.BANDWIDTH)
+        spec = p.fx_rows(torch.from_numpy(x).cuda(), "SPECTRUM").cpu().numpy()
+        cont_g = g.fx_rows(x, "CONTINUUM", gi.BANDWIDTH)
         p.fx_accumulate(x)
         integ = p.finalize("CONTINUUM", gi.BANDWIDTH)
-    for c in range(2):
-        ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, 1, h, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "CONTINUUM")
-        assert abs(cont[c, 0] - ref) < 1e-5 * abs(ref)
-    ref_all = np.mean([fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, 1, h, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "CONTINUUM")
-                       for c in range(2)])
-    assert abs(integ[0] - ref_all) < 1e-5 * abs(ref_all)
+    refs = [fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], ntaps, 1, h, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "CONTINUUM")
+            for c in range(3)]
+    for c in range(3):
+        assert abs(cont[c, 0] - refs[c]) < 1e-5 * abs(refs[c])
+        assert abs(cont_g[c, 0] - refs[c]) < 1e-5 * abs(refs[c])
+        assert abs(spec[c, 0, 0] / gi.BANDWIDTH - refs[c]) < 1e-5 * abs(refs[c])
+    assert abs(integ[0] - np.mean(refs)) < 1e-5 * abs(np.mean(refs))
 
 
 def test_empty_batches_and_errors(plan_mod, torch):
