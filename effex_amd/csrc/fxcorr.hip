@@ -715,6 +715,92 @@ __global__ __launch_bounds__(256) void stream1_acc_kernel(const cf* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// input conditioning: RTL-SDR uint8 IQ -> complex64 and per-chunk DC removal
+//   reference: pyrtlsdr packed-bytes-to-samples (byte - 127.5) / 127.5 [third party], and
+//   effex/effex.py:394-395  x = (x.real - x.real.mean()) + 1j * (x.imag - x.imag.mean())  per chunk, per antenna
+// ------------------------------------------------------------------------------------------
+// sums[stream] = {sum re, sum im} in float64; one workgroup per (stream, slice), fixed-order two-level sum
+__global__ __launch_bounds__(256) void dc_sum_c64_kernel(const cf* __restrict__ x, double* __restrict__ part,
+                                                        int64_t num_samp, int n_slices) {
+    __shared__ double red[256];
+    const int64_t s = blockIdx.y;
+    const int slice = blockIdx.x;
+    const int64_t per = (num_samp + n_slices - 1) / n_slices;
+    const int64_t lo = slice * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
+    double ar = 0.0, ai = 0.0;
+    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+        const cf v = x[s * num_samp + n];
+        ar += v.x;
+        ai += v.y;
+    }
+    ar = block_sum(ar, red);
+    ai = block_sum(ai, red);
+    if (threadIdx.x == 0) {
+        part[(s * n_slices + slice) * 2] = ar;
+        part[(s * n_slices + slice) * 2 + 1] = ai;
+    }
+}
+
+__global__ __launch_bounds__(256) void dc_sum_u8_kernel(const unsigned char* __restrict__ x, double* __restrict__ part,
+                                                       int64_t num_samp, int n_slices) {
+    __shared__ double red[256];
+    const int64_t s = blockIdx.y;
+    const int slice = blockIdx.x;
+    const int64_t per = (num_samp + n_slices - 1) / n_slices;
+    const int64_t lo = slice * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
+    unsigned long long ar = 0, ai = 0;      // byte sums are exact
+    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+        const unsigned short v = reinterpret_cast<const unsigned short*>(x)[s * num_samp + n];
+        ar += v & 0xFF;
+        ai += v >> 8;
+    }
+    const double sr = block_sum((double)ar, red);
+    const double si = block_sum((double)ai, red);
+    if (threadIdx.x == 0) {
+        part[(s * n_slices + slice) * 2] = sr;
+        part[(s * n_slices + slice) * 2 + 1] = si;
+    }
+}
+
+// out = x - mean (complex64 in place or out of place)
+__global__ void dc_apply_c64_kernel(const cf* __restrict__ x, cf* __restrict__ out, const double* __restrict__ part,
+                                    int64_t num_samp, int n_slices, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t s = idx / num_samp;
+        double mr = 0.0, mi = 0.0;
+        for (int k = 0; k < n_slices; ++k) {
+            mr += part[(s * n_slices + k) * 2];
+            mi += part[(s * n_slices + k) * 2 + 1];
+        }
+        const cf v = x[idx];
+        out[idx] = fxc::mk((float)((double)v.x - mr / (double)num_samp), (float)((double)v.y - mi / (double)num_samp));
+    }
+}
+
+// out = (byte - 127.5) / 127.5 [- mean]; remove_dc == 0 keeps the mean
+__global__ void convert_u8_kernel(const unsigned char* __restrict__ x, cf* __restrict__ out, const double* __restrict__ part,
+                                  int64_t num_samp, int n_slices, int64_t total, int remove_dc) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t s = idx / num_samp;
+        double mr = 127.5, mi = 127.5;      // without DC removal only the format offset is subtracted
+        if (remove_dc) {
+            mr = mi = 0.0;
+            for (int k = 0; k < n_slices; ++k) {
+                mr += part[(s * n_slices + k) * 2];
+                mi += part[(s * n_slices + k) * 2 + 1];
+            }
+            mr /= (double)num_samp;
+            mi /= (double)num_samp;
+        }
+        const unsigned short v = reinterpret_cast<const unsigned short*>(x)[idx];
+        // ((b - 127.5) - (mean_b - 127.5)) / 127.5 = (b - mean_b) / 127.5, formed in float64, rounded once
+        out[idx] = fxc::mk((float)(((double)(v & 0xFF) - mr) / 127.5), (float)(((double)(v >> 8) - mi) / 127.5));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // synthetic IQ (effex_amd/synth.py, bit for bit)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -1519,6 +1605,50 @@ int fxc_finalize(fxc_plan* p, void* out_host, int mode, double bandwidth, int re
     rc = fxc_finalize_sums(p, p->d_sums, out_host, mode, bandwidth);
     if (rc) return rc;
     if (reset) return fxc_acc_reset(p);
+    return FXC_OK;
+}
+
+static int conditioning_common(fxc_plan* p, int64_t n_streams, const void* x, void* out) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    if (n_streams < 0) return fail(p, FXC_ERR_ARG, "n_streams < 0");
+    if (n_streams > 65535) return fail(p, FXC_ERR_ARG, "at most 65535 streams per call");
+    if (n_streams > 0 && (!x || !out)) return fail(p, FXC_ERR_ARG, "NULL buffer");
+    return FXC_OK;
+}
+
+int fxc_remove_dc(fxc_plan* p, const void* x_dev, void* out_dev, int64_t n_streams) {
+    int rc = conditioning_common(p, n_streams, x_dev, out_dev);
+    if (rc || n_streams == 0) return rc;
+    FXC_HIP(p, hipSetDevice(p->device));
+    const int n_slices = 32;
+    rc = ensure_ws(p, n_streams * n_slices * 2 * (int64_t)sizeof(double));
+    if (rc) return rc;
+    double* part = static_cast<double*>(p->d_ws);
+    const int64_t total = n_streams * p->num_samp;
+    hipLaunchKernelGGL(dc_sum_c64_kernel, dim3(n_slices, (unsigned)n_streams), dim3(256), 0, p->stream,
+                       static_cast<const cf*>(x_dev), part, p->num_samp, n_slices);
+    hipLaunchKernelGGL(dc_apply_c64_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream,
+                       static_cast<const cf*>(x_dev), static_cast<cf*>(out_dev), part, p->num_samp, n_slices, total);
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+int fxc_convert_u8(fxc_plan* p, const void* iq_u8_dev, void* out_dev, int64_t n_streams, int remove_dc) {
+    int rc = conditioning_common(p, n_streams, iq_u8_dev, out_dev);
+    if (rc || n_streams == 0) return rc;
+    FXC_HIP(p, hipSetDevice(p->device));
+    const int n_slices = 32;
+    rc = ensure_ws(p, n_streams * n_slices * 2 * (int64_t)sizeof(double));
+    if (rc) return rc;
+    double* part = static_cast<double*>(p->d_ws);
+    const int64_t total = n_streams * p->num_samp;
+    if (remove_dc)
+        hipLaunchKernelGGL(dc_sum_u8_kernel, dim3(n_slices, (unsigned)n_streams), dim3(256), 0, p->stream,
+                           static_cast<const unsigned char*>(iq_u8_dev), part, p->num_samp, n_slices);
+    hipLaunchKernelGGL(convert_u8_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream,
+                       static_cast<const unsigned char*>(iq_u8_dev), static_cast<cf*>(out_dev), part, p->num_samp,
+                       n_slices, total, remove_dc ? 1 : 0);
+    FXC_HIP(p, hipGetLastError());
     return FXC_OK;
 }
 

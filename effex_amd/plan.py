@@ -198,6 +198,28 @@ class FxPlan(object):
     def sync(self):
         self._check(self._lib.fxc_sync(self._h))
 
+    # -- input conditioning (device resident) -----------------------------------------------
+    def remove_dc(self, x, out=None):
+        """Per-stream DC removal (effex.py:394-395) of a CUDA complex64 tensor [..., num_samp]; in place
+        unless ``out`` is given."""
+        import torch
+        if x.dtype != torch.complex64 or not x.is_cuda or not x.is_contiguous() or x.shape[-1] != self.num_samp:
+            raise ValueError("x must be a contiguous CUDA complex64 tensor [..., num_samp]")
+        out = x if out is None else out
+        self._check(self._lib.fxc_remove_dc(self._h, x.data_ptr(), out.data_ptr(), x.numel() // self.num_samp))
+        return out
+
+    def convert_u8(self, iq_u8, remove_dc=True):
+        """RTL-SDR interleaved uint8 I,Q [..., num_samp, 2] (CUDA) -> complex64 [..., num_samp]."""
+        import torch
+        if iq_u8.dtype != torch.uint8 or not iq_u8.is_cuda or not iq_u8.is_contiguous() \
+                or tuple(iq_u8.shape[-2:]) != (self.num_samp, 2):
+            raise ValueError("iq_u8 must be a contiguous CUDA uint8 tensor [..., num_samp, 2]")
+        out = torch.empty(iq_u8.shape[:-1], dtype=torch.complex64, device=iq_u8.device)
+        self._check(self._lib.fxc_convert_u8(self._h, iq_u8.data_ptr(), out.data_ptr(), out.numel() // self.num_samp,
+                                             int(bool(remove_dc))))
+        return out
+
     # -- measurement ------------------------------------------------------------------------
     def timer_start(self):
         self._check(self._lib.fxc_timer_start(self._h))

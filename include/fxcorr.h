@@ -116,6 +116,16 @@ int fxc_finalize(fxc_plan* plan, void* out_host, int mode, double bandwidth, int
 
 int fxc_sync(fxc_plan* plan);
 
+/* Input conditioning, device resident (both are steps the reference runs on the host
+ * just before the path).  Streams are [n_streams][num_samp] with the plan's num_samp; n_streams <= 65535.
+ *   fxc_remove_dc : out = x - mean(x) per stream, real and imaginary parts separately — effex.py:394-395
+ *                   (complex64 in, complex64 out; out may alias x; means formed in float64).
+ *   fxc_convert_u8: RTL-SDR interleaved unsigned 8-bit I,Q -> complex64 (byte - 127.5) / 127.5, what
+ *                   pyrtlsdr does for sdr.stream(format='samples') (effex.py:652); with remove_dc != 0 the
+ *                   per-stream mean is removed in the same pass from exact integer byte sums. */
+int fxc_remove_dc(fxc_plan* plan, const void* x_dev, void* out_dev, int64_t n_streams);
+int fxc_convert_u8(fxc_plan* plan, const void* iq_u8_dev, void* out_dev, int64_t n_streams, int remove_dc);
+
 /* Measurement hooks (bench.py): HIP events on the plan's stream.  fxc_timer_* bracket a region;
  * with kernel profiling on, every launch of the dominant kernel is bracketed by its own event
  * pair and fxc_kernel_time returns the summed duration and launch count since the last reset. */

@@ -154,6 +154,21 @@ def fx_integrate(x, nbins, window, rot=None, dtype=np.complex128):
 
 
 # --------------------------------------------------------------------------------------------
+# Input conditioning — effex/effex.py:394-395 and pyrtlsdr's byte -> sample conversion (effex.py:652)
+# --------------------------------------------------------------------------------------------
+def remove_dc(x):
+    """effex.py:394-395 — subtract the mean of the real and of the imaginary part (per chunk)."""
+    x = np.asarray(x)
+    return (x.real - x.real.mean()) + 1j * (x.imag - x.imag.mean())
+
+
+def u8_to_complex(iq_u8):
+    """pyrtlsdr ``packed_bytes_to_iq`` [third party, recollection]: interleaved uint8 I,Q -> complex128."""
+    b = np.asarray(iq_u8, dtype=np.float64)
+    return (b[..., 0] - 127.5) / 127.5 + 1j * (b[..., 1] - 127.5) / 127.5
+
+
+# --------------------------------------------------------------------------------------------
 # Output format — effex/effex.py:667-696 (consumers: effex.py:798, post_process.py:201-219)
 # --------------------------------------------------------------------------------------------
 def metadata_header(run_time, bandwidth, frequency, num_samp, nbins, gain, mode):

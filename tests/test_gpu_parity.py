@@ -339,6 +339,36 @@ def test_sharded_integration_equals_single_rank(plan_mod, torch):
     assert rel_err(out, ref) < 1e-12
 
 
+def test_input_conditioning_on_device(plan_mod, torch):
+    """SURVEY.md §8f #1: uint8 ingestion and per-chunk DC removal (effex.py:394-395) without leaving HBM."""
+    num_samp, n_chunks = 10007, 3
+    rng = np.random.default_rng(12)
+    u8 = rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)
+    u8[0, 0, :, 0] = np.clip(u8[0, 0, :, 0].astype(int) // 2 + 100, 0, 255)      # a stream with a strong DC offset
+    ud = torch.from_numpy(u8).cuda()
+    with plan_mod.FxPlan(2, 256, 4, num_samp) as p:
+        plain = p.convert_u8(ud, remove_dc=False).cpu().numpy()
+        ref_plain = fx_oracle.u8_to_complex(u8)
+        assert plain.shape == (n_chunks, 2, num_samp)
+        np.testing.assert_allclose(plain, ref_plain, rtol=0, atol=6e-8)
+        nodc = p.convert_u8(ud, remove_dc=True).cpu().numpy()
+        x = torch.from_numpy(ref_plain.astype(np.complex64)).cuda()
+        nodc2 = p.remove_dc(x.clone()).cpu().numpy()
+        for c in range(n_chunks):
+            for a in range(2):
+                ref = fx_oracle.remove_dc(ref_plain[c, a])
+                np.testing.assert_allclose(nodc[c, a], ref, rtol=0, atol=1e-7)
+                np.testing.assert_allclose(nodc2[c, a], fx_oracle.remove_dc(ref_plain[c, a].astype(np.complex64)),
+                                           rtol=0, atol=1.5e-7)
+                assert abs(nodc[c, a].mean()) < 1e-7
+        # conditioned input straight into the path
+        rows = p.fx_rows(p.convert_u8(ud, remove_dc=True)).cpu().numpy()
+        window = design_window(4, 256)
+        ref0 = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(ref_plain[0, 0]), fx_oracle.remove_dc(ref_plain[0, 1]), 4, 256,
+                                   window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+        assert rel_err(rows[0, 0], ref0) < TOL_VIS
+
+
 def test_device_synth_is_bit_identical(plan_mod, torch):
     n_chunks, n_ant, num_samp = 3, 3, 5000
     x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")
