@@ -59,6 +59,7 @@ SIGNATURES = {
     "fxc_sync": (_c.c_int, [_vp]),
     "fxc_remove_dc": (_c.c_int, [_vp, _vp, _vp, _c.c_int64]),
     "fxc_convert_u8": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int]),
+    "fxc_estimate_delay": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_double, _c.POINTER(_c.c_double)]),
     "fxc_timer_start": (_c.c_int, [_vp]),
     "fxc_timer_stop": (_c.c_int, [_vp, _c.POINTER(_c.c_double)]),
     "fxc_kernel_profiling": (_c.c_int, [_vp, _c.c_int]),

@@ -97,13 +97,14 @@ class Correlator(object):
 
     def __init__(self, run_time=1, bandwidth=2.4e6, frequency=1.4204e9, num_samp=2 ** 18, nbins=2 ** 12,
                  gain=49.6, mode='SPECTRUM', loglevel='INFO',
-                 source=None, device=0, max_num_samp=None, output_file=None, remove_dc=True):
+                 source=None, device=0, max_num_samp=None, output_file=None, remove_dc=True, calibrate=True):
         self.logger = logging.getLogger(__name__)
         self.logger.setLevel(getattr(logging, loglevel))
         self._max_num_samp = int(max_num_samp) if max_num_samp else Correlator._MAX_NUM_SAMP
         self.source = source if source is not None else SyntheticSource()
         self.device = device
         self.remove_dc = remove_dc
+        self.calibrate = calibrate      # the reference always calibrates on the first chunk pair (effex.py:353,399-401)
         self._fx_plan = None
         self._f_plans = {}
         self._rot_key = None
@@ -285,6 +286,25 @@ class Correlator(object):
         """effex.py:490-494."""
         return self._pfb_xcorr()
 
+    # -- delay calibration (effex.py:476-487, 558-627) --------------------------------------
+    def _estimate_delay_gaussian(self, iq_0, iq_1, rate):
+        """effex.py:583-627 — sub-sample delay between the channels in seconds (FFT cross-correlation,
+        arg-max, 3-point log-Gaussian peak), computed on the device."""
+        assert len(iq_0) == len(iq_1), ('Algorithm assumes input complex timeseries are of equal length.')
+        return self._plan().estimate_delay(iq_0, iq_1, rate)
+
+    def _estimate_delay(self, iq_0, iq_1, rate):
+        """effex.py:558-580."""
+        total_delay = self._estimate_delay_gaussian(iq_0, iq_1, rate)
+        if self.mode in ['TEST']:
+            total_delay -= self.test_delay_offset
+        return total_delay
+
+    def _calibrate_task(self):
+        """effex.py:476-487 — estimate and store the delay from the chunk pair currently staged."""
+        self.calibrated_delay = self._estimate_delay(self.gpu_iq_0, self.gpu_iq_1, self.bandwidth)
+        self.logger.info('Estimated delay (us): {}'.format(1e6 * self.calibrated_delay))
+
     def integrate(self, chunks):
         """Build extension: integrate a whole batch [n_chunks, 2, num_samp] (CUDA tensor
         or host array) into one visibility spectrum / scalar — same definition as averaging the
@@ -319,7 +339,8 @@ class Correlator(object):
             self.gpu_iq_1 = (self.gpu_iq_1.real - self.gpu_iq_1.real.mean()) + 1j * (self.gpu_iq_1.imag - self.gpu_iq_1.imag.mean())
 
     def run_state_machine(self):
-        """OFF -> STARTUP -> RUN ... -> SHUTDOWN -> OFF over the source's chunk pairs; one csv row each."""
+        """OFF -> STARTUP -> CALIBRATE -> RUN ... -> SHUTDOWN -> OFF over the source's chunk pairs; the first
+        pair calibrates the delay (unless ``calibrate=False``), every further pair writes one csv row."""
         rows = 0
         fh = None
         try:
@@ -330,13 +351,17 @@ class Correlator(object):
                     self._write_metadata()
                     fh = open(self.output_file, 'a')
                     self.start_time = time.time()
-                    self.state = 'RUN'
-                elif 'RUN' == self.state:
+                    self.state = 'CALIBRATE' if self.calibrate else 'RUN'
+                elif self.state in ('CALIBRATE', 'RUN'):
                     pair = self.source.read(int(self.num_samp))
                     if pair is None:
                         self.state = 'SHUTDOWN'
                         continue
                     self._stage(pair)
+                    if 'CALIBRATE' == self.state:      # consumes a chunk pair, writes no row (effex.py:399-401)
+                        self._calibrate_task()
+                        self.state = 'RUN'
+                        continue
                     if self.mode in ['TEST']:
                         self.calibrated_delay += self.test_delay_sweep_step      # effex.py:403-404
                     self._write_row(fh, self._run_task())

@@ -801,6 +801,74 @@ __global__ void convert_u8_kernel(const unsigned char* __restrict__ x, cf* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// delay calibration — effex/effex.py:583-627: zero-padded FFT cross-correlation,
+// arg-max of |xcorr|, 3-point log-Gaussian peak.  Runs once per calibration, so the FFT is a plain
+// global-memory radix-2 Stockham (log2 L passes); the linear correlation is the same for any padded
+// length L >= 2n, so L is the next power of two and lags are re-indexed to the reference's 2n layout.
+// ------------------------------------------------------------------------------------------
+__global__ void delay_pad_kernel(const cf* __restrict__ x, cf* __restrict__ out, int64_t n, int64_t len) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < len; idx += stride)
+        out[idx] = idx < n ? x[idx] : fxc::mk(0.f, 0.f);
+}
+
+// one radix-2 Stockham stage: natural order in, natural order out after log2(len) stages
+__global__ void stockham_stage_kernel(const cf* __restrict__ in, cf* __restrict__ out, int64_t half_len, int64_t p,
+                                      double sign) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < half_len; j += stride) {
+        const int64_t k = j & (p - 1);
+        double sn, cs;
+        sincospi(sign * (double)k / (double)p, &sn, &cs);
+        const cf u0 = in[j], u1 = in[j + half_len];
+        const float tr = (float)((double)u1.x * cs - (double)u1.y * sn);
+        const float ti = (float)((double)u1.x * sn + (double)u1.y * cs);
+        const int64_t jj = ((j - k) << 1) + k;
+        out[jj] = fxc::mk(u0.x + tr, u0.y + ti);
+        out[jj + p] = fxc::mk(u0.x - tr, u0.y - ti);
+    }
+}
+
+__global__ void mul_conj_kernel(cf* __restrict__ a, const cf* __restrict__ b, int64_t len) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < len; idx += stride)
+        a[idx] = fxc::cmulc(a[idx], b[idx]);
+}
+
+// arg-max of |r| over the reference's index i = 0..2n-1 (lag i - n, stored at (i - n) mod len); first maximum
+// wins like numpy.argmax.  best[0] = packed (|r|^2 as ordered bits << 32 | ~i) maximised with atomicMax.
+__global__ void delay_argmax_kernel(const cf* __restrict__ r, unsigned long long* __restrict__ best, int64_t n,
+                                    int64_t len) {
+    unsigned long long loc = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += stride) {
+        const int64_t pos = (i - n + len) & (len - 1);
+        const cf v = r[pos];
+        const float m = v.x * v.x + v.y * v.y;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (0xFFFFFFFFull - (unsigned)i);
+        loc = key > loc ? key : loc;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(loc, off);
+        loc = o > loc ? o : loc;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(best, loc);
+}
+
+// out3 = r at reference indices imax-1 (python wrap for -1), imax, imax+1
+__global__ void delay_fetch_kernel(const cf* __restrict__ r, const unsigned long long* __restrict__ best,
+                                   cf* __restrict__ out3, int64_t n, int64_t len) {
+    const int64_t imax = (int64_t)(0xFFFFFFFFull - (best[0] & 0xFFFFFFFFull));
+    const int d = threadIdx.x;
+    if (d < 3) {
+        int64_t i = imax - 1 + d;
+        if (i < 0) i += 2 * n;
+        if (i >= 2 * n) i = imax;   // flagged on the host (the reference raises IndexError there)
+        out3[d] = r[(i - n + len) & (len - 1)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // synthetic IQ (effex_amd/synth.py, bit for bit)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -1649,6 +1717,71 @@ int fxc_convert_u8(fxc_plan* p, const void* iq_u8_dev, void* out_dev, int64_t n_
                        static_cast<const unsigned char*>(iq_u8_dev), static_cast<cf*>(out_dev), part, p->num_samp,
                        n_slices, total, remove_dc ? 1 : 0);
     FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+int fxc_estimate_delay(fxc_plan* p, const void* iq0, const void* iq1, int64_t n, int mem_kind, double rate,
+                       double* delay_s) {
+    if (!p || !iq0 || !iq1 || !delay_s) return fail(p, FXC_ERR_ARG, "NULL argument");
+    if (n < 2 || n > (1ll << 28)) return fail(p, FXC_ERR_ARG, "n=%lld out of range", (long long)n);
+    if (!(rate > 0.0)) return fail(p, FXC_ERR_ARG, "rate must be > 0");
+    if (mem_kind != FXC_MEM_HOST && mem_kind != FXC_MEM_DEVICE) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
+    FXC_HIP(p, hipSetDevice(p->device));
+    int lg = 1;
+    while ((1ll << lg) < 2 * n) ++lg;
+    const int64_t len = 1ll << lg;
+    // workspace: 4 transform buffers + staging for host inputs + result words
+    const int64_t buf_bytes = len * (int64_t)sizeof(cf);
+    const int64_t stage_bytes = mem_kind == FXC_MEM_HOST ? 2 * n * (int64_t)sizeof(cf) : 0;
+    int rc = ensure_ws(p, 4 * buf_bytes + stage_bytes + 256);
+    if (rc) return rc;
+    char* ws = static_cast<char*>(p->d_ws);
+    cf* a[2] = {reinterpret_cast<cf*>(ws), reinterpret_cast<cf*>(ws + buf_bytes)};
+    cf* b[2] = {reinterpret_cast<cf*>(ws + 2 * buf_bytes), reinterpret_cast<cf*>(ws + 3 * buf_bytes)};
+    const cf *x0 = static_cast<const cf*>(iq0), *x1 = static_cast<const cf*>(iq1);
+    if (mem_kind == FXC_MEM_HOST) {
+        cf* st = reinterpret_cast<cf*>(ws + 4 * buf_bytes);
+        FXC_HIP(p, hipMemcpyAsync(st, iq0, (size_t)n * sizeof(cf), hipMemcpyHostToDevice, p->stream));
+        FXC_HIP(p, hipMemcpyAsync(st + n, iq1, (size_t)n * sizeof(cf), hipMemcpyHostToDevice, p->stream));
+        x0 = st;
+        x1 = st + n;
+    }
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + 4 * buf_bytes + stage_bytes);
+    cf* out3 = reinterpret_cast<cf*>(ws + 4 * buf_bytes + stage_bytes + 16);
+    const int g_len = grid_for(len, 256, p->cu_count), g_half = grid_for(len / 2, 256, p->cu_count);
+    hipLaunchKernelGGL(delay_pad_kernel, dim3(g_len), dim3(256), 0, p->stream, x0, a[0], n, len);
+    hipLaunchKernelGGL(delay_pad_kernel, dim3(g_len), dim3(256), 0, p->stream, x1, b[0], n, len);
+    int cur = 0;
+    for (int s = 0; s < lg; ++s, cur ^= 1) {   // forward transforms, kernel exp(-2 pi i ...) like cp.fft.fft
+        hipLaunchKernelGGL(stockham_stage_kernel, dim3(g_half), dim3(256), 0, p->stream, a[cur], a[cur ^ 1], len / 2,
+                           1ll << s, -1.0);
+        hipLaunchKernelGGL(stockham_stage_kernel, dim3(g_half), dim3(256), 0, p->stream, b[cur], b[cur ^ 1], len / 2,
+                           1ll << s, -1.0);
+    }
+    hipLaunchKernelGGL(mul_conj_kernel, dim3(g_len), dim3(256), 0, p->stream, a[cur], b[cur], len);   // f0 * conj(f1)
+    for (int s = 0; s < lg; ++s, cur ^= 1)     // inverse transform (un-normalised: the peak fit is scale free)
+        hipLaunchKernelGGL(stockham_stage_kernel, dim3(g_half), dim3(256), 0, p->stream, a[cur], a[cur ^ 1], len / 2,
+                           1ll << s, 1.0);
+    FXC_HIP(p, hipMemsetAsync(best, 0, 8, p->stream));
+    hipLaunchKernelGGL(delay_argmax_kernel, dim3(grid_for(2 * n, 256, p->cu_count)), dim3(256), 0, p->stream, a[cur], best,
+                       n, len);
+    hipLaunchKernelGGL(delay_fetch_kernel, dim3(1), dim3(64), 0, p->stream, a[cur], best, out3, n, len);
+    FXC_HIP(p, hipGetLastError());
+    unsigned long long h_best = 0;
+    cf h3[3];
+    FXC_HIP(p, hipMemcpyAsync(&h_best, best, 8, hipMemcpyDeviceToHost, p->stream));
+    FXC_HIP(p, hipMemcpyAsync(h3, out3, sizeof h3, hipMemcpyDeviceToHost, p->stream));
+    FXC_HIP(p, hipStreamSynchronize(p->stream));
+    const int64_t imax = (int64_t)(0xFFFFFFFFull - (h_best & 0xFFFFFFFFull));
+    if (imax + 1 >= 2 * n)
+        return fail(p, FXC_ERR_STATE, "correlation peak at the last lag (the reference raises IndexError here)");
+    // effex.py:619-625
+    const double xprev = std::hypot((double)h3[0].x, (double)h3[0].y);
+    const double xbest = std::hypot((double)h3[1].x, (double)h3[1].y);
+    const double xnext = std::hypot((double)h3[2].x, (double)h3[2].y);
+    const double delta = 0.5 * (std::log(xprev) - std::log(xnext)) /
+                         (std::log(xprev) - 2.0 * std::log(xbest) + std::log(xnext));
+    *delay_s = ((double)n - ((double)imax + delta)) / rate;
     return FXC_OK;
 }
 

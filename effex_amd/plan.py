@@ -220,6 +220,23 @@ class FxPlan(object):
                                              int(bool(remove_dc))))
         return out
 
+    # -- delay calibration ------------------------------------------------------------------
+    def estimate_delay(self, iq_0, iq_1, rate):
+        """Sub-sample delay between two equal-length streams in seconds (effex.py:583-627)."""
+        if len(iq_0) != len(iq_1):
+            raise AssertionError('Algorithm assumes input complex timeseries are of equal length.')
+        n = int(len(iq_0))
+        if _is_torch(iq_0):
+            a, b, kind = iq_0.contiguous(), iq_1.contiguous(), _lib.FXC_MEM_DEVICE
+            pa, pb = a.data_ptr(), b.data_ptr()
+        else:
+            a = np.ascontiguousarray(iq_0, dtype=np.complex64)
+            b = np.ascontiguousarray(iq_1, dtype=np.complex64)
+            kind, pa, pb = _lib.FXC_MEM_HOST, a.ctypes.data, b.ctypes.data
+        out = ctypes.c_double()
+        self._check(self._lib.fxc_estimate_delay(self._h, pa, pb, n, kind, float(rate), ctypes.byref(out)))
+        return out.value
+
     # -- measurement ------------------------------------------------------------------------
     def timer_start(self):
         self._check(self._lib.fxc_timer_start(self._h))

@@ -126,6 +126,13 @@ int fxc_sync(fxc_plan* plan);
 int fxc_remove_dc(fxc_plan* plan, const void* x_dev, void* out_dev, int64_t n_streams);
 int fxc_convert_u8(fxc_plan* plan, const void* iq_u8_dev, void* out_dev, int64_t n_streams, int remove_dc);
 
+/* Delay calibration — replaces Correlator._estimate_delay_gaussian, effex.py:583-627:
+ * zero-pad both streams, FFT, f0*conj(f1), inverse FFT, arg-max of |xcorr|, 3-point log-Gaussian peak;
+ * *delay_s = (n - (imax + delta)) / rate.  iq0, iq1: n complex64 samples each (host or device), any n.
+ * Uses the plan's device, stream and workspace; synchronises. */
+int fxc_estimate_delay(fxc_plan* plan, const void* iq0, const void* iq1, int64_t n, int mem_kind, double rate,
+                       double* delay_s);
+
 /* Measurement hooks (bench.py): HIP events on the plan's stream.  fxc_timer_* bracket a region;
  * with kernel profiling on, every launch of the dominant kernel is bracketed by its own event
  * pair and fxc_kernel_time returns the summed duration and launch count since the last reset. */

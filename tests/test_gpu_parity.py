@@ -161,27 +161,60 @@ def test_small_multichunk_rows(plan_mod, torch, golden):
         assert rel_err(integ[0], arrays["small_rows"].mean(axis=0)) < TOL_VIS
 
 
-def test_state_machine_writes_reference_csv(tmp_path, torch, golden):
-    """End to end: source -> staging (DC removal) -> HIP path -> csv readable by the reference's reader."""
+def _dc(x):
+    x = x.astype(np.complex128)
+    return ((x.real - x.real.mean()) + 1j * (x.imag - x.imag.mean())).astype(np.complex64)      # effex.py:394-395
+
+
+@pytest.mark.parametrize("calibrate", [True, False])
+def test_state_machine_writes_reference_csv(tmp_path, torch, golden, calibrate):
+    """End to end: source -> staging (DC removal) -> [calibration] -> HIP path -> csv the reference's reader loads."""
     from effex_amd.correlator import ArraySource, Correlator
     x = gi.small_input()
     path = str(tmp_path / "vis.csv")
-    cor = Correlator(num_samp=gi.SMALL_S, nbins=gi.SMALL_N, source=ArraySource(x), output_file=path)
-    assert cor.run_state_machine() == gi.SMALL_CHUNKS
+    cor = Correlator(num_samp=gi.SMALL_S, nbins=gi.SMALL_N, source=ArraySource(x), output_file=path,
+                     calibrate=calibrate)
+    first = 1 if calibrate else 0            # the reference's CALIBRATE state consumes the first chunk pair
+    assert cor.run_state_machine() == gi.SMALL_CHUNKS - first
     assert cor.state == 'OFF'
     lines = open(path).read().split('\n')
     assert lines[0] == fx_oracle.metadata_header(1, 2.4e6, 1.4204e9, gi.SMALL_S, gi.SMALL_N, 49.6, 'SPECTRUM').strip()
     data = np.loadtxt(path, dtype=np.complex128, delimiter=',', skiprows=2)      # post_process.py:219
-    assert data.shape == (gi.SMALL_CHUNKS, gi.SMALL_N)
+    assert data.shape == (gi.SMALL_CHUNKS - first, gi.SMALL_N)
+    delay = 0.0
+    if calibrate:
+        delay = fx_oracle.estimate_delay_gaussian(_dc(x[0, 0]), _dc(x[0, 1]), 2.4e6)
+        assert abs(cor.calibrated_delay - delay) * 2.4e6 < 2e-3                  # samples
+        assert abs(delay * 2.4e6 - 3) < 0.5          # the synthetic source delays antenna 1 by 3 samples (roll +3)
+        delay = cor.calibrated_delay
     window = design_window(4, gi.SMALL_N)
-    for c in range(gi.SMALL_CHUNKS):
-        a = x[c, 0].astype(np.complex128)
-        b = x[c, 1].astype(np.complex128)
-        a = (a.real - a.real.mean()) + 1j * (a.imag - a.imag.mean())            # effex.py:394-395
-        b = (b.real - b.real.mean()) + 1j * (b.imag - b.imag.mean())
-        ref = fx_oracle.pfb_xcorr(a.astype(np.complex64), b.astype(np.complex64), 4, gi.SMALL_N, window, 2.4e6,
-                                  1.4204e9, 0, 'SPECTRUM')
-        assert rel_err(data[c], ref) < TOL_VIS
+    for c in range(first, gi.SMALL_CHUNKS):
+        ref = fx_oracle.pfb_xcorr(_dc(x[c, 0]), _dc(x[c, 1]), 4, gi.SMALL_N, window, 2.4e6, 1.4204e9, delay, 'SPECTRUM')
+        assert rel_err(data[c - first], ref) < TOL_VIS
+
+
+def test_delay_calibration_against_reference(plan_mod, torch, golden):
+    """The reference's delay tests (tests/test_effex.py:92-121): 14 cases, |k - est*rate| < 0.5 sample and
+    |k/rate - est| < 1e-6 s, plus agreement with the reference's own estimate (golden)."""
+    from effex_amd.correlator import Correlator, SyntheticSource
+    meta, _ = golden
+    cor = Correlator(source=SyntheticSource())
+    try:
+        for g in meta["delay"]:
+            iq_0 = gi.noise_iq(g["num_samp"])
+            iq_1 = np.roll(iq_0, g["offset"])
+            est = cor._estimate_delay_gaussian(iq_0, iq_1, gi.DELAY_RATE)
+            assert abs(g["offset"] - est * gi.DELAY_RATE) < 0.5
+            assert abs(est - g["est"]) * gi.DELAY_RATE < 2e-3, g
+            est2 = cor._estimate_delay(torch.from_numpy(iq_0.astype(np.complex64)).cuda(),
+                                       torch.from_numpy(iq_1.astype(np.complex64)).cuda(), gi.DELAY_RATE)
+            assert abs(g["offset"] / gi.DELAY_RATE - est2) < 1e-6
+        cor.mode = 'TEST'
+        iq_0 = gi.noise_iq(4099)
+        est = cor._estimate_delay(iq_0, np.roll(iq_0, 5), gi.DELAY_RATE)
+        assert abs(est - (5 / gi.DELAY_RATE - cor.test_delay_offset)) < 1e-6
+    finally:
+        cor.close()
 
 
 # --------------------------------------------------------------------------------------------
