@@ -386,10 +386,11 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // vdst keeps its low half and receives src's low half in its high half; src gets the two high halves
-__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
+__device__ __forceinline__ void permlane32_swap(cf& a, cf& b) {
+    auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = fxc::mk(__uint_as_float(rx[0]), __uint_as_float(ry[0]));
+    b = fxc::mk(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
 }
 
 // this thread's 16 branch samples of frame i: element (255 - j) + 256 (15 - r); loads r = R0 .. R0+CNT-1.
@@ -522,8 +523,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             cf a = v[q], b = v[q + 8];
-            permlane32_swap(a.x, b.x);
-            permlane32_swap(a.y, b.y);
+            permlane32_swap(a, b);
             xacc(s, q, a, b);
         }
         FXC_STAMP(10);
