@@ -60,7 +60,8 @@ struct State {
     // ring of four frames of this thread's 16 branch samples: slot PH holds the frame being
     // channelised, the other three the PFB history (and, once dead, the prefetch of the next frame)
     cf h[4][16];
-    cf tw1a[3], tw1b[3];         // w4096^(j*a), a = 1..3 and w4096^(j*4b), b = 1..3: w^(j*k1) for k1 = a + 4b
+    cf tw1[16];                  // w4096^(j*k1), k1 = 1..15 ([0] unused): the kernel is VALU-issue bound, so 15
+                                 // twiddles in 30 VGPRs beat 6 stored powers + 9 extra complex multiplies
     cf acc[kAccPerThread];       // sum_i spec0*conj(spec1) for this lane's 8 bins
 };
 
@@ -116,27 +117,23 @@ FXC_HD void phase1_fir(const State& s, const f4* win, int tid, cf (&v)[16]) {
     }
 }
 
-// phase 1b: twiddle w4096^(j*k1) as a product of two stored powers (12 twiddle VGPRs instead of 30), fused
-// per k1 with the exchange-1 store so the stores trickle out between the multiplies instead of a burst
+// phase 1b: twiddle w4096^(j*k1) fused per k1 with the exchange-1 store, so the stores trickle out between
+// the multiplies instead of a burst of sixteen after them
 FXC_HD void phase1_twiddle_store(const State& s, cf (&v)[16], cf* region, int tid) {
     cf* mine = region + (tid >> 8) * kRegion + (tid & 255);
     mine[0] = v[0];
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
-        if (k1 & 3) v[k1] = cmul(v[k1], s.tw1a[(k1 & 3) - 1]);
-        if (k1 >> 2) v[k1] = cmul(v[k1], s.tw1b[(k1 >> 2) - 1]);
+        v[k1] = cmul(v[k1], s.tw1[k1]);
         mine[k1 * kRowPitch] = v[k1];
     }
 }
 
-// load this thread's stored twiddle powers from the [16][256] table w4096^(j*k1)
+// load this thread's twiddles from the [16][256] table w4096^(j*k1)
 FXC_HD void state_load_twiddles(State& s, const cf* tw1_table, int tid) {
     const int j = tid & 255;
 #pragma unroll
-    for (int a = 1; a < 4; ++a) {
-        s.tw1a[a - 1] = tw1_table[a * 256 + j];
-        s.tw1b[a - 1] = tw1_table[4 * a * 256 + j];
-    }
+    for (int k1 = 0; k1 < 16; ++k1) s.tw1[k1] = tw1_table[k1 * 256 + j];
 }
 
 // this lane's row for phases 2 and 3
