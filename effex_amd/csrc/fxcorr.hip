@@ -29,7 +29,7 @@ namespace {
 constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 channeliser kernels only
 constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
-constexpr int64_t kWorkspaceTarget = 1ll << 30;
+constexpr int64_t kWorkspaceTarget = 8ll << 30;   // upper bound of the lazily grown workspace (288 GB of HBM per GPU)
 
 // ------------------------------------------------------------------------------------------
 // generic path kernels (any ntaps <= 32, any n_ant, any nchan <= 16384)
@@ -301,7 +301,27 @@ __global__ __launch_bounds__(256) void xengine4096_kernel(const cf* __restrict__
 #pragma unroll
     for (int p = 0; p < NB; ++p) ar[p] = ai[p] = 0.f;
     const cf* base = spec + (c * A * n_pts) * fxc::fused::kN + pos;
-    for (int64_t i = 0; i < n_pts; ++i) {
+    // two spectra per trip: 2A independent 8-byte loads in flight before the A(A-1) multiply-accumulates
+    int64_t i = 0;
+    for (; i + 1 < n_pts; i += 2) {
+        cf z0[A], z1[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            z0[a] = base[((int64_t)a * n_pts + i) * fxc::fused::kN];
+            z1[a] = base[((int64_t)a * n_pts + i + 1) * fxc::fused::kN];
+        }
+        int p = 0;
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int b = a + 1; b < A; ++b, ++p) {
+                ar[p] += z0[a].x * z0[b].x + z0[a].y * z0[b].y;
+                ai[p] += z0[a].y * z0[b].x - z0[a].x * z0[b].y;
+                ar[p] += z1[a].x * z1[b].x + z1[a].y * z1[b].y;
+                ai[p] += z1[a].y * z1[b].x - z1[a].x * z1[b].y;
+            }
+    }
+    for (; i < n_pts; ++i) {
         cf z[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * n_pts + i) * fxc::fused::kN];

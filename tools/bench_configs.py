@@ -65,7 +65,7 @@ def main():
     report("configs[2](ii) continuum, reference semantics N=4096, S=2^20", 2, 4096, 4, 2 ** 20, 1024, "CONTINUUM", rows=True)
     report("configs[2](i) continuum streaming limit nchan=1, S=2^20", 2, 1, 4, 2 ** 20, 256, "CONTINUUM",
            window=np.array([0.4, 0.3, 0.2, 0.1]), rows=True)
-    report("configs[4] 8 antennas, 28 baselines, N=4096", 8, 4096, 4, 2 ** 18, 128, "SPECTRUM")
+    report("configs[4] 8 antennas, 28 baselines, N=4096", 8, 4096, 4, 2 ** 18, 256, "SPECTRUM")
     report("N=2048 T=32 (reference test shape), 2 antennas", 2, 2048, 32, 2 ** 18, 256, "SPECTRUM")
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "configs.json"), "w") as fh:
         json.dump(out, fh, indent=1)
