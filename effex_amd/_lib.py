@@ -60,6 +60,13 @@ SIGNATURES = {
     "fxc_remove_dc": (_c.c_int, [_vp, _vp, _vp, _c.c_int64]),
     "fxc_convert_u8": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int]),
     "fxc_estimate_delay": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_double, _c.POINTER(_c.c_double)]),
+    "fxc_pipe_create": (_c.c_int, [_c.POINTER(_vp), _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double]),
+    "fxc_pipe_acquire": (_c.c_int, [_vp, _c.POINTER(_vp)]),
+    "fxc_pipe_submit": (_c.c_int, [_vp]),
+    "fxc_pipe_push": (_c.c_int, [_vp, _vp]),
+    "fxc_pipe_pop": (_c.c_int, [_vp, _vp]),
+    "fxc_pipe_in_flight": (_c.c_int, [_vp]),
+    "fxc_pipe_destroy": (_c.c_int, [_vp]),
     "fxc_timer_start": (_c.c_int, [_vp]),
     "fxc_timer_stop": (_c.c_int, [_vp, _c.POINTER(_c.c_double)]),
     "fxc_kernel_profiling": (_c.c_int, [_vp, _c.c_int]),

@@ -930,6 +930,21 @@ thread_local std::string g_lib_error;
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------
+// host-fed front end: double-buffered pinned staging, H2D / compute / D2H on three
+// streams chained by events, so batch k+1 crosses PCIe while batch k is on the CUs.  Replaces the
+// reference's per-chunk blocking copies (effex/effex.py:391-392, 508-509, 693).
+// ------------------------------------------------------------------------------------------
+struct fxc_pipe_slot {
+    void* h_in = nullptr;    // pinned
+    void* h_out = nullptr;   // pinned
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    hipEvent_t ev_in = nullptr, ev_compute = nullptr, ev_out = nullptr;
+    bool busy = false;
+};
+
 struct fxc_plan {
     int device = 0, cu_count = 0;
     int n_ant = 0, n_base = 0, nchan = 0, ntaps = 0;
@@ -964,6 +979,17 @@ struct fxc_plan {
     int stamp_grid = 0;
     StreamTaps taps;               // nchan == 1: the FIR taps by value
     mutable std::string error;
+};
+
+struct fxc_pipe {
+    fxc_plan* plan = nullptr;
+    int64_t chunks = 0;
+    int depth = 0, mode = FXC_MODE_SPECTRUM;
+    double bandwidth = 1.0;
+    size_t in_bytes = 0, out_bytes = 0;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<fxc_pipe_slot> slots;
+    int64_t pushed = 0, popped = 0;
 };
 
 namespace {
@@ -1802,6 +1828,118 @@ int fxc_estimate_delay(fxc_plan* p, const void* iq0, const void* iq1, int64_t n,
     const double delta = 0.5 * (std::log(xprev) - std::log(xnext)) /
                          (std::log(xprev) - 2.0 * std::log(xbest) + std::log(xnext));
     *delay_s = ((double)n - ((double)imax + delta)) / rate;
+    return FXC_OK;
+}
+
+int fxc_pipe_destroy(fxc_pipe* q) {
+    if (!q) return FXC_OK;
+    (void)hipSetDevice(q->plan->device);
+    (void)hipStreamSynchronize(q->plan->stream);
+    if (q->s_in) (void)hipStreamSynchronize(q->s_in);
+    if (q->s_out) (void)hipStreamSynchronize(q->s_out);
+    for (auto& sl : q->slots) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+        if (sl.ev_compute) (void)hipEventDestroy(sl.ev_compute);
+        if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
+    }
+    if (q->s_in) (void)hipStreamDestroy(q->s_in);
+    if (q->s_out) (void)hipStreamDestroy(q->s_out);
+    delete q;
+    return FXC_OK;
+}
+
+int fxc_pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth) {
+    if (!out || !p) return fail(p, FXC_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (chunks_per_batch < 1 || depth < 1 || depth > 16) return fail(p, FXC_ERR_ARG, "bad batch size or depth");
+    if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
+    if (mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
+    if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
+    FXC_HIP(p, hipSetDevice(p->device));
+    fxc_pipe* q = new (std::nothrow) fxc_pipe();
+    if (!q) return fail(p, FXC_ERR_NOMEM, "host allocation failed");
+    q->plan = p;
+    q->chunks = chunks_per_batch;
+    q->depth = depth;
+    q->mode = mode;
+    q->bandwidth = bandwidth;
+    q->in_bytes = (size_t)chunks_per_batch * p->n_ant * p->num_samp * sizeof(cf);
+    q->out_bytes = mode == FXC_MODE_SPECTRUM ? (size_t)chunks_per_batch * p->n_base * p->nchan * sizeof(cf)
+                                             : (size_t)chunks_per_batch * p->n_base * sizeof(cd);
+    q->slots.resize((size_t)depth);
+    hipError_t e = hipStreamCreateWithFlags(&q->s_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&q->s_out, hipStreamNonBlocking);
+    for (auto& sl : q->slots) {
+        if (e == hipSuccess) e = hipHostMalloc(&sl.h_in, q->in_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(&sl.h_out, q->out_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&sl.d_in, q->in_bytes);
+        if (e == hipSuccess) e = hipMalloc(&sl.d_out, q->out_bytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_compute, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        fxc_pipe_destroy(q);
+        return fail(p, e == hipErrorOutOfMemory ? FXC_ERR_NOMEM : FXC_ERR_HIP, "pipeline setup failed: %s",
+                    hipGetErrorString(e));
+    }
+    *out = q;
+    return FXC_OK;
+}
+
+int fxc_pipe_in_flight(const fxc_pipe* q) { return q ? (int)(q->pushed - q->popped) : 0; }
+
+int fxc_pipe_acquire(fxc_pipe* q, void** in_host) {
+    if (!q || !in_host) return fail(q ? q->plan : nullptr, FXC_ERR_ARG, "NULL argument");
+    if (q->pushed - q->popped >= q->depth)
+        return fail(q->plan, FXC_ERR_STATE, "all %d slots in flight: pop first", q->depth);
+    *in_host = q->slots[(size_t)(q->pushed % q->depth)].h_in;      // popped, hence idle
+    return FXC_OK;
+}
+
+int fxc_pipe_submit(fxc_pipe* q) {
+    if (!q) return fail(nullptr, FXC_ERR_ARG, "NULL pipe");
+    fxc_plan* p = q->plan;
+    if (q->pushed - q->popped >= q->depth) return fail(p, FXC_ERR_STATE, "all %d slots in flight: pop first", q->depth);
+    FXC_HIP(p, hipSetDevice(p->device));
+    fxc_pipe_slot& sl = q->slots[(size_t)(q->pushed % q->depth)];
+    FXC_HIP(p, hipMemcpyAsync(sl.d_in, sl.h_in, q->in_bytes, hipMemcpyHostToDevice, q->s_in));
+    FXC_HIP(p, hipEventRecord(sl.ev_in, q->s_in));
+    FXC_HIP(p, hipStreamWaitEvent(p->stream, sl.ev_in, 0));
+    int rc = fx_rows_dev(p, static_cast<const cf*>(sl.d_in), sl.d_out, q->chunks, q->mode, q->bandwidth);
+    if (rc) return rc;
+    FXC_HIP(p, hipEventRecord(sl.ev_compute, p->stream));
+    FXC_HIP(p, hipStreamWaitEvent(q->s_out, sl.ev_compute, 0));
+    FXC_HIP(p, hipMemcpyAsync(sl.h_out, sl.d_out, q->out_bytes, hipMemcpyDeviceToHost, q->s_out));
+    FXC_HIP(p, hipEventRecord(sl.ev_out, q->s_out));
+    sl.busy = true;
+    q->pushed += 1;
+    return FXC_OK;
+}
+
+int fxc_pipe_push(fxc_pipe* q, const void* x_host) {
+    if (!q || !x_host) return fail(q ? q->plan : nullptr, FXC_ERR_ARG, "NULL argument");
+    void* dst = nullptr;
+    int rc = fxc_pipe_acquire(q, &dst);
+    if (rc) return rc;
+    std::memcpy(dst, x_host, q->in_bytes);
+    return fxc_pipe_submit(q);
+}
+
+int fxc_pipe_pop(fxc_pipe* q, void* out_host) {
+    if (!q || !out_host) return fail(q ? q->plan : nullptr, FXC_ERR_ARG, "NULL argument");
+    fxc_plan* p = q->plan;
+    if (q->pushed == q->popped) return fail(p, FXC_ERR_STATE, "nothing in flight");
+    FXC_HIP(p, hipSetDevice(p->device));
+    fxc_pipe_slot& sl = q->slots[(size_t)(q->popped % q->depth)];
+    FXC_HIP(p, hipEventSynchronize(sl.ev_out));
+    std::memcpy(out_host, sl.h_out, q->out_bytes);
+    sl.busy = false;
+    q->popped += 1;
     return FXC_OK;
 }
 

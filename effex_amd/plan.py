@@ -255,6 +255,60 @@ class FxPlan(object):
         return ms.value, n.value
 
 
+class FxPipeline(object):
+    """Host-fed, double-buffered front end on a plan (include/fxcorr.h ``fxc_pipe_*``): push batches of host
+    chunks, pop their visibility rows; H2D, compute and D2H of successive batches overlap."""
+
+    def __init__(self, plan, chunks_per_batch, depth=2, mode="SPECTRUM", bandwidth=1.0):
+        self.plan = plan
+        self.chunks = int(chunks_per_batch)
+        self.mode = MODES[mode.upper()]
+        self._h = ctypes.c_void_p()
+        plan._check(plan._lib.fxc_pipe_create(ctypes.byref(self._h), plan._h, self.chunks, int(depth), self.mode,
+                                              float(bandwidth)))
+
+    def push(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        if x.shape != (self.chunks, self.plan.n_ant, self.plan.num_samp):
+            raise ValueError("expected a batch of shape {}".format((self.chunks, self.plan.n_ant, self.plan.num_samp)))
+        self.plan._check(self.plan._lib.fxc_pipe_push(self._h, x.ctypes.data))
+
+    def acquire(self):
+        """Pinned input buffer of the next free slot as a numpy view [chunks, n_ant, num_samp] to fill in place."""
+        ptr = ctypes.c_void_p()
+        self.plan._check(self.plan._lib.fxc_pipe_acquire(self._h, ctypes.byref(ptr)))
+        shape = (self.chunks, self.plan.n_ant, self.plan.num_samp)
+        n = int(np.prod(shape))
+        buf = (ctypes.c_float * (2 * n)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.complex64).reshape(shape)
+
+    def submit(self):
+        self.plan._check(self.plan._lib.fxc_pipe_submit(self._h))
+
+    def pop(self):
+        if self.mode == _lib.FXC_MODE_SPECTRUM:
+            out = np.empty((self.chunks, self.plan.n_baselines, self.plan.nchan), dtype=np.complex64)
+        else:
+            out = np.empty((self.chunks, self.plan.n_baselines), dtype=np.complex128)
+        self.plan._check(self.plan._lib.fxc_pipe_pop(self._h, out.ctypes.data))
+        return out
+
+    @property
+    def in_flight(self):
+        return self.plan._lib.fxc_pipe_in_flight(self._h)
+
+    def close(self):
+        if self._h:
+            self.plan._lib.fxc_pipe_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def synth_fill(x, seed, first_chunk=0, delays=None, stream=None):
     """Fill a CUDA complex64 tensor [n_chunks, n_ant, num_samp] with the synthetic stream of
     ``effex_amd.synth`` (bit-identical), generated on the device."""

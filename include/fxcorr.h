@@ -29,6 +29,7 @@ extern "C" {
 #define FXC_VERSION 100 /* 0.1.0 */
 
 typedef struct fxc_plan fxc_plan; /* opaque; one per (device, configuration) */
+typedef struct fxc_pipe fxc_pipe; /* opaque; host-fed double-buffered front end on a plan */
 
 #define FXC_STREAM_OWNED ((void*)(intptr_t)-1)
 
@@ -132,6 +133,23 @@ int fxc_convert_u8(fxc_plan* plan, const void* iq_u8_dev, void* out_dev, int64_t
  * Uses the plan's device, stream and workspace; synchronises. */
 int fxc_estimate_delay(fxc_plan* plan, const void* iq0, const void* iq1, int64_t n, int mem_kind, double rate,
                        double* delay_s);
+
+/* Host-fed front end: replaces the reference's blocking per-chunk copies
+ * (effex.py:391-392, 508-509, 693).  A pipe owns `depth` slots of pinned host staging + device buffers.
+ * fxc_pipe_acquire hands the producer the pinned input buffer of the next free slot
+ * ([chunks_per_batch][n_ant][num_samp] complex64) to fill in place; fxc_pipe_submit queues
+ * H2D -> fxc_fx_rows -> D2H on three streams chained by events and returns; fxc_pipe_push = acquire + memcpy
+ * from any host memory + submit; fxc_pipe_pop waits for the oldest batch and copies its rows out (layout as
+ * fxc_fx_rows).  With depth >= 2 batch k+1 crosses PCIe while batch k computes.  acquire/submit/push fail with
+ * FXC_ERR_STATE when `depth` batches are in flight, pop when none is.
+ * The pipe uses the plan's stream and workspace: do not interleave other fxc_fx_* calls on the plan. */
+int fxc_pipe_create(fxc_pipe** out, fxc_plan* plan, int64_t chunks_per_batch, int depth, int mode, double bandwidth);
+int fxc_pipe_acquire(fxc_pipe* pipe, void** in_host);
+int fxc_pipe_submit(fxc_pipe* pipe);
+int fxc_pipe_push(fxc_pipe* pipe, const void* x_host);
+int fxc_pipe_pop(fxc_pipe* pipe, void* out_host);
+int fxc_pipe_in_flight(const fxc_pipe* pipe);
+int fxc_pipe_destroy(fxc_pipe* pipe);
 
 /* Measurement hooks (bench.py): HIP events on the plan's stream.  fxc_timer_* bracket a region;
  * with kernel profiling on, every launch of the dominant kernel is bracketed by its own event

@@ -402,6 +402,35 @@ def test_input_conditioning_on_device(plan_mod, torch):
         assert rel_err(rows[0, 0], ref0) < TOL_VIS
 
 
+@pytest.mark.parametrize("mode", ["SPECTRUM", "CONTINUUM"])
+def test_host_fed_pipeline(plan_mod, torch, mode):
+    """SURVEY.md §8f #4: double-buffered host-fed front end == the blocking host path, batch for batch."""
+    from effex_amd import _lib
+    num_samp, chunks, n_batches = 4096 * 5, 3, 5
+    x = synth.synth_iq(8, chunks * n_batches, 2, num_samp).reshape(n_batches, chunks, 2, num_samp)
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-7)
+        ref = [p.fx_rows(x[b], mode, gi.BANDWIDTH) for b in range(n_batches)]
+        with plan_mod.FxPipeline(p, chunks, depth=2, mode=mode, bandwidth=gi.BANDWIDTH) as pipe:
+            with pytest.raises(_lib.FxcError):
+                pipe.pop()                                   # nothing in flight
+            got = []
+            pipe.push(x[0])
+            for b in range(1, n_batches):
+                pipe.push(x[b])                              # batch b in flight while b-1 completes
+                assert pipe.in_flight == 2
+                got.append(pipe.pop())
+            with pytest.raises(ValueError):
+                pipe.push(x[0][:2])
+            got.append(pipe.pop())
+            assert pipe.in_flight == 0
+            pipe.acquire()[...] = x[2]                       # zero-copy producer path
+            pipe.submit()
+            np.testing.assert_array_equal(pipe.pop(), ref[2])
+        for b in range(n_batches):
+            np.testing.assert_array_equal(got[b], ref[b])
+
+
 def test_device_synth_is_bit_identical(plan_mod, torch):
     n_chunks, n_ant, num_samp = 3, 3, 5000
     x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")
