@@ -338,6 +338,15 @@ __global__ __launch_bounds__(256) void xengine4096_kernel(const cf* __restrict__
     for (int p = 0; p < NB; ++p) raw[(c * NB + p) * fxc::fused::kN + pos] = fxc::mk(ar[p], ai[p]);
 }
 
+// F-only kernel's spectrum order -> natural bin order (fxc_channelize on the fused path)
+__global__ void spec_unpermute_kernel(const cf* __restrict__ spec, cf* __restrict__ out, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int k = (int)(idx & (fxc::fused::kN - 1));
+        out[idx] = spec[(idx - k) + fxc::fused::specpos_of_bin(k)];
+    }
+}
+
 // sums = [n_base*nchan] raw sums + [1] {count, 0}
 __global__ void export_kernel(const cd* __restrict__ acc, cd* __restrict__ sums, int64_t n, double count) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -950,6 +959,7 @@ struct fxc_plan {
     int n_ant = 0, n_base = 0, nchan = 0, ntaps = 0;
     int64_t num_samp = 0, n_pts = 0;
     int path = FXC_PATH_GENERIC;
+    bool fused_f = false;          // nchan 4096 / ntaps 4: the F-only fused kernel also serves fxc_channelize
     bool pow2 = false;
     int lg2n = 0;
     hipStream_t stream = nullptr;
@@ -1068,9 +1078,35 @@ int drain_kernel_events(fxc_plan* p) {
     return FXC_OK;
 }
 
-// F-stage of `n_streams` streams: x -> spec (both device), generic path
-int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out);
+
+// F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
+// allow_fused: only for fxc_channelize, whose output is a caller buffer (the fused route stages in the workspace,
+// which the generic F+X callers use for `spec` itself)
+int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, bool allow_fused = false) {
     if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
+    if (p->fused_f && allow_fused && n_streams >= 2) {
+        // pairs of streams through the F-only fused kernel, then un-permute; an odd last stream goes generic
+        const int64_t pairs = n_streams / 2;
+        const int64_t per_pair = 2 * p->n_pts * fxc::fused::kN;
+        const int64_t pb_max = std::max<int64_t>(1, kWorkspaceTarget / (per_pair * (int64_t)sizeof(cf)));
+        for (int64_t p0 = 0; p0 < pairs; p0 += pb_max) {
+            const int64_t np = std::min(pb_max, pairs - p0);
+            int rc = ensure_ws(p, np * per_pair * (int64_t)sizeof(cf));
+            if (rc) return rc;
+            cf* tmp = reinterpret_cast<cf*>(p->d_ws);
+            rc = launch_fused(p, x + p0 * 2 * p->num_samp, np, tmp, true);
+            if (rc) return rc;
+            const int64_t total = np * per_pair;
+            hipLaunchKernelGGL(spec_unpermute_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream, tmp,
+                               spec + p0 * per_pair, total);
+            FXC_HIP(p, hipGetLastError());
+        }
+        if (n_streams & 1)
+            return run_channelize(p, x + (n_streams - 1) * p->num_samp, spec + (n_streams - 1) * p->n_pts * p->nchan, 1,
+                                  false);
+        return FXC_OK;
+    }
     const int64_t total = n_streams * p->n_pts * p->nchan;
     hipLaunchKernelGGL(pfb_fir_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream, x, p->d_win,
                        spec, p->num_samp, p->nchan, p->ntaps, p->n_pts, total);
@@ -1483,7 +1519,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     FXC_HIP(p, hipMalloc(&p->d_sums, (acc_n + 1) * sizeof(cd)));
     FXC_HIP(p, hipMalloc(&p->d_out, acc_n * sizeof(cd)));
 
-    if (p->path == FXC_PATH_FUSED) {
+    p->fused_f = (N == fxc::fused::kN && T == fxc::fused::kT && p->num_samp <= (1ll << 27) &&
+                  force_path != FXC_PATH_GENERIC);
+    if (p->path == FXC_PATH_FUSED || p->fused_f) {
         using namespace fxc::fused;
         std::vector<f4> w4((size_t)kN);
         for (int r = 0; r < 16; ++r)
@@ -1628,12 +1666,13 @@ int fxc_channelize(fxc_plan* p, const void* x, void* out, int64_t n_streams, int
     if (n_streams == 0) return FXC_OK;
     if (!x || !out) return fail(p, FXC_ERR_ARG, "NULL buffer");
     FXC_HIP(p, hipSetDevice(p->device));
-    if (mem_kind == FXC_MEM_DEVICE) return run_channelize(p, static_cast<const cf*>(x), static_cast<cf*>(out), n_streams);
+    if (mem_kind == FXC_MEM_DEVICE)
+        return run_channelize(p, static_cast<const cf*>(x), static_cast<cf*>(out), n_streams, true);
     if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
     const size_t xb = (size_t)n_streams * p->num_samp * sizeof(cf);
     const size_t ob = (size_t)n_streams * p->n_pts * p->nchan * sizeof(cf);
     return with_host_staging(p, x, xb, out, ob, [&](const cf* dx, void* dout) {
-        return run_channelize(p, dx, static_cast<cf*>(dout), n_streams);
+        return run_channelize(p, dx, static_cast<cf*>(dout), n_streams, true);
     });
 }
 

@@ -91,6 +91,24 @@ def test_channelize_matches_oracle(plan_mod, torch, nchan, ntaps, num_samp):
         assert rel_err(host[s], ref) < (2e-5 if (nchan & (nchan - 1)) else TOL_SPEC)
 
 
+@pytest.mark.parametrize("n_streams", [1, 2, 5])
+def test_channelize_default_shape_uses_fused_f_kernel(plan_mod, torch, n_streams):
+    """nchan 4096 / ntaps 4 (the constructor default): pairs of streams go through the F-only fused kernel,
+    an odd last stream through the generic kernels; both must agree with the oracle and with each other."""
+    num_samp = 4096 * 9 + 100
+    x = synth.synth_iq(17, n_streams, 1, num_samp)[:, 0]
+    window = design_window(4, 4096)
+    with plan_mod.FxPlan(1, 4096, 4, num_samp) as p, plan_mod.FxPlan(1, 4096, 4, num_samp, path="generic") as g:
+        spec = p.channelize(torch.from_numpy(x).cuda()).cpu().numpy()
+        spec_h = p.channelize(x)
+        spec_g = g.channelize(x)
+    np.testing.assert_array_equal(spec, spec_h)
+    for s_ in range(n_streams):
+        ref = fx_oracle.spectrometer_poly(x[s_], 4, 4096, window)
+        assert rel_err(spec[s_], ref) < TOL_SPEC
+        assert rel_err(spec[s_], spec_g[s_]) < TOL_SPEC
+
+
 def test_more_than_32_taps_raises(plan_mod):
     with pytest.raises(NotImplementedError):
         plan_mod.FxPlan(1, 64, 33, 64 * 64, window=np.zeros(64 * 33))
