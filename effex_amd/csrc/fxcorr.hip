@@ -5,7 +5,13 @@
 //   cusignal channelize_poly FFT half + conj      effex/effex.py:553   -> fft_pow2_kernel / dft_any_kernel / fused phases 1-3
 //   f0 * conj(f1 * rot), mean(axis=0), fftshift   effex/effex.py:516-521 -> xmul_kernel / fused X + finish kernels
 //   continuum tail mean_k / bandwidth             effex/effex.py:523-524 -> continuum kernels
-// Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap.  No CPU fallback.
+// and the steps either side of the path:
+//   per-chunk DC removal, uint8 -> complex        effex/effex.py:394-395, :652 -> dc_* / convert_u8 kernels
+//   delay calibration                             effex/effex.py:583-627 -> delay_* / stockham_stage kernels
+//   per-chunk blocking copies                     effex/effex.py:391-392, 508-509, 693 -> fxc_pipe_* (host side)
+// Paths: fused (nchan 4096, ntaps 4; 2 antennas in one kernel, 4/6/8 via F-only + X-engine), stream (nchan 1),
+// generic (everything else).  Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap, buffer loads.
+// No CPU fallback.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
