@@ -431,6 +431,9 @@ __device__ __forceinline__ void permlane32_swap(cf& a, cf& b) {
 // this thread's 16 branch samples of frame i: element (255 - j) + 256 (15 - r); loads r = R0 .. R0+CNT-1.
 // Buffer loads: one VGPR byte offset per thread, everything that varies with chunk / frame / r is scalar.
 typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+#ifndef FXC_LOAD_AUX
+#define FXC_LOAD_AUX 0   // cache policy of the IQ stream loads: bit 0 sc0, bit 1 nt, bit 4 sc1
+#endif
 template <int R0, int CNT>
 __device__ __forceinline__ void load_frame_part(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned voff,
                                                 int64_t i) {
@@ -439,7 +442,7 @@ __device__ __forceinline__ void load_frame_part(cf (&xr)[16], const cf* chunk_ba
     const unsigned soff = (unsigned)(i * fxc::fused::kN * (int64_t)sizeof(cf));
 #pragma unroll
     for (int r = R0; r < R0 + CNT; ++r) {
-        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff + (unsigned)(256 * (15 - r) * sizeof(cf)), 0);
+        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff + (unsigned)(256 * (15 - r) * sizeof(cf)), FXC_LOAD_AUX);
         xr[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
     }
 }

@@ -1,0 +1,13 @@
+#!/bin/bash
+# sample package power and sclk while each micro-benchmark mode runs
+for mode in sleep nop; do
+  ./tools/ubench/power_modes $mode 9 > /tmp/pm_$mode.log 2>&1 &
+  P=$!
+  sleep 5
+  for i in 1 2; do
+    rocm-smi --showpower --showclocks 2>&1 | grep -E "Power|sclk" | sed -e 's/.*: //' | tr '\n' ' '; echo
+    sleep 1
+  done
+  wait $P
+  cat /tmp/pm_$mode.log
+done
