@@ -26,6 +26,7 @@ FXC_MODE_CONTINUUM = 1
 FXC_PATH_GENERIC = 0
 FXC_PATH_FUSED = 1
 FXC_PATH_STREAM = 2
+FXC_PATH_TILED = 3
 
 
 class FxcInfo(ctypes.Structure):

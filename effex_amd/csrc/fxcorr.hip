@@ -24,6 +24,7 @@
 
 #include "../../include/fxcorr.h"
 #include "fx_fused4096.h"
+#include "fx_tiled.h"
 #include "fx_math.h"
 
 using fxc::cd;
@@ -259,32 +260,34 @@ __global__ void acc_add_kernel(const cf* __restrict__ raw, cd* __restrict__ acc,
     }
 }
 
-// fused accumulate, stage 1: part[split][slot] = sum over this split's chunks of the kernel's raw float32
-// rows (slot order, coalesced); fixed order -> bit-reproducible
-__global__ __launch_bounds__(256) void fused_reduce1_kernel(const cf* __restrict__ raw, cd* __restrict__ part,
-                                                           int64_t n_chunks, int n_splits) {
+// accumulate over many chunks, stage 1: part[split][slot] = sum over this split's rows of the kernels' raw
+// float32 rows (slot order, coalesced); fixed order -> bit-reproducible
+__global__ __launch_bounds__(256) void fused_reduce1_kernel(const cf* __restrict__ raw, cd* __restrict__ part, int nchan,
+                                                           int64_t n_rows, int n_splits) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     const int split = blockIdx.y;
+    if (slot >= nchan) return;
     double ar = 0.0, ai = 0.0;
-    for (int64_t c = split; c < n_chunks; c += n_splits) {
-        const cf r = raw[c * fxc::fused::kN + slot];
+    for (int64_t c = split; c < n_rows; c += n_splits) {
+        const cf r = raw[c * nchan + slot];
         ar += r.x;
         ai += r.y;
     }
     cd o;
     o.x = ar;
     o.y = ai;
-    part[(int64_t)split * fxc::fused::kN + slot] = o;
+    part[(int64_t)split * nchan + slot] = o;
 }
 
 // stage 2: acc[k] += sum_split part[split][slot(k)]
-__global__ void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict__ acc, int n_splits) {
+__global__ void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict__ acc, int nchan, int n_splits,
+                                     int slots) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= fxc::fused::kN) return;
-    const int slot = fxc::fused::slot_of_bin(k);
+    if (k >= nchan) return;
+    const int64_t slot = raw_index(k, slots);
     double ar = 0.0, ai = 0.0;
     for (int s = 0; s < n_splits; ++s) {
-        const cd v = part[(int64_t)s * fxc::fused::kN + slot];
+        const cd v = part[(int64_t)s * nchan + slot];
         ar += v.x;
         ai += v.y;
     }
@@ -638,6 +641,225 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// tiled fused 2-antenna kernel for nchan in {512, 1024, 2048, 4096, 8192}, any ntaps (phases in fx_tiled.h)
+// ------------------------------------------------------------------------------------------
+// PFB FIR of frame i for butterfly u: buffer loads, one VGPR byte offset per thread (xoff into the chunk's
+// stream pair, hoff into the window), everything that varies with frame / tap / branch is scalar
+template <class G>
+__device__ __forceinline__ void tiled_fir(cf (&v)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned xoff,
+                                          const float* win, unsigned win_bytes, unsigned hoff, int64_t i, int ntaps) {
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(win), 0, (int)win_bytes, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fxc::mk(0.f, 0.f);
+    const int tmax = (int64_t)(ntaps - 1) < i ? ntaps - 1 : (int)i;
+    for (int t = 0; t <= tmax; ++t) {
+        const unsigned sx = (unsigned)((i - t) * G::N * (int64_t)sizeof(cf));
+        const unsigned sh = (unsigned)(t * G::N * (int)sizeof(float));
+        cf xv[16];
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rx, xoff, sx + (unsigned)(G::P * (15 - r) * sizeof(cf)), 0);
+            xv[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+            hv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, hoff, sh + (unsigned)(G::P * r * sizeof(float)), 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fxc::cfma(hv[r], xv[r], v[r]);
+    }
+}
+
+// raw[(split * n_chunks + c) * N + k] = sum over the split's frames of spec0[i,k] * conj(spec1[i,k]), natural
+// bin order, float32.  Work item = (split, chunk); a split is a contiguous range of a chunk's frames (the
+// FIR reads its history from memory, so ranges are independent).
+template <class G>
+__global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
+                                                               int64_t n_chunks, int n_splits, int ntaps,
+                                                               const float* __restrict__ win, const cf* __restrict__ tw0_g,
+                                                               const cf* __restrict__ twA_g, const cf* __restrict__ tw16_g,
+                                                               cf* __restrict__ raw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* region = reinterpret_cast<cf*>(smem + G::kLdsRegion);
+    cf* tw16 = reinterpret_cast<cf*>(smem + G::kLdsTw16);
+    const int tid = threadIdx.x;
+    const int u = G::u_of(tid), ant = G::ant_of(tid);
+    for (int idx = tid; idx < 256; idx += G::kThreads) tw16[idx] = tw16_g[idx];
+    cf tw0[16], twA[16];
+    if (G::R0 > 1) G::load_tw0(tw0, tw0_g, u);
+    if (G::A3) G::load_twA(twA, twA_g, u);
+    __syncthreads();
+    cf* reg = region + ant * G::kRegion;
+    const unsigned chunk_bytes = (unsigned)(2 * num_samp * (int64_t)sizeof(cf));
+    const unsigned win_bytes = (unsigned)(ntaps * G::N * (int)sizeof(float));
+    const unsigned xoff = (unsigned)((ant * num_samp + (G::P - 1 - u)) * (int64_t)sizeof(cf));
+    const unsigned hoff = (unsigned)(u * (int)sizeof(float));
+    const int64_t per = (n_pts + n_splits - 1) / n_splits;
+    for (int64_t w = blockIdx.x; w < n_chunks * n_splits; w += gridDim.x) {
+        const int64_t c = w % n_chunks, split = w / n_chunks;
+        const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
+        const cf* chunk_base = x + c * 2 * num_samp;
+        cf acc[G::kAccPerThread];
+#pragma unroll
+        for (int q = 0; q < G::kAccPerThread; ++q) acc[q] = fxc::mk(0.f, 0.f);
+        for (int64_t i = i0; i < i1; ++i) {
+            cf v[16];
+            tiled_fir<G>(v, chunk_base, chunk_bytes, xoff, win, win_bytes, hoff, i, ntaps);
+            if (G::R0 > 1) G::prestage(v, tw0);
+            if (G::A3) {
+                if (G::R0 > 1) {
+                    __syncthreads();   // every wave has finished reading the previous spectrum's exchange rows
+                    G::store0(v, reg, u);
+                    __syncthreads();
+                    G::loadA(reg, u, v);
+                }
+                fxc::dft16(v);
+                __syncthreads();
+                G::twiddleA_store(v, twA, reg, u);
+                __syncthreads();
+            } else {
+                __syncthreads();
+                G::store0(v, reg, u);
+                __syncthreads();
+            }
+            G::loadB(reg, u, v);
+            fxc::dft16(v);
+            G::twiddleB(v, tw16, u);
+            wave_sync();       // the 16x16 transpose stays inside each 16-lane group: no s_barrier
+            G::storeT(v, reg, u);
+            wave_sync();
+            G::loadC(reg, u, v);
+            fxc::dft16(v);
+            // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins (see fused_step)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                cf a = v[q], b = v[q + 8];
+                permlane32_swap(a, b);
+                acc[q] = fxc::cadd(acc[q], fxc::cmulc(a, b));
+            }
+        }
+        cf* row = raw + (split * n_chunks + c) * G::N;
+#pragma unroll
+        for (int q = 0; q < G::kAccPerThread; ++q) row[G::bin_of(u, q + 8 * ant)] = acc[q];
+    }
+}
+
+// ntaps <= 4, nchan <= 2048 variant of the tiled kernel: every IQ sample is fetched once into a VGPR ring of
+// four frames (as in fx_fused4096_kernel) and the window sits in LDS.
+template <class G, int R0, int CNT>
+__device__ __forceinline__ void tiled_load_part(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned xoff,
+                                                int64_t frame) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    const unsigned soff = (unsigned)(frame * G::N * (int64_t)sizeof(cf));
+#pragma unroll
+    for (int r = R0; r < R0 + CNT; ++r) {
+        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(cf)), 0);
+        xr[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+    }
+}
+
+template <class G>
+struct TiledRing {
+    cf h[4][16];
+    cf tw0[16];
+    cf acc[G::kAccPerThread];
+};
+
+#define FXC_TILED_PREFETCH(R0)                                                          \
+    do {                                                                                \
+        FXC_SCHED_FENCE();                                                              \
+        tiled_load_part<G, R0, 4>(nx, chunk_base, chunk_bytes, xoff, nframe);           \
+        FXC_SCHED_FENCE();                                                              \
+    } while (0)
+
+// one spectrum of both antennas; frame i sits in ring slot PH, i1 = end of this work item's frame range
+template <class G, int PH>
+__device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, cf* reg, const cf* tw16, int u,
+                                                const cf* chunk_base, unsigned chunk_bytes, unsigned xoff, int64_t i,
+                                                int64_t i1) {
+    cf v[16];
+    G::template fir_ring<PH>(s.h, win, u, v);
+    // the oldest slot is dead: refill it with the next frame of the range (the current one again at the end,
+    // never used) -- unconditional so that no branch guards a definition of ring registers
+    const int64_t nframe = (i + 1 < i1) ? i + 1 : i;
+    cf (&nx)[16] = s.h[(PH + 1) & 3];
+    FXC_TILED_PREFETCH(0);
+    G::prestage(v, s.tw0);
+    FXC_TILED_PREFETCH(4);
+    __syncthreads();   // every wave has finished reading the previous spectrum's exchange rows
+    G::store0(v, reg, u);
+    __syncthreads();
+    G::loadB(reg, u, v);
+    FXC_TILED_PREFETCH(8);
+    fxc::dft16(v);
+    G::twiddleB(v, tw16, u);
+    wave_sync();
+    G::storeT(v, reg, u);
+    wave_sync();
+    FXC_TILED_PREFETCH(12);
+    G::loadC(reg, u, v);
+    fxc::dft16(v);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        cf a = v[q], b = v[q + 8];
+        permlane32_swap(a, b);
+        s.acc[q] = fxc::cadd(s.acc[q], fxc::cmulc(a, b));
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf* __restrict__ x, int64_t num_samp,
+                                                                      int64_t n_pts, int64_t n_chunks, int n_splits,
+                                                                      const f4* __restrict__ win_g,
+                                                                      const cf* __restrict__ tw0_g,
+                                                                      const cf* __restrict__ tw16_g, cf* __restrict__ raw) {
+    static_assert(!G::A3, "ring variant: nchan <= 2048");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* region = reinterpret_cast<cf*>(smem + G::kLdsRegion);
+    cf* tw16 = reinterpret_cast<cf*>(smem + G::kLdsTw16);
+    f4* win = reinterpret_cast<f4*>(smem + G::kLdsWin);
+    const int tid = threadIdx.x;
+    const int u = G::u_of(tid), ant = G::ant_of(tid);
+    for (int idx = tid; idx < 256; idx += G::kThreads) tw16[idx] = tw16_g[idx];
+    for (int idx = tid; idx < G::N; idx += G::kThreads) win[idx] = win_g[idx];
+    TiledRing<G> s;
+    G::load_tw0(s.tw0, tw0_g, u);
+    __syncthreads();
+    cf* reg = region + ant * G::kRegion;
+    const unsigned chunk_bytes = (unsigned)(2 * num_samp * (int64_t)sizeof(cf));
+    const unsigned xoff = (unsigned)((ant * num_samp + (G::P - 1 - u)) * (int64_t)sizeof(cf));
+    const int64_t per = (n_pts + n_splits - 1) / n_splits;
+    for (int64_t w = blockIdx.x; w < n_chunks * n_splits; w += gridDim.x) {
+        const int64_t c = w % n_chunks, split = w / n_chunks;
+        const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
+        const cf* chunk_base = x + c * 2 * num_samp;
+#pragma unroll
+        for (int q = 0; q < G::kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
+        // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the chunk)
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+            if (i0 - d >= 0) {
+                tiled_load_part<G, 0, 16>(s.h[4 - d], chunk_base, chunk_bytes, xoff, i0 - d);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s.h[4 - d][r] = fxc::mk(0.f, 0.f);
+            }
+        }
+        if (i0 < i1) tiled_load_part<G, 0, 16>(s.h[0], chunk_base, chunk_bytes, xoff, i0);
+        for (int64_t i = i0; i < i1; i += 4) {
+            tiled_ring_step<G, 0>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i, i1);
+            if (i + 1 < i1) tiled_ring_step<G, 1>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 1, i1);
+            if (i + 2 < i1) tiled_ring_step<G, 2>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 2, i1);
+            if (i + 3 < i1) tiled_ring_step<G, 3>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 3, i1);
+        }
+        cf* row = raw + (split * n_chunks + c) * G::N;
+#pragma unroll
+        for (int q = 0; q < G::kAccPerThread; ++q) row[G::bin_of(u, q + 8 * ant)] = s.acc[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // continuum streaming limit: nchan == 1, 2 antennas (BASELINE config 3(i))
 // The PFB degenerates to a T-tap FIR y_a[n] = sum_t h[t] x_a[n - t] (zero history per chunk), the FFT is
 // the identity and X is sum_n y_0[n] conj(y_1[n]).  One workgroup takes kStreamBlock consecutive
@@ -980,6 +1202,9 @@ struct fxc_plan {
     f4* d_win4 = nullptr;          // fused
     cf* d_tw1 = nullptr;
     cf* d_tw2 = nullptr;
+    cf* d_tw0 = nullptr;           // tiled: pre-stage twiddles [16][nchan/16]
+    int tiled_grid_max = 0;
+    bool tiled_ring = false;       // ntaps <= 4 and nchan <= 2048: VGPR frame ring + window in LDS
     unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int fused_grid_max = 0;
     cd* d_acc = nullptr;           // [n_base*nchan]
@@ -1220,6 +1445,67 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw) {
     return FXC_OK;
 }
 
+// ---- tiled path -------------------------------------------------------------------------------------
+template <class G>
+int tiled_setup(fxc_plan* p) {
+    const void* fn = reinterpret_cast<const void*>(&fx_tiled_kernel<G>);
+    int lds = G::kLdsBytes;
+    if constexpr (!G::A3) {
+        if (p->tiled_ring) {
+            fn = reinterpret_cast<const void*>(&fx_tiled_ring_kernel<G>);
+            lds = G::kLdsBytesRing;
+        }
+    }
+    FXC_HIP(p, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    int per_cu = 0;
+    FXC_HIP(p, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, G::kThreads, lds));
+    if (per_cu < 1) return fail(p, FXC_ERR_HIP, "tiled kernel for nchan=%d does not fit a CU", G::N);
+    p->tiled_grid_max = per_cu * p->cu_count;
+    return FXC_OK;
+}
+
+template <class G>
+void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw) {
+    const int grid = (int)std::min<int64_t>(nc * n_splits, p->tiled_grid_max);
+    if constexpr (!G::A3) {
+        if (p->tiled_ring) {
+            hipLaunchKernelGGL(fx_tiled_ring_kernel<G>, dim3(grid), dim3(G::kThreads), G::kLdsBytesRing, p->stream, x,
+                               p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw2, raw);
+            return;
+        }
+    }
+    hipLaunchKernelGGL(fx_tiled_kernel<G>, dim3(grid), dim3(G::kThreads), G::kLdsBytes, p->stream, x, p->num_samp, p->n_pts,
+                       nc, n_splits, p->ntaps, p->d_win, p->d_tw0, p->d_tw1, p->d_tw2, raw);
+}
+
+#define FXC_TILED_DISPATCH(p, CALL)                                                   \
+    switch ((p)->nchan) {                                                             \
+        case 512: { using G = fxc::tiled::Geo<2, false>; CALL; } break;               \
+        case 1024: { using G = fxc::tiled::Geo<4, false>; CALL; } break;              \
+        case 2048: { using G = fxc::tiled::Geo<8, false>; CALL; } break;              \
+        case 4096: { using G = fxc::tiled::Geo<1, true>; CALL; } break;               \
+        case 8192: { using G = fxc::tiled::Geo<2, true>; CALL; } break;               \
+        default: return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for nchan=%d", (p)->nchan); \
+    }
+
+bool tiled_nchan(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
+
+// frame ranges per chunk so that a launch has at least ~2 work items per resident workgroup
+int tiled_splits(const fxc_plan* p, int64_t n_chunks) {
+    const int64_t want = (2 * (int64_t)p->tiled_grid_max + n_chunks - 1) / n_chunks;
+    const int64_t most = std::max<int64_t>(1, p->n_pts / 8);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 256));
+}
+
+// raw[split][c][k] (natural bin order) for nc chunks starting at x
+int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw) {
+    KernelTimer kt(p);
+    FXC_TILED_DISPATCH(p, tiled_launch<G>(p, x, nc, n_splits, raw));
+    kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
 // nchan == 1 streaming path: raw[block][chunk] partial sums for nc chunks
 bool stream_is_t4(const fxc_plan* p) { return p->ntaps <= 4 && (p->num_samp % 2) == 0; }
 
@@ -1276,14 +1562,36 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
             if (rc) return rc;
             if (p->n_ant == 2) {   // many chunks, one baseline: two-stage reduce over chunks
                 hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, kFusedReduceSplits), dim3(256), 0, p->stream, raw,
-                                   part, nc, kFusedReduceSplits);
-                hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 256), dim3(256), 0, p->stream, part, p->d_acc,
-                                   kFusedReduceSplits);
+                                   part, kN, nc, kFusedReduceSplits);
+                hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 256), dim3(256), 0, p->stream, part, p->d_acc, kN,
+                                   kFusedReduceSplits, fused_layout(p));
             } else {
                 const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
                 hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream,
                                    raw, p->d_acc, p->nchan, p->n_base, nc, 1, fused_layout(p));
             }
+            FXC_HIP(p, hipGetLastError());
+        }
+    } else if (p->path == FXC_PATH_TILED) {
+        const int N = p->nchan;
+        const int n_splits = tiled_splits(p, n_chunks);
+        const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
+        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(n_chunks, kWorkspaceTarget / (row_bytes * n_splits)));
+        const int64_t raw_bytes = (cb * n_splits * row_bytes + 255) / 256 * 256;
+        const int64_t part_bytes = (int64_t)kFusedReduceSplits * N * (int64_t)sizeof(cd);
+        int rc = ensure_ws(p, raw_bytes + part_bytes);
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + raw_bytes);
+        const int kb = (N + 255) / 256;
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = tiled_raw_sums(p, x + c0 * 2 * p->num_samp, nc, n_splits, raw);
+            if (rc) return rc;
+            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kb, kFusedReduceSplits), dim3(256), 0, p->stream, raw, part, N,
+                               nc * n_splits, kFusedReduceSplits);
+            hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kb), dim3(256), 0, p->stream, part, p->d_acc, N,
+                               kFusedReduceSplits, 0);
             FXC_HIP(p, hipGetLastError());
         }
     } else {
@@ -1361,6 +1669,29 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
                                    dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot,
                                    p->nchan, rows, 1, (int64_t)0, cscale, fused_layout(p));
+            FXC_HIP(p, hipGetLastError());
+        }
+        return FXC_OK;
+    }
+    if (p->path == FXC_PATH_TILED) {
+        const int N = p->nchan;
+        const int n_splits = tiled_splits(p, n_chunks);
+        const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
+        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(n_chunks, kWorkspaceTarget / (row_bytes * n_splits)));
+        int rc = ensure_ws(p, cb * n_splits * row_bytes);
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = tiled_raw_sums(p, x + c0 * 2 * p->num_samp, nc, n_splits, raw);
+            if (rc) return rc;
+            if (mode == FXC_MODE_SPECTRUM)
+                hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc * N, 256, p->cu_count)), dim3(256), 0, p->stream,
+                                   raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, n_splits, nc * N, inv_pts, 0);
+            else
+                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
+                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, n_splits,
+                                   nc * N, cscale, 0);
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;
@@ -1462,7 +1793,7 @@ int fxc_plan_destroy(fxc_plan* p) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_stamps,
+    void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_stamps,
                     p->d_acc, p->d_sums, p->d_out, p->d_ws};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -1491,7 +1822,11 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     const bool stream_shape = (p->n_ant == 2 && N == 1);
     if (force_path == FXC_PATH_STREAM && !stream_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "the streaming kernel needs n_ant=2, nchan=1");
+    const bool tiled_shape = (p->n_ant == 2 && tiled_nchan(N) && p->num_samp <= (1ll << 27));
+    if (force_path == FXC_PATH_TILED && !tiled_shape)
+        return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for n_ant=%d nchan=%d", p->n_ant, N);
     p->path = FXC_PATH_GENERIC;
+    if (tiled_shape && (force_path == -1 || force_path == FXC_PATH_TILED)) p->path = FXC_PATH_TILED;
     if (fused_shape && (force_path == -1 || force_path == FXC_PATH_FUSED)) p->path = FXC_PATH_FUSED;
     if (stream_shape && (force_path == -1 || force_path == FXC_PATH_STREAM)) p->path = FXC_PATH_STREAM;
     for (int t = 0; t < kMaxTaps; ++t) p->taps.h[t] = t < T ? (float)window[t] : 0.f;
@@ -1566,6 +1901,55 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
+    if (p->path == FXC_PATH_TILED) {
+        // pre-stage twiddles wN^((u + P g) k) at [g + G k][u]; stage tables as on the fused path
+        const int P = N / 16, R0 = N >= 4096 ? N / 4096 : N / 256, G = 16 / R0;
+        std::vector<cf> tw0((size_t)16 * P);
+        for (int r = 0; r < 16; ++r)
+            for (int u = 0; u < P; ++u) {
+                const int g = r % G, k = r / G;
+                const double ph = kTwoPi * (double)(((int64_t)(u + P * g) * k) % N) / (double)N;
+                tw0[(size_t)r * P + u] = fxc::mk((float)std::cos(ph), (float)std::sin(ph));
+            }
+        FXC_HIP(p, hipMalloc(&p->d_tw0, tw0.size() * sizeof(cf)));
+        FXC_HIP(p, hipMemcpy(p->d_tw0, tw0.data(), tw0.size() * sizeof(cf), hipMemcpyHostToDevice));
+        if (!p->d_tw1) {
+            std::vector<cf> tw1((size_t)16 * 256), tw2((size_t)256);
+            for (int k1 = 0; k1 < 16; ++k1)
+                for (int jx = 0; jx < 256; ++jx) {
+                    const double ph = kTwoPi * (double)((jx * k1) % 4096) / 4096.0;
+                    tw1[k1 * 256 + jx] = fxc::mk((float)std::cos(ph), (float)std::sin(ph));
+                }
+            for (int q1 = 0; q1 < 16; ++q1)
+                for (int j0 = 0; j0 < 16; ++j0) {
+                    const double ph = kTwoPi * (double)(j0 * q1) / 256.0;
+                    tw2[q1 * 16 + j0] = fxc::mk((float)std::cos(ph), (float)std::sin(ph));
+                }
+            FXC_HIP(p, hipMalloc(&p->d_tw1, tw1.size() * sizeof(cf)));
+            FXC_HIP(p, hipMemcpy(p->d_tw1, tw1.data(), tw1.size() * sizeof(cf), hipMemcpyHostToDevice));
+            FXC_HIP(p, hipMalloc(&p->d_tw2, tw2.size() * sizeof(cf)));
+            FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
+        }
+        p->tiled_ring = (T <= 4 && N <= 2048);
+        if (p->tiled_ring) {
+            std::vector<f4> w4((size_t)N);
+            for (int r = 0; r < 16; ++r)
+                for (int u = 0; u < P; ++u) {
+                    const int m = u + P * r;
+                    f4 w;
+                    w.x = wf[m];
+                    w.y = T > 1 ? wf[(size_t)1 * N + m] : 0.f;
+                    w.z = T > 2 ? wf[(size_t)2 * N + m] : 0.f;
+                    w.w = T > 3 ? wf[(size_t)3 * N + m] : 0.f;
+                    w4[(size_t)r * P + u] = w;
+                }
+            FXC_HIP(p, hipMalloc(&p->d_win4, w4.size() * sizeof(f4)));
+            FXC_HIP(p, hipMemcpy(p->d_win4, w4.data(), w4.size() * sizeof(f4), hipMemcpyHostToDevice));
+        }
+        int rc = FXC_OK;
+        FXC_TILED_DISPATCH(p, rc = tiled_setup<G>(p));
+        if (rc) return rc;
+    }
     if (N > 1) {
         const int lds = N * (int)sizeof(cf);
         if (p->pow2)
@@ -1593,7 +1977,7 @@ int fxc_plan_create(fxc_plan** out, int device, int n_ant, int nchan, int ntaps,
     if (num_samp < nchan)
         return fail(nullptr, FXC_ERR_ARG, "num_samp=%lld shorter than one frame of nchan=%d", (long long)num_samp,
                     nchan);
-    if (force_path < -1 || force_path > FXC_PATH_STREAM) return fail(nullptr, FXC_ERR_ARG, "bad force_path");
+    if (force_path < -1 || force_path > FXC_PATH_TILED) return fail(nullptr, FXC_ERR_ARG, "bad force_path");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device available (this library has no CPU backend)");
@@ -1638,6 +2022,11 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
         info->grid = p->fused_grid_max;
         info->block = fxc::fused::kThreads;
         info->lds_bytes = fxc::fused::kLdsBytes;
+    } else if (p->path == FXC_PATH_TILED) {
+        info->grid = p->tiled_grid_max;
+        info->block = p->nchan / 8;
+        info->lds_bytes = 2 * (p->nchan + p->nchan / 16) * (int)sizeof(cf) + 256 * (int)sizeof(cf) +
+                          (p->tiled_ring ? p->nchan * (int)sizeof(f4) : 0);
     } else if (p->path == FXC_PATH_STREAM) {
         info->grid = (int)stream_blocks(p);
         info->block = 256;

@@ -13,8 +13,9 @@ from .window import design_window
 
 MODES = {"SPECTRUM": _lib.FXC_MODE_SPECTRUM, "CONTINUUM": _lib.FXC_MODE_CONTINUUM, "TEST": _lib.FXC_MODE_CONTINUUM}
 PATHS = {None: -1, "auto": -1, "generic": _lib.FXC_PATH_GENERIC, "fused": _lib.FXC_PATH_FUSED,
-         "stream": _lib.FXC_PATH_STREAM}
-PATH_NAMES = {_lib.FXC_PATH_GENERIC: "generic", _lib.FXC_PATH_FUSED: "fused", _lib.FXC_PATH_STREAM: "stream"}
+         "stream": _lib.FXC_PATH_STREAM, "tiled": _lib.FXC_PATH_TILED}
+PATH_NAMES = {_lib.FXC_PATH_GENERIC: "generic", _lib.FXC_PATH_FUSED: "fused", _lib.FXC_PATH_STREAM: "stream",
+              _lib.FXC_PATH_TILED: "tiled"}
 
 
 def _current_torch_stream(device):

@@ -48,7 +48,8 @@ enum fxc_mode { FXC_MODE_SPECTRUM = 0, FXC_MODE_CONTINUUM = 1 }; /* TEST == CONT
 enum fxc_path {
     FXC_PATH_GENERIC = 0, /* any shape: FIR / FFT / X kernels through a workspace                          */
     FXC_PATH_FUSED = 1,   /* nchan 4096, ntaps 4, 2 antennas (one kernel) or 4/6/8 (F-only kernel + X-engine) */
-    FXC_PATH_STREAM = 2   /* nchan 1, 2 antennas: the continuum streaming limit                             */
+    FXC_PATH_STREAM = 2,  /* nchan 1, 2 antennas: the continuum streaming limit                             */
+    FXC_PATH_TILED = 3    /* 2 antennas, nchan 512/1024/2048/4096/8192, any ntaps: one fused F+X kernel       */
 };
 
 typedef struct fxc_info {

@@ -51,3 +51,32 @@ def test_fused_phases_match_oracle(emul, num_samp):
     f1 = fx_oracle.spectrometer_poly(x[1], 4, 4096, w)
     ref = (f0 * np.conj(f1)).sum(axis=0)
     assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-6
+
+
+@pytest.fixture(scope="module")
+def emul_tiled():
+    src = os.path.join(HERE, "emul", "emul_tiled.cpp")
+    lib = os.path.join(HERE, "emul", "libemul_tiled.so")
+    deps = [src] + [os.path.join(HERE, "..", "effex_amd", "csrc", h) for h in ("fx_tiled.h", "fx_fused4096.h", "fx_math.h")]
+    if not os.path.isfile(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", lib, src], check=True)
+    return ctypes.CDLL(lib)
+
+
+@pytest.mark.parametrize("nchan,ntaps,frames,ring", [
+    (512, 4, 9, 0), (512, 4, 9, 1), (1024, 4, 6, 1), (2048, 4, 5, 1), (2048, 3, 5, 1), (1024, 1, 3, 1), (4096, 8, 4, 0),
+    (8192, 4, 3, 0), (2048, 32, 3, 0), (512, 7, 12, 0)])
+def test_tiled_phases_match_oracle(emul_tiled, nchan, ntaps, frames, ring):
+    """fx_tiled.h (the other --nfft values, effex.py:778): decomposition, padded exchange layout, bin mapping,
+    and the ntaps <= 4 ring variant, on the host."""
+    num_samp = nchan * frames + 13
+    x = synth.synth_iq(99, 1, 2, num_samp)[0]
+    w = design_window(ntaps, nchan)
+    out = np.zeros(nchan, np.complex128)
+    rc = emul_tiled.emul_tiled(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(num_samp), nchan, ntaps,
+                               w.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ring)
+    assert rc == 0
+    f0 = fx_oracle.spectrometer_poly(x[0], ntaps, nchan, w)
+    f1 = fx_oracle.spectrometer_poly(x[1], ntaps, nchan, w)
+    ref = (f0 * np.conj(f1)).sum(axis=0)
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-6

@@ -166,11 +166,12 @@ def test_drop_in_run_task(torch, golden):
         cor.close()
 
 
-def test_small_multichunk_rows(plan_mod, torch, golden):
+@pytest.mark.parametrize("path", ["tiled", "generic"])
+def test_small_multichunk_rows(plan_mod, torch, golden, path):
     _, arrays = golden
     x = gi.small_input()
-    with plan_mod.FxPlan(2, gi.SMALL_N, 4, gi.SMALL_S) as p:
-        assert p.path == "generic"
+    with plan_mod.FxPlan(2, gi.SMALL_N, 4, gi.SMALL_S, path=path) as p:
+        assert p.path == path
         rows = p.fx_rows(x, "SPECTRUM")                      # host buffers in, host rows out
         assert rows.shape == (gi.SMALL_CHUNKS, 1, gi.SMALL_N)
         assert rel_err(rows[:, 0], arrays["small_rows"]) < TOL_VIS
@@ -260,6 +261,37 @@ def test_batched_integration_matches_oracle(plan_mod, torch, path, n_chunks, num
         cont_rows = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
         np.testing.assert_allclose(cont_rows[:, 0], rows[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH,
                                    rtol=2e-5, atol=1e-7 * np.abs(cont_rows).max())
+
+
+@pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [
+    (512, 4, 7, 20, 5), (1024, 4, 3, 9, 0), (2048, 4, 5, 33, 100), (2048, 32, 2, 40, 0), (4096, 8, 2, 11, 7),
+    (8192, 4, 3, 6, 1), (1024, 1, 4, 5, 0), (512, 7, 300, 3, 0), (2048, 4, 1, 128, 0)])
+def test_tiled_path_matches_oracle(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
+    """The other --nfft values (effex.py:778) on the tiled fused kernel: rows, ragged tails, frame splits
+    (few chunks, many frames), integration in uneven calls, continuum."""
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(321, n_chunks, 2, num_samp)
+    window = design_window(ntaps, nchan)
+    rot = plan_mod.rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, -2e-7)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as p:
+        assert p.path == "tiled"
+        p.set_rot(rot)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        for c in range(min(n_chunks, 6)):
+            ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, -2e-7,
+                                      "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        p.fx_accumulate(xd[: n_chunks // 3 + 1])
+        p.fx_accumulate(xd[n_chunks // 3 + 1:])
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ[0], rows[:, 0].astype(np.complex128).mean(axis=0)) < 2e-6
+        cont_rows = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
+        np.testing.assert_allclose(cont_rows[:, 0], rows[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH,
+                                   rtol=2e-5, atol=1e-7 * np.abs(cont_rows).max())
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window, path="generic") as g:
+        g.set_rot(rot)
+        assert rel_err(rows, g.fx_rows(xd, "SPECTRUM").cpu().numpy()) < 4e-6
 
 
 def test_fused_and_generic_agree(plan_mod, torch):

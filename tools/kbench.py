@@ -18,14 +18,16 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--num-samp", type=int, default=262144)
     ap.add_argument("--rows", action="store_true")
+    ap.add_argument("--nchan", type=int, default=4096)
+    ap.add_argument("--ntaps", type=int, default=4)
+    ap.add_argument("--path", default=None)
     ap.add_argument("--tag", default=os.environ.get("FXCORR_LIB", "in-tree"))
     args = ap.parse_args()
     import torch
     from effex_amd.plan import FxPlan, synth_fill
     x = torch.empty((args.frames, 2, args.num_samp), dtype=torch.complex64, device="cuda")
     synth_fill(x, 1234)
-    plan = FxPlan(2, 4096, 4, args.num_samp)
-    assert plan.path == "fused"
+    plan = FxPlan(2, args.nchan, args.ntaps, args.num_samp, path=args.path)
     for _ in range(2):
         (plan.fx_rows(x) if args.rows else plan.fx_accumulate(x))
     plan.sync()
@@ -38,7 +40,7 @@ def main():
     times.sort()
     gb = args.frames * 2 * args.num_samp * 8 / 1e9
     med = times[len(times) // 2]
-    print(json.dumps({"tag": args.tag, "frames": args.frames, "median_ms": round(med, 4), "min_ms": round(times[0], 4),
+    print(json.dumps({"tag": args.tag, "path": plan.path, "nchan": args.nchan, "ntaps": args.ntaps, "frames": args.frames, "median_ms": round(med, 4), "min_ms": round(times[0], 4),
                       "GBps_median": round(gb / med * 1e3, 1), "GBps_best": round(gb / times[0] * 1e3, 1),
                       "frac_8TBs": round(gb / med * 1e3 / 8000, 4)}))
 
