@@ -762,7 +762,8 @@ __device__ __forceinline__ void tiled_load_part(cf (&xr)[16], const cf* chunk_ba
 template <class G>
 struct TiledRing {
     cf h[4][16];
-    cf tw0[16];
+    cf tw0[16];   // pre-stage twiddles (R0 > 1)
+    cf twA[16];   // stage-A twiddles (nchan 4096)
     cf acc[G::kAccPerThread];
 };
 
@@ -785,11 +786,20 @@ __device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, 
     const int64_t nframe = (i + 1 < i1) ? i + 1 : i;
     cf (&nx)[16] = s.h[(PH + 1) & 3];
     FXC_TILED_PREFETCH(0);
-    G::prestage(v, s.tw0);
-    FXC_TILED_PREFETCH(4);
-    __syncthreads();   // every wave has finished reading the previous spectrum's exchange rows
-    G::store0(v, reg, u);
-    __syncthreads();
+    if (G::A3) {
+        static_assert(!(G::A3 && G::R0 > 1), "ring variant: nchan <= 4096");
+        fxc::dft16(v);
+        FXC_TILED_PREFETCH(4);
+        __syncthreads();   // every wave has finished reading the previous spectrum's exchange rows
+        G::twiddleA_store(v, s.twA, reg, u);
+        __syncthreads();
+    } else {
+        G::prestage(v, s.tw0);
+        FXC_TILED_PREFETCH(4);
+        __syncthreads();
+        G::store0(v, reg, u);
+        __syncthreads();
+    }
     G::loadB(reg, u, v);
     FXC_TILED_PREFETCH(8);
     fxc::dft16(v);
@@ -813,8 +823,8 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
                                                                       int64_t n_pts, int64_t n_chunks, int n_splits,
                                                                       const f4* __restrict__ win_g,
                                                                       const cf* __restrict__ tw0_g,
+                                                                      const cf* __restrict__ twA_g,
                                                                       const cf* __restrict__ tw16_g, cf* __restrict__ raw) {
-    static_assert(!G::A3, "ring variant: nchan <= 2048");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* region = reinterpret_cast<cf*>(smem + G::kLdsRegion);
     cf* tw16 = reinterpret_cast<cf*>(smem + G::kLdsTw16);
@@ -824,7 +834,8 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
     for (int idx = tid; idx < 256; idx += G::kThreads) tw16[idx] = tw16_g[idx];
     for (int idx = tid; idx < G::N; idx += G::kThreads) win[idx] = win_g[idx];
     TiledRing<G> s;
-    G::load_tw0(s.tw0, tw0_g, u);
+    if (G::R0 > 1) G::load_tw0(s.tw0, tw0_g, u);
+    if (G::A3) G::load_twA(s.twA, twA_g, u);
     __syncthreads();
     cf* reg = region + ant * G::kRegion;
     const unsigned chunk_bytes = (unsigned)(2 * num_samp * (int64_t)sizeof(cf));
@@ -1204,7 +1215,9 @@ struct fxc_plan {
     cf* d_tw2 = nullptr;
     cf* d_tw0 = nullptr;           // tiled: pre-stage twiddles [16][nchan/16]
     int tiled_grid_max = 0;
-    bool tiled_ring = false;       // ntaps <= 4 and nchan <= 2048: VGPR frame ring + window in LDS
+    bool small_tiled = false;      // fused shape, path chosen automatically: calls with few chunks split frames
+                                   // over workgroups through the tiled ring kernel
+    bool tiled_ring = false;       // ntaps <= 4 and nchan <= 4096: VGPR frame ring + window in LDS
     unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int fused_grid_max = 0;
     cd* d_acc = nullptr;           // [n_base*nchan]
@@ -1450,7 +1463,7 @@ template <class G>
 int tiled_setup(fxc_plan* p) {
     const void* fn = reinterpret_cast<const void*>(&fx_tiled_kernel<G>);
     int lds = G::kLdsBytes;
-    if constexpr (!G::A3) {
+    if constexpr (G::N <= 4096) {
         if (p->tiled_ring) {
             fn = reinterpret_cast<const void*>(&fx_tiled_ring_kernel<G>);
             lds = G::kLdsBytesRing;
@@ -1467,10 +1480,10 @@ int tiled_setup(fxc_plan* p) {
 template <class G>
 void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw) {
     const int grid = (int)std::min<int64_t>(nc * n_splits, p->tiled_grid_max);
-    if constexpr (!G::A3) {
+    if constexpr (G::N <= 4096) {
         if (p->tiled_ring) {
             hipLaunchKernelGGL(fx_tiled_ring_kernel<G>, dim3(grid), dim3(G::kThreads), G::kLdsBytesRing, p->stream, x,
-                               p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw2, raw);
+                               p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw);
             return;
         }
     }
@@ -1487,6 +1500,12 @@ void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw) {
         case 8192: { using G = fxc::tiled::Geo<2, true>; CALL; } break;               \
         default: return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for nchan=%d", (p)->nchan); \
     }
+
+// this call goes through the tiled kernel: the tiled path, or a fused-shape plan with too few chunks to fill the
+// chip one chunk per workgroup
+bool use_tiled(const fxc_plan* p, int64_t n_chunks) {
+    return p->path == FXC_PATH_TILED || (p->small_tiled && n_chunks * 2 <= p->cu_count);
+}
 
 bool tiled_nchan(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
 
@@ -1546,7 +1565,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
             hipLaunchKernelGGL(stream1_acc_kernel, dim3(1), dim3(256), 0, p->stream, raw, p->d_acc, nc * blocks);
             FXC_HIP(p, hipGetLastError());
         }
-    } else if (p->path == FXC_PATH_FUSED) {
+    } else if (p->path == FXC_PATH_FUSED && !use_tiled(p, n_chunks)) {
         using namespace fxc::fused;
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
@@ -1572,7 +1591,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
             }
             FXC_HIP(p, hipGetLastError());
         }
-    } else if (p->path == FXC_PATH_TILED) {
+    } else if (use_tiled(p, n_chunks)) {
         const int N = p->nchan;
         const int n_splits = tiled_splits(p, n_chunks);
         const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
@@ -1649,7 +1668,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         }
         return FXC_OK;
     }
-    if (p->path == FXC_PATH_FUSED) {
+    if (p->path == FXC_PATH_FUSED && !use_tiled(p, n_chunks)) {
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
         int rc = ensure_ws(p, spec_bytes + raw_bytes);
@@ -1673,7 +1692,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         }
         return FXC_OK;
     }
-    if (p->path == FXC_PATH_TILED) {
+    if (use_tiled(p, n_chunks)) {
         const int N = p->nchan;
         const int n_splits = tiled_splits(p, n_chunks);
         const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
@@ -1901,7 +1920,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
-    if (p->path == FXC_PATH_TILED) {
+    p->small_tiled = (p->path == FXC_PATH_FUSED && p->n_ant == 2 && force_path == -1);
+    if (p->path == FXC_PATH_TILED || p->small_tiled) {
         // pre-stage twiddles wN^((u + P g) k) at [g + G k][u]; stage tables as on the fused path
         const int P = N / 16, R0 = N >= 4096 ? N / 4096 : N / 256, G = 16 / R0;
         std::vector<cf> tw0((size_t)16 * P);
@@ -1930,8 +1950,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             FXC_HIP(p, hipMalloc(&p->d_tw2, tw2.size() * sizeof(cf)));
             FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
         }
-        p->tiled_ring = (T <= 4 && N <= 2048);
-        if (p->tiled_ring) {
+        p->tiled_ring = (T <= 4 && N <= 4096);
+        if (p->tiled_ring && !p->d_win4) {
             std::vector<f4> w4((size_t)N);
             for (int r = 0; r < 16; ++r)
                 for (int u = 0; u < P; ++u) {

@@ -64,7 +64,7 @@ def emul_tiled():
 
 
 @pytest.mark.parametrize("nchan,ntaps,frames,ring", [
-    (512, 4, 9, 0), (512, 4, 9, 1), (1024, 4, 6, 1), (2048, 4, 5, 1), (2048, 3, 5, 1), (1024, 1, 3, 1), (4096, 8, 4, 0),
+    (512, 4, 9, 0), (512, 4, 9, 1), (1024, 4, 6, 1), (2048, 4, 5, 1), (2048, 3, 5, 1), (1024, 1, 3, 1), (4096, 8, 4, 0), (4096, 4, 6, 1),
     (8192, 4, 3, 0), (2048, 32, 3, 0), (512, 7, 12, 0)])
 def test_tiled_phases_match_oracle(emul_tiled, nchan, ntaps, frames, ring):
     """fx_tiled.h (the other --nfft values, effex.py:778): decomposition, padded exchange layout, bin mapping,

@@ -265,7 +265,7 @@ def test_batched_integration_matches_oracle(plan_mod, torch, path, n_chunks, num
 
 @pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [
     (512, 4, 7, 20, 5), (1024, 4, 3, 9, 0), (2048, 4, 5, 33, 100), (2048, 32, 2, 40, 0), (4096, 8, 2, 11, 7),
-    (8192, 4, 3, 6, 1), (1024, 1, 4, 5, 0), (512, 7, 300, 3, 0), (2048, 4, 1, 128, 0)])
+    (8192, 4, 3, 6, 1), (4096, 3, 2, 11, 7), (1024, 1, 4, 5, 0), (512, 7, 300, 3, 0), (2048, 4, 1, 128, 0)])
 def test_tiled_path_matches_oracle(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
     """The other --nfft values (effex.py:778) on the tiled fused kernel: rows, ragged tails, frame splits
     (few chunks, many frames), integration in uneven calls, continuum."""
@@ -292,6 +292,27 @@ def test_tiled_path_matches_oracle(plan_mod, torch, nchan, ntaps, n_chunks, fram
     with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window, path="generic") as g:
         g.set_rot(rot)
         assert rel_err(rows, g.fx_rows(xd, "SPECTRUM").cpu().numpy()) < 4e-6
+
+
+@pytest.mark.parametrize("n_chunks", [1, 2, 7])
+def test_headline_shape_small_calls_split_frames(plan_mod, torch, n_chunks):
+    """The reference hands over one chunk pair per call (effex.py:497-527): with too few chunks to give every CU
+    one, an automatically chosen plan splits the frames of a chunk over workgroups (tiled ring kernel); an
+    explicit "fused" plan keeps one workgroup per chunk.  Same rows either way."""
+    num_samp = 262144
+    x = synth.synth_iq(77, n_chunks, 2, num_samp)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as a, plan_mod.FxPlan(2, 4096, 4, num_samp, path="fused") as f:
+        assert a.path == "fused" and f.path == "fused"
+        ra = a.fx_rows(xd).cpu().numpy()
+        rf = f.fx_rows(xd).cpu().numpy()
+        assert rel_err(ra, rf) < 2e-6
+        ref = fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], 4, 4096, a.window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+        a.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 0.0)
+        assert rel_err(a.fx_rows(xd).cpu().numpy()[0, 0], ref) < TOL_VIS
+        a.fx_accumulate(xd)
+        f.fx_accumulate(xd)
+        assert rel_err(a.finalize("SPECTRUM"), f.finalize("SPECTRUM")) < 2e-6
 
 
 def test_fused_and_generic_agree(plan_mod, torch):
