@@ -9,8 +9,8 @@
 //   per-chunk DC removal, uint8 -> complex        effex/effex.py:394-395, :652 -> dc_* / convert_u8 kernels
 //   delay calibration                             effex/effex.py:583-627 -> delay_* / stockham_stage kernels
 //   per-chunk blocking copies                     effex/effex.py:391-392, 508-509, 693 -> fxc_pipe_* (host side)
-// Paths: fused (nchan 4096, ntaps 4; 2 antennas in one kernel, 4/6/8 via F-only + X-engine), stream (nchan 1),
-// generic (everything else).  Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap, buffer loads.
+// Paths: fused (nchan 4096, ntaps 4; 2 antennas in one kernel, 4/6/8 via F-only + X-engine), tiled (2 antennas,
+// nchan 512..8192, any ntaps: the fused design generalised, fx_tiled.h), stream (nchan 1), generic (everything else).  Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap, buffer loads.
 // No CPU fallback.
 #include <hip/hip_runtime.h>
 
