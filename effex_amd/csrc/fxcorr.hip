@@ -850,7 +850,7 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
         // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the chunk)
 #pragma unroll
         for (int d = 1; d < 4; ++d) {
-            if (i0 - d >= 0) {
+            if (i0 - d >= 0 && i0 < i1) {   // (an empty range at the end of a chunk loads nothing)
                 tiled_load_part<G, 0, 16>(s.h[4 - d], chunk_base, chunk_bytes, xoff, i0 - d);
             } else {
 #pragma unroll
