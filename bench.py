@@ -98,6 +98,35 @@ def pmc_traffic_per_frame():
     return best
 
 
+def power_sample(step, seconds=4.0):
+    """Package power and shader clock read by rocm-smi while `step` keeps the GPU busy (untimed, after the timed
+    region).  Evidence for DESIGN.md §6 (the kernel runs at the package power cap); None if rocm-smi is missing."""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end - 2.0:      # let the clocks settle under load first
+            step()
+        proc = subprocess.Popen([exe, "--showpower", "--showclocks", "--showmaxpower"], stdout=subprocess.PIPE,
+                                stderr=subprocess.DEVNULL, text=True)
+        while proc.poll() is None:
+            step()
+        text = proc.stdout.read()
+        watts = re.search(r"GPU\[0\]\s*:\s*(?:Current Socket|Average) Graphics Package Power \(W\):\s*([0-9.]+)", text)
+        cap = re.search(r"GPU\[0\].*?Max Graphics Package Power \(W\):\s*([0-9.]+)", text)
+        sclk = re.search(r"GPU\[0\].*?sclk clock level:.*?\((\d+)Mhz\)", text)
+        if not watts:
+            return None
+        return {"package_w": float(watts.group(1)), "cap_w": float(cap.group(1)) if cap else None,
+                "sclk_mhz": int(sclk.group(1)) if sclk else None, "source": "rocm-smi, sampled under load after the timed region"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +135,7 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES, help="integration frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power sample after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +210,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    power = power_sample(step) if (world == 1 and not args.no_power) else None
+
     if rank == 0:
         assert out is not None and np.isfinite(out).all() and np.abs(out).max() > 0
         samples = float(frames) * NUM_SAMP * world * args.steps
@@ -218,6 +250,7 @@ def main():
                          "traffic": None if pmc is None else int(pmc[0] * frames_per_launch),
                          "traffic_source": None if pmc is None else pmc[1]},
             "cpu_baseline": cpu,
+            "power": power,
         }
         print(json.dumps(line))
     if world > 1:

@@ -47,6 +47,20 @@ __global__ __launch_bounds__(512) void read_k(const float4* __restrict__ in, flo
     out[(blockIdx.x & 255) * 512 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
 }
 
+__global__ __launch_bounds__(512) void read8_k(const float2* __restrict__ in, float* out, size_t n_vec) {
+    float2 acc = {0, 0};
+    const size_t per_block = n_vec / gridDim.x;
+    const float2* p = in + (size_t)blockIdx.x * per_block;
+    for (size_t i = threadIdx.x; i < per_block; i += 512 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[i + 512 * k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; }
+    }
+    out[(blockIdx.x & 255) * 512 + threadIdx.x] = acc.x + acc.y;
+}
+
 __global__ __launch_bounds__(512) void sleep_k(float* out, int iters, int mode) {
     float s = threadIdx.x;
     for (int it = 0; it < iters; ++it) {
@@ -90,6 +104,7 @@ int main(int argc, char** argv) {
         if (!strcmp(mode, "fma")) hipLaunchKernelGGL(valu_k<1>, dim3(256), dim3(512), 0, 0, out, 200000);
         else if (!strcmp(mode, "add")) hipLaunchKernelGGL(valu_k<0>, dim3(256), dim3(512), 0, 0, out, 200000);
         else if (!strcmp(mode, "read")) hipLaunchKernelGGL(read_k, dim3(2048), dim3(512), 0, 0, in, out, n_vec, 0);
+        else if (!strcmp(mode, "read8")) hipLaunchKernelGGL(read8_k, dim3(2048), dim3(512), 0, 0, (const float2*)in, out, n_vec * 2);
         else if (!strcmp(mode, "fma_read")) hipLaunchKernelGGL(read_k, dim3(2048), dim3(512), 0, 0, in, out, n_vec, 6);
         else if (!strcmp(mode, "lds")) hipLaunchKernelGGL(lds_k, dim3(256), dim3(512), 0, 0, out, 100000);
         else if (!strcmp(mode, "sleep")) hipLaunchKernelGGL(sleep_k, dim3(256), dim3(512), 0, 0, out, 100000, 0);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # sample package power and sclk while each micro-benchmark mode runs
-for mode in sleep nop; do
+for mode in read read8 read read8; do
   ./tools/ubench/power_modes $mode 9 > /tmp/pm_$mode.log 2>&1 &
   P=$!
   sleep 5
