@@ -6,24 +6,35 @@
 #include <cstring>
 #include <chrono>
 
-template <int use_fma>
+typedef float v2f __attribute__((ext_vector_type(2)));
+// MODE: 0 v_add_f32, 1 v_fma_f32, 2 v_mul_f32, 3 v_pk_add_f32, 4 v_pk_fma_f32, 5 v_pk_mul_f32, 6 v_mov_b32
+template <int MODE>
 __global__ __launch_bounds__(512) void valu_k(float* out, int iters) {
     float a[16];
+    v2f p[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 1e-3f + i;
+    for (int i = 0; i < 16; ++i) { a[i] = threadIdx.x * 1e-3f + i; p[i] = v2f{a[i], a[i] + 1.f}; }
     float m = 1.0001f + threadIdx.x * 1e-9f, c = 0.5f + threadIdx.x * 1e-9f;
+    v2f pm = {m, 0.9999f}, pc = {c, 0.25f};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                if (use_fma) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
-                else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (MODE == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (MODE == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (MODE == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 3) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc));
+                if (MODE == 4) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pm), "v"(pc));
+                if (MODE == 5) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
+                if (MODE == 6) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(c));
             }
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += a[i];
+    for (int i = 0; i < 16; ++i) s += a[i] + p[i][0] + p[i][1];
+    extern __shared__ float dyn[];
+    if (s == 123.456f) dyn[threadIdx.x] = s;
     out[(blockIdx.x & 255) * blockDim.x + threadIdx.x] = s;
 }
 
@@ -89,7 +100,13 @@ __global__ __launch_bounds__(512) void lds_k(float* out, int iters) {
     out[(blockIdx.x & 255) * 512 + threadIdx.x] = s;
 }
 
+constexpr int kPin = 100 * 1024;   // dynamic LDS that forces one block per CU
+
+template <int M>
+static void pin() { hipFuncSetAttribute((const void*)valu_k<M>, hipFuncAttributeMaxDynamicSharedMemorySize, kPin); }
+
 int main(int argc, char** argv) {
+    pin<0>(); pin<1>(); pin<2>(); pin<3>(); pin<4>(); pin<5>(); pin<6>();
     const char* mode = argc > 1 ? argv[1] : "fma";
     const double seconds = argc > 2 ? atof(argv[2]) : 8.0;
     float* out; hipMalloc(&out, 256 * 512 * 4);
@@ -101,8 +118,13 @@ int main(int argc, char** argv) {
     double total_ms = 0; long launches = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() < seconds) {
         hipEventRecord(e0, 0);
-        if (!strcmp(mode, "fma")) hipLaunchKernelGGL(valu_k<1>, dim3(256), dim3(512), 0, 0, out, 200000);
-        else if (!strcmp(mode, "add")) hipLaunchKernelGGL(valu_k<0>, dim3(256), dim3(512), 0, 0, out, 200000);
+        if (!strcmp(mode, "fma")) hipLaunchKernelGGL(valu_k<1>, dim3(256), dim3(512), kPin, 0, out, 200000);
+        else if (!strcmp(mode, "add")) hipLaunchKernelGGL(valu_k<0>, dim3(256), dim3(512), kPin, 0, out, 200000);
+        else if (!strcmp(mode, "mul")) hipLaunchKernelGGL(valu_k<2>, dim3(256), dim3(512), kPin, 0, out, 200000);
+        else if (!strcmp(mode, "pk_add")) hipLaunchKernelGGL(valu_k<3>, dim3(256), dim3(512), kPin, 0, out, 200000);
+        else if (!strcmp(mode, "pk_fma")) hipLaunchKernelGGL(valu_k<4>, dim3(256), dim3(512), kPin, 0, out, 200000);
+        else if (!strcmp(mode, "pk_mul")) hipLaunchKernelGGL(valu_k<5>, dim3(256), dim3(512), kPin, 0, out, 200000);
+        else if (!strcmp(mode, "mov")) hipLaunchKernelGGL(valu_k<6>, dim3(256), dim3(512), kPin, 0, out, 200000);
         else if (!strcmp(mode, "read")) hipLaunchKernelGGL(read_k, dim3(2048), dim3(512), 0, 0, in, out, n_vec, 0);
         else if (!strcmp(mode, "read8")) hipLaunchKernelGGL(read8_k, dim3(2048), dim3(512), 0, 0, (const float2*)in, out, n_vec * 2);
         else if (!strcmp(mode, "fma_read")) hipLaunchKernelGGL(read_k, dim3(2048), dim3(512), 0, 0, in, out, n_vec, 6);
@@ -116,7 +138,7 @@ int main(int argc, char** argv) {
         total_ms += ms; ++launches;
     }
     const double ms = total_ms / launches;
-    if (!strcmp(mode, "fma") || !strcmp(mode, "add"))
+    if (!strcmp(mode, "fma") || !strcmp(mode, "add") || !strcmp(mode, "mul") || !strncmp(mode, "pk_", 3) || !strcmp(mode, "mov"))
         printf("%s: %.2f ms per launch, %.3f ns per wave-instruction per SIMD\n", mode, ms, ms * 1e6 / (200000.0 * 64 * 2));
     else if (strstr(mode, "read"))
         printf("%s: %.2f ms per launch, %.1f GB/s\n", mode, ms, n_vec * 16 / ms / 1e6);

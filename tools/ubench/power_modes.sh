@@ -1,6 +1,6 @@
 #!/bin/bash
 # sample package power and sclk while each micro-benchmark mode runs
-for mode in read read8 read read8; do
+for mode in add mul fma mov pk_add pk_mul pk_fma; do
   ./tools/ubench/power_modes $mode 9 > /tmp/pm_$mode.log 2>&1 &
   P=$!
   sleep 5
