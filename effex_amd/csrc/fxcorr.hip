@@ -1227,6 +1227,8 @@ struct fxc_plan {
     // workspace (grown on demand)
     void* d_ws = nullptr;
     int64_t ws_bytes = 0;
+    void* d_stage[2] = {nullptr, nullptr};   // host-buffer calls: device copies of x and out (grown on demand)
+    size_t stage_bytes[2] = {0, 0};
     // timing
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     bool profiling = false;
@@ -1750,21 +1752,27 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
 // host-buffer helper: stage in, run, stage out (synchronous)
 template <class Fn>
 int with_host_staging(fxc_plan* p, const void* x, size_t x_bytes, void* out, size_t out_bytes, Fn fn) {
-    void *dx = nullptr, *dout = nullptr;
-    int rc = FXC_OK;
-    hipError_t e = hipMalloc(&dx, x_bytes ? x_bytes : 1);
-    if (e == hipSuccess && out_bytes) e = hipMalloc(&dout, out_bytes);
-    if (e != hipSuccess) {
-        if (dx) (void)hipFree(dx);
-        return fail(p, FXC_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
+    // staging buffers live in the plan and only grow: the reference calls once per chunk pair (effex.py:490-494),
+    // and a hipMalloc / hipFree pair per call costs more than the copy of one chunk
+    const size_t want[2] = {x_bytes ? x_bytes : 1, out_bytes};
+    for (int k = 0; k < 2; ++k) {
+        if (want[k] <= p->stage_bytes[k]) continue;
+        FXC_HIP(p, hipStreamSynchronize(p->stream));
+        if (p->d_stage[k]) (void)hipFree(p->d_stage[k]);
+        p->d_stage[k] = nullptr;
+        p->stage_bytes[k] = 0;
+        const hipError_t em = hipMalloc(&p->d_stage[k], want[k]);
+        if (em != hipSuccess) return fail(p, FXC_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(em));
+        p->stage_bytes[k] = want[k];
     }
-    e = hipMemcpyAsync(dx, x, x_bytes, hipMemcpyHostToDevice, p->stream);
+    void* dx = p->d_stage[0];
+    void* dout = out_bytes ? p->d_stage[1] : nullptr;
+    int rc = FXC_OK;
+    hipError_t e = hipMemcpyAsync(dx, x, x_bytes, hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) rc = fn(static_cast<const cf*>(dx), dout);
     if (e == hipSuccess && rc == FXC_OK && out_bytes)
         e = hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, p->stream);
     hipError_t e2 = hipStreamSynchronize(p->stream);
-    (void)hipFree(dx);
-    if (dout) (void)hipFree(dout);
     if (rc != FXC_OK) return rc;
     if (e != hipSuccess) return fail(p, FXC_ERR_HIP, "host staging copy failed: %s", hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(p, FXC_ERR_HIP, "stream sync failed: %s", hipGetErrorString(e2));
@@ -1813,7 +1821,7 @@ int fxc_plan_destroy(fxc_plan* p) {
         (void)hipEventDestroy(e.second);
     }
     void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_stamps,
-                    p->d_acc, p->d_sums, p->d_out, p->d_ws};
+                    p->d_acc, p->d_sums, p->d_out, p->d_ws, p->d_stage[0], p->d_stage[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);

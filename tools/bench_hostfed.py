@@ -9,16 +9,20 @@ import numpy as np
 def main():
     from effex_amd import synth
     from effex_amd.plan import FxPlan, FxPipeline
-    num_samp, chunks, n_batches = 2 ** 18, 16, 12
+    num_samp = 2 ** 18
+    chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    n_batches = max(24, 3072 // chunks)        # >= 1 s of copies: the link needs ~0.1 s of traffic to reach full rate
     x = synth.synth_iq(3, chunks, 2, num_samp)
     batches = [x] * n_batches
     plan = FxPlan(2, 4096, 4, num_samp)
-    plan.fx_rows(x)                       # warm up
+    for _ in range(max(4, 512 // chunks)):
+        plan.fx_rows(x)                   # warm up (also ramps the link clocks)
     t0 = time.perf_counter()
     for b in batches:
         plan.fx_rows(b)
     t_block = time.perf_counter() - t0
-    with FxPipeline(plan, chunks, depth=2) as pipe:
+    with FxPipeline(plan, chunks, depth=depth) as pipe:
         pipe.push(batches[0]); pipe.pop()
         t0 = time.perf_counter()
         pipe.push(batches[0])
@@ -29,20 +33,23 @@ def main():
         t_pipe = time.perf_counter() - t0
         # zero-copy producer: the source writes straight into the pinned slot (fill time excluded: a real
         # source - file read, socket, SDR DMA - lands there anyway)
-        for _ in range(2):
+        for _ in range(depth):
             pipe.acquire()[...] = x
             pipe.submit()
-        pipe.pop(); pipe.pop()
+        for _ in range(depth):
+            pipe.pop()
         t0 = time.perf_counter()
-        pipe.acquire(); pipe.submit()
-        for _ in batches[1:]:
+        for _ in range(depth - 1):
+            pipe.acquire(); pipe.submit()
+        for _ in range(n_batches - (depth - 1)):
             pipe.acquire(); pipe.submit()
             pipe.pop()
-        pipe.pop()
+        for _ in range(depth - 1):
+            pipe.pop()
         t_zero = time.perf_counter() - t0
     samples = n_batches * chunks * num_samp
     gb = samples * 16 / 1e9
-    print(json.dumps({"workload": "2 antennas, num_samp 2^18, nchan 4096, %d chunk pairs per batch, host numpy in / rows out" % chunks,
+    print(json.dumps({"depth": depth, "workload": "2 antennas, num_samp 2^18, nchan 4096, %d chunk pairs per batch, host numpy in / rows out" % chunks,
                       "blocking_Msamples_per_s": round(samples / t_block / 1e6, 1), "blocking_GBps_in": round(gb / t_block, 2),
                       "pipelined_Msamples_per_s": round(samples / t_pipe / 1e6, 1), "pipelined_GBps_in": round(gb / t_pipe, 2),
                       "pipelined_zero_copy_Msamples_per_s": round(samples / t_zero / 1e6, 1),
