@@ -26,6 +26,10 @@ SMALL_S = 8192
 SMALL_N = 512
 SMALL_CHUNKS = 5
 
+# the other --nfft values (effex.py:778) at the reference's fixed ntaps = 4: (nbins, num_samp, chunk pairs, delay)
+NFFT_CASES = ((1024, 1024 * 12, 2, 1e-6), (2048, 2048 * 9 + 5, 2, -3e-7), (8192, 8192 * 5, 1, 1e-6))
+SEED_NFFT = 4321
+
 CSV_NBINS = 256
 CSV_S = 4096
 
@@ -74,6 +78,10 @@ def xcorr_input():
 
 def small_input():
     return synth.synth_iq(SEED_PARITY, SMALL_CHUNKS, 2, SMALL_S)
+
+
+def nfft_input(nbins, num_samp, chunks):
+    return synth.synth_iq(SEED_NFFT + nbins, chunks, 2, num_samp)
 
 
 def csv_row(mode):

@@ -103,6 +103,24 @@ def main():
         rows_out.append(np.asarray(cor2._run_task()))
     arrays["small_rows"] = np.stack(rows_out)
 
+    # (4c) the other --nfft values through the reference's own constructor + _run_task (num_samp set after
+    #      construction: the setter clamps to [2^8, 2^18] but does not require a power of two)
+    nfft_meta = []
+    for nbins, num_samp, chunks, delay in gi.NFFT_CASES:
+        fxn, corn = ref_standins.make_correlator(num_samp=num_samp, nbins=nbins)
+        assert corn.nbins == nbins and corn.ntaps == 4 and len(corn.window) == 4 * nbins
+        corn.calibrated_delay = delay
+        xin = gi.nfft_input(nbins, num_samp, chunks)
+        rows_n = []
+        for c in range(chunks):
+            corn.gpu_iq_0 = xin[c, 0].astype(np.complex128)
+            corn.gpu_iq_1 = xin[c, 1].astype(np.complex128)
+            rows_n.append(np.asarray(corn._run_task()))
+        key = "nfft_%d_rows" % nbins
+        arrays[key] = np.stack(rows_n)
+        nfft_meta.append({"nbins": nbins, "num_samp": num_samp, "chunks": chunks, "delay": delay, "key": key})
+    meta["nfft"] = nfft_meta
+
     # (5) csv bytes: _write_metadata + savetxt rows as _write_data does (effex.py:667-696)
     csv_meta = {}
     for mode in ("SPECTRUM", "CONTINUUM"):

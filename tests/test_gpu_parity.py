@@ -316,6 +316,19 @@ def test_headline_shape_small_calls_split_frames(plan_mod, torch, n_chunks):
         assert rel_err(a.finalize("SPECTRUM"), f.finalize("SPECTRUM")) < 2e-6
 
 
+def test_other_nfft_against_reference_goldens(plan_mod, torch, golden):
+    """--nfft 1024 / 2048 / 8192 rows produced by the reference's own _run_task (tests/golden), tiled kernels."""
+    meta, arrays = golden
+    for case in meta["nfft"]:
+        nbins, num_samp, chunks, delay = case["nbins"], case["num_samp"], case["chunks"], case["delay"]
+        x = gi.nfft_input(nbins, num_samp, chunks)
+        with plan_mod.FxPlan(2, nbins, 4, num_samp) as p:
+            assert p.path == "tiled"
+            p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, delay)
+            rows = p.fx_rows(x, "SPECTRUM")                  # host buffers in, host rows out
+            assert rel_err(rows[:, 0], arrays[case["key"]]) < TOL_VIS, nbins
+
+
 def test_fused_and_generic_agree(plan_mod, torch):
     x = torch.from_numpy(synth.synth_iq(5, 7, 2, 4096 * 10)).cuda()
     with plan_mod.FxPlan(2, 4096, 4, 4096 * 10, path="fused") as a, \

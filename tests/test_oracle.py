@@ -129,3 +129,15 @@ def test_delay_estimator(golden):
         est = fx_oracle.estimate_delay_gaussian(iq_0, np.roll(iq_0, g["offset"]), gi.DELAY_RATE)
         np.testing.assert_allclose(est, g["est"], rtol=1e-9, atol=1e-13)
         assert abs(g["offset"] - est * gi.DELAY_RATE) < 0.5
+
+
+def test_other_nfft_rows_match_reference(golden):
+    """The reference's constructor + _run_task at --nfft 1024 / 2048 / 8192 (effex.py:778), ragged num_samp."""
+    meta, arrays = golden
+    for case in meta["nfft"]:
+        nbins, num_samp, chunks, delay = case["nbins"], case["num_samp"], case["chunks"], case["delay"]
+        x = gi.nfft_input(nbins, num_samp, chunks)
+        w = design_window(4, nbins)
+        for c in range(chunks):
+            row = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, nbins, w, gi.BANDWIDTH, gi.FREQUENCY, delay, "SPECTRUM")
+            np.testing.assert_allclose(row, arrays[case["key"]][c], rtol=1e-10, atol=1e-18)
