@@ -63,7 +63,7 @@ def main():
     report("configs[1] headline, integrate", 2, 4096, 4, 2 ** 18, 4096, "SPECTRUM")
     report("configs[1] headline, one row per frame (reference time series)", 2, 4096, 4, 2 ** 18, 4096, "SPECTRUM", rows=True)
     report("configs[2](ii) continuum, reference semantics N=4096, S=2^20", 2, 4096, 4, 2 ** 20, 1024, "CONTINUUM", rows=True)
-    report("configs[2](i) continuum streaming limit nchan=1, S=2^20", 2, 1, 4, 2 ** 20, 256, "CONTINUUM",
+    report("configs[2](i) continuum streaming limit nchan=1, S=2^20", 2, 1, 4, 2 ** 20, 2048, "CONTINUUM",
            window=np.array([0.4, 0.3, 0.2, 0.1]), rows=True)
     report("configs[4] 8 antennas, 28 baselines, N=4096", 8, 4096, 4, 2 ** 18, 256, "SPECTRUM")
     report("N=2048 T=32 (reference test shape), 2 antennas", 2, 2048, 32, 2 ** 18, 256, "SPECTRUM")

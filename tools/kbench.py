@@ -27,7 +27,9 @@ def main():
     from effex_amd.plan import FxPlan, synth_fill
     x = torch.empty((args.frames, 2, args.num_samp), dtype=torch.complex64, device="cuda")
     synth_fill(x, 1234)
-    plan = FxPlan(2, args.nchan, args.ntaps, args.num_samp, path=args.path)
+    import numpy as np
+    window = np.array([0.4, 0.3, 0.2, 0.1][: args.ntaps]) if args.nchan == 1 else None
+    plan = FxPlan(2, args.nchan, args.ntaps, args.num_samp, window=window, path=args.path)
     for _ in range(2):
         (plan.fx_rows(x) if args.rows else plan.fx_accumulate(x))
     plan.sync()
