@@ -347,15 +347,6 @@ __global__ __launch_bounds__(256) void xengine4096_kernel(const cf* __restrict__
     for (int p = 0; p < NB; ++p) raw[(c * NB + p) * fxc::fused::kN + pos] = fxc::mk(ar[p], ai[p]);
 }
 
-// F-only kernel's spectrum order -> natural bin order (fxc_channelize on the fused path)
-__global__ void spec_unpermute_kernel(const cf* __restrict__ spec, cf* __restrict__ out, int64_t total) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const int k = (int)(idx & (fxc::fused::kN - 1));
-        out[idx] = spec[(idx - k) + fxc::fused::specpos_of_bin(k)];
-    }
-}
-
 // sums = [n_base*nchan] raw sums + [1] {count, 0}
 __global__ void export_kernel(const cd* __restrict__ acc, cd* __restrict__ sums, int64_t n, double count) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -670,15 +661,39 @@ __device__ __forceinline__ void tiled_fir(cf (&v)[16], const cf* chunk_base, uns
     }
 }
 
+// F-only tail of a tiled step: the two spectra of frame i leave in natural bin order.  Stage C leaves bin
+// bin_of(u, k2) in v[k2]; the exchange region serves as a transposition buffer (bin k at k + (k >> 4): the
+// 16 lanes of a group write 17 or R0 + 1/16 slots apart, conflict-free) and the rows go out 256 B per half-wave.
+// valid: this lane's stream exists (an odd stream count leaves the last pair half empty).
+template <class G>
+__device__ __forceinline__ void tiled_store_spectrum(const cf (&v)[16], cf* reg, int u, cf* out_row, bool valid) {
+    __syncthreads();   // every wave holds its stage-C outputs in registers: the rows can be overwritten
+    // bin_of(u, k2) = b0 + C k2 with C a multiple of 16, and P is one too: both index maps are one base + constants
+    constexpr int C = (G::A3 ? 256 : 16) * G::R0;
+    const int b0 = G::bin_of(u, 0);
+    cf* wr = reg + b0 + (b0 >> 4);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) wr[(C + C / 16) * k2] = v[k2];
+    __syncthreads();
+    if (valid) {
+        const cf* rd = reg + u + (u >> 4);
+        cf* dst = out_row + u;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) dst[G::P * n] = fxc::fused::lds_load(rd + (G::P + G::P / 16) * n);
+    }
+}
+
 // raw[(split * n_chunks + c) * N + k] = sum over the split's frames of spec0[i,k] * conj(spec1[i,k]), natural
 // bin order, float32.  Work item = (split, chunk); a split is a contiguous range of a chunk's frames (the
 // FIR reads its history from memory, so ranges are independent).
-template <class G>
+// SPEC: F-only -- a "chunk" is a pair of consecutive streams (n_streams of them in all), raw is the spectra
+// buffer [stream][i][k] and n_chunks the number of pairs.
+template <class G, bool SPEC>
 __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
                                                                int64_t n_chunks, int n_splits, int ntaps,
                                                                const float* __restrict__ win, const cf* __restrict__ tw0_g,
                                                                const cf* __restrict__ twA_g, const cf* __restrict__ tw16_g,
-                                                               cf* __restrict__ raw) {
+                                                               cf* __restrict__ raw, int64_t n_streams) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* region = reinterpret_cast<cf*>(smem + G::kLdsRegion);
     cf* tw16 = reinterpret_cast<cf*>(smem + G::kLdsTw16);
@@ -690,15 +705,18 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
     if (G::A3) G::load_twA(twA, twA_g, u);
     __syncthreads();
     cf* reg = region + ant * G::kRegion;
-    const unsigned chunk_bytes = (unsigned)(2 * num_samp * (int64_t)sizeof(cf));
     const unsigned win_bytes = (unsigned)(ntaps * G::N * (int)sizeof(float));
-    const unsigned xoff = (unsigned)((ant * num_samp + (G::P - 1 - u)) * (int64_t)sizeof(cf));
     const unsigned hoff = (unsigned)(u * (int)sizeof(float));
     const int64_t per = (n_pts + n_splits - 1) / n_splits;
     for (int64_t w = blockIdx.x; w < n_chunks * n_splits; w += gridDim.x) {
         const int64_t c = w % n_chunks, split = w / n_chunks;
         const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
         const cf* chunk_base = x + c * 2 * num_samp;
+        // F-only with an odd stream count: the missing second stream of the last pair re-reads the first
+        const bool valid = !SPEC || (2 * c + ant) < n_streams;
+        const int ant_ld = valid ? ant : 0;
+        const unsigned chunk_bytes = (unsigned)((SPEC && 2 * c + 1 >= n_streams ? 1 : 2) * num_samp * (int64_t)sizeof(cf));
+        const unsigned xoff = (unsigned)((ant_ld * num_samp + (G::P - 1 - u)) * (int64_t)sizeof(cf));
         cf acc[G::kAccPerThread];
 #pragma unroll
         for (int q = 0; q < G::kAccPerThread; ++q) acc[q] = fxc::mk(0.f, 0.f);
@@ -730,6 +748,10 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
             wave_sync();
             G::loadC(reg, u, v);
             fxc::dft16(v);
+            if (SPEC) {
+                tiled_store_spectrum<G>(v, reg, u, raw + ((2 * c + ant) * n_pts + i) * G::N, valid);
+                continue;
+            }
             // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins (see fused_step)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -738,6 +760,7 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
                 acc[q] = fxc::cadd(acc[q], fxc::cmulc(a, b));
             }
         }
+        if (SPEC) continue;
         cf* row = raw + (split * n_chunks + c) * G::N;
 #pragma unroll
         for (int q = 0; q < G::kAccPerThread; ++q) row[G::bin_of(u, q + 8 * ant)] = acc[q];
@@ -775,10 +798,10 @@ struct TiledRing {
     } while (0)
 
 // one spectrum of both antennas; frame i sits in ring slot PH, i1 = end of this work item's frame range
-template <class G, int PH>
+template <class G, int PH, bool SPEC>
 __device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, cf* reg, const cf* tw16, int u,
                                                 const cf* chunk_base, unsigned chunk_bytes, unsigned xoff, int64_t i,
-                                                int64_t i1) {
+                                                int64_t i1, cf* out_row, bool valid) {
     cf v[16];
     G::template fir_ring<PH>(s.h, win, u, v);
     // the oldest slot is dead: refill it with the next frame of the range (the current one again at the end,
@@ -810,6 +833,10 @@ __device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, 
     FXC_TILED_PREFETCH(12);
     G::loadC(reg, u, v);
     fxc::dft16(v);
+    if (SPEC) {
+        tiled_store_spectrum<G>(v, reg, u, out_row + i * G::N, valid);
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         cf a = v[q], b = v[q + 8];
@@ -818,13 +845,14 @@ __device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, 
     }
 }
 
-template <class G>
+template <class G, bool SPEC>
 __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf* __restrict__ x, int64_t num_samp,
                                                                       int64_t n_pts, int64_t n_chunks, int n_splits,
                                                                       const f4* __restrict__ win_g,
                                                                       const cf* __restrict__ tw0_g,
                                                                       const cf* __restrict__ twA_g,
-                                                                      const cf* __restrict__ tw16_g, cf* __restrict__ raw) {
+                                                                      const cf* __restrict__ tw16_g, cf* __restrict__ raw,
+                                                                      int64_t n_streams) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* region = reinterpret_cast<cf*>(smem + G::kLdsRegion);
     cf* tw16 = reinterpret_cast<cf*>(smem + G::kLdsTw16);
@@ -838,13 +866,16 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
     if (G::A3) G::load_twA(s.twA, twA_g, u);
     __syncthreads();
     cf* reg = region + ant * G::kRegion;
-    const unsigned chunk_bytes = (unsigned)(2 * num_samp * (int64_t)sizeof(cf));
-    const unsigned xoff = (unsigned)((ant * num_samp + (G::P - 1 - u)) * (int64_t)sizeof(cf));
     const int64_t per = (n_pts + n_splits - 1) / n_splits;
     for (int64_t w = blockIdx.x; w < n_chunks * n_splits; w += gridDim.x) {
         const int64_t c = w % n_chunks, split = w / n_chunks;
         const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
         const cf* chunk_base = x + c * 2 * num_samp;
+        const bool valid = !SPEC || (2 * c + ant) < n_streams;   // see fx_tiled_kernel
+        const int ant_ld = valid ? ant : 0;
+        const unsigned chunk_bytes = (unsigned)((SPEC && 2 * c + 1 >= n_streams ? 1 : 2) * num_samp * (int64_t)sizeof(cf));
+        const unsigned xoff = (unsigned)((ant_ld * num_samp + (G::P - 1 - u)) * (int64_t)sizeof(cf));
+        cf* out_row = SPEC ? raw + (2 * c + ant) * n_pts * G::N : nullptr;
 #pragma unroll
         for (int q = 0; q < G::kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
         // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the chunk)
@@ -859,11 +890,15 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
         }
         if (i0 < i1) tiled_load_part<G, 0, 16>(s.h[0], chunk_base, chunk_bytes, xoff, i0);
         for (int64_t i = i0; i < i1; i += 4) {
-            tiled_ring_step<G, 0>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i, i1);
-            if (i + 1 < i1) tiled_ring_step<G, 1>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 1, i1);
-            if (i + 2 < i1) tiled_ring_step<G, 2>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 2, i1);
-            if (i + 3 < i1) tiled_ring_step<G, 3>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 3, i1);
+            tiled_ring_step<G, 0, SPEC>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i, i1, out_row, valid);
+            if (i + 1 < i1)
+                tiled_ring_step<G, 1, SPEC>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 1, i1, out_row, valid);
+            if (i + 2 < i1)
+                tiled_ring_step<G, 2, SPEC>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 2, i1, out_row, valid);
+            if (i + 3 < i1)
+                tiled_ring_step<G, 3, SPEC>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 3, i1, out_row, valid);
         }
+        if (SPEC) continue;
         cf* row = raw + (split * n_chunks + c) * G::N;
 #pragma unroll
         for (int q = 0; q < G::kAccPerThread; ++q) row[G::bin_of(u, q + 8 * ant)] = s.acc[q];
@@ -1201,7 +1236,6 @@ struct fxc_plan {
     int n_ant = 0, n_base = 0, nchan = 0, ntaps = 0;
     int64_t num_samp = 0, n_pts = 0;
     int path = FXC_PATH_GENERIC;
-    bool fused_f = false;          // nchan 4096 / ntaps 4: the F-only fused kernel also serves fxc_channelize
     bool pow2 = false;
     int lg2n = 0;
     hipStream_t stream = nullptr;
@@ -1214,7 +1248,8 @@ struct fxc_plan {
     cf* d_tw1 = nullptr;
     cf* d_tw2 = nullptr;
     cf* d_tw0 = nullptr;           // tiled: pre-stage twiddles [16][nchan/16]
-    int tiled_grid_max = 0;
+    int tiled_grid_max = 0, tiled_grid_max_f = 0;   // resident workgroups of the F+X / F-only tiled kernels
+    bool tiled_f = false;          // the F-only tiled kernel serves fxc_channelize
     bool small_tiled = false;      // fused shape, path chosen automatically: calls with few chunks split frames
                                    // over workgroups through the tiled ring kernel
     bool tiled_ring = false;       // ntaps <= 4 and nchan <= 4096: VGPR frame ring + window in LDS
@@ -1330,32 +1365,12 @@ int drain_kernel_events(fxc_plan* p) {
 int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out);
 
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
-// allow_fused: only for fxc_channelize, whose output is a caller buffer (the fused route stages in the workspace,
-// which the generic F+X callers use for `spec` itself)
-int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, bool allow_fused = false) {
+int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams);
+
+int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
     if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
-    if (p->fused_f && allow_fused && n_streams >= 2) {
-        // pairs of streams through the F-only fused kernel, then un-permute; an odd last stream goes generic
-        const int64_t pairs = n_streams / 2;
-        const int64_t per_pair = 2 * p->n_pts * fxc::fused::kN;
-        const int64_t pb_max = std::max<int64_t>(1, kWorkspaceTarget / (per_pair * (int64_t)sizeof(cf)));
-        for (int64_t p0 = 0; p0 < pairs; p0 += pb_max) {
-            const int64_t np = std::min(pb_max, pairs - p0);
-            int rc = ensure_ws(p, np * per_pair * (int64_t)sizeof(cf));
-            if (rc) return rc;
-            cf* tmp = reinterpret_cast<cf*>(p->d_ws);
-            rc = launch_fused(p, x + p0 * 2 * p->num_samp, np, tmp, true);
-            if (rc) return rc;
-            const int64_t total = np * per_pair;
-            hipLaunchKernelGGL(spec_unpermute_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream, tmp,
-                               spec + p0 * per_pair, total);
-            FXC_HIP(p, hipGetLastError());
-        }
-        if (n_streams & 1)
-            return run_channelize(p, x + (n_streams - 1) * p->num_samp, spec + (n_streams - 1) * p->n_pts * p->nchan, 1,
-                                  false);
-        return FXC_OK;
-    }
+    // the F-only tiled kernel writes natural-order spectra straight to `spec` (no workspace): any caller may use it
+    if (p->tiled_f) return tiled_channelize(p, x, spec, n_streams);
     const int64_t total = n_streams * p->n_pts * p->nchan;
     hipLaunchKernelGGL(pfb_fir_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream, x, p->d_win,
                        spec, p->num_samp, p->nchan, p->ntaps, p->n_pts, total);
@@ -1461,36 +1476,45 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw) {
 }
 
 // ---- tiled path -------------------------------------------------------------------------------------
-template <class G>
-int tiled_setup(fxc_plan* p) {
-    const void* fn = reinterpret_cast<const void*>(&fx_tiled_kernel<G>);
-    int lds = G::kLdsBytes;
+template <class G, bool SPEC>
+const void* tiled_fn(const fxc_plan* p, int* lds) {
+    *lds = G::kLdsBytes;
     if constexpr (G::N <= 4096) {
         if (p->tiled_ring) {
-            fn = reinterpret_cast<const void*>(&fx_tiled_ring_kernel<G>);
-            lds = G::kLdsBytesRing;
+            *lds = G::kLdsBytesRing;
+            return reinterpret_cast<const void*>(&fx_tiled_ring_kernel<G, SPEC>);
         }
     }
-    FXC_HIP(p, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    int per_cu = 0;
-    FXC_HIP(p, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, G::kThreads, lds));
-    if (per_cu < 1) return fail(p, FXC_ERR_HIP, "tiled kernel for nchan=%d does not fit a CU", G::N);
-    p->tiled_grid_max = per_cu * p->cu_count;
-    return FXC_OK;
+    return reinterpret_cast<const void*>(&fx_tiled_kernel<G, SPEC>);
 }
 
 template <class G>
-void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw) {
-    const int grid = (int)std::min<int64_t>(nc * n_splits, p->tiled_grid_max);
+int tiled_setup(fxc_plan* p) {
+    for (int spec = 0; spec < 2; ++spec) {
+        int lds = 0;
+        const void* fn = spec ? tiled_fn<G, true>(p, &lds) : tiled_fn<G, false>(p, &lds);
+        FXC_HIP(p, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int per_cu = 0;
+        FXC_HIP(p, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, G::kThreads, lds));
+        if (per_cu < 1) return fail(p, FXC_ERR_HIP, "tiled kernel for nchan=%d does not fit a CU", G::N);
+        (spec ? p->tiled_grid_max_f : p->tiled_grid_max) = per_cu * p->cu_count;
+    }
+    return FXC_OK;
+}
+
+// SPEC: x = n_streams consecutive streams, nc = pairs of them, raw = spectra [stream][i][k]
+template <class G, bool SPEC>
+void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, int64_t n_streams) {
+    const int grid = (int)std::min<int64_t>(nc * n_splits, SPEC ? p->tiled_grid_max_f : p->tiled_grid_max);
     if constexpr (G::N <= 4096) {
         if (p->tiled_ring) {
-            hipLaunchKernelGGL(fx_tiled_ring_kernel<G>, dim3(grid), dim3(G::kThreads), G::kLdsBytesRing, p->stream, x,
-                               p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw);
+            hipLaunchKernelGGL((fx_tiled_ring_kernel<G, SPEC>), dim3(grid), dim3(G::kThreads), G::kLdsBytesRing, p->stream, x,
+                               p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw, n_streams);
             return;
         }
     }
-    hipLaunchKernelGGL(fx_tiled_kernel<G>, dim3(grid), dim3(G::kThreads), G::kLdsBytes, p->stream, x, p->num_samp, p->n_pts,
-                       nc, n_splits, p->ntaps, p->d_win, p->d_tw0, p->d_tw1, p->d_tw2, raw);
+    hipLaunchKernelGGL((fx_tiled_kernel<G, SPEC>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, p->stream, x, p->num_samp,
+                       p->n_pts, nc, n_splits, p->ntaps, p->d_win, p->d_tw0, p->d_tw1, p->d_tw2, raw, n_streams);
 }
 
 #define FXC_TILED_DISPATCH(p, CALL)                                                   \
@@ -1512,8 +1536,9 @@ bool use_tiled(const fxc_plan* p, int64_t n_chunks) {
 bool tiled_nchan(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
 
 // frame ranges per chunk so that a launch has at least ~2 work items per resident workgroup
-int tiled_splits(const fxc_plan* p, int64_t n_chunks) {
-    const int64_t want = (2 * (int64_t)p->tiled_grid_max + n_chunks - 1) / n_chunks;
+int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false) {
+    const int64_t cap = f_only ? p->tiled_grid_max_f : p->tiled_grid_max;
+    const int64_t want = (2 * cap + n_chunks - 1) / n_chunks;
     const int64_t most = std::max<int64_t>(1, p->n_pts / 8);
     return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 256));
 }
@@ -1521,7 +1546,18 @@ int tiled_splits(const fxc_plan* p, int64_t n_chunks) {
 // raw[split][c][k] (natural bin order) for nc chunks starting at x
 int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw) {
     KernelTimer kt(p);
-    FXC_TILED_DISPATCH(p, tiled_launch<G>(p, x, nc, n_splits, raw));
+    FXC_TILED_DISPATCH(p, (tiled_launch<G, false>(p, x, nc, n_splits, raw, 2 * nc)));
+    kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+// F-stage only: n_streams consecutive streams -> spec[stream][i][k], pairs of streams per work item
+int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
+    const int64_t pairs = (n_streams + 1) / 2;
+    const int n_splits = tiled_splits(p, pairs, true);
+    KernelTimer kt(p);
+    FXC_TILED_DISPATCH(p, (tiled_launch<G, true>(p, x, pairs, n_splits, spec, n_streams)));
     kt.stop();
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
@@ -1890,9 +1926,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     FXC_HIP(p, hipMalloc(&p->d_sums, (acc_n + 1) * sizeof(cd)));
     FXC_HIP(p, hipMalloc(&p->d_out, acc_n * sizeof(cd)));
 
-    p->fused_f = (N == fxc::fused::kN && T == fxc::fused::kT && p->num_samp <= (1ll << 27) &&
-                  force_path != FXC_PATH_GENERIC);
-    if (p->path == FXC_PATH_FUSED || p->fused_f) {
+    if (p->path == FXC_PATH_FUSED) {
         using namespace fxc::fused;
         std::vector<f4> w4((size_t)kN);
         for (int r = 0; r < 16; ++r)
@@ -1929,7 +1963,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
     p->small_tiled = (p->path == FXC_PATH_FUSED && p->n_ant == 2 && force_path == -1);
-    if (p->path == FXC_PATH_TILED || p->small_tiled) {
+    p->tiled_f = (tiled_nchan(N) && p->num_samp <= (1ll << 27) && force_path != FXC_PATH_GENERIC);
+    if (p->path == FXC_PATH_TILED || p->small_tiled || p->tiled_f) {
         // pre-stage twiddles wN^((u + P g) k) at [g + G k][u]; stage tables as on the fused path
         const int P = N / 16, R0 = N >= 4096 ? N / 4096 : N / 256, G = 16 / R0;
         std::vector<cf> tw0((size_t)16 * P);
@@ -2093,12 +2128,12 @@ int fxc_channelize(fxc_plan* p, const void* x, void* out, int64_t n_streams, int
     if (!x || !out) return fail(p, FXC_ERR_ARG, "NULL buffer");
     FXC_HIP(p, hipSetDevice(p->device));
     if (mem_kind == FXC_MEM_DEVICE)
-        return run_channelize(p, static_cast<const cf*>(x), static_cast<cf*>(out), n_streams, true);
+        return run_channelize(p, static_cast<const cf*>(x), static_cast<cf*>(out), n_streams);
     if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
     const size_t xb = (size_t)n_streams * p->num_samp * sizeof(cf);
     const size_t ob = (size_t)n_streams * p->n_pts * p->nchan * sizeof(cf);
     return with_host_staging(p, x, xb, out, ob, [&](const cf* dx, void* dout) {
-        return run_channelize(p, dx, static_cast<cf*>(dout), n_streams, true);
+        return run_channelize(p, dx, static_cast<cf*>(dout), n_streams);
     });
 }
 

@@ -92,9 +92,9 @@ def test_channelize_matches_oracle(plan_mod, torch, nchan, ntaps, num_samp):
 
 
 @pytest.mark.parametrize("n_streams", [1, 2, 5])
-def test_channelize_default_shape_uses_fused_f_kernel(plan_mod, torch, n_streams):
-    """nchan 4096 / ntaps 4 (the constructor default): pairs of streams go through the F-only fused kernel,
-    an odd last stream through the generic kernels; both must agree with the oracle and with each other."""
+def test_channelize_default_shape_uses_f_only_kernel(plan_mod, torch, n_streams):
+    """nchan 4096 / ntaps 4 (the constructor default): pairs of streams go through the F-only tiled kernel (an odd
+    last stream as a half-empty pair); it must agree with the oracle and with the generic kernels."""
     num_samp = 4096 * 9 + 100
     x = synth.synth_iq(17, n_streams, 1, num_samp)[:, 0]
     window = design_window(4, 4096)
