@@ -60,8 +60,8 @@ struct State {
     // ring of four frames of this thread's 16 branch samples: slot PH holds the frame being
     // channelised, the other three the PFB history (and, once dead, the prefetch of the next frame)
     cf h[4][16];
-    cf tw1[16];                  // w4096^(j*k1), k1 = 1..15 ([0] unused): the kernel is VALU-issue bound, so 15
-                                 // twiddles in 30 VGPRs beat 6 stored powers + 9 extra complex multiplies
+    cf tw1[16];                  // w4096^(j*k1), k1 = 1..15 ([0] unused): 15 twiddles in 30 VGPRs beat 6 stored
+                                 // powers + 9 extra complex multiplies (the kernel is limited by energy per spectrum)
     cf acc[kAccPerThread];       // sum_i spec0*conj(spec1) for this lane's 8 bins
 };
 
