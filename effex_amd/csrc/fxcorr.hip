@@ -661,6 +661,58 @@ __device__ __forceinline__ void tiled_fir(cf (&v)[16], const cf* chunk_base, uns
     }
 }
 
+// Two frames per pass over the PFB history: v0 = FIR of frame i, v1 = FIR of frame i + 1 (computed only if
+// two == true).  At tap t the pass holds x[i + 1 - t] and x[i - t]; the next tap re-uses the older one and
+// loads one new frame, and every window coefficient is loaded once for both outputs: (ntaps + 1) frame loads
+// and ntaps window loads per two spectra instead of 2 ntaps of each.
+template <class G>
+__device__ __forceinline__ void tiled_fir2(cf (&v0)[16], cf (&v1)[16], bool two, const cf* chunk_base,
+                                           unsigned chunk_bytes, unsigned xoff, const float* win, unsigned win_bytes,
+                                           unsigned hoff, int64_t i, int ntaps) {
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(win), 0, (int)win_bytes, 0x00020000);
+    auto load_frame = [&](cf (&dst)[16], int64_t frame, bool present) {
+        if (present) {
+            const unsigned sx = (unsigned)(frame * G::N * (int64_t)sizeof(cf));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rx, xoff, sx + (unsigned)(G::P * (15 - r) * sizeof(cf)), 0);
+                dst[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r] = fxc::mk(0.f, 0.f);
+        }
+    };
+    auto tap = [&](int t, const cf (&xa)[16], const cf (&xb)[16]) {   // xa = x[i + 1 - t], xb = x[i - t]
+        const unsigned sh = (unsigned)(t * G::N * (int)sizeof(float));
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            hv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, hoff, sh + (unsigned)(G::P * r * sizeof(float)), 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v1[r] = fxc::cfma(hv[r], xa[r], v1[r]);
+            v0[r] = fxc::cfma(hv[r], xb[r], v0[r]);
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v0[r] = v1[r] = fxc::mk(0.f, 0.f);
+    cf xw[2][16];
+    load_frame(xw[0], i + 1, two);
+    load_frame(xw[1], i, true);
+    // taps in pairs so that the two-frame window rotates by renaming; a frame before the chunk start is zero
+    for (int t = 0; t < ntaps; t += 2) {
+        tap(t, xw[0], xw[1]);
+        load_frame(xw[0], i - t - 1, i - t - 1 >= 0);       // x[i - (t + 1)]: the older frame of tap t + 1
+        if (t + 1 < ntaps) {
+            tap(t + 1, xw[1], xw[0]);
+            load_frame(xw[1], i - t - 2, i - t - 2 >= 0);
+        }
+    }
+}
+
 // F-only tail of a tiled step: the two spectra of frame i leave in natural bin order.  Stage C leaves bin
 // bin_of(u, k2) in v[k2]; the exchange region serves as a transposition buffer (bin k at k + (k >> 4): the
 // 16 lanes of a group write 17 or R0 + 1/16 slots apart, conflict-free) and the rows go out 256 B per half-wave.
@@ -720,9 +772,8 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
         cf acc[G::kAccPerThread];
 #pragma unroll
         for (int q = 0; q < G::kAccPerThread; ++q) acc[q] = fxc::mk(0.f, 0.f);
-        for (int64_t i = i0; i < i1; ++i) {
-            cf v[16];
-            tiled_fir<G>(v, chunk_base, chunk_bytes, xoff, win, win_bytes, hoff, i, ntaps);
+        // everything after the FIR for one frame
+        auto finish = [&](cf (&v)[16], int64_t i) {
             if (G::R0 > 1) G::prestage(v, tw0);
             if (G::A3) {
                 if (G::R0 > 1) {
@@ -750,7 +801,7 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
             fxc::dft16(v);
             if (SPEC) {
                 tiled_store_spectrum<G>(v, reg, u, raw + ((2 * c + ant) * n_pts + i) * G::N, valid);
-                continue;
+                return;
             }
             // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins (see fused_step)
 #pragma unroll
@@ -758,6 +809,21 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
                 cf a = v[q], b = v[q + 8];
                 permlane32_swap(a, b);
                 acc[q] = fxc::cadd(acc[q], fxc::cmulc(a, b));
+            }
+        };
+        if (G::kThreads <= 512) {   // two frames per pass over the history (the 1024-thread geometry has no registers for it)
+            for (int64_t i = i0; i < i1; i += 2) {
+                cf v0[16], v1[16];
+                const bool two = i + 1 < i1;
+                tiled_fir2<G>(v0, v1, two, chunk_base, chunk_bytes, xoff, win, win_bytes, hoff, i, ntaps);
+                finish(v0, i);
+                if (two) finish(v1, i + 1);
+            }
+        } else {
+            for (int64_t i = i0; i < i1; ++i) {
+                cf v[16];
+                tiled_fir<G>(v, chunk_base, chunk_bytes, xoff, win, win_bytes, hoff, i, ntaps);
+                finish(v, i);
             }
         }
         if (SPEC) continue;
