@@ -418,11 +418,16 @@ def test_empty_batches_and_errors(plan_mod, torch):
 # --------------------------------------------------------------------------------------------
 # size-independent properties at the BASELINE size
 # --------------------------------------------------------------------------------------------
-def test_linearity_and_conjugate_symmetry_full_size(plan_mod, torch):
-    num_samp, n_chunks = 2 ** 18, 4
+@pytest.mark.parametrize("nchan,path,n_chunks", [(4096, "fused", 4), (4096, "fused", 300), (4096, None, 4),
+                                                 (2048, None, 4), (1024, None, 300), (8192, None, 3)])
+def test_linearity_and_conjugate_symmetry_full_size(plan_mod, torch, nchan, path, n_chunks):
+    """BASELINE.json's num_samp through size-independent properties: the headline kernel (explicit "fused": one
+    workgroup per chunk pair, also with more chunk pairs than CUs), the default plan's small-call route, and the
+    tiled kernels."""
+    num_samp = 2 ** 18
     x = torch.from_numpy(synth.synth_iq(77777, n_chunks, 2, num_samp)).cuda()
-    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
-        assert p.path == "fused"
+    with plan_mod.FxPlan(2, nchan, 4, num_samp, path=path) as p:
+        assert p.path == ("fused" if nchan == 4096 else "tiled")
         base = p.fx_rows(x).cpu().numpy().astype(np.complex128)
         scaled = p.fx_rows(x * 2.0).cpu().numpy().astype(np.complex128)          # exact: power of two
         np.testing.assert_array_equal(scaled, 4.0 * base)
