@@ -60,6 +60,8 @@ SIGNATURES = {
     "fxc_sync": (_c.c_int, [_vp]),
     "fxc_remove_dc": (_c.c_int, [_vp, _vp, _vp, _c.c_int64]),
     "fxc_convert_u8": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int]),
+    "fxc_fx_rows_u8": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double, _c.c_int]),
+    "fxc_fx_accumulate_u8": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int]),
     "fxc_estimate_delay": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_double, _c.POINTER(_c.c_double)]),
     "fxc_pipe_create": (_c.c_int, [_c.POINTER(_vp), _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double]),
     "fxc_pipe_acquire": (_c.c_int, [_vp, _c.POINTER(_vp)]),

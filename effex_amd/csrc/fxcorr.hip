@@ -441,6 +441,28 @@ __device__ __forceinline__ void load_frame_part(cf (&xr)[16], const cf* chunk_ba
     }
 }
 
+// uint8 ingest (RTL-SDR interleaved I,Q bytes): the same 16 branches as raw byte pairs, one
+// 16-bit load each -- a quarter of the complex64 stream's HBM bytes
+template <int R0, int CNT>
+__device__ __forceinline__ void load_frame_part_u8(unsigned (&raw)[16], const unsigned short* chunk_base,
+                                                   unsigned chunk_bytes, unsigned voff, int64_t i) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(chunk_base), 0,
+                                                                   (int)chunk_bytes, 0x00020000);
+    const unsigned soff = (unsigned)(i * fxc::fused::kN * (int64_t)sizeof(unsigned short));
+#pragma unroll
+    for (int r = R0; r < R0 + CNT; ++r)
+        raw[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff + (unsigned)(256 * (15 - r) * sizeof(unsigned short)), 0);
+}
+
+// byte pair -> complex64: (b - 127.5) / 127.5 minus the chunk's mean = b / 127.5 + off, off = -mean_byte / 127.5
+// (pyrtlsdr's conversion behind effex.py:652 and the DC removal of effex.py:394-395 in one fused multiply-add)
+__device__ __forceinline__ void convert_frame_u8(cf (&dst)[16], const unsigned (&raw)[16], cf off) {
+    const float k = 1.0f / 127.5f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        dst[r] = fxc::mk(fmaf((float)(raw[r] & 0xFFu), k, off.x), fmaf((float)((raw[r] >> 8) & 0xFFu), k, off.y));
+}
+
 // FXC_ABL: developer-only timing ablations (wrong results by design; the shipped build has FXC_ABL == 0):
 //   1 no barrier B0, 2 no barrier B1, 4 no exchange-1 LDS traffic, 8 no exchange-2 LDS traffic, 16 no IQ loads.
 // FXC_STAMPS: diagnostic build with s_memtime stamps between the phases, summed per wave in scalar
@@ -468,11 +490,15 @@ constexpr int kStampSegs = 12;
 #if (FXC_ABL & 16)
 #define FXC_PREFETCH(R0) ((void)0)
 #else
-#define FXC_PREFETCH(R0)                                                    \
-    do {                                                                    \
-        FXC_SCHED_FENCE();                                                  \
-        load_frame_part<R0, 4>(nx, nbase, chunk_bytes, voff, nframe);       \
-        FXC_SCHED_FENCE();                                                  \
+#define FXC_PREFETCH(R0)                                                                                        \
+    do {                                                                                                        \
+        FXC_SCHED_FENCE();                                                                                      \
+        if (U8)                                                                                                 \
+            load_frame_part_u8<R0, 4>(u8.raw, reinterpret_cast<const unsigned short*>(x) + (more ? nc : c) * 2 * num_samp, \
+                                      chunk_bytes, voff, nframe);                                               \
+        else                                                                                                    \
+            load_frame_part<R0, 4>(nx, nbase, chunk_bytes, voff, nframe);                                       \
+        FXC_SCHED_FENCE();                                                                                      \
     } while (0)
 #endif
 
@@ -481,10 +507,16 @@ constexpr int kStampSegs = 12;
 // which keeps the register allocator from doubling live ranges at merge points.
 // SPEC_OUT: the multi-antenna variant -- the pair of streams is only channelised and both spectra go to
 // HBM for xengine4096_kernel (rows_raw then is the spectra buffer [stream][i][specpos]).
-template <int PH, bool SPEC_OUT>
-__device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, cf* region, const cf* tw2, int tid,
-                                           const cf* x, int64_t num_samp, unsigned chunk_bytes, unsigned voff,
-                                           int64_t& c, int64_t& i, int64_t n_pts, int64_t n_chunks,
+// uint8 ingest state: the frame in flight as raw byte pairs and this chunk's conversion offsets
+struct U8State {
+    unsigned raw[16];
+    cf off;
+};
+
+template <int PH, bool SPEC_OUT, bool U8>
+__device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, const cf* dc, const f4* win, cf* region,
+                                           const cf* tw2, int tid, const cf* x, int64_t num_samp, unsigned chunk_bytes,
+                                           unsigned voff, int64_t& c, int64_t& i, int64_t n_pts, int64_t n_chunks,
                                            cf* rows_raw, unsigned long long (&seg)[kStampSegs],
                                            unsigned long long& t_prev) {
     using namespace fxc::fused;
@@ -492,7 +524,9 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
     if (i == 0) {    // zero PFB history at the start of every chunk
         asm volatile("" ::: "memory");   // keep this a (rarely taken) uniform branch, not 96 v_cndmask per frame
         state_reset_history<PH>(s);
+        if (U8) u8.off = dc[c * 2 + ((tid >> 8) & 1)];
     }
+    if (U8) convert_frame_u8(s.h[PH], u8.raw, u8.off);   // the frame fetched a step ago becomes ring slot PH
     cf v[16];
     phase1_fir<PH>(s, win, tid, v);      // first use of this frame: waits for its loads (issued a step ago)
     FXC_STAMP(2);
@@ -576,11 +610,13 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, const f4* win, 
 // of slot (fx_fused4096.h::slot_of_bin).  SPEC_OUT == true: rows_raw[(2c + ant) * n_pts + i][specpos] = the
 // spectra themselves.  A "chunk" here is a pair of consecutive antenna streams, so an even number of
 // antennas [n_chunks][A][S] is simply n_chunks * A/2 pairs.  stamps: diagnostic builds only.
-template <bool SPEC_OUT>
+// U8: x points at interleaved uint8 I,Q ([chunk][antenna][num_samp] byte pairs) and dc[chunk * 2 + antenna] holds the
+// conversion offsets (-mean_byte / 127.5, or -1 without DC removal) of each stream.
+template <bool SPEC_OUT, bool U8 = false>
 __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     const cf* __restrict__ x, int64_t num_samp, int64_t n_pts, int64_t n_chunks, const f4* __restrict__ win_g,
     const cf* __restrict__ tw1_g, const cf* __restrict__ tw2_g, cf* __restrict__ rows_raw,
-    unsigned long long* __restrict__ stamps) {
+    unsigned long long* __restrict__ stamps, const cf* __restrict__ dc) {
     using namespace fxc::fused;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f4* win = reinterpret_cast<f4*>(smem + kLdsWin);
@@ -601,9 +637,15 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     if (c >= n_chunks) return;
     const int64_t my_chunks = (n_chunks - c + gridDim.x - 1) / gridDim.x;
     const int64_t total = my_chunks * n_pts;
-    const unsigned voff = (unsigned)((ant * num_samp + (255 - j)) * (int64_t)sizeof(cf));
-    const unsigned chunk_bytes = (unsigned)(2 * num_samp * (int64_t)sizeof(cf));
-    load_frame_part<0, 16>(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
+    constexpr int64_t kSampleBytes = U8 ? sizeof(unsigned short) : sizeof(cf);
+    const unsigned voff = (unsigned)((ant * num_samp + (255 - j)) * kSampleBytes);
+    const unsigned chunk_bytes = (unsigned)(2 * num_samp * kSampleBytes);
+    U8State u8;
+    u8.off = fxc::mk(0.f, 0.f);
+    if (U8)
+        load_frame_part_u8<0, 16>(u8.raw, reinterpret_cast<const unsigned short*>(x) + c * 2 * num_samp, chunk_bytes, voff, 0);
+    else
+        load_frame_part<0, 16>(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
     unsigned long long seg[kStampSegs] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
 #if FXC_STAMPS
@@ -612,13 +654,13 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     // frame g of this workgroup's stream of frames sits in ring slot g & 3: unrolled by four so the
     // ring rotates by register renaming
     for (int64_t g = 0; g < total; g += 4) {
-        fused_step<0, SPEC_OUT>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+        fused_step<0, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
         if (g + 1 < total)
-            fused_step<1, SPEC_OUT>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+            fused_step<1, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
         if (g + 2 < total)
-            fused_step<2, SPEC_OUT>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+            fused_step<2, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
         if (g + 3 < total)
-            fused_step<3, SPEC_OUT>(s, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+            fused_step<3, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
     }
 #if FXC_STAMPS
     if (stamps && (tid & 63) == 0) {
@@ -1134,6 +1176,49 @@ __global__ __launch_bounds__(256) void dc_sum_u8_kernel(const unsigned char* __r
     }
 }
 
+// fused uint8 ingest: exact byte sums of whole streams, one workgroup per stream, 16-byte loads (8 samples per lane);
+// part[s * 2] = sum of I bytes, part[s * 2 + 1] = sum of Q bytes  (the n_slices = 1 layout of dc_sum_u8_kernel)
+__global__ __launch_bounds__(256) void dc_sum_u8_stream_kernel(const unsigned char* __restrict__ x, double* __restrict__ part,
+                                                              int64_t num_samp, int64_t n_streams) {
+    __shared__ double red[256];
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    for (int64_t s = blockIdx.x; s < n_streams; s += gridDim.x) {
+        const unsigned char* base = x + s * num_samp * 2;
+        // align to 16 bytes: head and tail bytes one sample at a time
+        const int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15) / 2);
+        const int64_t h = head < num_samp ? head : num_samp;
+        const int64_t n_vec = (num_samp - h) / 8;
+        const v4u* vp = reinterpret_cast<const v4u*>(base + h * 2);
+        unsigned long long ar = 0, ai = 0;
+        for (int64_t n = threadIdx.x; n < n_vec; n += 256) {
+            const v4u w = vp[n];
+            unsigned si = 0, sq = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                si = __builtin_amdgcn_sad_u8(w[k] & 0x00FF00FFu, 0u, si);
+                sq = __builtin_amdgcn_sad_u8((w[k] >> 8) & 0x00FF00FFu, 0u, sq);
+            }
+            ar += si;
+            ai += sq;
+        }
+        const unsigned short* sp = reinterpret_cast<const unsigned short*>(base);
+        for (int64_t n = threadIdx.x; n < h; n += 256) {
+            ar += sp[n] & 0xFF;
+            ai += sp[n] >> 8;
+        }
+        for (int64_t n = h + n_vec * 8 + threadIdx.x; n < num_samp; n += 256) {
+            ar += sp[n] & 0xFF;
+            ai += sp[n] >> 8;
+        }
+        const double sr = block_sum((double)ar, red);
+        const double si2 = block_sum((double)ai, red);
+        if (threadIdx.x == 0) {
+            part[s * 2] = sr;
+            part[s * 2 + 1] = si2;
+        }
+    }
+}
+
 // out = x - mean (complex64 in place or out of place)
 __global__ void dc_apply_c64_kernel(const cf* __restrict__ x, cf* __restrict__ out, const double* __restrict__ part,
                                     int64_t num_samp, int n_slices, int64_t total) {
@@ -1170,6 +1255,25 @@ __global__ void convert_u8_kernel(const unsigned char* __restrict__ x, cf* __res
         // ((b - 127.5) - (mean_b - 127.5)) / 127.5 = (b - mean_b) / 127.5, formed in float64, rounded once
         out[idx] = fxc::mk((float)(((double)(v & 0xFF) - mr) / 127.5), (float)(((double)(v >> 8) - mi) / 127.5));
     }
+}
+
+// conversion offsets of the fused uint8 ingest: dc[s] = -mean_byte / 127.5 per component (float64, rounded once), or
+// -1 when the mean is kept (only the format offset 127.5 is removed)
+__global__ void dc_offsets_u8_kernel(const double* __restrict__ part, cf* __restrict__ dc, int64_t n_streams, int n_slices,
+                                     int64_t num_samp, int remove_dc) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    double mr = 127.5, mi = 127.5;
+    if (remove_dc) {
+        mr = mi = 0.0;
+        for (int k = 0; k < n_slices; ++k) {
+            mr += part[(s * n_slices + k) * 2];
+            mi += part[(s * n_slices + k) * 2 + 1];
+        }
+        mr /= (double)num_samp;
+        mi /= (double)num_samp;
+    }
+    dc[s] = fxc::mk((float)(-mr / 127.5), (float)(-mi / 127.5));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1328,8 +1432,10 @@ struct fxc_plan {
     // workspace (grown on demand)
     void* d_ws = nullptr;
     int64_t ws_bytes = 0;
-    void* d_stage[2] = {nullptr, nullptr};   // host-buffer calls: device copies of x and out (grown on demand)
-    size_t stage_bytes[2] = {0, 0};
+    void* d_stage[3] = {nullptr, nullptr, nullptr};   // host-buffer calls: device copies of x and out; uint8 calls on
+    size_t stage_bytes[3] = {0, 0, 0};                // plans without the fused ingest: the converted samples
+    void* d_dc = nullptr;                            // uint8 ingest: byte sums + conversion offsets per stream
+    size_t dc_bytes = 0;
     // timing
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     bool profiling = false;
@@ -1428,7 +1534,7 @@ int drain_kernel_events(fxc_plan* p) {
     return FXC_OK;
 }
 
-int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out);
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8 = nullptr);
 
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams);
@@ -1486,7 +1592,8 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
 constexpr int kFusedReduceSplits = 64;
 
 // n_pairs = pairs of consecutive antenna streams to channelise; spec_out: write spectra instead of X sums
-int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out) {
+// dc_u8 != nullptr: x is the uint8 I,Q stream and dc_u8 its per-stream conversion offsets (2 antennas, X fused in)
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8) {
     using namespace fxc::fused;
     const int grid = (int)std::min<int64_t>(n_pairs, p->fused_grid_max);
     unsigned long long* stamps = nullptr;
@@ -1497,12 +1604,15 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
     p->stamp_grid = grid;
 #endif
     KernelTimer kt(p);
-    if (spec_out)
-        hipLaunchKernelGGL(fx_fused4096_kernel<true>, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x, p->num_samp,
-                           p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps);
+    if (dc_u8)
+        hipLaunchKernelGGL((fx_fused4096_kernel<false, true>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
+                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8);
+    else if (spec_out)
+        hipLaunchKernelGGL((fx_fused4096_kernel<true, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
+                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr);
     else
-        hipLaunchKernelGGL(fx_fused4096_kernel<false>, dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x, p->num_samp,
-                           p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps);
+        hipLaunchKernelGGL((fx_fused4096_kernel<false, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
+                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr);
     kt.stop();
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
@@ -1525,9 +1635,9 @@ int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec
 }
 
 // raw[c][p][layout] for nc chunks starting at x; spec = scratch for the multi-antenna path
-int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw) {
+int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, const cf* dc_u8 = nullptr) {
     using namespace fxc::fused;
-    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false);
+    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8);
     int rc = launch_fused(p, x, nc * (p->n_ant / 2), spec, true);
     if (rc) return rc;
     const dim3 grid(kN / 256, (unsigned)nc);
@@ -1654,7 +1764,9 @@ int stream_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* raw) {
 }
 
 // device-resident implementation of fx_accumulate
-int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
+// dc_u8 != nullptr (fused 2-antenna plans only): x is the uint8 I,Q stream [n_chunks][2][num_samp][2] and dc_u8 its
+// per-stream conversion offsets
+int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u8 = nullptr) {
     if (n_chunks == 0) return FXC_OK;
     if (p->path == FXC_PATH_STREAM) {
         const int64_t blocks = stream_blocks(p);
@@ -1669,8 +1781,9 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
             hipLaunchKernelGGL(stream1_acc_kernel, dim3(1), dim3(256), 0, p->stream, raw, p->d_acc, nc * blocks);
             FXC_HIP(p, hipGetLastError());
         }
-    } else if (p->path == FXC_PATH_FUSED && !use_tiled(p, n_chunks)) {
+    } else if (p->path == FXC_PATH_FUSED && (dc_u8 || !use_tiled(p, n_chunks))) {
         using namespace fxc::fused;
+        const int64_t in_bytes = (int64_t)p->n_ant * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
         const int64_t part_bytes = (int64_t)kFusedReduceSplits * kN * (int64_t)sizeof(cd);
@@ -1681,7 +1794,8 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
         cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + spec_bytes + raw_bytes);
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
-            rc = fused_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, spec, raw);
+            rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
+                                dc_u8 ? dc_u8 + c0 * 2 : nullptr);
             if (rc) return rc;
             if (p->n_ant == 2) {   // many chunks, one baseline: two-stage reduce over chunks
                 hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, kFusedReduceSplits), dim3(256), 0, p->stream, raw,
@@ -1746,7 +1860,8 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks) {
 }
 
 // device-resident implementation of fx_rows; out = cf[n_chunks][n_base][nchan] or cd[n_chunks][n_base]
-int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode, double bandwidth) {
+int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode, double bandwidth,
+                const cf* dc_u8 = nullptr) {
     if (n_chunks == 0) return FXC_OK;
     const float inv_pts = (float)(1.0 / (double)p->n_pts);
     const double cscale = 1.0 / ((double)p->n_pts * (double)p->nchan * bandwidth);
@@ -1772,7 +1887,8 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         }
         return FXC_OK;
     }
-    if (p->path == FXC_PATH_FUSED && !use_tiled(p, n_chunks)) {
+    if (p->path == FXC_PATH_FUSED && (dc_u8 || !use_tiled(p, n_chunks))) {
+        const int64_t in_bytes = (int64_t)p->n_ant * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
         int rc = ensure_ws(p, spec_bytes + raw_bytes);
@@ -1781,7 +1897,8 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
-            rc = fused_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, spec, raw);
+            rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
+                                dc_u8 ? dc_u8 + c0 * 2 : nullptr);
             if (rc) return rc;
             const int64_t rows = nc * p->n_base;
             if (mode == FXC_MODE_SPECTRUM)
@@ -1923,7 +2040,7 @@ int fxc_plan_destroy(fxc_plan* p) {
         (void)hipEventDestroy(e.second);
     }
     void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_stamps,
-                    p->d_acc, p->d_sums, p->d_out, p->d_ws, p->d_stage[0], p->d_stage[1]};
+                    p->d_acc, p->d_sums, p->d_out, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -2023,9 +2140,11 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipMalloc(&p->d_tw2, tw2.size() * sizeof(cf)));
         FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
         p->fused_grid_max = p->cu_count;   // one 512-thread workgroup (136 KiB LDS) per CU
-        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false>),
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<true>),
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<true, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
     p->small_tiled = (p->path == FXC_PATH_FUSED && p->n_ant == 2 && force_path == -1);
@@ -2330,6 +2449,97 @@ int fxc_convert_u8(fxc_plan* p, const void* iq_u8_dev, void* out_dev, int64_t n_
                        n_slices, total, remove_dc ? 1 : 0);
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
+}
+
+namespace {
+
+int grow(fxc_plan* p, void** buf, size_t* have, size_t want) {
+    if (want <= *have) return FXC_OK;
+    FXC_HIP(p, hipStreamSynchronize(p->stream));
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    const hipError_t e = hipMalloc(buf, want);
+    if (e != hipSuccess) return fail(p, FXC_ERR_NOMEM, "allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+    *have = want;
+    return FXC_OK;
+}
+
+// uint8 I,Q in: fused plans (2 antennas, nchan 4096, ntaps 4) read the bytes in the F+X kernel itself; every other plan
+// converts into a complex64 staging buffer first.  rows: fxc_fx_rows semantics (out != nullptr) or accumulate.
+int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks, int mode, double bandwidth, int remove_dc,
+              bool rows) {
+    constexpr int kSlices = 32;
+    const size_t row_elems = mode == FXC_MODE_SPECTRUM ? (size_t)p->n_base * p->nchan * sizeof(cf) : (size_t)p->n_base * sizeof(cd);
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += 16384) {          // dc_sum_u8_kernel's grid.y carries the stream index
+        const int64_t nc = std::min<int64_t>(16384, n_chunks - c0);
+        const int64_t n_streams = nc * p->n_ant;
+        const unsigned char* xb = x8 + c0 * p->n_ant * p->num_samp * 2;
+        void* ob = rows ? static_cast<char*>(out) + (size_t)c0 * row_elems : nullptr;
+        const size_t part_bytes = (size_t)n_streams * kSlices * 2 * sizeof(double);
+        int rc = grow(p, &p->d_dc, &p->dc_bytes, part_bytes + (size_t)n_streams * sizeof(cf));
+        if (rc) return rc;
+        double* part = static_cast<double*>(p->d_dc);
+        cf* dc = reinterpret_cast<cf*>(static_cast<char*>(p->d_dc) + part_bytes);
+        const bool fused_ingest = p->path == FXC_PATH_FUSED && p->n_ant == 2;
+        if (remove_dc && fused_ingest)
+            hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(n_streams, (int64_t)p->cu_count * 16)),
+                               dim3(256), 0, p->stream, xb, part, p->num_samp, n_streams);
+        else if (remove_dc)
+            hipLaunchKernelGGL(dc_sum_u8_kernel, dim3(kSlices, (unsigned)n_streams), dim3(256), 0, p->stream, xb, part,
+                               p->num_samp, kSlices);
+        if (fused_ingest) {
+            hipLaunchKernelGGL(dc_offsets_u8_kernel, dim3((unsigned)((n_streams + 255) / 256)), dim3(256), 0, p->stream, part,
+                               dc, n_streams, 1, p->num_samp, remove_dc ? 1 : 0);
+            FXC_HIP(p, hipGetLastError());
+            rc = rows ? fx_rows_dev(p, reinterpret_cast<const cf*>(xb), ob, nc, mode, bandwidth, dc)
+                      : fx_accumulate_dev(p, reinterpret_cast<const cf*>(xb), nc, dc);
+        } else {
+            const int64_t total = n_streams * p->num_samp;
+            rc = grow(p, &p->d_stage[2], &p->stage_bytes[2], (size_t)total * sizeof(cf));
+            if (rc) return rc;
+            cf* xc = static_cast<cf*>(p->d_stage[2]);
+            hipLaunchKernelGGL(convert_u8_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream, xb, xc,
+                               part, p->num_samp, kSlices, total, remove_dc ? 1 : 0);
+            FXC_HIP(p, hipGetLastError());
+            rc = rows ? fx_rows_dev(p, xc, ob, nc, mode, bandwidth) : fx_accumulate_dev(p, xc, nc);
+        }
+        if (rc) return rc;
+    }
+    return FXC_OK;
+}
+
+int fx_u8_entry(fxc_plan* p, const void* iq_u8, void* out, int64_t n_chunks, int mem_kind, int mode, double bandwidth,
+                int remove_dc, bool rows) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
+    if (n_chunks < 0) return fail(p, FXC_ERR_ARG, "n_chunks < 0");
+    if (rows && mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
+    if (rows && mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
+    if (n_chunks == 0) return FXC_OK;
+    if (!iq_u8 || (rows && !out)) return fail(p, FXC_ERR_ARG, "NULL buffer");
+    FXC_HIP(p, hipSetDevice(p->device));
+    if (mem_kind == FXC_MEM_DEVICE)
+        return fx_u8_dev(p, static_cast<const unsigned char*>(iq_u8), out, n_chunks, mode, bandwidth, remove_dc, rows);
+    if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
+    const size_t xb = (size_t)n_chunks * p->n_ant * p->num_samp * 2;
+    const size_t ob = !rows ? 0
+                            : (mode == FXC_MODE_SPECTRUM ? (size_t)n_chunks * p->n_base * p->nchan * sizeof(cf)
+                                                         : (size_t)n_chunks * p->n_base * sizeof(cd));
+    return with_host_staging(p, iq_u8, xb, out, ob, [&](const cf* dx, void* dout) {
+        return fx_u8_dev(p, reinterpret_cast<const unsigned char*>(dx), dout, n_chunks, mode, bandwidth, remove_dc, rows);
+    });
+}
+
+}  // namespace
+
+int fxc_fx_rows_u8(fxc_plan* p, const void* iq_u8, void* out, int64_t n_chunks, int mem_kind, int mode, double bandwidth,
+                   int remove_dc) {
+    return fx_u8_entry(p, iq_u8, out, n_chunks, mem_kind, mode, bandwidth, remove_dc, true);
+}
+
+int fxc_fx_accumulate_u8(fxc_plan* p, const void* iq_u8, int64_t n_chunks, int mem_kind, int remove_dc) {
+    return fx_u8_entry(p, iq_u8, nullptr, n_chunks, mem_kind, FXC_MODE_SPECTRUM, 1.0, remove_dc, false);
 }
 
 int fxc_estimate_delay(fxc_plan* p, const void* iq0, const void* iq1, int64_t n, int mem_kind, double rate,

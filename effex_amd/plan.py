@@ -221,6 +221,42 @@ class FxPlan(object):
                                              int(bool(remove_dc))))
         return out
 
+    def _in_u8(self, iq_u8):
+        """uint8 I,Q [n_chunks, n_ant, num_samp, 2] (CUDA tensor or host array) -> (pointer, mem_kind, n, keepalive)."""
+        tail = (self.n_ant, self.num_samp, 2)
+        if _is_torch(iq_u8):
+            import torch
+            if iq_u8.dtype != torch.uint8 or not iq_u8.is_cuda or not iq_u8.is_contiguous():
+                raise ValueError("device input must be a contiguous uint8 CUDA tensor")
+            shape, ptr, kind, keep = tuple(iq_u8.shape), iq_u8.data_ptr(), _lib.FXC_MEM_DEVICE, iq_u8
+        else:
+            keep = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+            shape, ptr, kind = keep.shape, keep.ctypes.data, _lib.FXC_MEM_HOST
+        if len(shape) == 3:
+            shape = (1,) + shape
+        if len(shape) != 4 or tuple(shape[1:]) != tail:
+            raise ValueError("expected shape [n, {}, {}, 2], got {}".format(self.n_ant, self.num_samp, shape))
+        return ptr, kind, shape[0], keep
+
+    def fx_rows_u8(self, iq_u8, mode="SPECTRUM", bandwidth=1.0, remove_dc=True):
+        """``fx_rows`` straight from RTL-SDR bytes: uint8 I,Q [n_chunks, n_ant, num_samp, 2], converted as pyrtlsdr does
+        (effex.py:652) with the per-stream mean removed (effex.py:394-395) unless ``remove_dc`` is false.  On fused
+        plans the F+X kernel reads the bytes itself."""
+        m = MODES[mode.upper()]
+        ptr, kind, n, keep = self._in_u8(iq_u8)
+        if m == _lib.FXC_MODE_SPECTRUM:
+            out, optr = self._out(iq_u8, (n, self.n_baselines, self.nchan), np.complex64)
+        else:
+            out, optr = self._out(iq_u8, (n, self.n_baselines), np.complex128)
+        self._check(self._lib.fxc_fx_rows_u8(self._h, ptr, optr, n, kind, m, float(bandwidth), int(bool(remove_dc))))
+        return out
+
+    def fx_accumulate_u8(self, iq_u8, remove_dc=True):
+        """``fx_accumulate`` straight from RTL-SDR bytes (see ``fx_rows_u8``)."""
+        ptr, kind, n, keep = self._in_u8(iq_u8)
+        self._check(self._lib.fxc_fx_accumulate_u8(self._h, ptr, n, kind, int(bool(remove_dc))))
+        return n
+
     # -- delay calibration ------------------------------------------------------------------
     def estimate_delay(self, iq_0, iq_1, rate):
         """Sub-sample delay between two equal-length streams in seconds (effex.py:583-627)."""

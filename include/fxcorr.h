@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FXC_VERSION 100 /* 0.1.0 */
+#define FXC_VERSION 101 /* 0.1.0 */
 
 typedef struct fxc_plan fxc_plan; /* opaque; one per (device, configuration) */
 typedef struct fxc_pipe fxc_pipe; /* opaque; host-fed double-buffered front end on a plan */
@@ -127,6 +127,16 @@ int fxc_sync(fxc_plan* plan);
  *                   per-stream mean is removed in the same pass from exact integer byte sums. */
 int fxc_remove_dc(fxc_plan* plan, const void* x_dev, void* out_dev, int64_t n_streams);
 int fxc_convert_u8(fxc_plan* plan, const void* iq_u8_dev, void* out_dev, int64_t n_streams, int remove_dc);
+
+/* F+X straight from the RTL-SDR byte stream: iq_u8 = [n_chunks][n_ant][num_samp] interleaved unsigned 8-bit I,Q
+ * (2 bytes per sample), converted as fxc_convert_u8 does (remove_dc != 0: per-stream mean removed, effex.py:394-395)
+ * and then processed exactly like fxc_fx_rows / fxc_fx_accumulate.  On fused plans (2 antennas, nchan 4096, ntaps 4)
+ * the F+X kernel loads the bytes itself -- a quarter of the complex64 stream's HBM traffic, no intermediate copy;
+ * other plans convert into a staging buffer first.  Replaces, for byte sources, the chain pyrtlsdr conversion
+ * (effex.py:652) -> host DC removal (effex.py:394-395) -> cp.array copies (effex.py:508-509) -> _pfb_xcorr. */
+int fxc_fx_rows_u8(fxc_plan* plan, const void* iq_u8, void* out, int64_t n_chunks, int mem_kind, int mode,
+                   double bandwidth, int remove_dc);
+int fxc_fx_accumulate_u8(fxc_plan* plan, const void* iq_u8, int64_t n_chunks, int mem_kind, int remove_dc);
 
 /* Delay calibration — replaces Correlator._estimate_delay_gaussian, effex.py:583-627:
  * zero-pad both streams, FFT, f0*conj(f1), inverse FFT, arg-max of |xcorr|, 3-point log-Gaussian peak;

@@ -492,6 +492,41 @@ def test_input_conditioning_on_device(plan_mod, torch):
         assert rel_err(rows[0, 0], ref0) < TOL_VIS
 
 
+@pytest.mark.parametrize("nchan,frames,n_chunks,remove_dc", [(4096, 9, 3, True), (4096, 5, 300, True), (4096, 6, 2, False),
+                                                             (1024, 12, 4, True), (64, 40, 2, True)])
+def test_fx_straight_from_rtlsdr_bytes(plan_mod, torch, nchan, frames, n_chunks, remove_dc):
+    """fxc_fx_rows_u8 / fxc_fx_accumulate_u8: the byte stream of the reference's receivers (pyrtlsdr conversion behind
+    effex.py:652, DC removal of effex.py:394-395) straight into F+X.  The headline shape reads the bytes inside the
+    fused kernel; other plans convert first.  Checked against the oracle chain and against the two-step device path."""
+    num_samp = nchan * frames + 37
+    rng = np.random.default_rng(2024 + nchan)
+    u8 = rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)
+    u8[0, 0, :, 0] = np.clip(u8[0, 0, :, 0].astype(int) // 2 + 90, 0, 255)        # a stream with a strong DC offset
+    u8[:, 1, 5:, :] = (u8[:, 0, :-5, :] // 2 + u8[:, 1, 5:, :] // 2)              # common signal, 5 samples late
+    ud = torch.from_numpy(u8).cuda()
+    window = design_window(4, nchan)
+    with plan_mod.FxPlan(2, nchan, 4, num_samp) as p:
+        rows = p.fx_rows_u8(ud, "SPECTRUM", remove_dc=remove_dc).cpu().numpy()
+        two_step = p.fx_rows(p.convert_u8(ud, remove_dc=remove_dc)).cpu().numpy()
+        assert rel_err(rows, two_step) < TOL_VIS       # the fused ingest rounds b / 127.5 + off once in float32
+        ref_plain = fx_oracle.u8_to_complex(u8[:2])
+        for c in range(min(n_chunks, 2)):
+            a0, a1 = ref_plain[c, 0], ref_plain[c, 1]
+            if remove_dc:
+                a0, a1 = fx_oracle.remove_dc(a0), fx_oracle.remove_dc(a1)
+            ref = fx_oracle.pfb_xcorr(a0, a1, 4, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        rows_host = p.fx_rows_u8(u8, "SPECTRUM", remove_dc=remove_dc)            # host bytes in, host rows out
+        np.testing.assert_array_equal(rows_host, rows)
+        cont = p.fx_rows_u8(ud, "CONTINUUM", gi.BANDWIDTH, remove_dc=remove_dc).cpu().numpy()
+        np.testing.assert_allclose(cont[:, 0], rows[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH,
+                                   rtol=2e-5, atol=1e-7 * np.abs(cont).max())
+        p.fx_accumulate_u8(ud[: n_chunks // 2], remove_dc=remove_dc)
+        p.fx_accumulate_u8(ud[n_chunks // 2:], remove_dc=remove_dc)
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ[0], rows[:, 0].astype(np.complex128).mean(axis=0)) < 2e-6
+
+
 @pytest.mark.parametrize("mode", ["SPECTRUM", "CONTINUUM"])
 def test_host_fed_pipeline(plan_mod, torch, mode):
     """SURVEY.md §8f #4: double-buffered host-fed front end == the blocking host path, batch for batch."""
