@@ -413,6 +413,18 @@ def test_empty_batches_and_errors(plan_mod, torch):
             p.fx_accumulate(torch.empty((1, 2, 100), dtype=torch.complex64, device="cuda"))
         with pytest.raises(ValueError):
             p.fx_rows(torch.empty((1, 2, 4096), dtype=torch.complex64, device="cuda"), "CONTINUUM", 0.0)
+        # byte ingest: empty batch, wrong shape, wrong dtype, bad bandwidth
+        assert p.fx_accumulate_u8(torch.empty((0, 2, 4096, 2), dtype=torch.uint8, device="cuda")) == 0
+        assert p.fx_rows_u8(np.empty((0, 2, 4096, 2), np.uint8)).shape == (0, 1, 256)
+        with pytest.raises(ValueError):
+            p.fx_rows_u8(torch.empty((1, 2, 4096), dtype=torch.uint8, device="cuda"))
+        with pytest.raises(ValueError):
+            p.fx_rows_u8(torch.empty((1, 2, 4096, 2), dtype=torch.int8, device="cuda"))
+        with pytest.raises(ValueError):
+            p.fx_rows_u8(torch.zeros((1, 2, 4096, 2), dtype=torch.uint8, device="cuda"), "CONTINUUM", 0.0)
+    with plan_mod.FxPlan(1, 256, 4, 4096) as p1:
+        with pytest.raises(ValueError):                # cross-correlation needs two streams
+            p1.fx_rows_u8(torch.zeros((1, 1, 4096, 2), dtype=torch.uint8, device="cuda"))
 
 
 # --------------------------------------------------------------------------------------------
