@@ -444,23 +444,27 @@ __device__ __forceinline__ void load_frame_part(cf (&xr)[16], const cf* chunk_ba
 // uint8 ingest (RTL-SDR interleaved I,Q bytes): the same 16 branches as raw byte pairs, one
 // 16-bit load each -- a quarter of the complex64 stream's HBM bytes
 template <int R0, int CNT>
-__device__ __forceinline__ void load_frame_part_u8(unsigned (&raw)[16], const unsigned short* chunk_base,
+__device__ __forceinline__ void load_frame_part_u8(cf (&xr)[16], const unsigned short* chunk_base,
                                                    unsigned chunk_bytes, unsigned voff, int64_t i) {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(chunk_base), 0,
                                                                    (int)chunk_bytes, 0x00020000);
     const unsigned soff = (unsigned)(i * fxc::fused::kN * (int64_t)sizeof(unsigned short));
 #pragma unroll
-    for (int r = R0; r < R0 + CNT; ++r)
-        raw[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff + (unsigned)(256 * (15 - r) * sizeof(unsigned short)), 0);
+    for (int r = R0; r < R0 + CNT; ++r)   // the byte pair waits in the slot's own register (bit pattern in .x)
+        xr[r].x = __uint_as_float(
+            (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff + (unsigned)(256 * (15 - r) * sizeof(unsigned short)), 0));
 }
 
 // byte pair -> complex64: (b - 127.5) / 127.5 minus the chunk's mean = b / 127.5 + off, off = -mean_byte / 127.5
 // (pyrtlsdr's conversion behind effex.py:652 and the DC removal of effex.py:394-395 in one fused multiply-add)
-__device__ __forceinline__ void convert_frame_u8(cf (&dst)[16], const unsigned (&raw)[16], cf off) {
+// (in place: the raw pair sits in the slot's .x register, see load_frame_part_u8)
+__device__ __forceinline__ void convert_frame_u8(cf (&h)[16], cf off) {
     const float k = 1.0f / 127.5f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        dst[r] = fxc::mk(fmaf((float)(raw[r] & 0xFFu), k, off.x), fmaf((float)((raw[r] >> 8) & 0xFFu), k, off.y));
+    for (int r = 0; r < 16; ++r) {
+        const unsigned raw = __float_as_uint(h[r].x);
+        h[r] = fxc::mk(fmaf((float)(raw & 0xFFu), k, off.x), fmaf((float)((raw >> 8) & 0xFFu), k, off.y));
+    }
 }
 
 // FXC_ABL: developer-only timing ablations (wrong results by design; the shipped build has FXC_ABL == 0):
@@ -494,7 +498,7 @@ constexpr int kStampSegs = 12;
     do {                                                                                                        \
         FXC_SCHED_FENCE();                                                                                      \
         if (U8)                                                                                                 \
-            load_frame_part_u8<R0, 4>(u8.raw, reinterpret_cast<const unsigned short*>(x) + (more ? nc : c) * 2 * num_samp, \
+            load_frame_part_u8<R0, 4>(nx, reinterpret_cast<const unsigned short*>(x) + (more ? nc : c) * 2 * num_samp, \
                                       chunk_bytes, voff, nframe);                                               \
         else                                                                                                    \
             load_frame_part<R0, 4>(nx, nbase, chunk_bytes, voff, nframe);                                       \
@@ -507,9 +511,8 @@ constexpr int kStampSegs = 12;
 // which keeps the register allocator from doubling live ranges at merge points.
 // SPEC_OUT: the multi-antenna variant -- the pair of streams is only channelised and both spectra go to
 // HBM for xengine4096_kernel (rows_raw then is the spectra buffer [stream][i][specpos]).
-// uint8 ingest state: the frame in flight as raw byte pairs and this chunk's conversion offsets
+// uint8 ingest state: this chunk's conversion offsets
 struct U8State {
-    unsigned raw[16];
     cf off;
 };
 
@@ -526,7 +529,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
         state_reset_history<PH>(s);
         if (U8) u8.off = dc[c * 2 + ((tid >> 8) & 1)];
     }
-    if (U8) convert_frame_u8(s.h[PH], u8.raw, u8.off);   // the frame fetched a step ago becomes ring slot PH
+    if (U8) convert_frame_u8(s.h[PH], u8.off);   // the byte pairs fetched a step ago become the samples of slot PH
     cf v[16];
     phase1_fir<PH>(s, win, tid, v);      // first use of this frame: waits for its loads (issued a step ago)
     FXC_STAMP(2);
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     U8State u8;
     u8.off = fxc::mk(0.f, 0.f);
     if (U8)
-        load_frame_part_u8<0, 16>(u8.raw, reinterpret_cast<const unsigned short*>(x) + c * 2 * num_samp, chunk_bytes, voff, 0);
+        load_frame_part_u8<0, 16>(s.h[0], reinterpret_cast<const unsigned short*>(x) + c * 2 * num_samp, chunk_bytes, voff, 0);
     else
         load_frame_part<0, 16>(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
     unsigned long long seg[kStampSegs] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -890,26 +893,44 @@ __device__ __forceinline__ void tiled_load_part(cf (&xr)[16], const cf* chunk_ba
     }
 }
 
+// uint8 ingest (see load_frame_part_u8): chunk_base then points at byte pairs
+template <class G, int R0, int CNT>
+__device__ __forceinline__ void tiled_load_part_u8(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes,
+                                                   unsigned xoff, int64_t frame) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    const unsigned soff = (unsigned)(frame * G::N * (int64_t)sizeof(unsigned short));
+#pragma unroll
+    for (int r = R0; r < R0 + CNT; ++r)
+        xr[r].x = __uint_as_float(
+            (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(unsigned short)), 0));
+}
+
 template <class G>
 struct TiledRing {
     cf h[4][16];
     cf tw0[16];   // pre-stage twiddles (R0 > 1)
     cf twA[16];   // stage-A twiddles (nchan 4096)
     cf acc[G::kAccPerThread];
+    U8State u8;   // uint8 ingest only
 };
 
-#define FXC_TILED_PREFETCH(R0)                                                          \
-    do {                                                                                \
-        FXC_SCHED_FENCE();                                                              \
-        tiled_load_part<G, R0, 4>(nx, chunk_base, chunk_bytes, xoff, nframe);           \
-        FXC_SCHED_FENCE();                                                              \
+#define FXC_TILED_PREFETCH(R0)                                                                  \
+    do {                                                                                        \
+        FXC_SCHED_FENCE();                                                                      \
+        if (U8)                                                                                 \
+            tiled_load_part_u8<G, R0, 4>(nx, chunk_base, chunk_bytes, xoff, nframe);            \
+        else                                                                                    \
+            tiled_load_part<G, R0, 4>(nx, chunk_base, chunk_bytes, xoff, nframe);               \
+        FXC_SCHED_FENCE();                                                                      \
     } while (0)
 
 // one spectrum of both antennas; frame i sits in ring slot PH, i1 = end of this work item's frame range
-template <class G, int PH, bool SPEC>
+template <class G, int PH, bool SPEC, bool U8>
 __device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, cf* reg, const cf* tw16, int u,
                                                 const cf* chunk_base, unsigned chunk_bytes, unsigned xoff, int64_t i,
                                                 int64_t i1, cf* out_row, bool valid) {
+    if (U8) convert_frame_u8(s.h[PH], s.u8.off);   // the byte pairs fetched a step ago become the samples of slot PH
     cf v[16];
     G::template fir_ring<PH>(s.h, win, u, v);
     // the oldest slot is dead: refill it with the next frame of the range (the current one again at the end,
@@ -953,14 +974,16 @@ __device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, 
     }
 }
 
-template <class G, bool SPEC>
+template <class G, bool SPEC, bool U8 = false>
 __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf* __restrict__ x, int64_t num_samp,
                                                                       int64_t n_pts, int64_t n_chunks, int n_splits,
                                                                       const f4* __restrict__ win_g,
                                                                       const cf* __restrict__ tw0_g,
                                                                       const cf* __restrict__ twA_g,
                                                                       const cf* __restrict__ tw16_g, cf* __restrict__ raw,
-                                                                      int64_t n_streams) {
+                                                                      int64_t n_streams, const cf* __restrict__ dc) {
+    static_assert(!(SPEC && U8), "uint8 ingest: F+X only");
+    constexpr int64_t kSampleBytes = U8 ? sizeof(unsigned short) : sizeof(cf);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* region = reinterpret_cast<cf*>(smem + G::kLdsRegion);
     cf* tw16 = reinterpret_cast<cf*>(smem + G::kLdsTw16);
@@ -978,11 +1001,12 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
     for (int64_t w = blockIdx.x; w < n_chunks * n_splits; w += gridDim.x) {
         const int64_t c = w % n_chunks, split = w / n_chunks;
         const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
-        const cf* chunk_base = x + c * 2 * num_samp;
+        const cf* chunk_base = reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c * 2 * num_samp * kSampleBytes);
         const bool valid = !SPEC || (2 * c + ant) < n_streams;   // see fx_tiled_kernel
         const int ant_ld = valid ? ant : 0;
-        const unsigned chunk_bytes = (unsigned)((SPEC && 2 * c + 1 >= n_streams ? 1 : 2) * num_samp * (int64_t)sizeof(cf));
-        const unsigned xoff = (unsigned)((ant_ld * num_samp + (G::P - 1 - u)) * (int64_t)sizeof(cf));
+        const unsigned chunk_bytes = (unsigned)((SPEC && 2 * c + 1 >= n_streams ? 1 : 2) * num_samp * kSampleBytes);
+        const unsigned xoff = (unsigned)((ant_ld * num_samp + (G::P - 1 - u)) * kSampleBytes);
+        if (U8) s.u8.off = dc[c * 2 + ant];
         cf* out_row = SPEC ? raw + (2 * c + ant) * n_pts * G::N : nullptr;
 #pragma unroll
         for (int q = 0; q < G::kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
@@ -990,21 +1014,31 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
 #pragma unroll
         for (int d = 1; d < 4; ++d) {
             if (i0 - d >= 0 && i0 < i1) {   // (an empty range at the end of a chunk loads nothing)
-                tiled_load_part<G, 0, 16>(s.h[4 - d], chunk_base, chunk_bytes, xoff, i0 - d);
+                if (U8) {
+                    tiled_load_part_u8<G, 0, 16>(s.h[4 - d], chunk_base, chunk_bytes, xoff, i0 - d);
+                    convert_frame_u8(s.h[4 - d], s.u8.off);
+                } else {
+                    tiled_load_part<G, 0, 16>(s.h[4 - d], chunk_base, chunk_bytes, xoff, i0 - d);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s.h[4 - d][r] = fxc::mk(0.f, 0.f);
             }
         }
-        if (i0 < i1) tiled_load_part<G, 0, 16>(s.h[0], chunk_base, chunk_bytes, xoff, i0);
+        if (i0 < i1) {
+            if (U8)
+                tiled_load_part_u8<G, 0, 16>(s.h[0], chunk_base, chunk_bytes, xoff, i0);
+            else
+                tiled_load_part<G, 0, 16>(s.h[0], chunk_base, chunk_bytes, xoff, i0);
+        }
         for (int64_t i = i0; i < i1; i += 4) {
-            tiled_ring_step<G, 0, SPEC>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i, i1, out_row, valid);
+            tiled_ring_step<G, 0, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i, i1, out_row, valid);
             if (i + 1 < i1)
-                tiled_ring_step<G, 1, SPEC>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 1, i1, out_row, valid);
+                tiled_ring_step<G, 1, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 1, i1, out_row, valid);
             if (i + 2 < i1)
-                tiled_ring_step<G, 2, SPEC>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 2, i1, out_row, valid);
+                tiled_ring_step<G, 2, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 2, i1, out_row, valid);
             if (i + 3 < i1)
-                tiled_ring_step<G, 3, SPEC>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 3, i1, out_row, valid);
+                tiled_ring_step<G, 3, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 3, i1, out_row, valid);
         }
         if (SPEC) continue;
         cf* row = raw + (split * n_chunks + c) * G::N;
@@ -1658,7 +1692,7 @@ const void* tiled_fn(const fxc_plan* p, int* lds) {
     if constexpr (G::N <= 4096) {
         if (p->tiled_ring) {
             *lds = G::kLdsBytesRing;
-            return reinterpret_cast<const void*>(&fx_tiled_ring_kernel<G, SPEC>);
+            return reinterpret_cast<const void*>(&fx_tiled_ring_kernel<G, SPEC, false>);
         }
     }
     return reinterpret_cast<const void*>(&fx_tiled_kernel<G, SPEC>);
@@ -1675,17 +1709,31 @@ int tiled_setup(fxc_plan* p) {
         if (per_cu < 1) return fail(p, FXC_ERR_HIP, "tiled kernel for nchan=%d does not fit a CU", G::N);
         (spec ? p->tiled_grid_max_f : p->tiled_grid_max) = per_cu * p->cu_count;
     }
+    if constexpr (G::N <= 4096) {
+        if (p->tiled_ring)   // the uint8-ingest variant shares the F+X variant's launch geometry
+            FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_tiled_ring_kernel<G, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytesRing));
+    }
     return FXC_OK;
 }
 
 // SPEC: x = n_streams consecutive streams, nc = pairs of them, raw = spectra [stream][i][k]
 template <class G, bool SPEC>
-void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, int64_t n_streams) {
+void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, int64_t n_streams, const cf* dc_u8 = nullptr) {
     const int grid = (int)std::min<int64_t>(nc * n_splits, SPEC ? p->tiled_grid_max_f : p->tiled_grid_max);
     if constexpr (G::N <= 4096) {
         if (p->tiled_ring) {
-            hipLaunchKernelGGL((fx_tiled_ring_kernel<G, SPEC>), dim3(grid), dim3(G::kThreads), G::kLdsBytesRing, p->stream, x,
-                               p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw, n_streams);
+            if constexpr (!SPEC) {
+                if (dc_u8) {   // uint8 ingest: x is the byte stream
+                    hipLaunchKernelGGL((fx_tiled_ring_kernel<G, false, true>), dim3(grid), dim3(G::kThreads), G::kLdsBytesRing,
+                                       p->stream, x, p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1,
+                                       p->d_tw2, raw, n_streams, dc_u8);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((fx_tiled_ring_kernel<G, SPEC, false>), dim3(grid), dim3(G::kThreads), G::kLdsBytesRing,
+                               p->stream, x, p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw,
+                               n_streams, (const cf*)nullptr);
             return;
         }
     }
@@ -1720,9 +1768,9 @@ int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false) {
 }
 
 // raw[split][c][k] (natural bin order) for nc chunks starting at x
-int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw) {
+int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
     KernelTimer kt(p);
-    FXC_TILED_DISPATCH(p, (tiled_launch<G, false>(p, x, nc, n_splits, raw, 2 * nc)));
+    FXC_TILED_DISPATCH(p, (tiled_launch<G, false>(p, x, nc, n_splits, raw, 2 * nc, dc_u8)));
     kt.stop();
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
@@ -1811,6 +1859,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         }
     } else if (use_tiled(p, n_chunks)) {
         const int N = p->nchan;
+        const int64_t in_bytes = (int64_t)2 * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         const int n_splits = tiled_splits(p, n_chunks);
         const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
         const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(n_chunks, kWorkspaceTarget / (row_bytes * n_splits)));
@@ -1823,7 +1872,8 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         const int kb = (N + 255) / 256;
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
-            rc = tiled_raw_sums(p, x + c0 * 2 * p->num_samp, nc, n_splits, raw);
+            rc = tiled_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, n_splits,
+                                raw, dc_u8 ? dc_u8 + c0 * 2 : nullptr);
             if (rc) return rc;
             hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kb, kFusedReduceSplits), dim3(256), 0, p->stream, raw, part, N,
                                nc * n_splits, kFusedReduceSplits);
@@ -1915,6 +1965,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
     }
     if (use_tiled(p, n_chunks)) {
         const int N = p->nchan;
+        const int64_t in_bytes = (int64_t)2 * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         const int n_splits = tiled_splits(p, n_chunks);
         const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
         const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(n_chunks, kWorkspaceTarget / (row_bytes * n_splits)));
@@ -1923,7 +1974,8 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         cf* raw = reinterpret_cast<cf*>(p->d_ws);
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
-            rc = tiled_raw_sums(p, x + c0 * 2 * p->num_samp, nc, n_splits, raw);
+            rc = tiled_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, n_splits,
+                                raw, dc_u8 ? dc_u8 + c0 * 2 : nullptr);
             if (rc) return rc;
             if (mode == FXC_MODE_SPECTRUM)
                 hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc * N, 256, p->cu_count)), dim3(256), 0, p->stream,
@@ -2481,7 +2533,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
         if (rc) return rc;
         double* part = static_cast<double*>(p->d_dc);
         cf* dc = reinterpret_cast<cf*>(static_cast<char*>(p->d_dc) + part_bytes);
-        const bool fused_ingest = p->path == FXC_PATH_FUSED && p->n_ant == 2;
+        const bool fused_ingest = (p->path == FXC_PATH_FUSED && p->n_ant == 2) || (p->path == FXC_PATH_TILED && p->tiled_ring);
         if (remove_dc && fused_ingest)
             hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(n_streams, (int64_t)p->cu_count * 16)),
                                dim3(256), 0, p->stream, xb, part, p->num_samp, n_streams);

@@ -505,11 +505,12 @@ def test_input_conditioning_on_device(plan_mod, torch):
 
 
 @pytest.mark.parametrize("nchan,frames,n_chunks,remove_dc", [(4096, 9, 3, True), (4096, 5, 300, True), (4096, 6, 2, False),
-                                                             (1024, 12, 4, True), (64, 40, 2, True)])
+                                                             (1024, 12, 4, True), (2048, 7, 3, True), (512, 300, 1, True),
+                                                             (8192, 3, 2, True), (64, 40, 2, True)])
 def test_fx_straight_from_rtlsdr_bytes(plan_mod, torch, nchan, frames, n_chunks, remove_dc):
     """fxc_fx_rows_u8 / fxc_fx_accumulate_u8: the byte stream of the reference's receivers (pyrtlsdr conversion behind
-    effex.py:652, DC removal of effex.py:394-395) straight into F+X.  The headline shape reads the bytes inside the
-    fused kernel; other plans convert first.  Checked against the oracle chain and against the two-step device path."""
+    effex.py:652, DC removal of effex.py:394-395) straight into F+X.  The headline shape and the tiled ring kernels read
+    the bytes inside the kernel (also across frame-range splits); other plans convert first.  Checked against the oracle chain and against the two-step device path."""
     num_samp = nchan * frames + 37
     rng = np.random.default_rng(2024 + nchan)
     u8 = rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)

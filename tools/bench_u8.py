@@ -12,9 +12,10 @@ def main():
     import torch
     from effex_amd.plan import FxPlan
     num_samp, frames = 262144, int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    nchan = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     g = torch.Generator(device="cuda").manual_seed(1)
     u8 = torch.randint(0, 256, (frames, 2, num_samp, 2), dtype=torch.uint8, device="cuda", generator=g)
-    with FxPlan(2, 4096, 4, num_samp) as plan:
+    with FxPlan(2, nchan, 4, num_samp) as plan:
         for remove_dc in (True, False):
             for _ in range(2):
                 plan.fx_accumulate_u8(u8, remove_dc=remove_dc)
@@ -30,7 +31,7 @@ def main():
             plan.kernel_profiling(False)
             ts.sort()
             ms = ts[len(ts) // 2]
-            print(json.dumps({"remove_dc": remove_dc, "frames": frames, "call_ms": round(ms, 3), "fused_kernel_ms": round(kms / n, 3),
+            print(json.dumps({"nchan": nchan, "remove_dc": remove_dc, "frames": frames, "call_ms": round(ms, 3), "fused_kernel_ms": round(kms / n, 3),
                               "Msamples_per_s_call": round(frames * num_samp / ms / 1e3, 1),
                               "Msamples_per_s_kernel": round(frames * num_samp / (kms / n) / 1e3, 1),
                               "u8_GBps_kernel": round(frames * num_samp * 4 / (kms / n) / 1e6, 1)}))
