@@ -27,7 +27,10 @@ class IQSource(object):
     gain = None     # tuner gain            — RtlSdr.gain, effex.py:305-306
 
     def read(self, num_samp):
-        """Return (iq_0, iq_1), each ``num_samp`` complex samples, or None when the stream ends."""
+        """Return (iq_0, iq_1), each ``num_samp`` complex samples, or None when the stream ends.
+
+        A source may instead hand over the receivers' raw bytes — two uint8 arrays [num_samp, 2] of interleaved
+        I,Q (pyrtlsdr's ``format='bytes'``): conversion, DC removal and F+X then happen in one device call."""
         raise NotImplementedError
 
     def close(self):
@@ -277,6 +280,11 @@ class Correlator(object):
     def _pfb_xcorr(self):
         """effex.py:497-527 — one visibility from the chunk pair in ``gpu_iq_0`` / ``gpu_iq_1``."""
         plan = self._plan()
+        u8 = getattr(self, "_u8_pair", None)
+        if u8 is not None:          # byte source: convert + de-mean + F+X in one device call
+            if self.mode in ('CONTINUUM', 'TEST'):
+                return plan.fx_rows_u8(u8, 'CONTINUUM', self.bandwidth, remove_dc=self.remove_dc)[0, 0]
+            return plan.fx_rows_u8(u8, 'SPECTRUM', remove_dc=self.remove_dc)[0, 0].astype(np.complex128)
         # one pass per stream into a reused complex64 staging array (np.stack + astype costs 8 ms per chunk pair)
         n = len(self.gpu_iq_0)
         pair = getattr(self, "_pair_buf", None)
@@ -338,6 +346,17 @@ class Correlator(object):
     # -- control loop (host orchestration only; effex.py:326-417 without the hardware) ------
     def _stage(self, pair):
         iq_0, iq_1 = pair
+        self._u8_pair = None
+        if np.asarray(iq_0).dtype == np.uint8:
+            # raw receiver bytes [num_samp, 2]: the RUN state hands them to the device as they are; CALIBRATE (one
+            # chunk pair per run) needs samples, converted as pyrtlsdr does (effex.py:652)
+            b0 = np.ascontiguousarray(iq_0, dtype=np.uint8).reshape(-1, 2)
+            b1 = np.ascontiguousarray(iq_1, dtype=np.uint8).reshape(-1, 2)
+            if 'CALIBRATE' != self.state:
+                self._u8_pair = np.stack([b0, b1])[None]
+                return
+            iq_0 = ((b0[:, 0].astype(np.float64) - 127.5) + 1j * (b0[:, 1].astype(np.float64) - 127.5)) / 127.5
+            iq_1 = ((b1[:, 0].astype(np.float64) - 127.5) + 1j * (b1[:, 1].astype(np.float64) - 127.5)) / 127.5
         self.gpu_iq_0 = np.asarray(iq_0)
         self.gpu_iq_1 = np.asarray(iq_1)
         if self.remove_dc:   # effex.py:394-395 (host numpy in the reference as well)

@@ -212,6 +212,29 @@ def test_state_machine_writes_reference_csv(tmp_path, torch, golden, calibrate):
         assert rel_err(data[c - first], ref) < TOL_VIS
 
 
+def test_state_machine_on_a_byte_source(tmp_path, torch):
+    """A source that hands over the receivers' bytes (pyrtlsdr format='bytes') writes the same csv as the same data
+    handed over as samples: calibration on the first pair, then one fused convert + de-mean + F+X call per pair."""
+    from effex_amd.correlator import ArraySource, Correlator
+    n_chunks, num_samp, nbins = 5, 4096 * 6, 4096
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, size=(n_chunks, num_samp + 3, 2), dtype=np.uint8)
+    own = rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)
+    u8 = np.empty((n_chunks, 2, num_samp, 2), np.uint8)
+    u8[:, 0] = base[:, 3:] // 2 + own[:, 0] // 2          # common signal, antenna 1 three samples late
+    u8[:, 1] = base[:, :-3] // 2 + own[:, 1] // 2
+    samples = fx_oracle.u8_to_complex(u8).astype(np.complex128)
+    rows = {}
+    for name, chunks in (("bytes", u8), ("samples", samples)):
+        path = str(tmp_path / (name + ".csv"))
+        cor = Correlator(num_samp=num_samp, nbins=nbins, source=ArraySource(chunks), output_file=path)
+        assert cor.run_state_machine() == n_chunks - 1
+        rows[name] = (np.loadtxt(path, dtype=np.complex128, delimiter=',', skiprows=2), cor.calibrated_delay)
+    assert abs(rows["bytes"][1] - rows["samples"][1]) * 2.4e6 < 1e-3          # same calibrated delay (samples)
+    assert abs(rows["bytes"][1] * 2.4e6 - 3) < 0.5
+    assert rel_err(rows["bytes"][0], rows["samples"][0]) < TOL_VIS
+
+
 def test_delay_calibration_against_reference(plan_mod, torch, golden):
     """The reference's delay tests (tests/test_effex.py:92-121): 14 cases, |k - est*rate| < 0.5 sample and
     |k/rate - est| < 1e-6 s, plus agreement with the reference's own estimate (golden)."""
