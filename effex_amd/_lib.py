@@ -64,6 +64,7 @@ SIGNATURES = {
     "fxc_fx_accumulate_u8": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int]),
     "fxc_estimate_delay": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_double, _c.POINTER(_c.c_double)]),
     "fxc_pipe_create": (_c.c_int, [_c.POINTER(_vp), _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double]),
+    "fxc_pipe_create_u8": (_c.c_int, [_c.POINTER(_vp), _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double, _c.c_int]),
     "fxc_pipe_acquire": (_c.c_int, [_vp, _c.POINTER(_vp)]),
     "fxc_pipe_submit": (_c.c_int, [_vp]),
     "fxc_pipe_push": (_c.c_int, [_vp, _vp]),

@@ -1487,6 +1487,8 @@ struct fxc_pipe {
     int depth = 0, mode = FXC_MODE_SPECTRUM;
     double bandwidth = 1.0;
     size_t in_bytes = 0, out_bytes = 0;
+    bool u8 = false;           // batches are RTL-SDR byte pairs (fxc_pipe_create_u8)
+    int remove_dc = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<fxc_pipe_slot> slots;
     int64_t pushed = 0, popped = 0;
@@ -2680,7 +2682,20 @@ int fxc_pipe_destroy(fxc_pipe* q) {
     return FXC_OK;
 }
 
+static int pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth, bool u8,
+                       int remove_dc);
+
 int fxc_pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth) {
+    return pipe_create(out, p, chunks_per_batch, depth, mode, bandwidth, false, 0);
+}
+
+int fxc_pipe_create_u8(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth,
+                       int remove_dc) {
+    return pipe_create(out, p, chunks_per_batch, depth, mode, bandwidth, true, remove_dc);
+}
+
+static int pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth, bool u8,
+                       int remove_dc) {
     if (!out || !p) return fail(p, FXC_ERR_ARG, "NULL argument");
     *out = nullptr;
     if (chunks_per_batch < 1 || depth < 1 || depth > 16) return fail(p, FXC_ERR_ARG, "bad batch size or depth");
@@ -2695,7 +2710,9 @@ int fxc_pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int d
     q->depth = depth;
     q->mode = mode;
     q->bandwidth = bandwidth;
-    q->in_bytes = (size_t)chunks_per_batch * p->n_ant * p->num_samp * sizeof(cf);
+    q->u8 = u8;
+    q->remove_dc = remove_dc;
+    q->in_bytes = (size_t)chunks_per_batch * p->n_ant * p->num_samp * (u8 ? 2 : sizeof(cf));
     q->out_bytes = mode == FXC_MODE_SPECTRUM ? (size_t)chunks_per_batch * p->n_base * p->nchan * sizeof(cf)
                                              : (size_t)chunks_per_batch * p->n_base * sizeof(cd);
     q->slots.resize((size_t)depth);
@@ -2738,7 +2755,9 @@ int fxc_pipe_submit(fxc_pipe* q) {
     FXC_HIP(p, hipMemcpyAsync(sl.d_in, sl.h_in, q->in_bytes, hipMemcpyHostToDevice, q->s_in));
     FXC_HIP(p, hipEventRecord(sl.ev_in, q->s_in));
     FXC_HIP(p, hipStreamWaitEvent(p->stream, sl.ev_in, 0));
-    int rc = fx_rows_dev(p, static_cast<const cf*>(sl.d_in), sl.d_out, q->chunks, q->mode, q->bandwidth);
+    int rc = q->u8 ? fx_u8_dev(p, static_cast<const unsigned char*>(sl.d_in), sl.d_out, q->chunks, q->mode, q->bandwidth,
+                               q->remove_dc, true)
+                   : fx_rows_dev(p, static_cast<const cf*>(sl.d_in), sl.d_out, q->chunks, q->mode, q->bandwidth);
     if (rc) return rc;
     FXC_HIP(p, hipEventRecord(sl.ev_compute, p->stream));
     FXC_HIP(p, hipStreamWaitEvent(q->s_out, sl.ev_compute, 0));

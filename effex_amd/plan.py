@@ -296,28 +296,38 @@ class FxPipeline(object):
     """Host-fed, double-buffered front end on a plan (include/fxcorr.h ``fxc_pipe_*``): push batches of host
     chunks, pop their visibility rows; H2D, compute and D2H of successive batches overlap."""
 
-    def __init__(self, plan, chunks_per_batch, depth=2, mode="SPECTRUM", bandwidth=1.0):
+    def __init__(self, plan, chunks_per_batch, depth=2, mode="SPECTRUM", bandwidth=1.0, u8=False, remove_dc=True):
+        """``u8``: batches are the receivers' bytes, uint8 [chunks, n_ant, num_samp, 2] (``fxc_pipe_create_u8``)."""
         self.plan = plan
         self.chunks = int(chunks_per_batch)
         self.mode = MODES[mode.upper()]
+        self.u8 = bool(u8)
+        self._shape = (self.chunks, plan.n_ant, plan.num_samp) + ((2,) if self.u8 else ())
+        self._dtype = np.uint8 if self.u8 else np.complex64
         self._h = ctypes.c_void_p()
-        plan._check(plan._lib.fxc_pipe_create(ctypes.byref(self._h), plan._h, self.chunks, int(depth), self.mode,
-                                              float(bandwidth)))
+        if self.u8:
+            plan._check(plan._lib.fxc_pipe_create_u8(ctypes.byref(self._h), plan._h, self.chunks, int(depth), self.mode,
+                                                     float(bandwidth), int(bool(remove_dc))))
+        else:
+            plan._check(plan._lib.fxc_pipe_create(ctypes.byref(self._h), plan._h, self.chunks, int(depth), self.mode,
+                                                  float(bandwidth)))
 
     def push(self, x):
-        x = np.ascontiguousarray(x, dtype=np.complex64)
-        if x.shape != (self.chunks, self.plan.n_ant, self.plan.num_samp):
-            raise ValueError("expected a batch of shape {}".format((self.chunks, self.plan.n_ant, self.plan.num_samp)))
+        x = np.ascontiguousarray(x, dtype=self._dtype)
+        if x.shape != self._shape:
+            raise ValueError("expected a batch of shape {}".format(self._shape))
         self.plan._check(self.plan._lib.fxc_pipe_push(self._h, x.ctypes.data))
 
     def acquire(self):
-        """Pinned input buffer of the next free slot as a numpy view [chunks, n_ant, num_samp] to fill in place."""
+        """Pinned input buffer of the next free slot as a numpy view (the batch shape) to fill in place."""
         ptr = ctypes.c_void_p()
         self.plan._check(self.plan._lib.fxc_pipe_acquire(self._h, ctypes.byref(ptr)))
-        shape = (self.chunks, self.plan.n_ant, self.plan.num_samp)
-        n = int(np.prod(shape))
-        buf = (ctypes.c_float * (2 * n)).from_address(ptr.value)
-        return np.frombuffer(buf, dtype=np.complex64).reshape(shape)
+        n = int(np.prod(self._shape))
+        if self.u8:
+            buf = (ctypes.c_uint8 * n).from_address(ptr.value)
+        else:
+            buf = (ctypes.c_float * (2 * n)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=self._dtype).reshape(self._shape)
 
     def submit(self):
         self.plan._check(self.plan._lib.fxc_pipe_submit(self._h))

@@ -155,6 +155,10 @@ int fxc_estimate_delay(fxc_plan* plan, const void* iq0, const void* iq1, int64_t
  * FXC_ERR_STATE when `depth` batches are in flight, pop when none is.
  * The pipe uses the plan's stream and workspace: do not interleave other fxc_fx_* calls on the plan. */
 int fxc_pipe_create(fxc_pipe** out, fxc_plan* plan, int64_t chunks_per_batch, int depth, int mode, double bandwidth);
+/* the same pipe fed with RTL-SDR bytes: batches are [chunks_per_batch][n_ant][num_samp] interleaved uint8 I,Q and go
+ * through fxc_fx_rows_u8 (a quarter of the PCIe traffic of complex64 samples) */
+int fxc_pipe_create_u8(fxc_pipe** out, fxc_plan* plan, int64_t chunks_per_batch, int depth, int mode, double bandwidth,
+                       int remove_dc);
 int fxc_pipe_acquire(fxc_pipe* pipe, void** in_host);
 int fxc_pipe_submit(fxc_pipe* pipe);
 int fxc_pipe_push(fxc_pipe* pipe, const void* x_host);

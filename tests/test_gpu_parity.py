@@ -592,6 +592,28 @@ def test_host_fed_pipeline(plan_mod, torch, mode):
             np.testing.assert_array_equal(got[b], ref[b])
 
 
+def test_host_fed_pipeline_on_bytes(plan_mod, torch):
+    """fxc_pipe_create_u8: the double-buffered front end fed with the receivers' bytes equals fxc_fx_rows_u8."""
+    num_samp, chunks, n_batches = 4096 * 5, 3, 4
+    rng = np.random.default_rng(9)
+    batches = [rng.integers(0, 256, size=(chunks, 2, num_samp, 2), dtype=np.uint8) for _ in range(n_batches)]
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        ref = [p.fx_rows_u8(b) for b in batches]
+        with plan_mod.FxPipeline(p, chunks, depth=2, u8=True) as pipe:
+            got = []
+            pipe.push(batches[0])
+            for b in batches[1:]:
+                pipe.acquire()[...] = b
+                pipe.submit()
+                got.append(pipe.pop())
+            got.append(pipe.pop())
+            assert pipe.in_flight == 0
+            with pytest.raises(ValueError):
+                pipe.push(batches[0][:, :, :, 0])
+    for g, r in zip(got, ref):
+        np.testing.assert_array_equal(g, r)
+
+
 def test_device_synth_is_bit_identical(plan_mod, torch):
     n_chunks, n_ant, num_samp = 3, 3, 5000
     x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")

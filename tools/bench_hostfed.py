@@ -47,13 +47,33 @@ def main():
         for _ in range(depth - 1):
             pipe.pop()
         t_zero = time.perf_counter() - t0
+    # the same front end fed with the receivers' bytes (a quarter of the PCIe traffic)
+    u8 = np.random.default_rng(1).integers(0, 256, size=(chunks, 2, num_samp, 2), dtype=np.uint8)
+    with FxPipeline(plan, chunks, depth=depth, u8=True) as pipe:
+        for _ in range(depth):
+            pipe.acquire()[...] = u8
+            pipe.submit()
+        for _ in range(depth):
+            pipe.pop()
+        nb8 = 4 * n_batches
+        t0 = time.perf_counter()
+        for _ in range(depth - 1):
+            pipe.acquire(); pipe.submit()
+        for _ in range(nb8 - (depth - 1)):
+            pipe.acquire(); pipe.submit()
+            pipe.pop()
+        for _ in range(depth - 1):
+            pipe.pop()
+        t_u8 = time.perf_counter() - t0
     samples = n_batches * chunks * num_samp
     gb = samples * 16 / 1e9
     print(json.dumps({"depth": depth, "workload": "2 antennas, num_samp 2^18, nchan 4096, %d chunk pairs per batch, host numpy in / rows out" % chunks,
                       "blocking_Msamples_per_s": round(samples / t_block / 1e6, 1), "blocking_GBps_in": round(gb / t_block, 2),
                       "pipelined_Msamples_per_s": round(samples / t_pipe / 1e6, 1), "pipelined_GBps_in": round(gb / t_pipe, 2),
                       "pipelined_zero_copy_Msamples_per_s": round(samples / t_zero / 1e6, 1),
-                      "pipelined_zero_copy_GBps_in": round(gb / t_zero, 2)}))
+                      "pipelined_zero_copy_GBps_in": round(gb / t_zero, 2),
+                      "pipelined_bytes_zero_copy_Msamples_per_s": round(4 * samples / t_u8 / 1e6, 1),
+                      "pipelined_bytes_GBps_in": round(4 * samples * 4 / 1e9 / t_u8, 2)}))
 
 
 if __name__ == "__main__":
