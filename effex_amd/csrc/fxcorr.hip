@@ -1538,6 +1538,19 @@ int ensure_ws(fxc_plan* p, int64_t bytes) {
     return FXC_OK;
 }
 
+// grow-only device buffer owned by the plan (staging, conversion offsets)
+int grow(fxc_plan* p, void** buf, size_t* have, size_t want) {
+    if (want <= *have) return FXC_OK;
+    FXC_HIP(p, hipStreamSynchronize(p->stream));
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    const hipError_t e = hipMalloc(buf, want);
+    if (e != hipSuccess) return fail(p, FXC_ERR_NOMEM, "allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+    *have = want;
+    return FXC_OK;
+}
+
 struct KernelTimer {
     fxc_plan* p;
     hipEvent_t a = nullptr, b = nullptr;
@@ -2029,14 +2042,8 @@ int with_host_staging(fxc_plan* p, const void* x, size_t x_bytes, void* out, siz
     // and a hipMalloc / hipFree pair per call costs more than the copy of one chunk
     const size_t want[2] = {x_bytes ? x_bytes : 1, out_bytes};
     for (int k = 0; k < 2; ++k) {
-        if (want[k] <= p->stage_bytes[k]) continue;
-        FXC_HIP(p, hipStreamSynchronize(p->stream));
-        if (p->d_stage[k]) (void)hipFree(p->d_stage[k]);
-        p->d_stage[k] = nullptr;
-        p->stage_bytes[k] = 0;
-        const hipError_t em = hipMalloc(&p->d_stage[k], want[k]);
-        if (em != hipSuccess) return fail(p, FXC_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(em));
-        p->stage_bytes[k] = want[k];
+        const int rg = grow(p, &p->d_stage[k], &p->stage_bytes[k], want[k]);
+        if (rg) return rg;
     }
     void* dx = p->d_stage[0];
     void* dout = out_bytes ? p->d_stage[1] : nullptr;
@@ -2506,18 +2513,6 @@ int fxc_convert_u8(fxc_plan* p, const void* iq_u8_dev, void* out_dev, int64_t n_
 }
 
 namespace {
-
-int grow(fxc_plan* p, void** buf, size_t* have, size_t want) {
-    if (want <= *have) return FXC_OK;
-    FXC_HIP(p, hipStreamSynchronize(p->stream));
-    if (*buf) (void)hipFree(*buf);
-    *buf = nullptr;
-    *have = 0;
-    const hipError_t e = hipMalloc(buf, want);
-    if (e != hipSuccess) return fail(p, FXC_ERR_NOMEM, "allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
-    *have = want;
-    return FXC_OK;
-}
 
 // uint8 I,Q in: fused plans (2 antennas, nchan 4096, ntaps 4) read the bytes in the F+X kernel itself; every other plan
 // converts into a complex64 staging buffer first.  rows: fxc_fx_rows semantics (out != nullptr) or accumulate.
