@@ -75,6 +75,12 @@ class ArraySource(IQSource):
         self.closed = True
 
 
+def _without_mean(x):
+    """x minus its complex mean (= the mean of the real parts and of the imaginary parts), in complex128."""
+    z = np.asarray(x).astype(np.complex128)
+    return z - complex(z.real.mean(), z.imag.mean())
+
+
 class Correlator(object):
     # class constants — effex.py:34-35
     _states = ('OFF', 'STARTUP', 'RUN', 'CALIBRATE', 'SHUTDOWN')
@@ -359,9 +365,9 @@ class Correlator(object):
             iq_1 = ((b1[:, 0].astype(np.float64) - 127.5) + 1j * (b1[:, 1].astype(np.float64) - 127.5)) / 127.5
         self.gpu_iq_0 = np.asarray(iq_0)
         self.gpu_iq_1 = np.asarray(iq_1)
-        if self.remove_dc:   # effex.py:394-395 (host numpy in the reference as well)
-            self.gpu_iq_0 = (self.gpu_iq_0.real - self.gpu_iq_0.real.mean()) + 1j * (self.gpu_iq_0.imag - self.gpu_iq_0.imag.mean())
-            self.gpu_iq_1 = (self.gpu_iq_1.real - self.gpu_iq_1.real.mean()) + 1j * (self.gpu_iq_1.imag - self.gpu_iq_1.imag.mean())
+        if self.remove_dc:   # per-chunk mean of I and of Q removed on the host, as effex.py:394-395 does
+            self.gpu_iq_0 = _without_mean(self.gpu_iq_0)
+            self.gpu_iq_1 = _without_mean(self.gpu_iq_1)
 
     def run_state_machine(self):
         """OFF -> STARTUP -> CALIBRATE -> RUN ... -> SHUTDOWN -> OFF over the source's chunk pairs; the first
