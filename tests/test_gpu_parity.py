@@ -352,6 +352,35 @@ def test_other_nfft_against_reference_goldens(plan_mod, torch, golden):
             assert rel_err(rows[:, 0], arrays[case["key"]]) < TOL_VIS, nbins
 
 
+def test_randomized_shapes_tiled_vs_generic(plan_mod, torch):
+    """150 random (nchan, ntaps, frames, ragged tail, chunk count) draws: the tiled kernels (ring / plain, frame-range
+    splits, uint8 ingest where it applies) against the generic kernels, which share no code with them."""
+    rng = np.random.default_rng(20261002)
+    for case in range(150):
+        nchan = int(rng.choice([512, 1024, 2048, 4096, 8192]))
+        ntaps = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8, 13, 32]))
+        frames = int(rng.integers(1, 70 if nchan <= 1024 else 24))
+        n_chunks = int(rng.choice([1, 1, 2, 3, 7, 19]))
+        num_samp = nchan * frames + int(rng.integers(0, nchan))
+        x = torch.from_numpy(synth.synth_iq(1000 + case, n_chunks, 2, num_samp)).cuda()
+        tag = (case, nchan, ntaps, frames, n_chunks, num_samp)
+        with plan_mod.FxPlan(2, nchan, ntaps, num_samp, path="tiled") as t, \
+                plan_mod.FxPlan(2, nchan, ntaps, num_samp, path="generic") as g:
+            rt, rg = t.fx_rows(x).cpu().numpy(), g.fx_rows(x).cpu().numpy()
+            assert rel_err(rt, rg) < 4e-6, tag
+            t.fx_accumulate(x)
+            g.fx_accumulate(x)
+            assert rel_err(t.finalize("SPECTRUM"), g.finalize("SPECTRUM")) < 4e-6, tag
+            if case % 3 == 0:
+                u8 = torch.from_numpy(rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)).cuda()
+                assert rel_err(t.fx_rows_u8(u8).cpu().numpy(), g.fx_rows_u8(u8).cpu().numpy()) < TOL_VIS, tag
+            if case % 4 == 0:
+                xs = x.view(n_chunks * 2, num_samp)[: 2 * n_chunks - (case % 8 == 0)]      # sometimes an odd stream count
+                with plan_mod.FxPlan(1, nchan, ntaps, num_samp) as f, \
+                        plan_mod.FxPlan(1, nchan, ntaps, num_samp, path="generic") as fg:
+                    assert rel_err(f.channelize(xs).cpu().numpy(), fg.channelize(xs).cpu().numpy()) < TOL_SPEC, tag
+
+
 def test_fused_and_generic_agree(plan_mod, torch):
     x = torch.from_numpy(synth.synth_iq(5, 7, 2, 4096 * 10)).cuda()
     with plan_mod.FxPlan(2, 4096, 4, 4096 * 10, path="fused") as a, \
