@@ -1108,8 +1108,20 @@ __global__ __launch_bounds__(256) void stream1_kernel(const cf* __restrict__ x, 
 constexpr int kStream4Blocks = 16;   // workgroups per chunk
 typedef float v4f32 __attribute__((ext_vector_type(4)));
 
+// ntaps <= 4, even num_samp: a lane takes one sample pair of both streams with an aligned 16-byte load; the two
+// earlier pairs the FIR needs come from the neighbouring lanes (v_mov_b32_dpp wave_shr:1), so a wave covers 62 new
+// pairs plus 2 halo lanes and every pair is loaded exactly once per wave (the halo from L1 instead cost 5 %)
+__device__ __forceinline__ float lane_shr1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ v4f32 wave_shr1(v4f32 v) {
+    const float x = lane_shr1(v.x), y = lane_shr1(v.y), z = lane_shr1(v.z), w = lane_shr1(v.w);
+    v4f32 r = {x, y, z, w};
+    return r;
+}
+
 __global__ __launch_bounds__(256) void stream1_t4_kernel(const cf* __restrict__ x, cf* __restrict__ raw, int64_t num_samp,
-                                                        float h0, float h1, float h2, float h3, int64_t n_chunks) {
+                                                            float h0, float h1, float h2, float h3, int64_t n_chunks) {
     __shared__ cf red[256];
     const int64_t c = blockIdx.y;
     const int64_t pairs = num_samp / 2;
@@ -1119,13 +1131,14 @@ __global__ __launch_bounds__(256) void stream1_t4_kernel(const cf* __restrict__ 
     const v4f32* s0 = reinterpret_cast<const v4f32*>(x + (c * 2 + 0) * num_samp);
     const v4f32* s1 = reinterpret_cast<const v4f32*>(x + (c * 2 + 1) * num_samp);
     const v4f32 zero = {0.f, 0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ar = 0.f, ai = 0.f;
-    for (int64_t m = p0 + threadIdx.x; m < p1; m += 256) {
-        // q[a][0..2] = samples (2m-4, 2m-3), (2m-2, 2m-1), (2m, 2m+1) as (re, im, re, im)
-        const v4f32 a2 = s0[m], b2 = s1[m];
-        const v4f32 a1 = m >= 1 ? s0[m - 1] : zero, b1 = m >= 1 ? s1[m - 1] : zero;
-        const v4f32 a0 = m >= 2 ? s0[m - 2] : zero, b0 = m >= 2 ? s1[m - 2] : zero;
-        // y[2m] = h0 x[2m] + h1 x[2m-1] + h2 x[2m-2] + h3 x[2m-3];  y[2m+1] = h0 x[2m+1] + h1 x[2m] + h2 x[2m-1] + h3 x[2m-2]
+    for (int64_t base = p0 + wave * 62; base < p1; base += 4 * 62) {      // wave-uniform trip count
+        const int64_t m = base + lane - 2;
+        const bool in_range = m >= 0 && m < pairs;
+        const v4f32 a2 = in_range ? s0[m] : zero, b2 = in_range ? s1[m] : zero;
+        const v4f32 a1 = wave_shr1(a2), b1 = wave_shr1(b2);
+        const v4f32 a0 = wave_shr1(a1), b0 = wave_shr1(b1);
         const float y0er = h0 * a2[0] + h1 * a1[2] + h2 * a1[0] + h3 * a0[2];
         const float y0ei = h0 * a2[1] + h1 * a1[3] + h2 * a1[1] + h3 * a0[3];
         const float y0or = h0 * a2[2] + h1 * a2[0] + h2 * a1[2] + h3 * a1[0];
@@ -1134,8 +1147,10 @@ __global__ __launch_bounds__(256) void stream1_t4_kernel(const cf* __restrict__ 
         const float y1ei = h0 * b2[1] + h1 * b1[3] + h2 * b1[1] + h3 * b0[3];
         const float y1or = h0 * b2[2] + h1 * b2[0] + h2 * b1[2] + h3 * b1[0];
         const float y1oi = h0 * b2[3] + h1 * b2[1] + h2 * b1[3] + h3 * b1[1];
-        ar += y0er * y1er + y0ei * y1ei + y0or * y1or + y0oi * y1oi;
-        ai += y0ei * y1er - y0er * y1ei + y0oi * y1or - y0or * y1oi;
+        if (lane >= 2 && m < p1) {
+            ar += y0er * y1er + y0ei * y1ei + y0or * y1or + y0oi * y1oi;
+            ai += y0ei * y1er - y0er * y1ei + y0oi * y1or - y0or * y1oi;
+        }
     }
     red[threadIdx.x] = fxc::mk(ar, ai);
     __syncthreads();
