@@ -301,23 +301,23 @@ __global__ void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict
 // pos) keeps all A(A-1)/2 accumulators in registers over the chunk's P spectra and reads every spectrum
 // sample exactly once; raw[c][p][pos], baselines ordered (0,1),(0,2)..(A-2,A-1) -- effex.py:520 for A > 2
 template <int A>
-__global__ __launch_bounds__(256) void xengine4096_kernel(const cf* __restrict__ spec, cf* __restrict__ raw,
-                                                         int64_t n_pts) {
+__global__ __launch_bounds__(256) void xengine_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int64_t n_pts,
+                                                     int nchan) {
     constexpr int NB = A * (A - 1) / 2;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t c = blockIdx.y;
     float ar[NB], ai[NB];
 #pragma unroll
     for (int p = 0; p < NB; ++p) ar[p] = ai[p] = 0.f;
-    const cf* base = spec + (c * A * n_pts) * fxc::fused::kN + pos;
+    const cf* base = spec + (c * A * n_pts) * nchan + pos;
     // two spectra per trip: 2A independent 8-byte loads in flight before the A(A-1) multiply-accumulates
     int64_t i = 0;
     for (; i + 1 < n_pts; i += 2) {
         cf z0[A], z1[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-            z0[a] = base[((int64_t)a * n_pts + i) * fxc::fused::kN];
-            z1[a] = base[((int64_t)a * n_pts + i + 1) * fxc::fused::kN];
+            z0[a] = base[((int64_t)a * n_pts + i) * nchan];
+            z1[a] = base[((int64_t)a * n_pts + i + 1) * nchan];
         }
         int p = 0;
 #pragma unroll
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void xengine4096_kernel(const cf* __restrict__
     for (; i < n_pts; ++i) {
         cf z[A];
 #pragma unroll
-        for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * n_pts + i) * fxc::fused::kN];
+        for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * n_pts + i) * nchan];
         int p = 0;
 #pragma unroll
         for (int a = 0; a < A; ++a)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void xengine4096_kernel(const cf* __restrict__
             }
     }
 #pragma unroll
-    for (int p = 0; p < NB; ++p) raw[(c * NB + p) * fxc::fused::kN + pos] = fxc::mk(ar[p], ai[p]);
+    for (int p = 0; p < NB; ++p) raw[(c * NB + p) * nchan + pos] = fxc::mk(ar[p], ai[p]);
 }
 
 // sums = [n_base*nchan] raw sums + [1] {count, 0}
@@ -510,7 +510,7 @@ constexpr int kStampSegs = 12;
 // wave-uniform and none of it guards a *definition* of ring registers (the prefetch is unconditional),
 // which keeps the register allocator from doubling live ranges at merge points.
 // SPEC_OUT: the multi-antenna variant -- the pair of streams is only channelised and both spectra go to
-// HBM for xengine4096_kernel (rows_raw then is the spectra buffer [stream][i][specpos]).
+// HBM for xengine_kernel (rows_raw then is the spectra buffer [stream][i][specpos]).
 // uint8 ingest state: this chunk's conversion offsets
 struct U8State {
     cf off;
@@ -1683,13 +1683,12 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
 }
 
 // layout of the raw per-chunk sums the fused paths produce (see raw_index)
-int fused_layout(const fxc_plan* p) { return p->n_ant == 2 ? 1 : 2; }
+int fused_layout(const fxc_plan* p) { return p->n_ant == 2 ? 1 : (p->path == FXC_PATH_FUSED ? 2 : 0); }
 
 // chunks per pass on the fused paths: 2 antennas only need the raw rows; more antennas also the spectra
 int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec_bytes, int64_t* raw_bytes) {
-    using namespace fxc::fused;
-    const int64_t raw_per_chunk = (int64_t)p->n_base * kN * (int64_t)sizeof(cf);
-    const int64_t spec_per_chunk = p->n_ant == 2 ? 0 : (int64_t)p->n_ant * p->n_pts * kN * (int64_t)sizeof(cf);
+    const int64_t raw_per_chunk = (int64_t)p->n_base * p->nchan * (int64_t)sizeof(cf);
+    const int64_t spec_per_chunk = p->n_ant == 2 ? 0 : (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
     int64_t cb = kWorkspaceTarget / (raw_per_chunk + spec_per_chunk);
     if (cb < 1) cb = 1;
     if (cb > n_chunks) cb = n_chunks;
@@ -1702,13 +1701,16 @@ int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec
 int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, const cf* dc_u8 = nullptr) {
     using namespace fxc::fused;
     if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8);
-    int rc = launch_fused(p, x, nc * (p->n_ant / 2), spec, true);
+    // 4 / 6 / 8 antennas: spectra to HBM (the F-only fused kernel in its own spectrum order at nchan 4096 / ntaps 4,
+    // the F-only tiled kernel in natural order otherwise), then the register-resident X-engine
+    int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
+                                       : tiled_channelize(p, x, spec, nc * p->n_ant);
     if (rc) return rc;
-    const dim3 grid(kN / 256, (unsigned)nc);
+    const dim3 grid(p->nchan / 256, (unsigned)nc);
     switch (p->n_ant) {
-        case 4: hipLaunchKernelGGL(xengine4096_kernel<4>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts); break;
-        case 6: hipLaunchKernelGGL(xengine4096_kernel<6>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts); break;
-        case 8: hipLaunchKernelGGL(xengine4096_kernel<8>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts); break;
+        case 4: hipLaunchKernelGGL(xengine_kernel<4>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
+        case 6: hipLaunchKernelGGL(xengine_kernel<6>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
+        case 8: hipLaunchKernelGGL(xengine_kernel<8>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
         default: return fail(p, FXC_ERR_UNSUPPORTED, "no X-engine instantiation for n_ant=%d", p->n_ant);
     }
     FXC_HIP(p, hipGetLastError());
@@ -1859,7 +1861,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             hipLaunchKernelGGL(stream1_acc_kernel, dim3(1), dim3(256), 0, p->stream, raw, p->d_acc, nc * blocks);
             FXC_HIP(p, hipGetLastError());
         }
-    } else if (p->path == FXC_PATH_FUSED && (dc_u8 || !use_tiled(p, n_chunks))) {
+    } else if ((p->path == FXC_PATH_FUSED && (dc_u8 || !use_tiled(p, n_chunks))) || (p->path == FXC_PATH_TILED && p->n_ant > 2)) {
         using namespace fxc::fused;
         const int64_t in_bytes = (int64_t)p->n_ant * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         int64_t spec_bytes, raw_bytes;
@@ -1967,7 +1969,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         }
         return FXC_OK;
     }
-    if (p->path == FXC_PATH_FUSED && (dc_u8 || !use_tiled(p, n_chunks))) {
+    if ((p->path == FXC_PATH_FUSED && (dc_u8 || !use_tiled(p, n_chunks))) || (p->path == FXC_PATH_TILED && p->n_ant > 2)) {
         const int64_t in_bytes = (int64_t)p->n_ant * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
@@ -2136,7 +2138,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
 
     const int N = p->nchan, T = p->ntaps;
     // the fused kernel channelises pairs of antenna streams: 2 antennas (X fused in) or 4 / 6 / 8 (F-only +
-    // xengine4096_kernel); num_samp is bounded by the 32-bit buffer-descriptor range of one stream pair
+    // xengine_kernel); num_samp is bounded by the 32-bit buffer-descriptor range of one stream pair
     const bool fused_shape = ((p->n_ant == 2 || p->n_ant == 4 || p->n_ant == 6 || p->n_ant == 8) && N == fxc::fused::kN &&
                               T == fxc::fused::kT && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_FUSED && !fused_shape)
@@ -2144,7 +2146,10 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     const bool stream_shape = (p->n_ant == 2 && N == 1);
     if (force_path == FXC_PATH_STREAM && !stream_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "the streaming kernel needs n_ant=2, nchan=1");
-    const bool tiled_shape = (p->n_ant == 2 && tiled_nchan(N) && p->num_samp <= (1ll << 27));
+    // 2 antennas: X fused into the tiled kernel; 4 / 6 / 8: F-only tiled kernel + X-engine (nchan 8192 spectra rows are
+    // a multiple of 256 positions like all the others)
+    const bool tiled_shape = ((p->n_ant == 2 || p->n_ant == 4 || p->n_ant == 6 || p->n_ant == 8) && tiled_nchan(N) &&
+                              p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_TILED && !tiled_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for n_ant=%d nchan=%d", p->n_ant, N);
     p->path = FXC_PATH_GENERIC;
@@ -2545,7 +2550,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
         if (rc) return rc;
         double* part = static_cast<double*>(p->d_dc);
         cf* dc = reinterpret_cast<cf*>(static_cast<char*>(p->d_dc) + part_bytes);
-        const bool fused_ingest = (p->path == FXC_PATH_FUSED && p->n_ant == 2) || (p->path == FXC_PATH_TILED && p->tiled_ring);
+        const bool fused_ingest = p->n_ant == 2 && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && p->tiled_ring));
         if (remove_dc && fused_ingest)
             hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(n_streams, (int64_t)p->cu_count * 16)),
                                dim3(256), 0, p->stream, xb, part, p->num_samp, n_streams);
