@@ -1708,8 +1708,11 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
     if (rc) return rc;
     const dim3 grid(p->nchan / 256, (unsigned)nc);
     switch (p->n_ant) {
+        case 3: hipLaunchKernelGGL(xengine_kernel<3>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
         case 4: hipLaunchKernelGGL(xengine_kernel<4>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
+        case 5: hipLaunchKernelGGL(xengine_kernel<5>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
         case 6: hipLaunchKernelGGL(xengine_kernel<6>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
+        case 7: hipLaunchKernelGGL(xengine_kernel<7>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
         case 8: hipLaunchKernelGGL(xengine_kernel<8>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
         default: return fail(p, FXC_ERR_UNSUPPORTED, "no X-engine instantiation for n_ant=%d", p->n_ant);
     }
@@ -2146,10 +2149,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     const bool stream_shape = (p->n_ant == 2 && N == 1);
     if (force_path == FXC_PATH_STREAM && !stream_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "the streaming kernel needs n_ant=2, nchan=1");
-    // 2 antennas: X fused into the tiled kernel; 4 / 6 / 8: F-only tiled kernel + X-engine (nchan 8192 spectra rows are
-    // a multiple of 256 positions like all the others)
-    const bool tiled_shape = ((p->n_ant == 2 || p->n_ant == 4 || p->n_ant == 6 || p->n_ant == 8) && tiled_nchan(N) &&
-                              p->num_samp <= (1ll << 27));
+    // 2 antennas: X fused into the tiled kernel; 3 .. 8: F-only tiled kernel (an odd stream count leaves the last pair
+    // half empty) + X-engine
+    const bool tiled_shape = (p->n_ant >= 2 && p->n_ant <= 8 && tiled_nchan(N) && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_TILED && !tiled_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for n_ant=%d nchan=%d", p->n_ant, N);
     p->path = FXC_PATH_GENERIC;

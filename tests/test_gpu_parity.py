@@ -406,17 +406,18 @@ def test_eight_antennas_28_baselines(plan_mod, torch):
 
 
 @pytest.mark.parametrize("n_ant,nchan,ntaps", [(4, 4096, 4), (6, 4096, 4), (8, 4096, 4), (8, 1024, 4), (4, 2048, 4),
-                                               (6, 512, 3), (4, 8192, 4), (8, 2048, 8), (6, 4096, 5)])
+                                               (6, 512, 3), (4, 8192, 4), (8, 2048, 8), (6, 4096, 5), (3, 1024, 4), (5, 4096, 4),
+                                               (7, 2048, 4)])
 def test_multi_antenna_fused_path(plan_mod, torch, n_ant, nchan, ntaps):
-    """BASELINE config 5 shape: even antenna counts run an F-only kernel (fused at nchan 4096 / ntaps 4, tiled at the other
-    channel counts) + the register-resident X-engine."""
+    """BASELINE config 5 shape: 3 to 8 antennas run an F-only kernel (fused for even counts at nchan 4096 / ntaps 4, tiled
+    otherwise) + the register-resident X-engine."""
     num_samp, n_chunks = nchan * 6 + 11, 3
     x = synth.synth_iq(23, n_chunks, n_ant, num_samp)
     window = design_window(ntaps, nchan)
     rot = plan_mod.rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, 2e-7)
     with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp) as p, \
             plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, path="generic") as g:
-        assert p.path == ("fused" if (nchan, ntaps) == (4096, 4) else "tiled") and g.path == "generic"
+        assert p.path == ("fused" if (nchan, ntaps) == (4096, 4) and n_ant % 2 == 0 else "tiled") and g.path == "generic"
         assert p.n_baselines == n_ant * (n_ant - 1) // 2
         p.set_rot(rot)
         g.set_rot(rot)
