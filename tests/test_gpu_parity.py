@@ -374,6 +374,13 @@ def test_randomized_shapes_tiled_vs_generic(plan_mod, torch):
             if case % 3 == 0:
                 u8 = torch.from_numpy(rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)).cuda()
                 assert rel_err(t.fx_rows_u8(u8).cpu().numpy(), g.fx_rows_u8(u8).cpu().numpy()) < TOL_VIS, tag
+            if case % 5 == 0:                                        # 3 .. 8 antennas: F-only tiled kernel + X-engine
+                n_ant = int(rng.integers(3, 9))
+                xm = torch.from_numpy(synth.synth_iq(5000 + case, n_chunks, n_ant, num_samp)).cuda()
+                with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp) as m, \
+                        plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, path="generic") as mg:
+                    assert m.path in ("tiled", "fused") and mg.path == "generic", tag
+                    assert rel_err(m.fx_rows(xm).cpu().numpy(), mg.fx_rows(xm).cpu().numpy()) < 4e-6, tag + (n_ant,)
             if case % 4 == 0:
                 xs = x.view(n_chunks * 2, num_samp)[: 2 * n_chunks - (case % 8 == 0)]      # sometimes an odd stream count
                 with plan_mod.FxPlan(1, nchan, ntaps, num_samp) as f, \
