@@ -66,30 +66,40 @@ __global__ void pfb_fir_kernel(const cf* __restrict__ x, const float* __restrict
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
 
-// in-place spec[k] = sum_m v[m] exp(+2 pi i k m / N) for each row; N = 2^lg2n <= 16384; one WG per row
+// in-place spec[k] = sum_m v[m] exp(+2 pi i k m / N) for each row; N = 2^lg2n <= 16384.  One workgroup per row, or
+// 512 / N rows per workgroup when N < 512 (N/2 threads per row, each row in its own LDS slice)
 __global__ __launch_bounds__(256) void fft_pow2_kernel(cf* __restrict__ data, const cf* __restrict__ tw /* [N/2] */,
                                                       int nchan, int lg2n, int64_t n_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cf* buf = reinterpret_cast<cf*>(smem);
-    for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
-        cf* d = data + row * nchan;
-        for (int n = threadIdx.x; n < nchan; n += blockDim.x) buf[bitrev((unsigned)n, lg2n)] = d[n];
+    const int half_n = nchan >> 1;
+    const int rpw = (nchan < 512 && nchan >= 2) ? 512 / nchan : 1;      // rows per workgroup
+    const int tpr = rpw > 1 ? half_n : (int)blockDim.x;                 // threads per row
+    const int sub = rpw > 1 ? (int)threadIdx.x / tpr : 0;
+    const int lt = rpw > 1 ? (int)threadIdx.x % tpr : (int)threadIdx.x;
+    cf* buf = reinterpret_cast<cf*>(smem) + (int64_t)sub * nchan;
+    for (int64_t rb = (int64_t)blockIdx.x * rpw; rb < n_rows; rb += (int64_t)gridDim.x * rpw) {
+        const bool active = rb + sub < n_rows;
+        cf* d = data + (rb + sub) * nchan;
+        if (active)
+            for (int n = lt; n < nchan; n += tpr) buf[bitrev((unsigned)n, lg2n)] = d[n];
         __syncthreads();
         for (int s = 0; s < lg2n; ++s) {
             const int half = 1 << s;
             const int tstep = nchan >> (s + 1);
-            for (int b = threadIdx.x; b < (nchan >> 1); b += blockDim.x) {
-                const int pos = b & (half - 1);
-                const int i0 = ((b >> s) << (s + 1)) + pos;
-                const cf w = tw[pos * tstep];
-                const cf a = buf[i0];
-                const cf t = fxc::cmul(buf[i0 + half], w);
-                buf[i0] = fxc::cadd(a, t);
-                buf[i0 + half] = fxc::csub(a, t);
-            }
+            if (active)
+                for (int b = lt; b < half_n; b += tpr) {
+                    const int pos = b & (half - 1);
+                    const int i0 = ((b >> s) << (s + 1)) + pos;
+                    const cf w = tw[pos * tstep];
+                    const cf a = buf[i0];
+                    const cf t = fxc::cmul(buf[i0 + half], w);
+                    buf[i0] = fxc::cadd(a, t);
+                    buf[i0 + half] = fxc::csub(a, t);
+                }
             __syncthreads();
         }
-        for (int n = threadIdx.x; n < nchan; n += blockDim.x) d[n] = buf[n];
+        if (active)
+            for (int n = lt; n < nchan; n += tpr) d[n] = buf[n];
         __syncthreads();
     }
 }
@@ -1613,7 +1623,7 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
     const int64_t rows = n_streams * p->n_pts;
     if (p->nchan > 1) {
         const int grid = (int)std::min<int64_t>(rows, (int64_t)p->cu_count * 4);
-        const size_t lds = (size_t)p->nchan * sizeof(cf);
+        const size_t lds = (size_t)std::max(p->nchan, p->pow2 ? 512 : 0) * sizeof(cf);   // small N: 512 / N rows per workgroup
         if (p->pow2)
             hipLaunchKernelGGL(fft_pow2_kernel, dim3(grid), dim3(256), lds, p->stream, spec, p->d_tw, p->nchan,
                                p->lg2n, rows);
