@@ -4,8 +4,7 @@
 //
 // One workgroup of nchan/8 threads = nchan/16 butterflies per antenna; lanes 0-31 of every wave carry
 // antenna 0, lanes 32-63 antenna 1 of the same butterfly index u.  Decimation in frequency, in place:
-//   FIR       thread u gathers its 16 branches m = u + P r (P = nchan/16) from global memory (each IQ
-//             sample is re-read ntaps times, from L1/L2) and applies the window: v[r]
+//   FIR       thread u owns the 16 branches m = u + P r (P = nchan/16) and applies the window: v[r]
 //   pre-stage R0-point DFTs over q of v[g + G q] (G = 16/R0), twiddle wN^((u + P g) k)       [registers]
 //   stage A   (a = 3) radix-16 with stride 256, twiddle w4096^(n' k)                         [LDS, s_barrier]
 //   stage B   radix-16 with stride 16, twiddle w256^(n' k)                                   [LDS, s_barrier]
@@ -15,6 +14,11 @@
 // fx_fused4096.h.  Exchange layout: position p sits at p + 16 (p >> 8) (every 256 positions padded to 272
 // = 16 * 17), which makes the stride-256 and stride-16 accesses and the 17-pitch transpose conflict-free
 // and keeps the transpose of a 16-lane group inside the 272 slots that group alone reads in stage B.
+//
+// Kernels built from these phases (fxcorr.hip): fx_tiled_ring_kernel (ntaps <= 4, nchan <= 4096: four frames in a
+// VGPR ring + window quads in LDS, fir_ring), fx_tiled_kernel (any ntaps, nchan 8192: the FIR re-reads its history,
+// two frames per pass), each as F+X (v_permlane32_swap X-stage), F-only (natural-order spectra through a
+// transposition in the exchange region) and, for the ring kernel, uint8-ingest variants.
 //
 // The same source is compiled by g++ in tests/emul (host emulation; test infrastructure only).
 #pragma once
