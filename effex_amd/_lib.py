@@ -8,8 +8,15 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FXCORR_LIB: developer override to A/B kernel variants built elsewhere; the default is the in-tree build
-LIB_PATH = os.environ.get("FXCORR_LIB") or os.path.join(_HERE, "csrc", "libfxcorr.so")
+IN_TREE_LIB = os.path.join(_HERE, "csrc", "libfxcorr.so")
+# FXCORR_LIB: developer override to A/B kernel variants built elsewhere (tools/kbench.py); the default is the in-tree
+# build, and bench.py / the tests refuse anything else (``is_in_tree()``)
+LIB_PATH = os.environ.get("FXCORR_LIB") or IN_TREE_LIB
+
+
+def is_in_tree():
+    return os.path.realpath(LIB_PATH) == os.path.realpath(IN_TREE_LIB)
+
 
 FXC_OK = 0
 FXC_ERR_ARG = -1
@@ -18,6 +25,8 @@ FXC_ERR_HIP = -3
 FXC_ERR_NOMEM = -4
 FXC_ERR_NODEVICE = -5
 FXC_ERR_STATE = -6
+FXC_ERR_COMM = -7
+FXC_COMM_ID_BYTES = 128
 
 FXC_MEM_HOST = 0
 FXC_MEM_DEVICE = 1
@@ -47,6 +56,7 @@ SIGNATURES = {
     "fxc_plan_create": (_c.c_int, [_c.POINTER(_vp), _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _vp, _vp,
                                    _c.c_int]),
     "fxc_plan_destroy": (_c.c_int, [_vp]),
+    "fxc_set_stream": (_c.c_int, [_vp, _vp]),
     "fxc_plan_get_info": (_c.c_int, [_vp, _c.POINTER(FxcInfo)]),
     "fxc_last_error": (_c.c_char_p, [_vp]),
     "fxc_set_rot": (_c.c_int, [_vp, _vp]),
@@ -57,6 +67,10 @@ SIGNATURES = {
     "fxc_acc_export": (_c.c_int, [_vp, _vp]),
     "fxc_finalize_sums": (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_double]),
     "fxc_finalize": (_c.c_int, [_vp, _vp, _c.c_int, _c.c_double, _c.c_int]),
+    "fxc_comm_unique_id": (_c.c_int, [_vp]),
+    "fxc_comm_create": (_c.c_int, [_c.POINTER(_vp), _c.c_int, _c.c_int, _c.c_int, _vp]),
+    "fxc_comm_destroy": (_c.c_int, [_vp]),
+    "fxc_reduce": (_c.c_int, [_vp, _vp, _c.c_int]),
     "fxc_sync": (_c.c_int, [_vp]),
     "fxc_remove_dc": (_c.c_int, [_vp, _vp, _vp, _c.c_int64]),
     "fxc_convert_u8": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int]),

@@ -272,10 +272,18 @@ class Correlator(object):
 
     def _plan(self):
         n = int(self.num_samp)
-        if self._fx_plan is None or (self._fx_plan.num_samp, self._fx_plan.nchan) != (n, int(self.nbins)):
+        nb = int(self.nbins)
+        if self._fx_plan is None or (self._fx_plan.num_samp, self._fx_plan.nchan) != (n, nb):
             if self._fx_plan is not None:
                 self._fx_plan.close()
-            self._fx_plan = FxPlan(2, int(self.nbins), self.ntaps, n, window=self.window, device=self.device)
+            # The window is designed once, for the constructor's nbins (effex.py:126-127), and the nbins setter only
+            # stores the new value (effex.py:287-294): after ``cor.nbins = ...`` the reference channelises with the stale
+            # window, and channelize_poly derives its tap count from it (len(h) / n_chans, first ntaps * n_chans taps).
+            ntaps_w = int(len(self.window) / nb)
+            if ntaps_w < 1:
+                raise ValueError("nbins = {} exceeds the {} taps of the window designed at construction "
+                                 "(effex.py:126-127)".format(nb, len(self.window)))
+            self._fx_plan = FxPlan(2, nb, ntaps_w, n, window=np.asarray(self.window)[:ntaps_w * nb], device=self.device)
             self._rot_key = None
         key = (self.bandwidth, self.frequency, self.calibrated_delay)
         if key != self._rot_key:      # rot only changes on calibration / TEST sweep

@@ -80,6 +80,61 @@ FXC_HD void state_reset_all(State& s) {
     for (int q = 0; q < kAccPerThread; ++q) s.acc[q] = mk(0.f, 0.f);
 }
 
+// Work split of one launch (fxcorr.hip::fx_fused4096_kernel): its n_chunks * n_pts frames form one sequence and
+// workgroup b of g walks the contiguous range [range_begin(b), range_begin(b + 1)) of it, chunk boundaries or not.
+// Raw rows: row u covers chunks [u unit, (u + 1) unit); the workgroup that owns a row's first frame stores what it
+// computes of it in row u, a workgroup whose range starts inside a row stores its share of that row in its
+// leading-part row n_rows + b (all zeros when the range starts on a row boundary).
+struct RangeWalk {
+    long long c, i;        // chunk and frame of the spectrum being computed
+    long long left;        // frames of the range still to do, this one included
+    long long row;         // raw row the sums in progress go to
+    long long unit, n_chunks, n_pts, n_rows;
+    bool lead;             // the range starts inside a row
+};
+
+FXC_HD RangeWalk range_walk_init(long long b, long long g, long long n_chunks, long long n_pts, long long unit) {
+    RangeWalk w;
+    const long long n_frames = n_chunks * n_pts;
+    const long long f0 = range_begin(b, n_frames, g);
+    w.left = range_begin(b + 1, n_frames, g) - f0;
+    w.c = f0 / n_pts;
+    w.i = f0 - w.c * n_pts;
+    w.unit = unit;
+    w.n_chunks = n_chunks;
+    w.n_pts = n_pts;
+    w.n_rows = (n_chunks + unit - 1) / unit;
+    w.lead = !(w.i == 0 && w.c % unit == 0);
+    w.row = w.lead ? w.n_rows + b : w.c / unit;
+    return w;
+}
+
+// the spectrum of (c, i) is the last one of the row in progress: last frame of the range, of a row or of the launch
+FXC_HD bool range_walk_row_ends(const RangeWalk& w) {
+    return w.left == 1 || (w.i + 1 == w.n_pts && ((w.c + 1) % w.unit == 0 || w.c + 1 == w.n_chunks));
+}
+
+// the frame to fetch while (c, i) is computed: the next one of the range (next frame of the chunk or frame 0 of the
+// next chunk); at the very end of the range the current frame again (never used)
+FXC_HD void range_walk_prefetch(const RangeWalk& w, long long& pc, long long& pi) {
+    pc = w.c;
+    pi = w.i;
+    if (w.left > 1 && ++pi == w.n_pts) {
+        pi = 0;
+        pc += 1;
+    }
+}
+
+// move on to the next frame of the range; call after the row store when range_walk_row_ends()
+FXC_HD void range_walk_advance(RangeWalk& w, bool row_ended) {
+    if (++w.i == w.n_pts) {
+        w.i = 0;
+        w.c += 1;
+    }
+    w.left -= 1;
+    if (row_ended) w.row = w.c / w.unit;
+}
+
 // element offset (in cf) inside one frame of the sample this thread feeds to branch j + 256 r
 FXC_HD int sample_offset(int j, int r) { return (kN - 1) - j - 256 * r; }
 

@@ -26,6 +26,11 @@ struct __attribute__((aligned(16))) cd {
     double x, y;
 };
 
+// Frame-range work split of the fused kernel: n items over g workgroups, workgroup b owns [range_begin(b),
+// range_begin(b + 1)); range_owner(f) is the workgroup whose range holds item f.
+FXC_HD long long range_begin(long long b, long long n, long long g) { return b * n / g; }
+FXC_HD long long range_owner(long long f, long long n, long long g) { return ((f + 1) * g + n - 1) / n - 1; }
+
 FXC_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
 FXC_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
 FXC_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }

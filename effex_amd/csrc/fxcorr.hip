@@ -13,6 +13,8 @@
 // nchan 512..8192, any ntaps: the fused design generalised, fx_tiled.h), stream (nchan 1), generic (everything else).  Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap, buffer loads.
 // No CPU fallback.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is bound at run time (rccl_api)
 
 #include <cmath>
 #include <cstdarg>
@@ -182,10 +184,30 @@ __device__ __forceinline__ int64_t raw_index(int k, int slots) {
     return slots == 1 ? fxc::fused::slot_of_bin(k) : (slots == 2 ? fxc::fused::specpos_of_bin(k) : k);
 }
 
+// The 2-antenna fused kernel splits a launch's frames over workgroups without regard to chunk boundaries
+// (fx_fused4096_kernel): row c of raw then lacks the frames that later workgroups took over, which sit in those
+// workgroups' leading-part rows raw[offset + b * nchan ...].  n_frames == 0: the rows are complete.
+struct LeadRows {
+    int64_t n_frames, n_pts, offset;
+    int grid;
+};
+
+__device__ __forceinline__ void add_lead_rows(const cf* __restrict__ raw, const LeadRows& lr, int64_t row, int nchan,
+                                              int64_t ridx, float& ar, float& ai) {
+    if (lr.n_frames == 0) return;
+    const int64_t b_lo = fxc::range_owner(row * lr.n_pts, lr.n_frames, lr.grid);
+    const int64_t b_hi = fxc::range_owner((row + 1) * lr.n_pts - 1, lr.n_frames, lr.grid);
+    for (int64_t b = b_lo + 1; b <= b_hi; ++b) {   // the workgroups that start strictly inside chunk `row`
+        const cf r = raw[lr.offset + b * nchan + ridx];
+        ar += r.x;
+        ai += r.y;
+    }
+}
+
 // SPECTRUM rows: out[c][p][(k + N/2) % N] = (sum_split raw) * conj(rot[k]) / n_pts   (effex.py:520-521)
 __global__ void rows_spectrum_kernel(const cf* __restrict__ raw, cf* __restrict__ out, const cd* __restrict__ rot,
                                      int nchan, int64_t rows, int n_splits, int64_t split_stride, float inv_pts,
-                                     int slots) {
+                                     int slots, LeadRows lead) {
     const int64_t total = rows * nchan;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -197,6 +219,7 @@ __global__ void rows_spectrum_kernel(const cf* __restrict__ raw, cf* __restrict_
             ar += r.x;
             ai += r.y;
         }
+        add_lead_rows(raw, lead, row, nchan, raw_index(k, slots), ar, ai);
         const float cr = (float)rot[k].x, ci = (float)rot[k].y;
         // (ar + i ai) * (cr - i ci)
         const float orr = (ar * cr + ai * ci) * inv_pts;
@@ -223,7 +246,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 __global__ __launch_bounds__(256) void rows_continuum_kernel(const cf* __restrict__ raw, cd* __restrict__ out,
                                                             const cd* __restrict__ rot, int nchan, int64_t rows,
                                                             int n_splits, int64_t split_stride, double scale,
-                                                            int slots) {
+                                                            int slots, LeadRows lead) {
     __shared__ double red[256];
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         double ar = 0.0, ai = 0.0;
@@ -234,6 +257,10 @@ __global__ __launch_bounds__(256) void rows_continuum_kernel(const cf* __restric
                 xr += r.x;
                 xi += r.y;
             }
+            float lr_re = 0.f, lr_im = 0.f;
+            add_lead_rows(raw, lead, row, nchan, raw_index(k, slots), lr_re, lr_im);
+            xr += lr_re;
+            xi += lr_im;
             const cd w = rot[k];
             ar += xr * w.x + xi * w.y;
             ai += xi * w.x - xr * w.y;
@@ -508,7 +535,7 @@ constexpr int kStampSegs = 12;
     do {                                                                                                        \
         FXC_SCHED_FENCE();                                                                                      \
         if (U8)                                                                                                 \
-            load_frame_part_u8<R0, 4>(nx, reinterpret_cast<const unsigned short*>(x) + (more ? nc : c) * 2 * num_samp, \
+            load_frame_part_u8<R0, 4>(nx, reinterpret_cast<const unsigned short*>(x) + pc * 2 * num_samp,       \
                                       chunk_bytes, voff, nframe);                                               \
         else                                                                                                    \
             load_frame_part<R0, 4>(nx, nbase, chunk_bytes, voff, nframe);                                       \
@@ -529,11 +556,11 @@ struct U8State {
 template <int PH, bool SPEC_OUT, bool U8>
 __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, const cf* dc, const f4* win, cf* region,
                                            const cf* tw2, int tid, const cf* x, int64_t num_samp, unsigned chunk_bytes,
-                                           unsigned voff, int64_t& c, int64_t& i, int64_t n_pts, int64_t n_chunks,
-                                           cf* rows_raw, unsigned long long (&seg)[kStampSegs],
-                                           unsigned long long& t_prev) {
+                                           unsigned voff, fxc::fused::RangeWalk& pos, cf* rows_raw,
+                                           unsigned long long (&seg)[kStampSegs], unsigned long long& t_prev) {
     using namespace fxc::fused;
-    FXC_STAMP(0);    // loop overhead and the (rare) chunk-end store since the previous step's last stamp
+    const int64_t c = pos.c, i = pos.i, n_pts = pos.n_pts;
+    FXC_STAMP(0);    // loop overhead and the (rare) row store since the previous step's last stamp
     if (i == 0) {    // zero PFB history at the start of every chunk
         asm volatile("" ::: "memory");   // keep this a (rarely taken) uniform branch, not 96 v_cndmask per frame
         state_reset_history<PH>(s);
@@ -543,18 +570,13 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
     cf v[16];
     phase1_fir<PH>(s, win, tid, v);      // first use of this frame: waits for its loads (issued a step ago)
     FXC_STAMP(2);
-    // The oldest ring slot is dead now: refill it with the next frame this workgroup will process (next
-    // frame of the chunk, or frame 0 of its next chunk; at the very end the current frame again, never
-    // used).  The 16 loads go out in four groups spread over the step: eight waves bursting 16 loads
-    // each at the same point stall in the in-order vector-memory issue (measured -7 %).
-    int64_t ni = i + 1, nc = c;
-    if (ni == n_pts) {
-        ni = 0;
-        nc = c + gridDim.x;
-    }
-    const bool more = nc < n_chunks;
-    const cf* nbase = x + (more ? nc : c) * 2 * num_samp;
-    const int64_t nframe = more ? ni : i;
+    // The oldest ring slot is dead now: refill it with the next frame of this workgroup's range (next frame of
+    // the chunk, or frame 0 of the next chunk; at the very end the current frame again, never used).  The 16
+    // loads go out in four groups spread over the step: eight waves bursting 16 loads each at the same point
+    // stall in the in-order vector-memory issue (measured -7 %).
+    long long pc, nframe;
+    range_walk_prefetch(pos, pc, nframe);
+    const cf* nbase = x + pc * 2 * num_samp;
     cf (&nx)[16] = s.h[(PH + 1) & 3];
     FXC_PREFETCH(0);
     fxc::dft16(v);
@@ -606,30 +628,42 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
             xacc(s, q, a, b);
         }
         FXC_STAMP(10);
-        if (i + 1 == n_pts) {   // chunk done: store this lane's 8 bins of the chunk's raw sum (fire and forget)
-            cf* row = rows_raw + c * kN;
+    }
+    // a raw row ends with the last frame of every `unit`-th chunk, of the last chunk and of this workgroup's
+    // range: store this lane's 8 bins (fire and forget)
+    const bool row_ends = !SPEC_OUT && range_walk_row_ends(pos);
+    if (row_ends) {
+        cf* row = rows_raw + pos.row * kN + tid;
 #pragma unroll
-            for (int q = 0; q < kAccPerThread; ++q) {
-                row[q * kThreads + tid] = s.acc[q];
-                s.acc[q] = fxc::mk(0.f, 0.f);
-            }
+        for (int q = 0; q < kAccPerThread; ++q) {
+            row[q * kThreads] = s.acc[q];
+            s.acc[q] = fxc::mk(0.f, 0.f);
         }
     }
-    c = nc;
-    i = ni;
+    range_walk_advance(pos, row_ends);
 }
 
-// SPEC_OUT == false: rows_raw[c][slot] = sum_i spec0[i,k] * conj(spec1[i,k]) of chunk c in float32, k = bin
-// of slot (fx_fused4096.h::slot_of_bin).  SPEC_OUT == true: rows_raw[(2c + ant) * n_pts + i][specpos] = the
-// spectra themselves.  A "chunk" here is a pair of consecutive antenna streams, so an even number of
-// antennas [n_chunks][A][S] is simply n_chunks * A/2 pairs.  stamps: diagnostic builds only.
+// Work split: the launch's n_chunks * n_pts frames form one global sequence and workgroup b takes the contiguous
+// range [b F / G, (b + 1) F / G) of it, so every workgroup gets the same number of frames (+-1) whatever
+// n_chunks % G is.  A range that starts inside a chunk reloads the (up to) three frames of PFB history before it;
+// a range that runs over a chunk boundary resets the history there (fused_step).
+// SPEC_OUT == false: raw rows, float32, slot order (fx_fused4096.h::slot_of_bin).  A row covers `unit` consecutive
+// chunks (row u = chunks [u unit, (u + 1) unit); unit = 1 for per-chunk visibilities):
+//   rows_raw[u][slot]             = sum over the frames of row u from its first one to the end of the range of the
+//                                   workgroup that owns that first frame (usually the whole row)
+//   rows_raw[n_rows + b][slot]    = workgroup b's leading part: the frames from the start of its range to the end of
+//                                   the row that range starts inside (zeros if it starts on a row boundary)
+// so row u in full = rows_raw[u] + sum of rows_raw[n_rows + b] over the workgroups b that start strictly inside it
+// (range_owner() finds them), and the sum of all n_rows + G rows is the integration.
+// SPEC_OUT == true: rows_raw[(2c + ant) * n_pts + i][specpos] = the spectra themselves.  A "chunk" here is a pair
+// of consecutive antenna streams, so an even number of antennas [n_chunks][A][S] is simply n_chunks * A/2 pairs.
 // U8: x points at interleaved uint8 I,Q ([chunk][antenna][num_samp] byte pairs) and dc[chunk * 2 + antenna] holds the
-// conversion offsets (-mean_byte / 127.5, or -1 without DC removal) of each stream.
+// conversion offsets (-mean_byte / 127.5, or -1 without DC removal) of each stream.  stamps: diagnostic builds only.
 template <bool SPEC_OUT, bool U8 = false>
 __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     const cf* __restrict__ x, int64_t num_samp, int64_t n_pts, int64_t n_chunks, const f4* __restrict__ win_g,
     const cf* __restrict__ tw1_g, const cf* __restrict__ tw2_g, cf* __restrict__ rows_raw,
-    unsigned long long* __restrict__ stamps, const cf* __restrict__ dc) {
+    unsigned long long* __restrict__ stamps, const cf* __restrict__ dc, int64_t unit) {
     using namespace fxc::fused;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f4* win = reinterpret_cast<f4*>(smem + kLdsWin);
@@ -638,6 +672,15 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
 
     const int tid = threadIdx.x;
     const int ant = tid >> 8, j = tid & 255;
+    RangeWalk pos = range_walk_init(blockIdx.x, gridDim.x, n_chunks, n_pts, unit);
+    const int64_t total = pos.left;
+    if (!SPEC_OUT && (!pos.lead || total == 0)) {            // no leading part: its row reads as zeros
+        cf* lead_row = rows_raw + (pos.n_rows + blockIdx.x) * kN + tid;
+#pragma unroll
+        for (int q = 0; q < kAccPerThread; ++q) lead_row[q * kThreads] = fxc::mk(0.f, 0.f);
+    }
+    if (total == 0) return;
+
     for (int idx = tid; idx < kN; idx += kThreads) win[idx] = win_g[idx];
     if (tid < 256) tw2[tid] = tw2_g[tid];
     State s;
@@ -646,34 +689,46 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     for (int q = 0; q < kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
     __syncthreads();
 
-    int64_t c = blockIdx.x, i = 0;
-    if (c >= n_chunks) return;
-    const int64_t my_chunks = (n_chunks - c + gridDim.x - 1) / gridDim.x;
-    const int64_t total = my_chunks * n_pts;
     constexpr int64_t kSampleBytes = U8 ? sizeof(unsigned short) : sizeof(cf);
     const unsigned voff = (unsigned)((ant * num_samp + (255 - j)) * kSampleBytes);
     const unsigned chunk_bytes = (unsigned)(2 * num_samp * kSampleBytes);
     U8State u8;
-    u8.off = fxc::mk(0.f, 0.f);
+    u8.off = U8 ? dc[pos.c * 2 + ant] : fxc::mk(0.f, 0.f);
+    // ring prologue: frame i -> slot 0, its history i-1, i-2, i-3 -> slots 3, 2, 1 (zeros before the chunk start)
+    const cf* cbase = reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + pos.c * 2 * num_samp * kSampleBytes);
+#pragma unroll
+    for (int d = 1; d < 4; ++d) {
+        if (pos.i - d >= 0) {
+            if (U8) {
+                load_frame_part_u8<0, 16>(s.h[4 - d], reinterpret_cast<const unsigned short*>(cbase), chunk_bytes, voff, pos.i - d);
+                convert_frame_u8(s.h[4 - d], u8.off);
+            } else {
+                load_frame_part<0, 16>(s.h[4 - d], cbase, chunk_bytes, voff, pos.i - d);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s.h[4 - d][r] = fxc::mk(0.f, 0.f);
+        }
+    }
     if (U8)
-        load_frame_part_u8<0, 16>(s.h[0], reinterpret_cast<const unsigned short*>(x) + c * 2 * num_samp, chunk_bytes, voff, 0);
+        load_frame_part_u8<0, 16>(s.h[0], reinterpret_cast<const unsigned short*>(cbase), chunk_bytes, voff, pos.i);
     else
-        load_frame_part<0, 16>(s.h[0], x + c * 2 * num_samp, chunk_bytes, voff, 0);
+        load_frame_part<0, 16>(s.h[0], cbase, chunk_bytes, voff, pos.i);
     unsigned long long seg[kStampSegs] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
 #if FXC_STAMPS
     t_prev = __builtin_amdgcn_s_memtime();
 #endif
-    // frame g of this workgroup's stream of frames sits in ring slot g & 3: unrolled by four so the
-    // ring rotates by register renaming
+    // frame g of this workgroup's range sits in ring slot g & 3: unrolled by four so the ring rotates by
+    // register renaming
     for (int64_t g = 0; g < total; g += 4) {
-        fused_step<0, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+        fused_step<0, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg, t_prev);
         if (g + 1 < total)
-            fused_step<1, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+            fused_step<1, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg, t_prev);
         if (g + 2 < total)
-            fused_step<2, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+            fused_step<2, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg, t_prev);
         if (g + 3 < total)
-            fused_step<3, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, c, i, n_pts, n_chunks, rows_raw, seg, t_prev);
+            fused_step<3, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg, t_prev);
     }
 #if FXC_STAMPS
     if (stamps && (tid & 63) == 0) {
@@ -1469,6 +1524,8 @@ struct fxc_plan {
     int lg2n = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipEvent_t ev_order = nullptr;   // orders the old stream's work before the new one's (fxc_set_stream)
+    int live_pipes = 0;              // fxc_pipe objects that hold a pointer to this plan
     // device tables
     float* d_win = nullptr;        // [ntaps*nchan] float (generic)
     cf* d_tw = nullptr;            // generic FFT twiddles
@@ -1512,6 +1569,7 @@ struct fxc_pipe {
     int depth = 0, mode = FXC_MODE_SPECTRUM;
     double bandwidth = 1.0;
     size_t in_bytes = 0, out_bytes = 0;
+    bool counted = false;      // registered in plan->live_pipes
     bool u8 = false;           // batches are RTL-SDR byte pairs (fxc_pipe_create_u8)
     int remove_dc = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;
@@ -1533,6 +1591,28 @@ int fail(const fxc_plan* p, int status, const char* fmt, ...) {
         g_lib_error = buf;
     return status;
 }
+
+// Every ABI entry runs on the plan's device and leaves the caller's current device as it found it (a process
+// that drives several GPUs, or torch's own notion of the current device, must not see it change).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false, ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) {
+            ok = hipSetDevice(device) == hipSuccess;
+            changed = ok && prev >= 0;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define FXC_DEVICE(p, device)                                                                  \
+    DeviceGuard device_guard__(device);                                                        \
+    if (!device_guard__.ok) return fail(p, FXC_ERR_HIP, "hipSetDevice(%d) failed", (int)(device))
 
 #define FXC_HIP(p, call)                                                                                       \
     do {                                                                                                       \
@@ -1608,7 +1688,8 @@ int drain_kernel_events(fxc_plan* p) {
     return FXC_OK;
 }
 
-int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8 = nullptr);
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8 = nullptr,
+                 int64_t unit = 1);
 
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams);
@@ -1665,11 +1746,35 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
 
 constexpr int kFusedReduceSplits = 64;
 
+// workgroups of a fused launch over n_pairs chunk pairs: one per CU, fewer when that would leave a workgroup under
+// four frames (each range reloads up to three frames of history)
+int fused_grid(const fxc_plan* p, int64_t n_pairs) {
+    const int64_t frames = n_pairs * p->n_pts;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(frames / 4, p->fused_grid_max));
+}
+
+// chunks per raw row when only the integration is wanted: float32 sums of up to 256 spectra
+int64_t fused_unit(const fxc_plan* p) { return std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(1, p->n_pts), 64)); }
+
+// raw rows a 2-antenna fused launch over nc chunks writes: ceil(nc / unit) rows + one leading-part row per workgroup
+int64_t fused_rows(const fxc_plan* p, int64_t nc, int64_t unit) { return (nc + unit - 1) / unit + fused_grid(p, nc); }
+
+LeadRows fused_lead(const fxc_plan* p, int64_t nc) {
+    LeadRows lr;
+    lr.n_frames = nc * p->n_pts;
+    lr.n_pts = p->n_pts;
+    lr.offset = nc * (int64_t)fxc::fused::kN;
+    lr.grid = fused_grid(p, nc);
+    return lr;
+}
+const LeadRows kNoLead = {0, 0, 0, 0};
+
 // n_pairs = pairs of consecutive antenna streams to channelise; spec_out: write spectra instead of X sums
 // dc_u8 != nullptr: x is the uint8 I,Q stream and dc_u8 its per-stream conversion offsets (2 antennas, X fused in)
-int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8) {
+// unit: chunks per raw row (fx_fused4096_kernel)
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8, int64_t unit) {
     using namespace fxc::fused;
-    const int grid = (int)std::min<int64_t>(n_pairs, p->fused_grid_max);
+    const int grid = fused_grid(p, n_pairs);
     unsigned long long* stamps = nullptr;
 #if FXC_STAMPS
     if (!p->d_stamps) FXC_HIP(p, hipMalloc(&p->d_stamps, (size_t)p->fused_grid_max * 8 * kStampSegs * 8));
@@ -1680,13 +1785,15 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
     KernelTimer kt(p);
     if (dc_u8)
         hipLaunchKernelGGL((fx_fused4096_kernel<false, true>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8);
+                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, unit);
     else if (spec_out)
         hipLaunchKernelGGL((fx_fused4096_kernel<true, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr);
+                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
+                           (int64_t)1);
     else
         hipLaunchKernelGGL((fx_fused4096_kernel<false, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr);
+                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
+                           unit);
     kt.stop();
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
@@ -1702,15 +1809,18 @@ int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec
     int64_t cb = kWorkspaceTarget / (raw_per_chunk + spec_per_chunk);
     if (cb < 1) cb = 1;
     if (cb > n_chunks) cb = n_chunks;
+    if (p->n_ant > 2 && cb > 65535) cb = 65535;   // xengine_kernel carries the chunk in grid.y
     *spec_bytes = (cb * spec_per_chunk + 255) / 256 * 256;
-    *raw_bytes = (cb * raw_per_chunk + 255) / 256 * 256;
+    // 2 antennas: one leading-part row per workgroup after the chunk rows (fx_fused4096_kernel)
+    *raw_bytes = ((cb + (p->n_ant == 2 ? p->fused_grid_max : 0)) * raw_per_chunk + 255) / 256 * 256;
     return cb;
 }
 
-// raw[c][p][layout] for nc chunks starting at x; spec = scratch for the multi-antenna path
-int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, const cf* dc_u8 = nullptr) {
+// raw[c][p][layout] for nc chunks starting at x; spec = scratch for the multi-antenna path.  2 antennas: rows of
+// `unit` chunks + leading-part rows (fused_rows() of them in all)
+int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, const cf* dc_u8 = nullptr, int64_t unit = 1) {
     using namespace fxc::fused;
-    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8);
+    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8, unit);
     // 4 / 6 / 8 antennas: spectra to HBM (the F-only fused kernel in its own spectrum order at nchan 4096 / ntaps 4,
     // the F-only tiled kernel in natural order otherwise), then the register-resident X-engine
     int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
@@ -1887,12 +1997,13 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + spec_bytes + raw_bytes);
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
+            const int64_t unit = fused_unit(p);
             rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
-                                dc_u8 ? dc_u8 + c0 * 2 : nullptr);
+                                dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit);
             if (rc) return rc;
-            if (p->n_ant == 2) {   // many chunks, one baseline: two-stage reduce over chunks
+            if (p->n_ant == 2) {   // one baseline: two-stage reduce over all the raw rows (leading parts included)
                 hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, kFusedReduceSplits), dim3(256), 0, p->stream, raw,
-                                   part, kN, nc, kFusedReduceSplits);
+                                   part, kN, fused_rows(p, nc, unit), kFusedReduceSplits);
                 hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 256), dim3(256), 0, p->stream, part, p->d_acc, kN,
                                    kFusedReduceSplits, fused_layout(p));
             } else {
@@ -1973,11 +2084,11 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
             // raw[block][chunk]: the blocks play the role of the generic path's splits (nchan = n_base = 1)
             if (mode == FXC_MODE_SPECTRUM)
                 hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc, 256, p->cu_count)), dim3(256), 0, p->stream, raw,
-                                   static_cast<cf*>(out) + c0, p->d_rot, 1, nc, nb, nc, inv_pts, 0);
+                                   static_cast<cf*>(out) + c0, p->d_rot, 1, nc, nb, nc, inv_pts, 0, kNoLead);
             else
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
                                    dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, 1, nc, nb, nc,
-                                   cscale, 0);
+                                   cscale, 0, kNoLead);
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;
@@ -1996,14 +2107,15 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
                                 dc_u8 ? dc_u8 + c0 * 2 : nullptr);
             if (rc) return rc;
             const int64_t rows = nc * p->n_base;
+            const LeadRows lead = p->n_ant == 2 ? fused_lead(p, nc) : kNoLead;
             if (mode == FXC_MODE_SPECTRUM)
                 hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(rows * p->nchan, 256, p->cu_count)), dim3(256), 0,
                                    p->stream, raw, static_cast<cf*>(out) + c0 * p->n_base * p->nchan, p->d_rot, p->nchan,
-                                   rows, 1, (int64_t)0, inv_pts, fused_layout(p));
+                                   rows, 1, (int64_t)0, inv_pts, fused_layout(p), lead);
             else
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
                                    dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot,
-                                   p->nchan, rows, 1, (int64_t)0, cscale, fused_layout(p));
+                                   p->nchan, rows, 1, (int64_t)0, cscale, fused_layout(p), lead);
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;
@@ -2024,11 +2136,11 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
             if (rc) return rc;
             if (mode == FXC_MODE_SPECTRUM)
                 hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc * N, 256, p->cu_count)), dim3(256), 0, p->stream,
-                                   raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, n_splits, nc * N, inv_pts, 0);
+                                   raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, n_splits, nc * N, inv_pts, 0, kNoLead);
             else
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
                                    dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, n_splits,
-                                   nc * N, cscale, 0);
+                                   nc * N, cscale, 0, kNoLead);
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;
@@ -2055,11 +2167,11 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         if (mode == FXC_MODE_SPECTRUM)
             hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(rows * p->nchan, 256, p->cu_count)), dim3(256), 0,
                                p->stream, raw, static_cast<cf*>(out) + c0 * p->n_base * p->nchan, p->d_rot, p->nchan,
-                               rows, g.n_splits, split_stride, inv_pts, 0);
+                               rows, g.n_splits, split_stride, inv_pts, 0, kNoLead);
         else
             hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
                                dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot, p->nchan,
-                               rows, g.n_splits, split_stride, cscale, 0);
+                               rows, g.n_splits, split_stride, cscale, 0, kNoLead);
         FXC_HIP(p, hipGetLastError());
     }
     return FXC_OK;
@@ -2108,6 +2220,7 @@ const char* fxc_status_string(int status) {
         case FXC_ERR_NOMEM: return "out of device memory";
         case FXC_ERR_NODEVICE: return "no HIP device";
         case FXC_ERR_STATE: return "invalid call sequence";
+        case FXC_ERR_COMM: return "RCCL unavailable or a collective failed";
         default: return "unknown status";
     }
 }
@@ -2124,7 +2237,9 @@ const char* fxc_last_error(const fxc_plan* plan) { return plan ? plan->error.c_s
 
 int fxc_plan_destroy(fxc_plan* p) {
     if (!p) return FXC_OK;
-    (void)hipSetDevice(p->device);
+    if (p->live_pipes > 0)
+        return fail(p, FXC_ERR_STATE, "%d pipe(s) still use this plan: destroy them first", p->live_pipes);
+    DeviceGuard device_guard__(p->device);
     (void)hipStreamSynchronize(p->stream);
     for (auto& e : p->kev) {
         (void)hipEventDestroy(e.first);
@@ -2136,6 +2251,7 @@ int fxc_plan_destroy(fxc_plan* p) {
         if (b) (void)hipFree(b);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
     if (p->ev_t1) (void)hipEventDestroy(p->ev_t1);
+    if (p->ev_order) (void)hipEventDestroy(p->ev_order);
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return FXC_OK;
@@ -2148,6 +2264,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     if (p->own_stream) FXC_HIP(p, hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     FXC_HIP(p, hipEventCreate(&p->ev_t0));
     FXC_HIP(p, hipEventCreate(&p->ev_t1));
+    FXC_HIP(p, hipEventCreateWithFlags(&p->ev_order, hipEventDisableTiming));
 
     const int N = p->nchan, T = p->ntaps;
     // the fused kernel channelises pairs of antenna streams: 2 antennas (X fused in) or 4 / 6 / 8 (F-only +
@@ -2323,7 +2440,7 @@ int fxc_plan_create(fxc_plan** out, int device, int n_ant, int nchan, int ntaps,
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device available (this library has no CPU backend)");
     if (device < 0 || device >= ndev) return fail(nullptr, FXC_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, FXC_ERR_HIP, "hipSetDevice(%d) failed", device);
+    FXC_DEVICE(nullptr, device);
 
     fxc_plan* p = new (std::nothrow) fxc_plan();
     if (!p) return fail(nullptr, FXC_ERR_NOMEM, "host allocation failed");
@@ -2385,16 +2502,147 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
 
 int fxc_set_rot(fxc_plan* p, const double* rot_re_im) {
     if (!p || !rot_re_im) return fail(p, FXC_ERR_ARG, "NULL argument");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     // ordered after any queued finish kernel that still reads the old table
     FXC_HIP(p, hipStreamSynchronize(p->stream));
     FXC_HIP(p, hipMemcpy(p->d_rot, rot_re_im, (size_t)p->nchan * sizeof(cd), hipMemcpyHostToDevice));
     return FXC_OK;
 }
 
+int fxc_set_stream(fxc_plan* p, void* stream) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    if (p->own_stream) return fail(p, FXC_ERR_STATE, "the plan owns its stream (FXC_STREAM_OWNED)");
+    hipStream_t next = static_cast<hipStream_t>(stream);
+    if (next == p->stream) return FXC_OK;
+    FXC_DEVICE(p, p->device);
+    // the plan's workspace, accumulator and tables are shared by everything it launches: what is queued on the old
+    // stream completes before anything on the new one starts (device-side dependency, no host wait)
+    FXC_HIP(p, hipEventRecord(p->ev_order, p->stream));
+    FXC_HIP(p, hipStreamWaitEvent(next, p->ev_order, 0));
+    p->stream = next;
+    return FXC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU reduce: one RCCL sum of the exported accumulators over xGMI, enqueued on the plan's
+// stream.  librccl is bound at run time (the copy the process already has -- PyTorch ships one -- else ROCm's), so
+// single-GPU users need no RCCL at all.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string error;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return &api;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)   // a copy that is already mapped wins: one RCCL per process
+        if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    for (size_t k = 0; !api.handle && k < sizeof names / sizeof *names; ++k) api.handle = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL);
+    if (!api.handle) {
+        const char* why = dlerror();
+        api.error = std::string("librccl not found: ") + (why ? why : "dlopen failed");
+        return &api;
+    }
+    bool ok = true;
+    auto bind = [&](const char* sym) {
+        void* f = dlsym(api.handle, sym);
+        if (!f) {
+            ok = false;
+            api.error = std::string("librccl lacks ") + sym;
+        }
+        return f;
+    };
+    api.get_unique_id = reinterpret_cast<decltype(api.get_unique_id)>(bind("ncclGetUniqueId"));
+    api.comm_init_rank = reinterpret_cast<decltype(api.comm_init_rank)>(bind("ncclCommInitRank"));
+    api.comm_destroy = reinterpret_cast<decltype(api.comm_destroy)>(bind("ncclCommDestroy"));
+    api.reduce = reinterpret_cast<decltype(api.reduce)>(bind("ncclReduce"));
+    api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(bind("ncclAllReduce"));
+    api.error_string = reinterpret_cast<decltype(api.error_string)>(bind("ncclGetErrorString"));
+    if (!ok) {
+        api.handle = nullptr;
+    }
+    return &api;
+}
+
+int rccl_fail(const fxc_plan* p, const RcclApi* api, const char* what, ncclResult_t r) {
+    return fail(p, FXC_ERR_COMM, "%s failed: %s", what, api->error_string ? api->error_string(r) : "RCCL error");
+}
+
+}  // namespace
+
+int fxc_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(nullptr, FXC_ERR_ARG, "id_out is NULL");
+    static_assert(sizeof(ncclUniqueId) == FXC_COMM_ID_BYTES, "FXC_COMM_ID_BYTES must match ncclUniqueId");
+    RcclApi* api = rccl_api();
+    if (!api->handle) return fail(nullptr, FXC_ERR_COMM, "%s", api->error.c_str());
+    ncclUniqueId id;
+    const ncclResult_t r = api->get_unique_id(&id);
+    if (r != ncclSuccess) return rccl_fail(nullptr, api, "ncclGetUniqueId", r);
+    std::memcpy(id_out, &id, sizeof id);
+    return FXC_OK;
+}
+
+int fxc_comm_create(void** rccl_comm_out, int device, int rank, int world_size, const void* id) {
+    if (!rccl_comm_out || !id) return fail(nullptr, FXC_ERR_ARG, "NULL argument");
+    *rccl_comm_out = nullptr;
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(nullptr, FXC_ERR_ARG, "rank %d outside world of %d", rank, world_size);
+    RcclApi* api = rccl_api();
+    if (!api->handle) return fail(nullptr, FXC_ERR_COMM, "%s", api->error.c_str());
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(nullptr, FXC_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    FXC_DEVICE(nullptr, device);
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = api->comm_init_rank(&comm, world_size, uid, rank);
+    if (r != ncclSuccess) return rccl_fail(nullptr, api, "ncclCommInitRank", r);
+    *rccl_comm_out = comm;
+    return FXC_OK;
+}
+
+int fxc_comm_destroy(void* rccl_comm) {
+    if (!rccl_comm) return FXC_OK;
+    RcclApi* api = rccl_api();
+    if (!api->handle) return fail(nullptr, FXC_ERR_COMM, "%s", api->error.c_str());
+    const ncclResult_t r = api->comm_destroy(static_cast<ncclComm_t>(rccl_comm));
+    if (r != ncclSuccess) return rccl_fail(nullptr, api, "ncclCommDestroy", r);
+    return FXC_OK;
+}
+
+int fxc_reduce(fxc_plan* p, void* rccl_comm, int root) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    FXC_DEVICE(p, p->device);
+    int rc = fxc_acc_export(p, p->d_sums);
+    if (rc) return rc;
+    if (!rccl_comm) return FXC_OK;          // single rank: the exported sums are the reduced sums
+    RcclApi* api = rccl_api();
+    if (!api->handle) return fail(p, FXC_ERR_COMM, "%s", api->error.c_str());
+    // raw float64 sums + the spectra count, in place, ordered on the plan's stream behind the export
+    const size_t count = 2 * ((size_t)p->n_base * p->nchan + 1);
+    ncclComm_t comm = static_cast<ncclComm_t>(rccl_comm);
+    const ncclResult_t r = root < 0 ? api->all_reduce(p->d_sums, p->d_sums, count, ncclFloat64, ncclSum, comm, p->stream)
+                                    : api->reduce(p->d_sums, p->d_sums, count, ncclFloat64, ncclSum, root, comm, p->stream);
+    if (r != ncclSuccess) return rccl_fail(p, api, root < 0 ? "ncclAllReduce" : "ncclReduce", r);
+    return FXC_OK;
+}
+
 int fxc_sync(fxc_plan* p) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     FXC_HIP(p, hipStreamSynchronize(p->stream));
     return FXC_OK;
 }
@@ -2404,7 +2652,7 @@ int fxc_channelize(fxc_plan* p, const void* x, void* out, int64_t n_streams, int
     if (n_streams < 0) return fail(p, FXC_ERR_ARG, "n_streams < 0");
     if (n_streams == 0) return FXC_OK;
     if (!x || !out) return fail(p, FXC_ERR_ARG, "NULL buffer");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     if (mem_kind == FXC_MEM_DEVICE)
         return run_channelize(p, static_cast<const cf*>(x), static_cast<cf*>(out), n_streams);
     if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
@@ -2421,7 +2669,7 @@ int fxc_fx_accumulate(fxc_plan* p, const void* x, int64_t n_chunks, int mem_kind
     if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
     if (n_chunks == 0) return FXC_OK;
     if (!x) return fail(p, FXC_ERR_ARG, "NULL buffer");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     if (mem_kind == FXC_MEM_DEVICE) return fx_accumulate_dev(p, static_cast<const cf*>(x), n_chunks);
     if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
     const size_t xb = (size_t)n_chunks * p->n_ant * p->num_samp * sizeof(cf);
@@ -2437,7 +2685,7 @@ int fxc_fx_rows(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mem
     if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
     if (n_chunks == 0) return FXC_OK;
     if (!x || !out) return fail(p, FXC_ERR_ARG, "NULL buffer");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     if (mem_kind == FXC_MEM_DEVICE) return fx_rows_dev(p, static_cast<const cf*>(x), out, n_chunks, mode, bandwidth);
     if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
     const size_t xb = (size_t)n_chunks * p->n_ant * p->num_samp * sizeof(cf);
@@ -2450,7 +2698,7 @@ int fxc_fx_rows(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mem
 
 int fxc_acc_reset(fxc_plan* p) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     FXC_HIP(p, hipMemsetAsync(p->d_acc, 0, (size_t)p->n_base * p->nchan * sizeof(cd), p->stream));
     p->spectra_count = 0.0;
     return FXC_OK;
@@ -2458,7 +2706,7 @@ int fxc_acc_reset(fxc_plan* p) {
 
 int fxc_acc_export(fxc_plan* p, void* sums_dev) {
     if (!p || !sums_dev) return fail(p, FXC_ERR_ARG, "NULL argument");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     const int64_t n = (int64_t)p->n_base * p->nchan;
     hipLaunchKernelGGL(export_kernel, dim3(grid_for(n + 1, 256, p->cu_count)), dim3(256), 0, p->stream, p->d_acc,
                        static_cast<cd*>(sums_dev), n, p->spectra_count);
@@ -2467,10 +2715,11 @@ int fxc_acc_export(fxc_plan* p, void* sums_dev) {
 }
 
 int fxc_finalize_sums(fxc_plan* p, const void* sums_dev, void* out_host, int mode, double bandwidth) {
-    if (!p || !sums_dev || !out_host) return fail(p, FXC_ERR_ARG, "NULL argument");
+    if (!p || !out_host) return fail(p, FXC_ERR_ARG, "NULL argument");
+    if (!sums_dev) sums_dev = p->d_sums;     // what fxc_reduce left in the plan
     if (mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
     if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     const cd* sums = static_cast<const cd*>(sums_dev);
     size_t out_bytes;
     if (mode == FXC_MODE_SPECTRUM) {
@@ -2511,7 +2760,7 @@ static int conditioning_common(fxc_plan* p, int64_t n_streams, const void* x, vo
 int fxc_remove_dc(fxc_plan* p, const void* x_dev, void* out_dev, int64_t n_streams) {
     int rc = conditioning_common(p, n_streams, x_dev, out_dev);
     if (rc || n_streams == 0) return rc;
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     const int n_slices = 32;
     rc = ensure_ws(p, n_streams * n_slices * 2 * (int64_t)sizeof(double));
     if (rc) return rc;
@@ -2528,7 +2777,7 @@ int fxc_remove_dc(fxc_plan* p, const void* x_dev, void* out_dev, int64_t n_strea
 int fxc_convert_u8(fxc_plan* p, const void* iq_u8_dev, void* out_dev, int64_t n_streams, int remove_dc) {
     int rc = conditioning_common(p, n_streams, iq_u8_dev, out_dev);
     if (rc || n_streams == 0) return rc;
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     const int n_slices = 32;
     rc = ensure_ws(p, n_streams * n_slices * 2 * (int64_t)sizeof(double));
     if (rc) return rc;
@@ -2552,8 +2801,14 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
               bool rows) {
     constexpr int kSlices = 32;
     const size_t row_elems = mode == FXC_MODE_SPECTRUM ? (size_t)p->n_base * p->nchan * sizeof(cf) : (size_t)p->n_base * sizeof(cd);
-    for (int64_t c0 = 0; c0 < n_chunks; c0 += 16384) {          // dc_sum_u8_kernel's grid.y carries the stream index
-        const int64_t nc = std::min<int64_t>(16384, n_chunks - c0);
+    // chunks per pass: dc_sum_u8_kernel carries the stream index in grid.y (<= 65535 streams), and plans without the
+    // fused ingest convert a pass into a complex64 staging buffer that stays within the workspace target
+    const bool fused_in = p->n_ant == 2 && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && p->tiled_ring));
+    int64_t per_pass = std::min<int64_t>(16384, 65535 / p->n_ant);
+    if (!fused_in) per_pass = std::min<int64_t>(per_pass, kWorkspaceTarget / ((int64_t)p->n_ant * p->num_samp * (int64_t)sizeof(cf)));
+    per_pass = std::max<int64_t>(1, per_pass);
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += per_pass) {
+        const int64_t nc = std::min<int64_t>(per_pass, n_chunks - c0);
         const int64_t n_streams = nc * p->n_ant;
         const unsigned char* xb = x8 + c0 * p->n_ant * p->num_samp * 2;
         void* ob = rows ? static_cast<char*>(out) + (size_t)c0 * row_elems : nullptr;
@@ -2562,7 +2817,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
         if (rc) return rc;
         double* part = static_cast<double*>(p->d_dc);
         cf* dc = reinterpret_cast<cf*>(static_cast<char*>(p->d_dc) + part_bytes);
-        const bool fused_ingest = p->n_ant == 2 && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && p->tiled_ring));
+        const bool fused_ingest = fused_in;
         if (remove_dc && fused_ingest)
             hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(n_streams, (int64_t)p->cu_count * 16)),
                                dim3(256), 0, p->stream, xb, part, p->num_samp, n_streams);
@@ -2599,7 +2854,7 @@ int fx_u8_entry(fxc_plan* p, const void* iq_u8, void* out, int64_t n_chunks, int
     if (rows && mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
     if (n_chunks == 0) return FXC_OK;
     if (!iq_u8 || (rows && !out)) return fail(p, FXC_ERR_ARG, "NULL buffer");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     if (mem_kind == FXC_MEM_DEVICE)
         return fx_u8_dev(p, static_cast<const unsigned char*>(iq_u8), out, n_chunks, mode, bandwidth, remove_dc, rows);
     if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
@@ -2629,7 +2884,7 @@ int fxc_estimate_delay(fxc_plan* p, const void* iq0, const void* iq1, int64_t n,
     if (n < 2 || n > (1ll << 28)) return fail(p, FXC_ERR_ARG, "n=%lld out of range", (long long)n);
     if (!(rate > 0.0)) return fail(p, FXC_ERR_ARG, "rate must be > 0");
     if (mem_kind != FXC_MEM_HOST && mem_kind != FXC_MEM_DEVICE) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     int lg = 1;
     while ((1ll << lg) < 2 * n) ++lg;
     const int64_t len = 1ll << lg;
@@ -2690,7 +2945,8 @@ int fxc_estimate_delay(fxc_plan* p, const void* iq0, const void* iq1, int64_t n,
 
 int fxc_pipe_destroy(fxc_pipe* q) {
     if (!q) return FXC_OK;
-    (void)hipSetDevice(q->plan->device);
+    DeviceGuard device_guard__(q->plan->device);
+    if (q->counted) q->plan->live_pipes -= 1;
     (void)hipStreamSynchronize(q->plan->stream);
     if (q->s_in) (void)hipStreamSynchronize(q->s_in);
     if (q->s_out) (void)hipStreamSynchronize(q->s_out);
@@ -2729,7 +2985,7 @@ static int pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, in
     if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
     if (mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
     if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     fxc_pipe* q = new (std::nothrow) fxc_pipe();
     if (!q) return fail(p, FXC_ERR_NOMEM, "host allocation failed");
     q->plan = p;
@@ -2759,6 +3015,8 @@ static int pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, in
         return fail(p, e == hipErrorOutOfMemory ? FXC_ERR_NOMEM : FXC_ERR_HIP, "pipeline setup failed: %s",
                     hipGetErrorString(e));
     }
+    p->live_pipes += 1;
+    q->counted = true;
     *out = q;
     return FXC_OK;
 }
@@ -2777,7 +3035,7 @@ int fxc_pipe_submit(fxc_pipe* q) {
     if (!q) return fail(nullptr, FXC_ERR_ARG, "NULL pipe");
     fxc_plan* p = q->plan;
     if (q->pushed - q->popped >= q->depth) return fail(p, FXC_ERR_STATE, "all %d slots in flight: pop first", q->depth);
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     fxc_pipe_slot& sl = q->slots[(size_t)(q->pushed % q->depth)];
     FXC_HIP(p, hipMemcpyAsync(sl.d_in, sl.h_in, q->in_bytes, hipMemcpyHostToDevice, q->s_in));
     FXC_HIP(p, hipEventRecord(sl.ev_in, q->s_in));
@@ -2808,7 +3066,7 @@ int fxc_pipe_pop(fxc_pipe* q, void* out_host) {
     if (!q || !out_host) return fail(q ? q->plan : nullptr, FXC_ERR_ARG, "NULL argument");
     fxc_plan* p = q->plan;
     if (q->pushed == q->popped) return fail(p, FXC_ERR_STATE, "nothing in flight");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     fxc_pipe_slot& sl = q->slots[(size_t)(q->popped % q->depth)];
     FXC_HIP(p, hipEventSynchronize(sl.ev_out));
     std::memcpy(out_host, sl.h_out, q->out_bytes);
@@ -2819,14 +3077,14 @@ int fxc_pipe_pop(fxc_pipe* q, void* out_host) {
 
 int fxc_timer_start(fxc_plan* p) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     FXC_HIP(p, hipEventRecord(p->ev_t0, p->stream));
     return FXC_OK;
 }
 
 int fxc_timer_stop(fxc_plan* p, double* elapsed_ms) {
     if (!p || !elapsed_ms) return fail(p, FXC_ERR_ARG, "NULL argument");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     FXC_HIP(p, hipEventRecord(p->ev_t1, p->stream));
     FXC_HIP(p, hipEventSynchronize(p->ev_t1));
     float ms = 0.f;
@@ -2843,7 +3101,7 @@ int fxc_kernel_profiling(fxc_plan* p, int enable) {
 
 int fxc_kernel_time(fxc_plan* p, double* total_ms, int64_t* launches, int reset) {
     if (!p || !total_ms || !launches) return fail(p, FXC_ERR_ARG, "NULL argument");
-    FXC_HIP(p, hipSetDevice(p->device));
+    FXC_DEVICE(p, p->device);
     int rc = drain_kernel_events(p);
     if (rc) return rc;
 #if FXC_STAMPS
@@ -2880,7 +3138,7 @@ int fxc_synth_fill(int device, void* stream, void* x_dev, uint64_t seed, int64_t
     if (n_chunks < 0 || n_ant < 1 || num_samp < 1 || tone_period < 1) return fail(nullptr, FXC_ERR_ARG, "bad size");
     if (n_chunks == 0) return FXC_OK;
     const fxc_plan* p = nullptr;
-    FXC_HIP(p, hipSetDevice(device));
+    FXC_DEVICE(p, device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float lut[256];
     for (int b = 0; b < 256; ++b) lut[b] = ((float)b - 127.5f) / 127.5f;

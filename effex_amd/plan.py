@@ -52,11 +52,16 @@ class FxPlan(object):
         if window.shape != (int(ntaps) * int(nchan),):
             raise ValueError("window must have ntaps*nchan = {} taps, got {}".format(ntaps * nchan, window.shape))
         self.window = window
-        # work is issued on the caller's stream so it is ordered with torch's own copies / kernels
+        self._pipes = []                                  # weak references to FxPipeline objects on this plan
+        # Work is issued on the caller's stream so it is ordered with torch's own copies / kernels.  stream=None
+        # follows torch's *current* stream call by call (``_follow``): under ``with torch.cuda.stream(s)`` the plan moves
+        # to ``s`` (fxc_set_stream orders the two streams with an event), so inputs, kernels and outputs stay ordered.
+        self._follow = stream is None
         if stream is None:
             stream = _current_torch_stream(int(device))
         elif stream == "owned":
             stream = -1                                   # FXC_STREAM_OWNED
+        self._stream = int(stream)
         stream_ptr = ctypes.c_void_p(int(stream) & 0xFFFFFFFFFFFFFFFF) if stream else None
         rc = self._lib.fxc_plan_create(ctypes.byref(self._h), int(device), int(n_ant), int(nchan), int(ntaps),
                                        int(num_samp), window.ctypes.data, stream_ptr, PATHS[path])
@@ -74,8 +79,30 @@ class FxPlan(object):
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            for ref in list(getattr(self, "_pipes", ())):     # pipes hold a pointer to the plan: they go first
+                pipe = ref()
+                if pipe is not None:
+                    pipe.close()
+            self._pipes = []
             self._lib.fxc_plan_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+    def _sync_stream(self):
+        """Plans created with stream=None issue every call on torch's current stream of their device."""
+        if not self._follow:
+            return
+        cur = _current_torch_stream(self.device)
+        if cur != self._stream:
+            self._check(self._lib.fxc_set_stream(self._h, ctypes.c_void_p(cur) if cur else None))
+            self._stream = cur
+
+    def set_stream(self, stream):
+        """Issue the plan's work on ``stream`` (a raw hipStream_t / ``torch.cuda.Stream.cuda_stream``) from now on and
+        stop following torch's current stream."""
+        self._follow = False
+        stream = int(stream)
+        self._check(self._lib.fxc_set_stream(self._h, ctypes.c_void_p(stream) if stream else None))
+        self._stream = stream
 
     def __del__(self):
         try:
@@ -97,6 +124,7 @@ class FxPlan(object):
 
     def _in(self, x, shape_tail):
         """-> (pointer, mem_kind, leading count, keepalive)."""
+        self._sync_stream()
         if _is_torch(x):
             import torch
             if x.dtype != torch.complex64 or not x.is_cuda or not x.is_contiguous():
@@ -165,6 +193,7 @@ class FxPlan(object):
         return out
 
     def acc_reset(self):
+        self._sync_stream()
         self._check(self._lib.fxc_acc_reset(self._h))
 
     def acc_export(self, sums):
@@ -173,6 +202,7 @@ class FxPlan(object):
         if sums.dtype != torch.complex128 or sums.numel() != self.n_baselines * self.nchan + 1 \
                 or not sums.is_contiguous() or not sums.is_cuda:
             raise ValueError("sums must be a contiguous CUDA complex128 tensor of n_baselines*nchan + 1 elements")
+        self._sync_stream()
         self._check(self._lib.fxc_acc_export(self._h, sums.data_ptr()))
         return sums
 
@@ -181,15 +211,26 @@ class FxPlan(object):
         return torch.empty(self.n_baselines * self.nchan + 1, dtype=torch.complex128,
                            device=torch.device("cuda", self.device))
 
-    def finalize_sums(self, sums, mode="SPECTRUM", bandwidth=1.0):
+    def finalize_sums(self, sums=None, mode="SPECTRUM", bandwidth=1.0):
+        """Visibilities from exported (and reduced) sums; ``sums=None``: the plan's own copy, as ``reduce`` leaves it."""
         m = MODES[mode.upper()]
         shape = (self.n_baselines, self.nchan) if m == _lib.FXC_MODE_SPECTRUM else (self.n_baselines,)
         out = np.empty(shape, dtype=np.complex128)
-        self._check(self._lib.fxc_finalize_sums(self._h, sums.data_ptr(), out.ctypes.data, m, float(bandwidth)))
+        self._sync_stream()
+        ptr = sums.data_ptr() if sums is not None else None
+        self._check(self._lib.fxc_finalize_sums(self._h, ptr, out.ctypes.data, m, float(bandwidth)))
         return out
+
+    def reduce(self, comm=None, root=0):
+        """``fxc_reduce``: export the accumulator into the plan and sum it over the ranks of ``comm`` (an ``RcclComm``;
+        None = single rank) on the plan's stream — ncclReduce to ``root``, ncclAllReduce if ``root`` is None."""
+        self._sync_stream()
+        handle = comm.handle if comm is not None else None
+        self._check(self._lib.fxc_reduce(self._h, handle, -1 if root is None else int(root)))
 
     def finalize(self, mode="SPECTRUM", bandwidth=1.0, reset=True):
         """Mean over everything accumulated, times conj(rot), fft-shifted -> numpy complex128."""
+        self._sync_stream()
         m = MODES[mode.upper()]
         shape = (self.n_baselines, self.nchan) if m == _lib.FXC_MODE_SPECTRUM else (self.n_baselines,)
         out = np.empty(shape, dtype=np.complex128)
@@ -207,6 +248,7 @@ class FxPlan(object):
         if x.dtype != torch.complex64 or not x.is_cuda or not x.is_contiguous() or x.shape[-1] != self.num_samp:
             raise ValueError("x must be a contiguous CUDA complex64 tensor [..., num_samp]")
         out = x if out is None else out
+        self._sync_stream()
         self._check(self._lib.fxc_remove_dc(self._h, x.data_ptr(), out.data_ptr(), x.numel() // self.num_samp))
         return out
 
@@ -216,6 +258,7 @@ class FxPlan(object):
         if iq_u8.dtype != torch.uint8 or not iq_u8.is_cuda or not iq_u8.is_contiguous() \
                 or tuple(iq_u8.shape[-2:]) != (self.num_samp, 2):
             raise ValueError("iq_u8 must be a contiguous CUDA uint8 tensor [..., num_samp, 2]")
+        self._sync_stream()
         out = torch.empty(iq_u8.shape[:-1], dtype=torch.complex64, device=iq_u8.device)
         self._check(self._lib.fxc_convert_u8(self._h, iq_u8.data_ptr(), out.data_ptr(), out.numel() // self.num_samp,
                                              int(bool(remove_dc))))
@@ -224,6 +267,7 @@ class FxPlan(object):
     def _in_u8(self, iq_u8):
         """uint8 I,Q [n_chunks, n_ant, num_samp, 2] (CUDA tensor or host array) -> (pointer, mem_kind, n, keepalive)."""
         tail = (self.n_ant, self.num_samp, 2)
+        self._sync_stream()
         if _is_torch(iq_u8):
             import torch
             if iq_u8.dtype != torch.uint8 or not iq_u8.is_cuda or not iq_u8.is_contiguous():
@@ -263,7 +307,13 @@ class FxPlan(object):
         if len(iq_0) != len(iq_1):
             raise AssertionError('Algorithm assumes input complex timeseries are of equal length.')
         n = int(len(iq_0))
-        if _is_torch(iq_0):
+        self._sync_stream()
+        if _is_torch(iq_0) or _is_torch(iq_1):
+            import torch
+            for t in (iq_0, iq_1):
+                if not _is_torch(t) or t.dtype != torch.complex64 or not t.is_cuda or t.dim() != 1 \
+                        or t.device.index != self.device:
+                    raise ValueError("device inputs must both be 1-D complex64 CUDA tensors on device {}".format(self.device))
             a, b, kind = iq_0.contiguous(), iq_1.contiguous(), _lib.FXC_MEM_DEVICE
             pa, pb = a.data_ptr(), b.data_ptr()
         else:
@@ -311,6 +361,8 @@ class FxPipeline(object):
         else:
             plan._check(plan._lib.fxc_pipe_create(ctypes.byref(self._h), plan._h, self.chunks, int(depth), self.mode,
                                                   float(bandwidth)))
+        import weakref
+        plan._pipes.append(weakref.ref(self))      # FxPlan.close() closes its pipes first
 
     def push(self, x):
         x = np.ascontiguousarray(x, dtype=self._dtype)
@@ -348,6 +400,47 @@ class FxPipeline(object):
         if self._h:
             self.plan._lib.fxc_pipe_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class RcclComm(object):
+    """One rank of an RCCL communicator made by libfxcorr (``fxc_comm_*``) for ``FxPlan.reduce``.
+
+    ``unique_id()`` on rank 0 gives the 128 bytes every rank needs; how they travel is the caller's business
+    (``effex_amd.sharding.make_comm`` broadcasts them through ``torch.distributed``).  Creation is collective."""
+
+    def __init__(self, device, rank, world_size, unique_id):
+        self._lib = _lib.load()
+        self.handle = ctypes.c_void_p()
+        if len(unique_id) != _lib.FXC_COMM_ID_BYTES:
+            raise ValueError("unique_id must be {} bytes".format(_lib.FXC_COMM_ID_BYTES))
+        buf = (ctypes.c_char * _lib.FXC_COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _lib.check(self._lib.fxc_comm_create(ctypes.byref(self.handle), int(device), int(rank), int(world_size),
+                                             ctypes.cast(buf, ctypes.c_void_p)), None)
+        self.rank, self.world_size, self.device = int(rank), int(world_size), int(device)
+
+    @staticmethod
+    def unique_id():
+        lib = _lib.load()
+        buf = (ctypes.c_char * _lib.FXC_COMM_ID_BYTES)()
+        _lib.check(lib.fxc_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), None)
+        return bytes(buf.raw)
+
+    def close(self):
+        if self.handle:
+            self._lib.fxc_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
 
     def __enter__(self):
         return self

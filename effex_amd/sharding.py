@@ -4,9 +4,20 @@ Chunks are independent (``channelize_poly`` starts every chunk with zero PFB his
 processes chunk pairs one at a time with no carried state, effex/effex.py:391-410), so each rank
 integrates a contiguous range of the global chunk index on its own GPU with no data-path collective.
 The only exchange is one sum-reduction of the exported accumulators — ``n_baselines*nchan + 1``
-complex128 (raw cross-spectra sums + the spectra count; 64 KiB for 2 antennas) — through
-``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests), issued once
-per integration, then ``fxc_finalize_sums`` on the root.  The reduce is latency-bound at this size.
+complex128 (raw cross-spectra sums + the spectra count; 64 KiB for 2 antennas) — once per integration,
+then ``fxc_finalize_sums`` on the root.  Two transports:
+
+* ``RcclComm`` (``fxc_comm_*`` / ``fxc_reduce``, include/fxcorr.h): libfxcorr calls RCCL itself and enqueues
+  the ncclReduce on the plan's stream right behind the export — no host synchronisation anywhere between the
+  last F+X kernel and the finalize.  ``make_comm`` builds it, handing the unique id round through
+  ``torch.distributed``.
+* ``torch.distributed`` (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests): the collective is issued on
+  torch's current stream; a plan that follows that stream (the default) needs no host wait either — the
+  collective is stream-ordered behind the export and the finalize behind the collective.  A plan on a stream
+  of its own is fenced with ``plan.sync()`` first.
+
+No scaling curve has been measured yet (the builder has one GPU); the control flow is exercised by
+tests/test_dist_gloo.py (world 2 and 3, gloo) and by ``bench.py --dry-run-dist``.
 """
 
 
@@ -18,7 +29,7 @@ def chunk_range(rank, world_size, n_chunks):
 
 
 def reduce_sums(sums, root=0, group=None, to_all=False):
-    """Sum the exported accumulators across ranks (in place).  Returns ``sums``.
+    """Sum the exported accumulators across ranks (in place) through ``torch.distributed``.  Returns ``sums``.
 
     complex128 is reduced through its float64 view so every backend accepts it.
     """
@@ -34,12 +45,33 @@ def reduce_sums(sums, root=0, group=None, to_all=False):
     return sums
 
 
-class ShardedIntegrator(object):
-    """One per rank: integrates this rank's chunks on its GPU, then reduces and finalises."""
+def make_comm(device, rank, world_size, group=None):
+    """An ``RcclComm`` over the ranks of the initialised ``torch.distributed`` group: rank 0 draws the unique id,
+    ``broadcast_object_list`` carries it, every rank joins (collective, blocking).  Returns None for one rank."""
+    if world_size == 1:
+        return None
+    import torch.distributed as dist
+    from .plan import RcclComm
+    box = [RcclComm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return RcclComm(device, rank, world_size, box[0])
 
-    def __init__(self, plan, rank=0, world_size=1, group=None):
-        self.plan, self.rank, self.world_size, self.group = plan, rank, world_size, group
-        self.sums = plan.new_sums()
+
+class ShardedIntegrator(object):
+    """One per rank: integrates this rank's chunks on its GPU, then reduces and finalises.
+
+    ``comm``: an ``RcclComm`` -> ``fxc_reduce`` (RCCL called by libfxcorr on the plan's stream); None -> the
+    exported sums go through ``torch.distributed`` (``group``)."""
+
+    def __init__(self, plan, rank=0, world_size=1, group=None, comm=None):
+        self.plan, self.rank, self.world_size, self.group, self.comm = plan, rank, world_size, group, comm
+        self.sums = None if comm is not None else plan.new_sums()
+
+    @property
+    def transport(self):
+        if self.world_size == 1:
+            return "none (single rank)"
+        return "rccl (fxc_reduce)" if self.comm is not None else "torch.distributed"
 
     def my_range(self, n_chunks):
         return chunk_range(self.rank, self.world_size, n_chunks)
@@ -48,14 +80,15 @@ class ShardedIntegrator(object):
         return self.plan.fx_accumulate(x_local)
 
     def reduce(self, root=0, to_all=False):
-        """Export this rank's accumulator and sum it across ranks (async on the device until the
-        collective's own synchronisation)."""
-        import torch
+        """Export this rank's accumulator and sum it across ranks; asynchronous on the device."""
+        if self.comm is not None:
+            self.plan.reduce(self.comm, None if to_all else root)
+            return None
         self.plan.acc_export(self.sums)
-        self.plan.sync()           # the plan's stream produced `sums`; the collective runs on torch's
-        reduce_sums(self.sums, root=root, group=self.group, to_all=to_all)
-        if self.sums.is_cuda:
-            torch.cuda.current_stream(self.sums.device).synchronize()
+        if self.world_size > 1:
+            if not getattr(self.plan, "_follow", False):
+                self.plan.sync()       # a plan on its own stream: fence it before torch's stream takes over
+            reduce_sums(self.sums, root=root, group=self.group, to_all=to_all)
         return self.sums
 
     def finalize(self, mode="SPECTRUM", bandwidth=1.0, root=0, to_all=False):
@@ -63,6 +96,6 @@ class ShardedIntegrator(object):
         self.reduce(root=root, to_all=to_all)
         out = None
         if to_all or self.rank == root:
-            out = self.plan.finalize_sums(self.sums, mode, bandwidth)
+            out = self.plan.finalize_sums(self.sums, mode, bandwidth)     # sums None: the plan's reduced copy
         self.plan.acc_reset()
         return out

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FXC_VERSION 101 /* 0.1.0 */
+#define FXC_VERSION 102 /* 0.1.0 */
 
 typedef struct fxc_plan fxc_plan; /* opaque; one per (device, configuration) */
 typedef struct fxc_pipe fxc_pipe; /* opaque; host-fed double-buffered front end on a plan */
@@ -40,7 +40,8 @@ enum fxc_status {
     FXC_ERR_HIP = -3,         /* a HIP runtime call failed; message has hipGetErrorString        */
     FXC_ERR_NOMEM = -4,
     FXC_ERR_NODEVICE = -5,
-    FXC_ERR_STATE = -6        /* call sequence error (e.g. finalize with nothing accumulated)    */
+    FXC_ERR_STATE = -6,       /* call sequence error (e.g. finalize with nothing accumulated)    */
+    FXC_ERR_COMM = -7         /* librccl could not be bound, or an RCCL call failed              */
 };
 
 enum fxc_mem_kind { FXC_MEM_HOST = 0, FXC_MEM_DEVICE = 1 };
@@ -76,7 +77,11 @@ const char* fxc_status_string(int status);
  * force_path: -1 = choose automatically, else an fxc_path (FUSED fails if the shape has none). */
 int fxc_plan_create(fxc_plan** out, int device, int n_ant, int nchan, int ntaps, int64_t num_samp,
                     const double* window, void* stream, int force_path);
-int fxc_plan_destroy(fxc_plan* plan);
+int fxc_plan_destroy(fxc_plan* plan); /* FXC_ERR_STATE while an fxc_pipe still uses the plan */
+/* Move the plan to another hipStream_t (e.g. when the caller's current stream changes, `with torch.cuda.stream(s)`):
+ * everything already queued on the old stream is ordered before what follows on the new one by an event, no host
+ * wait.  Not for plans that own their stream. */
+int fxc_set_stream(fxc_plan* plan, void* stream);
 int fxc_plan_get_info(const fxc_plan* plan, fxc_info* info);
 const char* fxc_last_error(const fxc_plan* plan);
 
@@ -110,7 +115,21 @@ int fxc_fx_rows(fxc_plan* plan, const void* x, void* out, int64_t n_chunks, int 
  * fxc_finalize_sums on the root. */
 int fxc_acc_reset(fxc_plan* plan);
 int fxc_acc_export(fxc_plan* plan, void* sums_dev);
+/* sums_dev == NULL: the plan's own copy, as fxc_reduce leaves it */
 int fxc_finalize_sums(fxc_plan* plan, const void* sums_dev, void* out_host, int mode, double bandwidth);
+
+/* The reduce itself: export the plan's accumulator and sum it over the ranks of `rccl_comm`
+ * (an ncclComm_t; NULL = single rank) with one ncclReduce to `root` (root < 0: ncclAllReduce), float64, in place, on
+ * the plan's stream -- no host synchronisation between the F+X kernels, the collective and fxc_finalize_sums(plan,
+ * NULL, ...) on the root.  64 KiB for two antennas; latency-bound over xGMI.
+ * fxc_comm_*: the communicator for it.  Rank 0 calls fxc_comm_unique_id and hands the FXC_COMM_ID_BYTES bytes to
+ * every rank by any channel (bench.py: torch.distributed broadcast); every rank then calls fxc_comm_create (blocking,
+ * collective: ncclCommInitRank on `device`).  librccl is bound at run time; FXC_ERR_COMM if it cannot be. */
+#define FXC_COMM_ID_BYTES 128
+int fxc_comm_unique_id(void* id_out);
+int fxc_comm_create(void** rccl_comm_out, int device, int rank, int world_size, const void* id);
+int fxc_comm_destroy(void* rccl_comm);
+int fxc_reduce(fxc_plan* plan, void* rccl_comm, int root);
 
 /* Single-GPU finalize: mean over everything accumulated, times conj(rot), fftshift; D2H.
  *   SPECTRUM : out_host = [n_baselines][nchan] complex128;  CONTINUUM: [n_baselines] complex128.

@@ -30,6 +30,11 @@ SMALL_CHUNKS = 5
 NFFT_CASES = ((1024, 1024 * 12, 2, 1e-6), (2048, 2048 * 9 + 5, 2, -3e-7), (8192, 8192 * 5, 1, 1e-6))
 SEED_NFFT = 4321
 
+# nbins changed AFTER construction (tests/test_effex.py:142-144): the window built once by the constructor for 4096 bins
+# (effex.py:126-127) stays, and channelize_poly derives its tap count from it: (new nbins, num_samp, chunk pairs, delay)
+STALE_NBINS_CASES = ((2048, 2048 * 12 + 3, 2, 1e-6), (8192, 8192 * 4, 1, 0.0), (1000, 1000 * 6 + 7, 1, -2e-7))
+SEED_STALE = 2468
+
 CSV_NBINS = 256
 CSV_S = 4096
 
@@ -82,6 +87,10 @@ def small_input():
 
 def nfft_input(nbins, num_samp, chunks):
     return synth.synth_iq(SEED_NFFT + nbins, chunks, 2, num_samp)
+
+
+def stale_input(nbins, num_samp, chunks):
+    return synth.synth_iq(SEED_STALE + nbins, chunks, 2, num_samp)
 
 
 def csv_row(mode):

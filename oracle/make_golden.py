@@ -121,6 +121,28 @@ def main():
         nfft_meta.append({"nbins": nbins, "num_samp": num_samp, "chunks": chunks, "delay": delay, "key": key})
     meta["nfft"] = nfft_meta
 
+    # (4d) nbins changed after construction (tests/test_effex.py:142-144; effex.py:287-294 only stores the value): the
+    #      4 * 4096-tap window of the constructor stays (effex.py:126-127) and _run_task channelises with it
+    stale_meta = []
+    for nbins, num_samp, chunks, delay in gi.STALE_NBINS_CASES:
+        fxs, cors = ref_standins.make_correlator()     # (the constructor asserts num_samp >= 4 * 4096, effex.py:118-124)
+        assert cors.nbins == 4096 and len(cors.window) == 4 * 4096
+        cors.nbins = nbins
+        cors.num_samp = num_samp
+        assert len(cors.window) == 4 * 4096          # stale on purpose
+        cors.calibrated_delay = delay
+        xin = gi.stale_input(nbins, num_samp, chunks)
+        rows_s = []
+        for c in range(chunks):
+            cors.gpu_iq_0 = xin[c, 0].astype(np.complex128)
+            cors.gpu_iq_1 = xin[c, 1].astype(np.complex128)
+            rows_s.append(np.asarray(cors._run_task()))
+        key = "stale_nbins_%d_rows" % nbins
+        arrays[key] = np.stack(rows_s)
+        stale_meta.append({"nbins": nbins, "num_samp": num_samp, "chunks": chunks, "delay": delay, "key": key,
+                           "window_len": int(len(cors.window)), "ntaps_effective": int(len(cors.window) / nbins)})
+    meta["stale_nbins"] = stale_meta
+
     # (5) csv bytes: _write_metadata + savetxt rows as _write_data does (effex.py:667-696)
     csv_meta = {}
     for mode in ("SPECTRUM", "CONTINUUM"):

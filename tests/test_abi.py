@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.fxc_version() == 101
+    assert lib.fxc_version() == 102
     assert lib.fxc_status_string(0) == b"ok"
     assert b"unsupported" in lib.fxc_status_string(_lib.FXC_ERR_UNSUPPORTED)
 
@@ -54,6 +54,12 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.fxc_plan_create(ctypes.byref(h), 0, 2, 64, 4, 4096, None, None, -1) == _lib.FXC_ERR_ARG
     assert lib.fxc_plan_create(None, 0, 2, 64, 4, 4096, win, None, -1) == _lib.FXC_ERR_ARG
     assert lib.fxc_sync(None) == _lib.FXC_ERR_ARG
+    assert lib.fxc_set_stream(None, None) == _lib.FXC_ERR_ARG
+    assert lib.fxc_reduce(None, None, 0) == _lib.FXC_ERR_ARG
+    assert lib.fxc_comm_unique_id(None) == _lib.FXC_ERR_ARG
+    assert lib.fxc_comm_create(None, 0, 0, 1, None) == _lib.FXC_ERR_ARG
+    assert lib.fxc_comm_destroy(None) == _lib.FXC_OK
+    assert b"RCCL" in lib.fxc_status_string(_lib.FXC_ERR_COMM)
     assert lib.fxc_plan_destroy(None) == _lib.FXC_OK
 
 
@@ -71,3 +77,14 @@ def test_no_cpu_backend(lib):
     from effex_amd.plan import FxPlan
     with pytest.raises(_lib.FxcError):
         FxPlan(2, 64, 4, 4096)
+
+
+def test_bench_refuses_a_foreign_library(monkeypatch, tmp_path):
+    """bench.py measures the in-tree build only: FXCORR_LIB (the developer A/B override) makes it exit."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FXCORR_LIB=str(tmp_path / "libother.so"))
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "1"],
+                          env=env, capture_output=True, text=True, timeout=120)
+    assert proc.returncode != 0 and "in-tree library only" in proc.stderr
+    assert _lib.is_in_tree()

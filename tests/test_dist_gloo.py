@@ -1,9 +1,12 @@
-"""world_size-2 gloo test of the sharding plumbing on CPU.
+"""gloo tests of the sharding plumbing on CPU, world sizes 2 and 3.
 
 The device arithmetic is covered by tests/test_gpu_parity.py::test_sharded_integration_equals_single_rank;
-here two processes own disjoint chunk ranges, each builds the tensor its GPU would export (raw
+here several processes own disjoint chunk ranges and either (a) build the tensor their GPU would export (raw
 cross-spectra sums + spectra count — produced by the oracle, which is what the HIP path is checked
-against), and the reduced result must equal the single-rank integration."""
+against) and reduce it, or (b) drive ``ShardedIntegrator.finalize()`` itself through a plan whose
+export / finalize_sums are implemented with the oracle; the result must equal the single-rank integration.
+``bench.py --dry-run-dist`` runs bench.py's own multi-rank control flow under ``torch.distributed.run``."""
+import subprocess
 import os
 import socket
 import sys
@@ -104,3 +107,119 @@ def test_two_rank_reduce_equals_single_rank(to_all):
     assert results[0][2][NCHAN].real == N_CHUNKS * (NUM_SAMP // NCHAN)
     if to_all:
         np.testing.assert_array_equal(results[1][2], results[0][2])
+
+
+class OraclePlan(object):
+    """Stands in for FxPlan on a machine without a GPU: the same surface ShardedIntegrator uses (new_sums,
+    fx_accumulate, acc_export, finalize_sums, acc_reset, sync), with the oracle doing the arithmetic."""
+    n_baselines, nchan, _follow = 1, NCHAN, True
+
+    def __init__(self, window, rot):
+        self.window, self.rot = window, rot
+        self.acc = np.zeros(NCHAN + 1, dtype=np.complex128)
+        self.resets = 0
+
+    def new_sums(self):
+        import torch
+        return torch.zeros(NCHAN + 1, dtype=torch.complex128)
+
+    def fx_accumulate(self, x):
+        self.acc += _local_sums(x, 0, len(x), self.window)
+        return len(x)
+
+    def acc_export(self, sums):
+        import torch
+        sums.copy_(torch.from_numpy(self.acc))
+        return sums
+
+    def finalize_sums(self, sums, mode="SPECTRUM", bandwidth=1.0):
+        s = sums.numpy()
+        vis = np.fft.fftshift(s[:NCHAN] / s[NCHAN].real * np.conj(self.rot))       # effex.py:520-521
+        return vis[None, :] if mode == "SPECTRUM" else np.array([vis.mean() / bandwidth])
+
+    def acc_reset(self):
+        self.acc[:] = 0
+        self.resets += 1
+
+    def sync(self):
+        pass
+
+
+def _integrator_worker(rank, world, port, to_all, queue):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import fx_oracle
+    from effex_amd import sharding, synth
+    from effex_amd.window import design_window
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rot = fx_oracle.rot_table(NCHAN, 2.4e6, 1.4204e9, 1e-6)
+        plan = OraclePlan(design_window(NTAPS, NCHAN), rot)
+        integ = sharding.ShardedIntegrator(plan, rank, world)
+        assert integ.transport == "torch.distributed"
+        lo, hi = integ.my_range(N_CHUNKS)
+        outs = []
+        for _ in range(2):                     # two integrations back to back: the reset in between matters
+            integ.accumulate(synth.synth_iq(1234, hi - lo, 2, NUM_SAMP, first_chunk=lo))
+            outs.append(integ.finalize("SPECTRUM", 2.4e6, root=world - 1, to_all=to_all))
+        queue.put((rank, (lo, hi), outs, plan.resets))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,to_all", [(2, False), (2, True), (3, False), (3, True)])
+def test_sharded_integrator_finalize_over_gloo(world, to_all):
+    """ShardedIntegrator.finalize(): export -> reduce to a non-zero root (or all-reduce) -> finalize on the root ->
+    reset, twice in a row, for world sizes 2 and 3."""
+    import torch.multiprocessing as mp
+    import fx_oracle
+    from effex_amd import synth
+    from effex_amd.window import design_window
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_integrator_worker, args=(r, world, port, to_all, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in procs:
+        rank, rng, outs, resets = queue.get(timeout=180)
+        results[rank] = (rng, outs, resets)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [results[r][0] for r in range(world)] == [((r * N_CHUNKS) // world, ((r + 1) * N_CHUNKS) // world)
+                                                     for r in range(world)]
+    x = synth.synth_iq(1234, N_CHUNKS, 2, NUM_SAMP)
+    rot = fx_oracle.rot_table(NCHAN, 2.4e6, 1.4204e9, 1e-6)
+    ref = fx_oracle.fx_integrate(x, NCHAN, design_window(NTAPS, NCHAN), rot=rot)
+    root = world - 1
+    for rank in range(world):
+        _, outs, resets = results[rank]
+        assert resets == 2
+        for out in outs:
+            if to_all or rank == root:
+                np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-20)
+            else:
+                assert out is None
+
+
+def test_bench_dry_run_dist_two_ranks():
+    """bench.py's world > 1 control flow (rank env, first_chunk per rank, ShardedIntegrator, barrier, max-over-ranks
+    timing) under torch.distributed.run --nproc-per-node 2 on gloo / CPU tensors."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--dry-run-dist"]
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # rank 0 alone prints the line
+    line = json.loads(lines[0])
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["steps"] == 3 and line["frames_per_rank"] == 100
+    assert line["first_chunk_last_rank"] == 100 and line["transport"] == "torch.distributed"
+    assert line["mean_chunk_index"] == 99.5      # mean over both ranks' chunk ranges: the reduce reached the root

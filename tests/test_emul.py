@@ -80,3 +80,35 @@ def test_tiled_phases_match_oracle(emul_tiled, nchan, ntaps, frames, ring):
     f1 = fx_oracle.spectrometer_poly(x[1], ntaps, nchan, w)
     ref = (f0 * np.conj(f1)).sum(axis=0)
     assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-6
+
+
+@pytest.fixture(scope="module")
+def emul_sched():
+    src = os.path.join(HERE, "emul", "emul_sched.cpp")
+    lib = os.path.join(HERE, "emul", "libemul_sched.so")
+    deps = [src] + [os.path.join(HERE, "..", "effex_amd", "csrc", h) for h in ("fx_fused4096.h", "fx_math.h")]
+    if not os.path.isfile(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", lib, src], check=True)
+    return ctypes.CDLL(lib)
+
+
+@pytest.mark.parametrize("n_chunks,n_pts,grid,unit", [
+    (10000, 64, 256, 1), (10000, 64, 256, 4), (257, 64, 256, 1), (255, 64, 256, 4), (1, 64, 16, 1), (1, 64, 16, 4),
+    (3, 16, 12, 1), (7, 5, 8, 1), (7, 5, 8, 3), (100, 1, 25, 1), (100, 1, 25, 64), (5, 3, 256, 1), (2, 1, 256, 4),
+    (1000, 256, 256, 1), (33, 7, 31, 2)])
+def test_fused_frame_range_schedule(emul_sched, n_chunks, n_pts, grid, unit):
+    """fx_fused4096_kernel's work split (frame ranges that ignore chunk boundaries, rows + leading-part rows,
+    ring history at range starts): every frame once, per-chunk and total sums rebuilt as the finishing kernels do."""
+    rng = np.random.default_rng(n_chunks * 131 + n_pts * 7 + grid + unit)
+    w = rng.integers(1, 1000, size=n_chunks * n_pts).astype(np.float64)
+    per_chunk = np.zeros(n_chunks, np.float64)
+    total = ctypes.c_double()
+    fmin, fmax = ctypes.c_int64(), ctypes.c_int64()
+    rc = emul_sched.emul_fused_schedule(ctypes.c_int64(n_chunks), ctypes.c_int64(n_pts), grid, ctypes.c_int64(unit),
+                                        w.ctypes.data_as(ctypes.c_void_p), per_chunk.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.byref(total), ctypes.byref(fmin), ctypes.byref(fmax))
+    assert rc == 0
+    assert total.value == w.sum()
+    assert fmax.value - fmin.value <= 1                      # balanced whatever n_chunks % grid is
+    if unit == 1:
+        assert np.array_equal(per_chunk, w.reshape(n_chunks, n_pts).sum(axis=1))

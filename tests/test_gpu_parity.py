@@ -166,6 +166,34 @@ def test_drop_in_run_task(torch, golden):
         cor.close()
 
 
+def test_drop_in_nbins_changed_after_construction(torch, golden):
+    """cor.nbins = ... after construction (tests/test_effex.py:142-144): like the reference, the drop-in keeps the
+    window designed for the constructor's nbins (effex.py:126-127, 287-294) and channelises with len(window) / nbins
+    taps of it — against rows the reference's own _run_task produced that way (tests/golden)."""
+    from effex_amd.correlator import Correlator, SyntheticSource
+    meta, arrays = golden
+    for case in meta["stale_nbins"]:
+        nbins, num_samp, chunks, delay = case["nbins"], case["num_samp"], case["chunks"], case["delay"]
+        x = gi.stale_input(nbins, num_samp, chunks)
+        cor = Correlator(source=SyntheticSource())
+        try:
+            window_before = cor.window.copy()
+            cor.nbins = nbins
+            cor.num_samp = num_samp
+            assert cor.nbins == nbins and np.array_equal(cor.window, window_before)
+            cor.calibrated_delay = delay
+            for c in range(chunks):
+                cor.gpu_iq_0, cor.gpu_iq_1 = x[c, 0], x[c, 1]
+                vis = cor._run_task()
+                assert vis.shape == (nbins,)
+                assert rel_err(vis, arrays[case["key"]][c]) < TOL_VIS, (nbins, c)
+            cor.nbins = 2 ** 15        # more bins than window taps: channelize_poly would get zero taps
+            with pytest.raises(ValueError):
+                cor._run_task()
+        finally:
+            cor.close()
+
+
 @pytest.mark.parametrize("path", ["tiled", "generic"])
 def test_small_multichunk_rows(plan_mod, torch, golden, path):
     _, arrays = golden
@@ -284,6 +312,114 @@ def test_batched_integration_matches_oracle(plan_mod, torch, path, n_chunks, num
         cont_rows = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
         np.testing.assert_allclose(cont_rows[:, 0], rows[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH,
                                    rtol=2e-5, atol=1e-7 * np.abs(cont_rows).max())
+
+
+@pytest.mark.parametrize("n_chunks,frames,extra", [(259, 5, 0), (3, 300, 77), (700, 2, 0), (257, 1, 9), (1, 64, 0),
+                                                   (517, 3, 1)])
+def test_fused_frame_ranges_ignore_chunk_boundaries(plan_mod, torch, n_chunks, frames, extra):
+    """The headline kernel hands every workgroup an equal range of the launch's frames (n_chunks % CUs != 0, ranges
+    that start mid-chunk and reload PFB history, several workgroups inside one chunk, chunks shorter than a range):
+    per-chunk rows against the oracle and against the generic kernels, integration (rows of several chunks +
+    leading-part rows) against the float64 mean of the rows, SPECTRUM and CONTINUUM, complex64 and uint8 input."""
+    num_samp = 4096 * frames + extra
+    x = synth.synth_iq(4242, n_chunks, 2, num_samp)
+    window = design_window(4, 4096)
+    rot = plan_mod.rot_table(4096, gi.BANDWIDTH, gi.FREQUENCY, 2e-7)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp, path="fused") as p, \
+            plan_mod.FxPlan(2, 4096, 4, num_samp, path="generic") as g:
+        p.set_rot(rot)
+        g.set_rot(rot)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        rows_g = g.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        assert rel_err(rows, rows_g) < 4e-6
+        for c in sorted({0, 1 % n_chunks, n_chunks // 2, n_chunks - 1}):
+            ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, 4096, window, gi.BANDWIDTH, gi.FREQUENCY, 2e-7, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        p.fx_accumulate(xd)
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ[0], rows[:, 0].astype(np.complex128).mean(axis=0)) < 4e-6
+        p.fx_accumulate(xd[: n_chunks // 2])          # uneven calls: every launch has its own ranges
+        p.fx_accumulate(xd[n_chunks // 2:])
+        assert rel_err(p.finalize("SPECTRUM")[0], integ[0]) < 4e-6
+        cont = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
+        np.testing.assert_allclose(cont[:, 0], rows[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH,
+                                   rtol=2e-5, atol=1e-7 * np.abs(cont).max())
+        # the same ranges on the uint8-ingest variant of the kernel
+        b = np.random.default_rng(5).integers(0, 256, size=(min(n_chunks, 300), 2, num_samp, 2), dtype=np.uint8)
+        bd = torch.from_numpy(b).cuda()
+        rows_b = p.fx_rows_u8(bd, "SPECTRUM", remove_dc=True).cpu().numpy()
+        rows_bg = g.fx_rows_u8(bd, "SPECTRUM", remove_dc=True).cpu().numpy()
+        assert rel_err(rows_b, rows_bg) < 1e-5
+        p.fx_accumulate_u8(bd, remove_dc=True)
+        assert rel_err(p.finalize("SPECTRUM")[0], rows_b[:, 0].astype(np.complex128).mean(axis=0)) < 1e-5
+
+
+def test_ten_thousand_frame_accumulation(plan_mod, torch):
+    """BASELINE configs[1] integrates 10 000 frames: float32 sums of up to 256 spectra per raw row, float64 across rows
+    (fxcorr.hip::fused_unit, fused_reduce1/2_kernel).  A pool of 25 distinct chunk pairs cycled to 10 400 frames of 16
+    spectra must equal the float64 mean of the per-chunk rows, and the oracle's mean over the pool, to 1e-5 of max|vis|
+    (SURVEY.md §8d 'parity tolerance to state')."""
+    num_samp, pool_n, reps = 4096 * 16, 25, 416
+    pool = synth.synth_iq(90210, pool_n, 2, num_samp)
+    window = design_window(4, 4096)
+    xd = torch.from_numpy(pool).cuda().repeat(reps, 1, 1).contiguous()
+    assert xd.shape[0] == 10400
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        assert p.path == "fused"
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-6)
+        p.fx_accumulate(xd)
+        integ = p.finalize("SPECTRUM")[0]
+        rows = p.fx_rows(xd[:pool_n], "SPECTRUM").cpu().numpy()[:, 0].astype(np.complex128)
+    assert rel_err(integ, rows.mean(axis=0)) < 2e-6
+    ref = np.mean([fx_oracle.pfb_xcorr(pool[c, 0], pool[c, 1], 4, 4096, window, gi.BANDWIDTH, gi.FREQUENCY, 1e-6,
+                                       "SPECTRUM") for c in range(pool_n)], axis=0)
+    assert rel_err(integ, ref) < TOL_VIS
+
+
+def test_continuum_reference_semantics_full_size(plan_mod, torch):
+    """BASELINE configs[2](ii): reference CONTINUUM (effex.py:523-524) at N = 4096 with num_samp = 2^20 (the reference
+    clamps num_samp to 2^18, effex.py:282-283; lifted here): oracle on one chunk pair, the rest by property."""
+    num_samp, n_chunks = 2 ** 20, 3
+    x = synth.synth_iq(1234, n_chunks, 2, num_samp)
+    window = design_window(4, 4096)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp, path="fused") as p, plan_mod.FxPlan(2, 4096, 4, num_samp) as a:
+        for q in (p, a):
+            q.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-6)
+        cont = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
+        cont_a = a.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()       # default plan: frame-split small call
+        spec = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        p.fx_accumulate(xd)
+        integ = p.finalize("CONTINUUM", gi.BANDWIDTH)
+    ref = fx_oracle.pfb_xcorr(x[1, 0], x[1, 1], 4, 4096, window, gi.BANDWIDTH, gi.FREQUENCY, 1e-6, "CONTINUUM")
+    assert abs(cont[1, 0] - ref) < TOL_VIS * abs(ref)
+    assert abs(cont_a[1, 0] - ref) < TOL_VIS * abs(ref)
+    np.testing.assert_allclose(cont[:, 0], spec[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH, rtol=2e-5)
+    np.testing.assert_allclose(integ[0], cont[:, 0].mean(), rtol=2e-5)
+
+
+def test_eight_antennas_full_size(plan_mod, torch):
+    """BASELINE configs[4] at its own size: 8 antennas, 28 baselines, nchan 4096, num_samp 262144: oracle
+    (fx_integrate) on one chunk, linearity and conjugate symmetry across the antenna order on the batch."""
+    n_ant, num_samp, n_chunks = 8, 2 ** 18, 3
+    x = synth.synth_iq(808, n_chunks, n_ant, num_samp)
+    window = design_window(4, 4096)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(n_ant, 4096, 4, num_samp) as p:
+        assert p.path == "fused" and p.n_baselines == 28
+        rows = p.fx_rows(xd).cpu().numpy().astype(np.complex128)
+        p.fx_accumulate(xd)
+        integ = p.finalize("SPECTRUM")
+        np.testing.assert_array_equal(p.fx_rows(xd * 2.0).cpu().numpy().astype(np.complex128), 4.0 * rows)
+        rev = p.fx_rows(xd.flip(1).contiguous()).cpu().numpy().astype(np.complex128)
+    ref = fx_oracle.fx_integrate(x[1:2], 4096, window)
+    assert rel_err(rows[1], ref) < TOL_VIS
+    assert rel_err(integ, rows.mean(axis=0)) < 2e-6
+    # baseline (a, b) of the reversed antenna order is conj of baseline (7 - b, 7 - a) of the original
+    pairs = [(a, b) for a in range(n_ant) for b in range(a + 1, n_ant)]
+    for idx, (a, b) in enumerate(pairs):
+        assert rel_err(rev[:, idx], np.conj(rows[:, pairs.index((n_ant - 1 - b, n_ant - 1 - a))])) < 1e-6
 
 
 @pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [
@@ -442,7 +578,8 @@ def test_multi_antenna_fused_path(plan_mod, torch, n_ant, nchan, ntaps):
                                atol=1e-7 * np.abs(cont).max())
 
 
-@pytest.mark.parametrize("ntaps,num_samp", [(4, 2 ** 16 + 3), (4, 2 ** 16), (3, 4098), (32, 5000), (1, 2048), (4, 100)])
+@pytest.mark.parametrize("ntaps,num_samp", [(4, 2 ** 16 + 3), (4, 2 ** 16), (3, 4098), (32, 5000), (1, 2048), (4, 100),
+                                            (4, 2 ** 20), (4, 2 ** 20 + 2), (5, 2 ** 20)])   # BASELINE configs[2](i) at full size
 def test_continuum_streaming_limit_nchan1(plan_mod, torch, ntaps, num_samp):
     """BASELINE config 3(i): nchan = 1, the PFB degenerates to a T-tap FIR and X to sum y0*conj(y1)."""
     x = synth.synth_iq(31, 3, 2, num_samp)
@@ -535,6 +672,74 @@ def test_sharded_integration_equals_single_rank(plan_mod, torch):
             total = sums if total is None else total + sums
         out = whole.finalize_sums(total, "SPECTRUM")
     assert rel_err(out, ref) < 1e-12
+
+
+def test_reduce_through_rccl_on_the_plan_stream(plan_mod, torch):
+    """fxc_comm_* / fxc_reduce (include/fxcorr.h): libfxcorr binds librccl itself, builds a
+    communicator and enqueues ncclReduce / ncclAllReduce of the exported sums on the plan's stream.  One GPU here, so a
+    world of one: what must hold is that the path runs and leaves the integration unchanged."""
+    from effex_amd import sharding
+    num_samp, n_chunks = 4096 * 8, 9
+    x = torch.from_numpy(synth.synth_iq(5, n_chunks, 2, num_samp)).cuda()
+    uid = plan_mod.RcclComm.unique_id()
+    assert len(uid) == 128
+    with plan_mod.RcclComm(0, 0, 1, uid) as comm, plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-6)
+        p.fx_accumulate(x)
+        ref = p.finalize("SPECTRUM", reset=False)
+        for root in (0, None):                         # ncclReduce to rank 0, ncclAllReduce
+            p.reduce(comm, root)
+            np.testing.assert_array_equal(p.finalize_sums(None, "SPECTRUM"), ref)
+        p.reduce(None, 0)                              # no communicator: export only
+        np.testing.assert_array_equal(p.finalize_sums(None, "SPECTRUM"), ref)
+        p.acc_reset()
+        integ = sharding.ShardedIntegrator(p, 0, 1, comm=comm)
+        integ.accumulate(x)
+        np.testing.assert_array_equal(integ.finalize("SPECTRUM", gi.BANDWIDTH), ref)
+        with pytest.raises(ValueError):
+            plan_mod.RcclComm(0, 1, 1, uid)            # rank outside the world
+
+
+def test_plan_follows_the_callers_stream_and_device(plan_mod, torch):
+    """A plan made without a stream issues every call on torch's *current* stream (fxc_set_stream), so inputs produced
+    and outputs consumed under ``with torch.cuda.stream(s)`` are ordered with the kernels; and no ABI entry leaves
+    the process on another current device."""
+    num_samp, n_chunks = 4096 * 6, 40
+    x = torch.from_numpy(synth.synth_iq(6, n_chunks, 2, num_samp)).cuda()
+    side = torch.cuda.Stream()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        base = p.fx_rows(x).cpu().numpy()
+        default_stream = p._stream
+        for _ in range(3):
+            with torch.cuda.stream(side):
+                big = torch.empty((64, 1024, 1024), device="cuda").normal_()      # keeps `side` busy ahead of the input
+                xs = x * (2.0 + 0.0 * big[0, 0, 0])                                # produced on `side`, after `big`
+                rows = p.fx_rows(xs)
+                assert p._stream == side.cuda_stream
+                got = rows.cpu().numpy()                                           # consumed on `side`
+            np.testing.assert_array_equal(got, 4.0 * base)
+            np.testing.assert_array_equal(p.fx_rows(x).cpu().numpy(), base)        # back on the default stream
+            assert p._stream == default_stream
+        assert torch.cuda.current_device() == 0
+    with plan_mod.FxPlan(2, 4096, 4, num_samp, stream="owned") as q:
+        with pytest.raises(Exception):
+            q.set_stream(side.cuda_stream)                                         # a plan that owns its stream keeps it
+
+
+def test_pipes_are_closed_before_their_plan(plan_mod, torch):
+    """An fxc_pipe holds a pointer to its plan: fxc_plan_destroy refuses while one is alive, and FxPlan.close()
+    closes its pipes first."""
+    from effex_amd import _lib
+    p = plan_mod.FxPlan(2, 512, 4, 4096)
+    pipe = plan_mod.FxPipeline(p, 2, depth=2)
+    lib = _lib.load()
+    assert lib.fxc_plan_destroy(p._h) == _lib.FXC_ERR_STATE
+    x = synth.synth_iq(8, 2, 2, 4096)
+    pipe.push(x)
+    assert pipe.pop().shape == (2, 1, 512)
+    p.close()
+    assert not pipe._h                        # closed by the plan
+    pipe.close()                              # idempotent
 
 
 def test_input_conditioning_on_device(plan_mod, torch):

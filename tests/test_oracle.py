@@ -141,3 +141,18 @@ def test_other_nfft_rows_match_reference(golden):
         for c in range(chunks):
             row = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, nbins, w, gi.BANDWIDTH, gi.FREQUENCY, delay, "SPECTRUM")
             np.testing.assert_allclose(row, arrays[case["key"]][c], rtol=1e-10, atol=1e-18)
+
+
+def test_stale_window_after_nbins_change_matches_reference(golden):
+    """nbins set after construction (tests/test_effex.py:142-144): the reference keeps the constructor's 4 * 4096-tap
+    window (effex.py:126-127) and channelize_poly derives len(h) / nbins taps from it — 8 taps at 2048 bins, 2 at 8192,
+    16 (of the first 16 000 coefficients) at 1000."""
+    meta, arrays = golden
+    w = design_window(4, 4096)
+    for case in meta["stale_nbins"]:
+        nbins, num_samp, chunks, delay = case["nbins"], case["num_samp"], case["chunks"], case["delay"]
+        assert case["window_len"] == len(w) and case["ntaps_effective"] == len(w) // nbins
+        x = gi.stale_input(nbins, num_samp, chunks)
+        for c in range(chunks):
+            row = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, nbins, w, gi.BANDWIDTH, gi.FREQUENCY, delay, "SPECTRUM")
+            np.testing.assert_allclose(row, arrays[case["key"]][c], rtol=1e-10, atol=1e-18)
