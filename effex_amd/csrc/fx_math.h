@@ -28,8 +28,8 @@ struct __attribute__((aligned(16))) cd {
 
 // Frame-range work split of the fused kernel: n items over g workgroups, workgroup b owns [range_begin(b),
 // range_begin(b + 1)); range_owner(f) is the workgroup whose range holds item f.
-FXC_HD long long range_begin(long long b, long long n, long long g) { return b * n / g; }
-FXC_HD long long range_owner(long long f, long long n, long long g) { return ((f + 1) * g + n - 1) / n - 1; }
+FXC_HD int range_begin(int b, int n, int g) { return (int)((long long)b * n / g); }
+FXC_HD int range_owner(int f, int n, int g) { return (int)((((long long)f + 1) * g + n - 1) / n - 1); }
 
 FXC_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
 FXC_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
@@ -37,6 +37,10 @@ FXC_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
 FXC_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 // a * conj(b)
 FXC_HD cf cmulc(cf a, cf b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+// acc + a * conj(b) as four fused multiply-adds (two per component, no separate multiply or add)
+FXC_HD cf cmulc_acc(cf acc, cf a, cf b) {
+    return mk(__builtin_fmaf(a.y, b.y, __builtin_fmaf(a.x, b.x, acc.x)), __builtin_fmaf(-a.x, b.y, __builtin_fmaf(a.y, b.x, acc.y)));
+}
 FXC_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
 // multiply by +i
 FXC_HD cf muli(cf a) { return mk(-a.y, a.x); }
@@ -54,28 +58,54 @@ FXC_HD void dft4(cf& a, cf& b, cf& c, cf& d) {
 
 // 16-point DFT, kernel exp(+2*pi*i*n*k/16), natural order in and out:
 //   n = 4*n1 + n0, k = c + 4*d:  w16^(nk) = w4^(n1 c) * w16^(n0 c) * w4^(n0 d)
-// stage A: four DFT4 over n1 and the internal twiddles; stage B: four DFT4 over n0 + reorder
+// stage A: four DFT4 over n1 and the internal twiddles; stage B: four DFT4 over n0 + reorder.
+// The four twiddles w16^2, w16^6 = sqrt(1/2) (+-1 +- i) are left as un-scaled rotations u = (x -+ y, x +- y) by
+// stage A; stage B folds the sqrt(1/2) into its first butterflies (a +- R2 u: two FMAs instead of a multiply, an add
+// and a subtract per component).
 FXC_HD void dft16_a(cf (&v)[16]) {
     const float C1 = 0.92387953251128673848f;  // cos(pi/8)
     const float S1 = 0.38268343236508978178f;  // sin(pi/8)
-    const float R2 = 0.70710678118654752440f;  // sqrt(1/2)
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) dft4(v[n0], v[4 + n0], v[8 + n0], v[12 + n0]);
     // now v[4*c + n0] = Z[n0][c]; twiddle by w16^(n0*c)
     v[5] = cmul(v[5], mk(C1, S1));                      // e = 1
-    v[6] = mk((v[6].x - v[6].y) * R2, (v[6].x + v[6].y) * R2);    // e = 2
+    v[6] = mk(v[6].x - v[6].y, v[6].x + v[6].y);        // e = 2, times sqrt 2
     v[7] = cmul(v[7], mk(S1, C1));                      // e = 3
-    v[9] = mk((v[9].x - v[9].y) * R2, (v[9].x + v[9].y) * R2);    // e = 2
+    v[9] = mk(v[9].x - v[9].y, v[9].x + v[9].y);        // e = 2, times sqrt 2
     v[10] = muli(v[10]);                                // e = 4
-    v[11] = mk((-v[11].x - v[11].y) * R2, (v[11].x - v[11].y) * R2);  // e = 6
+    v[11] = mk(-v[11].x - v[11].y, v[11].x - v[11].y);  // e = 6, times sqrt 2
     v[13] = cmul(v[13], mk(S1, C1));                    // e = 3
-    v[14] = mk((-v[14].x - v[14].y) * R2, (v[14].x - v[14].y) * R2);  // e = 6
+    v[14] = mk(-v[14].x - v[14].y, v[14].x - v[14].y);  // e = 6, times sqrt 2
     v[15] = cmul(v[15], mk(-C1, -S1));                  // e = 9
 }
 
+// dft4 whose third input arrives as c / R2 (an un-scaled rotation): t0 = a + R2 c, t1 = a - R2 c
+FXC_HD void dft4_c_scaled(cf& a, cf& b, cf& c, cf& d) {
+    const float R2 = 0.70710678118654752440f;  // sqrt(1/2)
+    cf t0 = mk(__builtin_fmaf(R2, c.x, a.x), __builtin_fmaf(R2, c.y, a.y));
+    cf t1 = mk(__builtin_fmaf(-R2, c.x, a.x), __builtin_fmaf(-R2, c.y, a.y));
+    cf t2 = cadd(b, d), t3 = muli(csub(b, d));
+    a = cadd(t0, t2);
+    b = cadd(t1, t3);
+    c = csub(t0, t2);
+    d = csub(t1, t3);
+}
+// ... second and fourth inputs arrive un-scaled: t2 = R2 (b + d), t3 = i R2 (b - d), folded into the outputs
+FXC_HD void dft4_bd_scaled(cf& a, cf& b, cf& c, cf& d) {
+    const float R2 = 0.70710678118654752440f;
+    cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = muli(csub(b, d));
+    a = mk(__builtin_fmaf(R2, t2.x, t0.x), __builtin_fmaf(R2, t2.y, t0.y));
+    b = mk(__builtin_fmaf(R2, t3.x, t1.x), __builtin_fmaf(R2, t3.y, t1.y));
+    c = mk(__builtin_fmaf(-R2, t2.x, t0.x), __builtin_fmaf(-R2, t2.y, t0.y));
+    d = mk(__builtin_fmaf(-R2, t3.x, t1.x), __builtin_fmaf(-R2, t3.y, t1.y));
+}
+
 FXC_HD void dft16_b(cf (&v)[16]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    // after stage A the un-scaled entries are v[6] (c = 1), v[9], v[11] (c = 2: second and fourth input), v[14] (c = 3)
+    dft4(v[0], v[1], v[2], v[3]);
+    dft4_c_scaled(v[4], v[5], v[6], v[7]);
+    dft4_bd_scaled(v[8], v[9], v[10], v[11]);
+    dft4_c_scaled(v[12], v[13], v[14], v[15]);
     // now v[4*c + d] = Y[c + 4*d]; transpose the 4x4 index to natural order
 #pragma unroll
     for (int c = 0; c < 4; ++c)

@@ -184,19 +184,20 @@ __device__ __forceinline__ int64_t raw_index(int k, int slots) {
     return slots == 1 ? fxc::fused::slot_of_bin(k) : (slots == 2 ? fxc::fused::specpos_of_bin(k) : k);
 }
 
-// The 2-antenna fused kernel splits a launch's frames over workgroups without regard to chunk boundaries
-// (fx_fused4096_kernel): row c of raw then lacks the frames that later workgroups took over, which sit in those
-// workgroups' leading-part rows raw[offset + b * nchan ...].  n_frames == 0: the rows are complete.
+// The 2-antenna fused kernel splits the last chunks of a launch (its tail) over workgroups without regard to chunk
+// boundaries (fx_fused4096.h::RangeWalk): row c of such a chunk lacks the frames that later workgroups took over, which
+// sit in those workgroups' leading-part rows raw[offset + b * nchan ...].  n_frames == 0: every row is complete.
 struct LeadRows {
-    int64_t n_frames, n_pts, offset;
+    int64_t first_chunk, n_frames, n_pts, offset;   // the tail: chunks from first_chunk on, n_frames frames in all
     int grid;
 };
 
 __device__ __forceinline__ void add_lead_rows(const cf* __restrict__ raw, const LeadRows& lr, int64_t row, int nchan,
                                               int64_t ridx, float& ar, float& ai) {
-    if (lr.n_frames == 0) return;
-    const int64_t b_lo = fxc::range_owner(row * lr.n_pts, lr.n_frames, lr.grid);
-    const int64_t b_hi = fxc::range_owner((row + 1) * lr.n_pts - 1, lr.n_frames, lr.grid);
+    if (lr.n_frames == 0 || row < lr.first_chunk) return;
+    const int64_t t = row - lr.first_chunk;   // chunk of the tail (fx_fused4096.h::range_walk_tail)
+    const int64_t b_lo = fxc::range_owner(t * lr.n_pts, lr.n_frames, lr.grid);
+    const int64_t b_hi = fxc::range_owner((t + 1) * lr.n_pts - 1, lr.n_frames, lr.grid);
     for (int64_t b = b_lo + 1; b <= b_hi; ++b) {   // the workgroups that start strictly inside chunk `row`
         const cf r = raw[lr.offset + b * nchan + ridx];
         ar += r.x;
@@ -535,7 +536,7 @@ constexpr int kStampSegs = 12;
     do {                                                                                                        \
         FXC_SCHED_FENCE();                                                                                      \
         if (U8)                                                                                                 \
-            load_frame_part_u8<R0, 4>(nx, reinterpret_cast<const unsigned short*>(x) + pc * 2 * num_samp,       \
+            load_frame_part_u8<R0, 4>(nx, reinterpret_cast<const unsigned short*>(x) + (int64_t)pc * 2 * num_samp, \
                                       chunk_bytes, voff, nframe);                                               \
         else                                                                                                    \
             load_frame_part<R0, 4>(nx, nbase, chunk_bytes, voff, nframe);                                       \
@@ -559,7 +560,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
                                            unsigned voff, fxc::fused::RangeWalk& pos, cf* rows_raw,
                                            unsigned long long (&seg)[kStampSegs], unsigned long long& t_prev) {
     using namespace fxc::fused;
-    const int64_t c = pos.c, i = pos.i, n_pts = pos.n_pts;
+    const int64_t c = pos.c, i = pos.i, n_pts = pos.n_pts;   // (the walk itself is 32-bit: scalar registers are scarce)
     FXC_STAMP(0);    // loop overhead and the (rare) row store since the previous step's last stamp
     if (i == 0) {    // zero PFB history at the start of every chunk
         asm volatile("" ::: "memory");   // keep this a (rarely taken) uniform branch, not 96 v_cndmask per frame
@@ -574,9 +575,9 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
     // the chunk, or frame 0 of the next chunk; at the very end the current frame again, never used).  The 16
     // loads go out in four groups spread over the step: eight waves bursting 16 loads each at the same point
     // stall in the in-order vector-memory issue (measured -7 %).
-    long long pc, nframe;
+    int pc, nframe;
     range_walk_prefetch(pos, pc, nframe);
-    const cf* nbase = x + pc * 2 * num_samp;
+    const cf* nbase = x + (int64_t)pc * 2 * num_samp;
     cf (&nx)[16] = s.h[(PH + 1) & 3];
     FXC_PREFETCH(0);
     fxc::dft16(v);
@@ -633,7 +634,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
     // range: store this lane's 8 bins (fire and forget)
     const bool row_ends = !SPEC_OUT && range_walk_row_ends(pos);
     if (row_ends) {
-        cf* row = rows_raw + pos.row * kN + tid;
+        cf* row = rows_raw + (int64_t)pos.row * kN + tid;
 #pragma unroll
         for (int q = 0; q < kAccPerThread; ++q) {
             row[q * kThreads] = s.acc[q];
@@ -643,18 +644,11 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
     range_walk_advance(pos, row_ends);
 }
 
-// Work split: the launch's n_chunks * n_pts frames form one global sequence and workgroup b takes the contiguous
-// range [b F / G, (b + 1) F / G) of it, so every workgroup gets the same number of frames (+-1) whatever
-// n_chunks % G is.  A range that starts inside a chunk reloads the (up to) three frames of PFB history before it;
-// a range that runs over a chunk boundary resets the history there (fused_step).
-// SPEC_OUT == false: raw rows, float32, slot order (fx_fused4096.h::slot_of_bin).  A row covers `unit` consecutive
-// chunks (row u = chunks [u unit, (u + 1) unit); unit = 1 for per-chunk visibilities):
-//   rows_raw[u][slot]             = sum over the frames of row u from its first one to the end of the range of the
-//                                   workgroup that owns that first frame (usually the whole row)
-//   rows_raw[n_rows + b][slot]    = workgroup b's leading part: the frames from the start of its range to the end of
-//                                   the row that range starts inside (zeros if it starts on a row boundary)
-// so row u in full = rows_raw[u] + sum of rows_raw[n_rows + b] over the workgroups b that start strictly inside it
-// (range_owner() finds them), and the sum of all n_rows + G rows is the integration.
+// Work split and raw-row layout: fx_fused4096.h::RangeWalk (whole chunks dealt round-robin, then the last
+// n_chunks % (workgroups * seg) chunks as equal frame ranges).
+// SPEC_OUT == false: rows_raw = range_rows() raw rows, float32, slot order (fx_fused4096.h::slot_of_bin);
+// rows_are_chunks: row c = chunk c (+ leading-part rows for tail chunks shared by several workgroups), else rows of
+// `unit` chunks whose total is the integration.
 // SPEC_OUT == true: rows_raw[(2c + ant) * n_pts + i][specpos] = the spectra themselves.  A "chunk" here is a pair
 // of consecutive antenna streams, so an even number of antennas [n_chunks][A][S] is simply n_chunks * A/2 pairs.
 // U8: x points at interleaved uint8 I,Q ([chunk][antenna][num_samp] byte pairs) and dc[chunk * 2 + antenna] holds the
@@ -663,7 +657,7 @@ template <bool SPEC_OUT, bool U8 = false>
 __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     const cf* __restrict__ x, int64_t num_samp, int64_t n_pts, int64_t n_chunks, const f4* __restrict__ win_g,
     const cf* __restrict__ tw1_g, const cf* __restrict__ tw2_g, cf* __restrict__ rows_raw,
-    unsigned long long* __restrict__ stamps, const cf* __restrict__ dc, int64_t unit) {
+    unsigned long long* __restrict__ stamps, const cf* __restrict__ dc, int seg, int unit, int rows_are_chunks) {
     using namespace fxc::fused;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f4* win = reinterpret_cast<f4*>(smem + kLdsWin);
@@ -672,15 +666,6 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
 
     const int tid = threadIdx.x;
     const int ant = tid >> 8, j = tid & 255;
-    RangeWalk pos = range_walk_init(blockIdx.x, gridDim.x, n_chunks, n_pts, unit);
-    const int64_t total = pos.left;
-    if (!SPEC_OUT && (!pos.lead || total == 0)) {            // no leading part: its row reads as zeros
-        cf* lead_row = rows_raw + (pos.n_rows + blockIdx.x) * kN + tid;
-#pragma unroll
-        for (int q = 0; q < kAccPerThread; ++q) lead_row[q * kThreads] = fxc::mk(0.f, 0.f);
-    }
-    if (total == 0) return;
-
     for (int idx = tid; idx < kN; idx += kThreads) win[idx] = win_g[idx];
     if (tid < 256) tw2[tid] = tw2_g[tid];
     State s;
@@ -693,51 +678,68 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     const unsigned voff = (unsigned)((ant * num_samp + (255 - j)) * kSampleBytes);
     const unsigned chunk_bytes = (unsigned)(2 * num_samp * kSampleBytes);
     U8State u8;
-    u8.off = U8 ? dc[pos.c * 2 + ant] : fxc::mk(0.f, 0.f);
-    // ring prologue: frame i -> slot 0, its history i-1, i-2, i-3 -> slots 3, 2, 1 (zeros before the chunk start)
-    const cf* cbase = reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + pos.c * 2 * num_samp * kSampleBytes);
-#pragma unroll
-    for (int d = 1; d < 4; ++d) {
-        if (pos.i - d >= 0) {
-            if (U8) {
-                load_frame_part_u8<0, 16>(s.h[4 - d], reinterpret_cast<const unsigned short*>(cbase), chunk_bytes, voff, pos.i - d);
-                convert_frame_u8(s.h[4 - d], u8.off);
-            } else {
-                load_frame_part<0, 16>(s.h[4 - d], cbase, chunk_bytes, voff, pos.i - d);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s.h[4 - d][r] = fxc::mk(0.f, 0.f);
-        }
-    }
-    if (U8)
-        load_frame_part_u8<0, 16>(s.h[0], reinterpret_cast<const unsigned short*>(cbase), chunk_bytes, voff, pos.i);
-    else
-        load_frame_part<0, 16>(s.h[0], cbase, chunk_bytes, voff, pos.i);
-    unsigned long long seg[kStampSegs] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u8.off = fxc::mk(0.f, 0.f);
+    unsigned long long seg_t[kStampSegs] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
+    int64_t frames_done = 0;
 #if FXC_STAMPS
     t_prev = __builtin_amdgcn_s_memtime();
 #endif
-    // frame g of this workgroup's range sits in ring slot g & 3: unrolled by four so the ring rotates by
-    // register renaming
-    for (int64_t g = 0; g < total; g += 4) {
-        fused_step<0, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg, t_prev);
-        if (g + 1 < total)
-            fused_step<1, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg, t_prev);
-        if (g + 2 < total)
-            fused_step<2, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg, t_prev);
-        if (g + 3 < total)
-            fused_step<3, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg, t_prev);
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {   // 0: whole chunks, round-robin; 1: this workgroup's range of the tail
+        RangeWalk pos = part == 0 ? range_walk_rounds(blockIdx.x, gridDim.x, (int)n_chunks, (int)n_pts, seg, unit, rows_are_chunks != 0)
+                                  : range_walk_tail(blockIdx.x, gridDim.x, (int)n_chunks, (int)n_pts, seg, unit, rows_are_chunks != 0);
+        const int total = pos.left;
+        if (!SPEC_OUT && part == 1 && (!pos.lead || total == 0)) {   // no leading part: its row reads as zeros
+            const RangeSplit sp = range_split(gridDim.x, (int)n_chunks, seg, unit, rows_are_chunks != 0);
+            cf* lead_row = rows_raw + (int64_t)(sp.rows_rounds + sp.n_tail + blockIdx.x) * kN + tid;
+#pragma unroll
+            for (int q = 0; q < kAccPerThread; ++q) lead_row[q * kThreads] = fxc::mk(0.f, 0.f);
+        }
+        if (total == 0) continue;
+        if (U8) u8.off = dc[(int64_t)pos.c * 2 + ant];
+        // ring prologue: frame i -> slot 0, its history i-1, i-2, i-3 -> slots 3, 2, 1 (zeros before the chunk start)
+        const cf* cbase = reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + (int64_t)pos.c * 2 * num_samp * kSampleBytes);
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+            if (pos.i - d >= 0) {
+                if (U8) {
+                    load_frame_part_u8<0, 16>(s.h[4 - d], reinterpret_cast<const unsigned short*>(cbase), chunk_bytes, voff, pos.i - d);
+                    convert_frame_u8(s.h[4 - d], u8.off);
+                } else {
+                    load_frame_part<0, 16>(s.h[4 - d], cbase, chunk_bytes, voff, pos.i - d);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s.h[4 - d][r] = fxc::mk(0.f, 0.f);
+            }
+        }
+        if (U8)
+            load_frame_part_u8<0, 16>(s.h[0], reinterpret_cast<const unsigned short*>(cbase), chunk_bytes, voff, pos.i);
+        else
+            load_frame_part<0, 16>(s.h[0], cbase, chunk_bytes, voff, pos.i);
+        // frame g of the part sits in ring slot g & 3: unrolled by four so the ring rotates by register renaming
+#pragma unroll 1
+        for (int g = 0; g < total; g += 4) {
+            fused_step<0, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg_t, t_prev);
+            if (g + 1 < total)
+                fused_step<1, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg_t, t_prev);
+            if (g + 2 < total)
+                fused_step<2, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg_t, t_prev);
+            if (g + 3 < total)
+                fused_step<3, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg_t, t_prev);
+        }
+        frames_done += total;
     }
 #if FXC_STAMPS
     if (stamps && (tid & 63) == 0) {
         unsigned long long* dst = stamps + ((int64_t)blockIdx.x * (kThreads / 64) + (tid >> 6)) * kStampSegs;
-        for (int k = 0; k < kStampSegs; ++k) dst[k] = seg[k];
-        dst[kStampSegs - 1] = (unsigned long long)total;
+        for (int k = 0; k < kStampSegs; ++k) dst[k] = seg_t[k];
+        dst[kStampSegs - 1] = (unsigned long long)frames_done;
     }
 #else
     (void)stamps;
+    (void)frames_done;
 #endif
 }
 
@@ -1541,6 +1543,7 @@ struct fxc_plan {
     bool tiled_ring = false;       // ntaps <= 4 and nchan <= 4096: VGPR frame ring + window in LDS
     unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int fused_grid_max = 0;
+    int64_t fused_seg = 1;         // chunks per round-robin segment of the fused kernel (fx_fused4096.h::RangeWalk)
     cd* d_acc = nullptr;           // [n_base*nchan]
     cd* d_sums = nullptr;          // [n_base*nchan + 1]
     cd* d_out = nullptr;           // finalize staging [n_base*nchan]
@@ -1689,7 +1692,7 @@ int drain_kernel_events(fxc_plan* p) {
 }
 
 int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8 = nullptr,
-                 int64_t unit = 1);
+                 int64_t unit = 1, bool rows_are_chunks = true);
 
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams);
@@ -1746,9 +1749,11 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
 
 constexpr int kFusedReduceSplits = 64;
 
-// workgroups of a fused launch over n_pairs chunk pairs: one per CU, fewer when that would leave a workgroup under
-// four frames (each range reloads up to three frames of history)
+// workgroups of a fused launch over n_pairs chunk pairs: one per CU; a launch with fewer chunks than that is all
+// tail (frame ranges), on fewer workgroups when a range would be under four frames (each reloads up to three
+// frames of history)
 int fused_grid(const fxc_plan* p, int64_t n_pairs) {
+    if (n_pairs >= p->fused_grid_max) return p->fused_grid_max;
     const int64_t frames = n_pairs * p->n_pts;
     return (int)std::max<int64_t>(1, std::min<int64_t>(frames / 4, p->fused_grid_max));
 }
@@ -1756,25 +1761,32 @@ int fused_grid(const fxc_plan* p, int64_t n_pairs) {
 // chunks per raw row when only the integration is wanted: float32 sums of up to 256 spectra
 int64_t fused_unit(const fxc_plan* p) { return std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(1, p->n_pts), 64)); }
 
-// raw rows a 2-antenna fused launch over nc chunks writes: ceil(nc / unit) rows + one leading-part row per workgroup
-int64_t fused_rows(const fxc_plan* p, int64_t nc, int64_t unit) { return (nc + unit - 1) / unit + fused_grid(p, nc); }
+// raw rows a 2-antenna fused launch over nc chunks writes (leading-part rows included)
+int64_t fused_rows(const fxc_plan* p, int64_t nc, int64_t unit, bool rows_are_chunks) {
+    return fxc::fused::range_split(fused_grid(p, nc), (int)nc, (int)p->fused_seg, (int)unit, rows_are_chunks).n_rows;
+}
 
 LeadRows fused_lead(const fxc_plan* p, int64_t nc) {
+    const fxc::fused::RangeSplit sp = fxc::fused::range_split(fused_grid(p, nc), (int)nc, (int)p->fused_seg, 1, true);
     LeadRows lr;
-    lr.n_frames = nc * p->n_pts;
+    lr.first_chunk = sp.n_full;
+    lr.n_frames = sp.n_tail * p->n_pts;
     lr.n_pts = p->n_pts;
     lr.offset = nc * (int64_t)fxc::fused::kN;
     lr.grid = fused_grid(p, nc);
     return lr;
 }
-const LeadRows kNoLead = {0, 0, 0, 0};
+const LeadRows kNoLead = {0, 0, 0, 0, 0};
 
 // n_pairs = pairs of consecutive antenna streams to channelise; spec_out: write spectra instead of X sums
 // dc_u8 != nullptr: x is the uint8 I,Q stream and dc_u8 its per-stream conversion offsets (2 antennas, X fused in)
-// unit: chunks per raw row (fx_fused4096_kernel)
-int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8, int64_t unit) {
+// unit / rows_are_chunks: the raw-row layout (fx_fused4096.h::RangeWalk)
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8, int64_t unit,
+                 bool rows_are_chunks) {
     using namespace fxc::fused;
     const int grid = fused_grid(p, n_pairs);
+    const int seg = (int)p->fused_seg;
+    if (n_pairs * p->n_pts >= (1ll << 31)) return fail(p, FXC_ERR_ARG, "more than 2^31 frames in one launch");
     unsigned long long* stamps = nullptr;
 #if FXC_STAMPS
     if (!p->d_stamps) FXC_HIP(p, hipMalloc(&p->d_stamps, (size_t)p->fused_grid_max * 8 * kStampSegs * 8));
@@ -1785,15 +1797,16 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
     KernelTimer kt(p);
     if (dc_u8)
         hipLaunchKernelGGL((fx_fused4096_kernel<false, true>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, unit);
+                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, seg, (int)unit,
+                           rows_are_chunks ? 1 : 0);
     else if (spec_out)
         hipLaunchKernelGGL((fx_fused4096_kernel<true, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
                            p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
-                           (int64_t)1);
+                           seg, 1, 1);
     else
         hipLaunchKernelGGL((fx_fused4096_kernel<false, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
                            p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
-                           unit);
+                           seg, (int)unit, rows_are_chunks ? 1 : 0);
     kt.stop();
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
@@ -1818,9 +1831,10 @@ int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec
 
 // raw[c][p][layout] for nc chunks starting at x; spec = scratch for the multi-antenna path.  2 antennas: rows of
 // `unit` chunks + leading-part rows (fused_rows() of them in all)
-int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, const cf* dc_u8 = nullptr, int64_t unit = 1) {
+int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, const cf* dc_u8 = nullptr, int64_t unit = 1,
+                   bool rows_are_chunks = true) {
     using namespace fxc::fused;
-    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8, unit);
+    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8, unit, rows_are_chunks);
     // 4 / 6 / 8 antennas: spectra to HBM (the F-only fused kernel in its own spectrum order at nchan 4096 / ntaps 4,
     // the F-only tiled kernel in natural order otherwise), then the register-resident X-engine
     int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
@@ -1999,11 +2013,11 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             const int64_t nc = std::min(cb, n_chunks - c0);
             const int64_t unit = fused_unit(p);
             rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
-                                dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit);
+                                dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit, false);
             if (rc) return rc;
             if (p->n_ant == 2) {   // one baseline: two-stage reduce over all the raw rows (leading parts included)
                 hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, kFusedReduceSplits), dim3(256), 0, p->stream, raw,
-                                   part, kN, fused_rows(p, nc, unit), kFusedReduceSplits);
+                                   part, kN, fused_rows(p, nc, unit, false), kFusedReduceSplits);
                 hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 256), dim3(256), 0, p->stream, part, p->d_acc, kN,
                                    kFusedReduceSplits, fused_layout(p));
             } else {
@@ -2350,6 +2364,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipMalloc(&p->d_tw2, tw2.size() * sizeof(cf)));
         FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
         p->fused_grid_max = p->cu_count;   // one 512-thread workgroup (136 KiB LDS) per CU
+        if (const char* e = std::getenv("FXC_FUSED_SEG")) p->fused_seg = std::max<int64_t>(1, std::atoll(e));   // developer knob
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<true, false>),

@@ -92,23 +92,27 @@ def emul_sched():
     return ctypes.CDLL(lib)
 
 
-@pytest.mark.parametrize("n_chunks,n_pts,grid,unit", [
-    (10000, 64, 256, 1), (10000, 64, 256, 4), (257, 64, 256, 1), (255, 64, 256, 4), (1, 64, 16, 1), (1, 64, 16, 4),
-    (3, 16, 12, 1), (7, 5, 8, 1), (7, 5, 8, 3), (100, 1, 25, 1), (100, 1, 25, 64), (5, 3, 256, 1), (2, 1, 256, 4),
-    (1000, 256, 256, 1), (33, 7, 31, 2)])
-def test_fused_frame_range_schedule(emul_sched, n_chunks, n_pts, grid, unit):
-    """fx_fused4096_kernel's work split (frame ranges that ignore chunk boundaries, rows + leading-part rows,
-    ring history at range starts): every frame once, per-chunk and total sums rebuilt as the finishing kernels do."""
+@pytest.mark.parametrize("n_chunks,n_pts,grid,seg,unit", [
+    (10000, 64, 256, 1, 4), (10000, 64, 256, 1, 1), (10000, 64, 256, 4, 4), (10240, 64, 256, 1, 4), (257, 64, 256, 1, 1),
+    (255, 64, 256, 1, 4), (1, 64, 16, 1, 1), (1, 64, 16, 1, 4), (3, 16, 12, 1, 1), (7, 5, 8, 1, 1), (23, 5, 8, 1, 3),
+    (100, 1, 25, 1, 1), (103, 1, 25, 2, 64), (5, 3, 256, 1, 1), (2, 1, 256, 1, 4), (1000, 256, 256, 1, 1), (33, 7, 31, 2, 2),
+    (700, 2, 256, 3, 64), (517, 3, 256, 1, 64)])
+@pytest.mark.parametrize("rows_are_chunks", [1, 0])
+def test_fused_work_split(emul_sched, n_chunks, n_pts, grid, seg, unit, rows_are_chunks):
+    """fx_fused4096_kernel's work split (whole chunks round-robin, then equal frame ranges of the tail that ignore
+    chunk boundaries; rows + leading-part rows; ring history at range starts and across segment jumps): every frame
+    once, per-chunk and total sums rebuilt as the finishing kernels do."""
     rng = np.random.default_rng(n_chunks * 131 + n_pts * 7 + grid + unit)
     w = rng.integers(1, 1000, size=n_chunks * n_pts).astype(np.float64)
     per_chunk = np.zeros(n_chunks, np.float64)
     total = ctypes.c_double()
-    fmin, fmax = ctypes.c_int64(), ctypes.c_int64()
-    rc = emul_sched.emul_fused_schedule(ctypes.c_int64(n_chunks), ctypes.c_int64(n_pts), grid, ctypes.c_int64(unit),
+    fmin, fmax, n_rows = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    rc = emul_sched.emul_fused_schedule(n_chunks, n_pts, grid, seg, unit, rows_are_chunks,
                                         w.ctypes.data_as(ctypes.c_void_p), per_chunk.ctypes.data_as(ctypes.c_void_p),
-                                        ctypes.byref(total), ctypes.byref(fmin), ctypes.byref(fmax))
+                                        ctypes.byref(total), ctypes.byref(fmin), ctypes.byref(fmax), ctypes.byref(n_rows))
     assert rc == 0
     assert total.value == w.sum()
     assert fmax.value - fmin.value <= 1                      # balanced whatever n_chunks % grid is
-    if unit == 1:
+    if rows_are_chunks:
+        assert n_rows.value == n_chunks + grid
         assert np.array_equal(per_chunk, w.reshape(n_chunks, n_pts).sum(axis=1))
