@@ -59,38 +59,41 @@ FXC_HD void dft4(cf& a, cf& b, cf& c, cf& d) {
 // 16-point DFT, kernel exp(+2*pi*i*n*k/16), natural order in and out:
 //   n = 4*n1 + n0, k = c + 4*d:  w16^(nk) = w4^(n1 c) * w16^(n0 c) * w4^(n0 d)
 // stage A: four DFT4 over n1 and the internal twiddles; stage B: four DFT4 over n0 + reorder.
-// The four twiddles w16^2, w16^6 = sqrt(1/2) (+-1 +- i) are left as un-scaled rotations u = (x -+ y, x +- y) by
-// stage A; stage B folds the sqrt(1/2) into its first butterflies (a +- R2 u: two FMAs instead of a multiply, an add
-// and a subtract per component).
+// No internal twiddle costs a multiply of its own: stage A leaves them as un-scaled rotations and stage B folds the
+// common scale into the fused multiply-adds of its butterflies (144 instructions in all = the 144 additions of a
+// split-radix DFT-16, with its 24 multiplications riding along):
+//   w16^2, w16^6 = sqrt(1/2) (+-1 +- i):   u = (x -+ y, x +- y), scale R2
+//   w16^1, w16^3, w16^9 = C1 (1 + i t), C1 (t + i), -C1 (1 + i t) with C1 = cos(pi/8), t = tan(pi/8): two FMAs
+//   each for u, scale C1 -- and the two twiddled inputs of one butterfly share that scale.
 FXC_HD void dft16_a(cf (&v)[16]) {
-    const float C1 = 0.92387953251128673848f;  // cos(pi/8)
-    const float S1 = 0.38268343236508978178f;  // sin(pi/8)
+    const float T1 = 0.41421356237309504880f;  // tan(pi/8)
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) dft4(v[n0], v[4 + n0], v[8 + n0], v[12 + n0]);
-    // now v[4*c + n0] = Z[n0][c]; twiddle by w16^(n0*c)
-    v[5] = cmul(v[5], mk(C1, S1));                      // e = 1
-    v[6] = mk(v[6].x - v[6].y, v[6].x + v[6].y);        // e = 2, times sqrt 2
-    v[7] = cmul(v[7], mk(S1, C1));                      // e = 3
-    v[9] = mk(v[9].x - v[9].y, v[9].x + v[9].y);        // e = 2, times sqrt 2
-    v[10] = muli(v[10]);                                // e = 4
-    v[11] = mk(-v[11].x - v[11].y, v[11].x - v[11].y);  // e = 6, times sqrt 2
-    v[13] = cmul(v[13], mk(S1, C1));                    // e = 3
-    v[14] = mk(-v[14].x - v[14].y, v[14].x - v[14].y);  // e = 6, times sqrt 2
-    v[15] = cmul(v[15], mk(-C1, -S1));                  // e = 9
+    // now v[4*c + n0] = Z[n0][c]; twiddle by w16^(n0*c), scales left to stage B
+    v[5] = mk(__builtin_fmaf(-T1, v[5].y, v[5].x), __builtin_fmaf(T1, v[5].x, v[5].y));        // e = 1: (1 + i t) / C1
+    v[6] = mk(v[6].x - v[6].y, v[6].x + v[6].y);                                               // e = 2, times sqrt 2
+    v[7] = mk(__builtin_fmaf(T1, v[7].x, -v[7].y), __builtin_fmaf(T1, v[7].y, v[7].x));        // e = 3: (t + i) / C1
+    v[9] = mk(v[9].x - v[9].y, v[9].x + v[9].y);                                               // e = 2, times sqrt 2
+    v[10] = muli(v[10]);                                                                       // e = 4
+    v[11] = mk(-v[11].x - v[11].y, v[11].x - v[11].y);                                         // e = 6, times sqrt 2
+    v[13] = mk(__builtin_fmaf(T1, v[13].x, -v[13].y), __builtin_fmaf(T1, v[13].y, v[13].x));   // e = 3: (t + i) / C1
+    v[14] = mk(-v[14].x - v[14].y, v[14].x - v[14].y);                                         // e = 6, times sqrt 2
+    v[15] = mk(__builtin_fmaf(T1, v[15].y, -v[15].x), __builtin_fmaf(-T1, v[15].x, -v[15].y)); // e = 9: -(1 + i t) / C1
 }
 
-// dft4 whose third input arrives as c / R2 (an un-scaled rotation): t0 = a + R2 c, t1 = a - R2 c
-FXC_HD void dft4_c_scaled(cf& a, cf& b, cf& c, cf& d) {
+// dft4 whose third input arrives as c / R2 and whose second and fourth as b / C1, d / C1
+FXC_HD void dft4_scaled_c_bd(cf& a, cf& b, cf& c, cf& d) {
     const float R2 = 0.70710678118654752440f;  // sqrt(1/2)
+    const float C1 = 0.92387953251128673848f;  // cos(pi/8)
     cf t0 = mk(__builtin_fmaf(R2, c.x, a.x), __builtin_fmaf(R2, c.y, a.y));
     cf t1 = mk(__builtin_fmaf(-R2, c.x, a.x), __builtin_fmaf(-R2, c.y, a.y));
     cf t2 = cadd(b, d), t3 = muli(csub(b, d));
-    a = cadd(t0, t2);
-    b = cadd(t1, t3);
-    c = csub(t0, t2);
-    d = csub(t1, t3);
+    a = mk(__builtin_fmaf(C1, t2.x, t0.x), __builtin_fmaf(C1, t2.y, t0.y));
+    b = mk(__builtin_fmaf(C1, t3.x, t1.x), __builtin_fmaf(C1, t3.y, t1.y));
+    c = mk(__builtin_fmaf(-C1, t2.x, t0.x), __builtin_fmaf(-C1, t2.y, t0.y));
+    d = mk(__builtin_fmaf(-C1, t3.x, t1.x), __builtin_fmaf(-C1, t3.y, t1.y));
 }
-// ... second and fourth inputs arrive un-scaled: t2 = R2 (b + d), t3 = i R2 (b - d), folded into the outputs
+// ... second and fourth inputs arrive as b / R2, d / R2: t2 = R2 (b + d), t3 = i R2 (b - d), folded into the outputs
 FXC_HD void dft4_bd_scaled(cf& a, cf& b, cf& c, cf& d) {
     const float R2 = 0.70710678118654752440f;
     cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = muli(csub(b, d));
@@ -101,11 +104,11 @@ FXC_HD void dft4_bd_scaled(cf& a, cf& b, cf& c, cf& d) {
 }
 
 FXC_HD void dft16_b(cf (&v)[16]) {
-    // after stage A the un-scaled entries are v[6] (c = 1), v[9], v[11] (c = 2: second and fourth input), v[14] (c = 3)
+    // after stage A: v[5], v[7], v[13], v[15] lack the factor C1, v[6], v[9], v[11], v[14] the factor R2
     dft4(v[0], v[1], v[2], v[3]);
-    dft4_c_scaled(v[4], v[5], v[6], v[7]);
+    dft4_scaled_c_bd(v[4], v[5], v[6], v[7]);
     dft4_bd_scaled(v[8], v[9], v[10], v[11]);
-    dft4_c_scaled(v[12], v[13], v[14], v[15]);
+    dft4_scaled_c_bd(v[12], v[13], v[14], v[15]);
     // now v[4*c + d] = Y[c + 4*d]; transpose the 4x4 index to natural order
 #pragma unroll
     for (int c = 0; c < 4; ++c)

@@ -299,7 +299,8 @@ __global__ void acc_add_kernel(const cf* __restrict__ raw, cd* __restrict__ acc,
 }
 
 // accumulate over many chunks, stage 1: part[split][slot] = sum over this split's rows of the kernels' raw
-// float32 rows (slot order, coalesced); fixed order -> bit-reproducible
+// float32 rows (slot order, coalesced); fixed order -> bit-reproducible.  Latency-bound (a thread walks its rows one
+// load after the other), so the launch uses as many splits as leave each a handful of rows (fused_reduce_splits)
 __global__ __launch_bounds__(256) void fused_reduce1_kernel(const cf* __restrict__ raw, cd* __restrict__ part, int nchan,
                                                            int64_t n_rows, int n_splits) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,72 +318,88 @@ __global__ __launch_bounds__(256) void fused_reduce1_kernel(const cf* __restrict
     part[(int64_t)split * nchan + slot] = o;
 }
 
-// stage 2: acc[k] += sum_split part[split][slot(k)]
-__global__ void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict__ acc, int nchan, int n_splits,
-                                     int slots) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nchan) return;
-    const int64_t slot = raw_index(k, slots);
+// stage 2: acc[k] += sum_split part[split][slot(k)]; 16 bins x 16 threads per workgroup, each thread sums every 16th
+// split and the 16 sub-sums are combined in a fixed order
+__global__ __launch_bounds__(256) void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict__ acc, int nchan,
+                                                           int n_splits, int slots) {
+    __shared__ cd sub[16][17];
+    const int kl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kl;
     double ar = 0.0, ai = 0.0;
-    for (int s = 0; s < n_splits; ++s) {
-        const cd v = part[(int64_t)s * nchan + slot];
-        ar += v.x;
-        ai += v.y;
+    if (k < nchan) {
+        const int64_t slot = raw_index(k, slots);
+        for (int s = sl; s < n_splits; s += 16) {
+            const cd v = part[(int64_t)s * nchan + slot];
+            ar += v.x;
+            ai += v.y;
+        }
     }
-    cd a = acc[k];
-    a.x += ar;
-    a.y += ai;
-    acc[k] = a;
+    sub[sl][kl].x = ar;
+    sub[sl][kl].y = ai;
+    __syncthreads();
+    if (sl == 0 && k < nchan) {
+        cd a = acc[k];
+        for (int j = 0; j < 16; ++j) {
+            a.x += sub[j][kl].x;
+            a.y += sub[j][kl].y;
+        }
+        acc[k] = a;
+    }
 }
 
-// multi-antenna X-engine on the F-only kernel's spectra: spec[(c*A + a)*P + i][pos]; one thread per (chunk,
-// pos) keeps all A(A-1)/2 accumulators in registers over the chunk's P spectra and reads every spectrum
-// sample exactly once; raw[c][p][pos], baselines ordered (0,1),(0,2)..(A-2,A-1) -- effex.py:520 for A > 2
+// multi-antenna X-engine on the F-only kernel's spectra: spec[(c*A + a)*P + i][pos]; one thread per (chunk group,
+// pos) keeps all A(A-1)/2 accumulators in registers over the spectra of `cg` consecutive chunks (cg = 1: one raw
+// row per chunk; the integration takes float32 sums of up to 256 spectra, like the 2-antenna kernel's rows) and
+// reads every spectrum sample exactly once; raw[group][p][pos], baselines ordered (0,1),(0,2)..(A-2,A-1) --
+// effex.py:520 for A > 2
 template <int A>
 __global__ __launch_bounds__(256) void xengine_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int64_t n_pts,
-                                                     int nchan) {
+                                                     int nchan, int64_t n_chunks, int cg) {
     constexpr int NB = A * (A - 1) / 2;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t c = blockIdx.y;
+    const int64_t grp = blockIdx.y;
     float ar[NB], ai[NB];
 #pragma unroll
     for (int p = 0; p < NB; ++p) ar[p] = ai[p] = 0.f;
-    const cf* base = spec + (c * A * n_pts) * nchan + pos;
-    // two spectra per trip: 2A independent 8-byte loads in flight before the A(A-1) multiply-accumulates
-    int64_t i = 0;
-    for (; i + 1 < n_pts; i += 2) {
-        cf z0[A], z1[A];
+    const int64_t c_end = (grp + 1) * cg < n_chunks ? (grp + 1) * cg : n_chunks;
+    for (int64_t c = grp * cg; c < c_end; ++c) {
+        const cf* base = spec + (c * A * n_pts) * nchan + pos;
+        // two spectra per trip: 2A independent 8-byte loads in flight before the A(A-1) multiply-accumulates
+        int64_t i = 0;
+        for (; i + 1 < n_pts; i += 2) {
+            cf z0[A], z1[A];
 #pragma unroll
-        for (int a = 0; a < A; ++a) {
-            z0[a] = base[((int64_t)a * n_pts + i) * nchan];
-            z1[a] = base[((int64_t)a * n_pts + i + 1) * nchan];
+            for (int a = 0; a < A; ++a) {
+                z0[a] = base[((int64_t)a * n_pts + i) * nchan];
+                z1[a] = base[((int64_t)a * n_pts + i + 1) * nchan];
+            }
+            int p = 0;
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+#pragma unroll
+                for (int b = a + 1; b < A; ++b, ++p) {
+                    ar[p] += z0[a].x * z0[b].x + z0[a].y * z0[b].y;
+                    ai[p] += z0[a].y * z0[b].x - z0[a].x * z0[b].y;
+                    ar[p] += z1[a].x * z1[b].x + z1[a].y * z1[b].y;
+                    ai[p] += z1[a].y * z1[b].x - z1[a].x * z1[b].y;
+                }
         }
-        int p = 0;
+        for (; i < n_pts; ++i) {
+            cf z[A];
 #pragma unroll
-        for (int a = 0; a < A; ++a)
+            for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * n_pts + i) * nchan];
+            int p = 0;
 #pragma unroll
-            for (int b = a + 1; b < A; ++b, ++p) {
-                ar[p] += z0[a].x * z0[b].x + z0[a].y * z0[b].y;
-                ai[p] += z0[a].y * z0[b].x - z0[a].x * z0[b].y;
-                ar[p] += z1[a].x * z1[b].x + z1[a].y * z1[b].y;
-                ai[p] += z1[a].y * z1[b].x - z1[a].x * z1[b].y;
-            }
-    }
-    for (; i < n_pts; ++i) {
-        cf z[A];
+            for (int a = 0; a < A; ++a)
 #pragma unroll
-        for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * n_pts + i) * nchan];
-        int p = 0;
-#pragma unroll
-        for (int a = 0; a < A; ++a)
-#pragma unroll
-            for (int b = a + 1; b < A; ++b, ++p) {
-                ar[p] += z[a].x * z[b].x + z[a].y * z[b].y;
-                ai[p] += z[a].y * z[b].x - z[a].x * z[b].y;
-            }
+                for (int b = a + 1; b < A; ++b, ++p) {
+                    ar[p] += z[a].x * z[b].x + z[a].y * z[b].y;
+                    ai[p] += z[a].y * z[b].x - z[a].x * z[b].y;
+                }
+        }
     }
 #pragma unroll
-    for (int p = 0; p < NB; ++p) raw[(c * NB + p) * nchan + pos] = fxc::mk(ar[p], ai[p]);
+    for (int p = 0; p < NB; ++p) raw[(grp * NB + p) * nchan + pos] = fxc::mk(ar[p], ai[p]);
 }
 
 // sums = [n_base*nchan] raw sums + [1] {count, 0}
@@ -1747,7 +1764,9 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
     return cb;
 }
 
-constexpr int kFusedReduceSplits = 64;
+constexpr int kFusedReduceSplits = 256;   // most splits of the two-stage reduce over raw rows (size of `part`)
+// splits that leave each thread of stage 1 about four rows to walk
+int fused_reduce_splits(int64_t n_rows) { return (int)std::max<int64_t>(16, std::min<int64_t>(kFusedReduceSplits, n_rows / 4)); }
 
 // workgroups of a fused launch over n_pairs chunk pairs: one per CU; a launch with fewer chunks than that is all
 // tail (frame ranges), on fewer workgroups when a range would be under four frames (each reloads up to three
@@ -1836,18 +1855,20 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
     using namespace fxc::fused;
     if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8, unit, rows_are_chunks);
     // 4 / 6 / 8 antennas: spectra to HBM (the F-only fused kernel in its own spectrum order at nchan 4096 / ntaps 4,
-    // the F-only tiled kernel in natural order otherwise), then the register-resident X-engine
+    // the F-only tiled kernel in natural order otherwise), then the register-resident X-engine.  unit = chunks per
+    // raw row here too: ceil(nc / unit) rows come out
     int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
                                        : tiled_channelize(p, x, spec, nc * p->n_ant);
     if (rc) return rc;
-    const dim3 grid(p->nchan / 256, (unsigned)nc);
+    const int cg = (int)unit;
+    const dim3 grid(p->nchan / 256, (unsigned)((nc + cg - 1) / cg));
     switch (p->n_ant) {
-        case 3: hipLaunchKernelGGL(xengine_kernel<3>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
-        case 4: hipLaunchKernelGGL(xengine_kernel<4>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
-        case 5: hipLaunchKernelGGL(xengine_kernel<5>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
-        case 6: hipLaunchKernelGGL(xengine_kernel<6>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
-        case 7: hipLaunchKernelGGL(xengine_kernel<7>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
-        case 8: hipLaunchKernelGGL(xengine_kernel<8>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan); break;
+        case 3: hipLaunchKernelGGL(xengine_kernel<3>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 4: hipLaunchKernelGGL(xengine_kernel<4>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 5: hipLaunchKernelGGL(xengine_kernel<5>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 6: hipLaunchKernelGGL(xengine_kernel<6>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 7: hipLaunchKernelGGL(xengine_kernel<7>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 8: hipLaunchKernelGGL(xengine_kernel<8>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
         default: return fail(p, FXC_ERR_UNSUPPORTED, "no X-engine instantiation for n_ant=%d", p->n_ant);
     }
     FXC_HIP(p, hipGetLastError());
@@ -2016,14 +2037,16 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
                                 dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit, false);
             if (rc) return rc;
             if (p->n_ant == 2) {   // one baseline: two-stage reduce over all the raw rows (leading parts included)
-                hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, kFusedReduceSplits), dim3(256), 0, p->stream, raw,
-                                   part, kN, fused_rows(p, nc, unit, false), kFusedReduceSplits);
-                hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 256), dim3(256), 0, p->stream, part, p->d_acc, kN,
-                                   kFusedReduceSplits, fused_layout(p));
-            } else {
+                const int64_t n_rows = fused_rows(p, nc, unit, false);
+                const int splits = fused_reduce_splits(n_rows);
+                hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, splits), dim3(256), 0, p->stream, raw, part, kN,
+                                   n_rows, splits);
+                hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 16), dim3(256), 0, p->stream, part, p->d_acc, kN, splits,
+                                   fused_layout(p));
+            } else {   // raw rows of `unit` chunks each
                 const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
                 hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream,
-                                   raw, p->d_acc, p->nchan, p->n_base, nc, 1, fused_layout(p));
+                                   raw, p->d_acc, p->nchan, p->n_base, (nc + unit - 1) / unit, 1, fused_layout(p));
             }
             FXC_HIP(p, hipGetLastError());
         }
@@ -2045,10 +2068,10 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             rc = tiled_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, n_splits,
                                 raw, dc_u8 ? dc_u8 + c0 * 2 : nullptr);
             if (rc) return rc;
-            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kb, kFusedReduceSplits), dim3(256), 0, p->stream, raw, part, N,
-                               nc * n_splits, kFusedReduceSplits);
-            hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kb), dim3(256), 0, p->stream, part, p->d_acc, N,
-                               kFusedReduceSplits, 0);
+            const int splits = fused_reduce_splits(nc * n_splits);
+            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kb, splits), dim3(256), 0, p->stream, raw, part, N, nc * n_splits,
+                               splits);
+            hipLaunchKernelGGL(fused_reduce2_kernel, dim3((N + 15) / 16), dim3(256), 0, p->stream, part, p->d_acc, N, splits, 0);
             FXC_HIP(p, hipGetLastError());
         }
     } else {
