@@ -14,10 +14,20 @@ piece of arithmetic that is *not* in the reference tree is ``cusignal.filtering.
 name only).  Its published definition (the Python reference loop in cusignal's own documentation /
 tests: a per-branch shift register fed with the conjugated, branch-reversed input frame, dotted
 with the conjugated polyphase taps, followed by ``conj(fft(.))``) is restated here twice — literal
-loop and vectorised closed form — and the two are checked against each other and against the
-reference's own test criterion (``tests/test_effex.py:62-89``, tone arg-max within 1 %).
-Everything finer than "the tone lands in the right bin" is pinned by that definition only
-(SURVEY.md §4.3); this is recorded in DESIGN.md.
+loop and vectorised closed form — and the two are checked against each other.  What pins which fact of that
+third-party function (``tests/test_oracle.py``):
+
+* tap order (``h[t N + m]`` meets ``x[(i - t) N + N - 1 - m]``), branch reversal, zero history before sample 0,
+  dropped tail, unit scale: the **filter-bank identity** — channel k equals the input filtered with the prototype
+  modulated to that channel and decimated by N, computed with ``scipy.signal.lfilter`` from first principles
+  (``test_channelizer_is_the_textbook_analysis_filter_bank``, 1e-11), which shares no code or memory with the
+  restatement;
+* sign of the frequency axis: the same identity, and independently the **reference's own test** criterion
+  (``tests/test_effex.py:62-89``, tone arg-max within 1 %, all 32 cases);
+* that cusignal's kernel IS this filter bank (in particular its output conjugation ``conj(fft(.))`` over conjugated
+  inputs, which equals the +i kernel only for the real prototype filters the reference designs): **cusignal's
+  published definition only** — cusignal is not in this image and cannot be executed; a release whose CUDA kernel
+  deviated from its own documented loop could not be detected offline.  Recorded in DESIGN.md.
 
 Every function cites the reference lines it follows (paths are relative to /root/reference).
 """

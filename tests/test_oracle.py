@@ -156,3 +156,30 @@ def test_stale_window_after_nbins_change_matches_reference(golden):
         for c in range(chunks):
             row = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], 4, nbins, w, gi.BANDWIDTH, gi.FREQUENCY, delay, "SPECTRUM")
             np.testing.assert_allclose(row, arrays[case["key"]][c], rtol=1e-10, atol=1e-18)
+
+
+@pytest.mark.parametrize("nchan,ntaps,n_samples", [(8, 3, 8 * 9), (16, 4, 16 * 7 + 5), (64, 1, 64 * 4), (32, 8, 32 * 20 + 31),
+                                                   (256, 4, 256 * 6 + 100)])
+def test_channelizer_is_the_textbook_analysis_filter_bank(nchan, ntaps, n_samples):
+    """Independent pin of the restated cusignal.filtering.channelize_poly (call site effex.py:553), from first
+    principles rather than from the restatement's own loop form: channel k of a critically sampled analysis filter bank
+    is the input filtered with the prototype modulated to that channel, h[n] exp(+2 pi i k n / N), and decimated by N
+    (output i taken at sample i N + N - 1).  Random complex input, random real prototype, ragged length.
+    What this pins: tap order (h[t N + m] meets x[(i - t) N + N - 1 - m]), branch reversal, the zero history before
+    sample 0, the dropped tail, the unit scale and the sign of the frequency axis.  (The reference's own tone test pins the
+    frequency sign a second time; the output conjugation convention conj(fft(conj(.))) is equivalent to this +i kernel for
+    the real prototype filters the reference designs, effex.py:126-127.)"""
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(nchan * 100 + ntaps)
+    x = rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples)
+    h = rng.standard_normal(ntaps * nchan)
+    n_pts = n_samples // nchan
+    n = np.arange(len(h))
+    ref = np.empty((nchan, n_pts), dtype=np.complex128)
+    for k in range(nchan):
+        y = lfilter(h * np.exp(2j * np.pi * k * n / nchan), 1.0, x)
+        ref[k] = y[nchan - 1::nchan][:n_pts]
+    scale = np.abs(ref).max()
+    assert np.abs(fx_oracle.channelize_poly(x, h, nchan) - ref).max() < 1e-11 * scale
+    if n_samples * nchan <= 1 << 16:       # the literal shift-register loop is slow
+        assert np.abs(fx_oracle.channelize_poly_loop(x, h, nchan) - ref).max() < 1e-11 * scale
