@@ -1132,6 +1132,72 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
 }
 
 // ------------------------------------------------------------------------------------------
+// PFB pre-filter for ntaps > 4 on the tiled channel counts (the reference's own test shape is taps = 32,
+// branches 2048 / 4096: /root/reference/tests/test_effex.py:62-66).  A register ring of four frames does not
+// stretch to 32 taps, and re-reading the history per spectrum costs (ntaps + 1) / 2 times the stream.  The FIR half of
+// channelize_poly (effex.py:553) works branch by branch, so it is applied in place of the samples first:
+//     y[i N + n] = sum_{t < T, i - t >= 0} h[t N + (N - 1 - n)] x[(i - t) N + n]
+// after which the tiled kernels run with a single unit tap on y (their branch m reads position N - 1 - m: exactly the
+// filtered branch).  A thread owns one sample position of one stream and walks its frames in blocks of TP: the block
+// in flight and the one before it sit in registers (2 TP complex), every sample is loaded once and every tap is
+// applied from registers.  HBM: stream in + stream out, then stream in again for the FFT/X kernel: 3 x algorithmic,
+// whatever ntaps is.
+// ------------------------------------------------------------------------------------------
+template <int TP>
+__device__ __forceinline__ void prefilter_block(const cf (&xo)[TP], const cf (&xn)[TP], const float (&hc)[TP], cf* yp,
+                                                int64_t stride, int64_t i0, int64_t i_end) {
+#pragma unroll
+    for (int k = 0; k < TP; ++k) {
+        float ar = 0.f, ai = 0.f;
+#pragma unroll
+        for (int t = 0; t < TP; ++t) {
+            const cf v = (k - t >= 0) ? xn[(k - t) >= 0 ? k - t : 0] : xo[(TP + k - t) < TP ? TP + k - t : 0];
+            ar = fmaf(hc[t], v.x, ar);
+            ai = fmaf(hc[t], v.y, ai);
+        }
+        if (i0 + k < i_end) yp[(i0 + k) * stride] = fxc::mk(ar, ai);
+    }
+}
+
+template <int TP>
+__device__ __forceinline__ void prefilter_load(cf (&xr)[TP], const cf* xp, int64_t stride, int64_t i0, int64_t n_pts) {
+#pragma unroll
+    for (int k = 0; k < TP; ++k) {
+        const int64_t i = i0 + k;
+        xr[k] = (i >= 0 && i < n_pts) ? xp[i * stride] : fxc::mk(0.f, 0.f);
+    }
+}
+
+// hcoef[t][n] = h[t N + (N - 1 - n)] for t < ntaps, zero rows up to TP; grid (N / 256, streams, frame splits)
+template <int TP>
+__global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict__ x, cf* __restrict__ y,
+                                                           const float* __restrict__ hcoef, int64_t num_samp, int nchan,
+                                                           int64_t n_pts, int64_t per_split) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int64_t s = blockIdx.y;
+    const int64_t i_begin = (int64_t)blockIdx.z * per_split;
+    const int64_t i_end = (i_begin + per_split < n_pts) ? i_begin + per_split : n_pts;
+    if (i_begin >= i_end) return;
+    float hc[TP];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) hc[t] = hcoef[(int64_t)t * nchan + n];
+    const cf* xp = x + s * num_samp + n;
+    cf* yp = y + s * num_samp + n;
+    cf xa[TP], xb[TP];
+    prefilter_load<TP>(xa, xp, nchan, i_begin - TP, n_pts);       // history (zeros before the stream's start)
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 2 * TP) {        // two blocks per trip: the pair swaps roles, no copies
+        prefilter_load<TP>(xb, xp, nchan, i0, n_pts);
+        prefilter_block<TP>(xa, xb, hc, yp, nchan, i0, i_end);
+        if (i0 + TP < i_end) {
+            prefilter_load<TP>(xa, xp, nchan, i0 + TP, n_pts);
+            prefilter_block<TP>(xb, xa, hc, yp, nchan, i0 + TP, i_end);
+        } else {
+            break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // continuum streaming limit: nchan == 1, 2 antennas (BASELINE config 3(i))
 // The PFB degenerates to a T-tap FIR y_a[n] = sum_t h[t] x_a[n - t] (zero history per chunk), the FFT is
 // the identity and X is sum_n y_0[n] conj(y_1[n]).  One workgroup takes kStreamBlock consecutive
@@ -1558,6 +1624,12 @@ struct fxc_plan {
     bool small_tiled = false;      // fused shape, path chosen automatically: calls with few chunks split frames
                                    // over workgroups through the tiled ring kernel
     bool tiled_ring = false;       // ntaps <= 4 and nchan <= 4096: VGPR frame ring + window in LDS
+    bool prefilter = false;        // ntaps > 4: pfb_prefilter_kernel first, then the tiled kernels with one unit tap
+    int pre_tp = 0;                // its register block: 8, 16 or 32 frames
+    float* d_hpre = nullptr;       // [pre_tp][nchan] reversed polyphase coefficients
+    float* d_ones = nullptr;       // [nchan] unit window of the plain tiled kernel behind the pre-filter
+    void* d_pre = nullptr;         // pre-filtered streams of one pass
+    size_t pre_bytes = 0;
     unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int fused_grid_max = 0;
     int64_t fused_seg = 1;         // chunks per round-robin segment of the fused kernel (fx_fused4096.h::RangeWalk)
@@ -1928,7 +2000,8 @@ void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, i
         }
     }
     hipLaunchKernelGGL((fx_tiled_kernel<G, SPEC>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, p->stream, x, p->num_samp,
-                       p->n_pts, nc, n_splits, p->ntaps, p->d_win, p->d_tw0, p->d_tw1, p->d_tw2, raw, n_streams);
+                       p->n_pts, nc, n_splits, p->prefilter ? 1 : p->ntaps, p->prefilter ? p->d_ones : p->d_win, p->d_tw0,
+                       p->d_tw1, p->d_tw2, raw, n_streams);
 }
 
 #define FXC_TILED_DISPATCH(p, CALL)                                                   \
@@ -1957,9 +2030,44 @@ int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 256));
 }
 
-// raw[split][c][k] (natural bin order) for nc chunks starting at x
+// streams the pre-filter handles per pass (its output stays within the workspace target)
+int64_t prefilter_streams_per_pass(const fxc_plan* p) {
+    if (!p->prefilter) return INT64_MAX;
+    int64_t n = kWorkspaceTarget / (p->num_samp * (int64_t)sizeof(cf));
+    n = std::min<int64_t>(n, 65534) & ~(int64_t)1;      // grid.y carries the stream; whole pairs
+    return std::max<int64_t>(2, n);
+}
+
+// y = pre-filtered copy of n_streams streams (plan buffer, grown on demand)
+int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_out) {
+    const int rg = grow(p, &p->d_pre, &p->pre_bytes, (size_t)n_streams * p->num_samp * sizeof(cf));
+    if (rg) return rg;
+    cf* y = static_cast<cf*>(p->d_pre);
+    const int tp = p->pre_tp;
+    // frame splits so that a few-stream call still fills the chip; each split reloads one block of history
+    const int64_t blocks = (int64_t)(p->nchan / 256) * n_streams;
+    int64_t fs = std::max<int64_t>(1, (2 * (int64_t)p->cu_count + blocks - 1) / blocks);
+    fs = std::min<int64_t>(fs, std::max<int64_t>(1, p->n_pts / (4 * tp)));
+    const int64_t per = ((p->n_pts + fs - 1) / fs + 2 * tp - 1) / (2 * tp) * (2 * tp);
+    const dim3 grid((unsigned)(p->nchan / 256), (unsigned)n_streams, (unsigned)((p->n_pts + per - 1) / per));
+    if (tp == 8)
+        hipLaunchKernelGGL(pfb_prefilter_kernel<8>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, p->n_pts, per);
+    else if (tp == 16)
+        hipLaunchKernelGGL(pfb_prefilter_kernel<16>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, p->n_pts, per);
+    else
+        hipLaunchKernelGGL(pfb_prefilter_kernel<32>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, p->n_pts, per);
+    FXC_HIP(p, hipGetLastError());
+    *y_out = y;
+    return FXC_OK;
+}
+
+// raw[split][c][k] (natural bin order) for nc chunks starting at x (nc * 2 <= prefilter_streams_per_pass())
 int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
     KernelTimer kt(p);
+    if (p->prefilter && !dc_u8) {
+        const int rc = tiled_prefilter(p, x, 2 * nc, &x);
+        if (rc) return rc;
+    }
     FXC_TILED_DISPATCH(p, (tiled_launch<G, false>(p, x, nc, n_splits, raw, 2 * nc, dc_u8)));
     kt.stop();
     FXC_HIP(p, hipGetLastError());
@@ -1968,10 +2076,19 @@ int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, 
 
 // F-stage only: n_streams consecutive streams -> spec[stream][i][k], pairs of streams per work item
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
-    const int64_t pairs = (n_streams + 1) / 2;
-    const int n_splits = tiled_splits(p, pairs, true);
     KernelTimer kt(p);
-    FXC_TILED_DISPATCH(p, (tiled_launch<G, true>(p, x, pairs, n_splits, spec, n_streams)));
+    const int64_t per_pass = prefilter_streams_per_pass(p);
+    for (int64_t s0 = 0; s0 < n_streams; s0 += per_pass) {
+        const int64_t ns = std::min(per_pass, n_streams - s0);
+        const cf* xs = x + s0 * p->num_samp;
+        if (p->prefilter) {
+            const int rc = tiled_prefilter(p, xs, ns, &xs);
+            if (rc) return rc;
+        }
+        const int64_t pairs = (ns + 1) / 2;
+        const int n_splits = tiled_splits(p, pairs, true);
+        FXC_TILED_DISPATCH(p, (tiled_launch<G, true>(p, xs, pairs, n_splits, spec + s0 * p->n_pts * p->nchan, ns)));
+    }
     kt.stop();
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
@@ -2055,7 +2172,8 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         const int64_t in_bytes = (int64_t)2 * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         const int n_splits = tiled_splits(p, n_chunks);
         const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
-        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(n_chunks, kWorkspaceTarget / (row_bytes * n_splits)));
+        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, prefilter_streams_per_pass(p) / 2),
+                                                                  kWorkspaceTarget / (row_bytes * n_splits)));
         const int64_t raw_bytes = (cb * n_splits * row_bytes + 255) / 256 * 256;
         const int64_t part_bytes = (int64_t)kFusedReduceSplits * N * (int64_t)sizeof(cd);
         int rc = ensure_ws(p, raw_bytes + part_bytes);
@@ -2162,7 +2280,8 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         const int64_t in_bytes = (int64_t)2 * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         const int n_splits = tiled_splits(p, n_chunks);
         const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
-        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(n_chunks, kWorkspaceTarget / (row_bytes * n_splits)));
+        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, prefilter_streams_per_pass(p) / 2),
+                                                                  kWorkspaceTarget / (row_bytes * n_splits)));
         int rc = ensure_ws(p, cb * n_splits * row_bytes);
         if (rc) return rc;
         cf* raw = reinterpret_cast<cf*>(p->d_ws);
@@ -2283,7 +2402,8 @@ int fxc_plan_destroy(fxc_plan* p) {
         (void)hipEventDestroy(e.second);
     }
     void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_stamps,
-                    p->d_acc, p->d_sums, p->d_out, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc};
+                    p->d_acc, p->d_sums, p->d_out, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
+                    p->d_ones, p->d_pre};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -2426,19 +2546,36 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             FXC_HIP(p, hipMalloc(&p->d_tw2, tw2.size() * sizeof(cf)));
             FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
         }
-        p->tiled_ring = (T <= 4 && N <= 4096);
-        if (p->tiled_ring && !p->d_win4) {
+        // more than four taps (or FXC_PREFILTER=1, a developer knob to compare at <= 4): the FIR runs as its own pass
+        const char* pre_env = std::getenv("FXC_PREFILTER");
+        p->prefilter = (T > 4 || (pre_env && std::atoi(pre_env) == 1));
+        if (p->prefilter) {
+            p->pre_tp = T <= 8 ? 8 : (T <= 16 ? 16 : 32);
+            std::vector<float> hp((size_t)p->pre_tp * N, 0.f), ones((size_t)N, 1.f);
+            for (int t = 0; t < T; ++t)
+                for (int n = 0; n < N; ++n) hp[(size_t)t * N + n] = wf[(size_t)t * N + (N - 1 - n)];
+            FXC_HIP(p, hipMalloc(&p->d_hpre, hp.size() * sizeof(float)));
+            FXC_HIP(p, hipMemcpy(p->d_hpre, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
+            FXC_HIP(p, hipMalloc(&p->d_ones, ones.size() * sizeof(float)));
+            FXC_HIP(p, hipMemcpy(p->d_ones, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        p->tiled_ring = ((T <= 4 || p->prefilter) && N <= 4096);
+        if (p->tiled_ring && (!p->d_win4 || p->prefilter)) {
             std::vector<f4> w4((size_t)N);
             for (int r = 0; r < 16; ++r)
                 for (int u = 0; u < P; ++u) {
                     const int m = u + P * r;
                     f4 w;
-                    w.x = wf[m];
-                    w.y = T > 1 ? wf[(size_t)1 * N + m] : 0.f;
-                    w.z = T > 2 ? wf[(size_t)2 * N + m] : 0.f;
-                    w.w = T > 3 ? wf[(size_t)3 * N + m] : 0.f;
+                    w.x = p->prefilter ? 1.f : wf[m];      // behind the pre-filter: one unit tap
+                    w.y = (T > 1 && !p->prefilter) ? wf[(size_t)1 * N + m] : 0.f;
+                    w.z = (T > 2 && !p->prefilter) ? wf[(size_t)2 * N + m] : 0.f;
+                    w.w = (T > 3 && !p->prefilter) ? wf[(size_t)3 * N + m] : 0.f;
                     w4[(size_t)r * P + u] = w;
                 }
+            if (p->d_win4) {
+                (void)hipFree(p->d_win4);
+                p->d_win4 = nullptr;
+            }
             FXC_HIP(p, hipMalloc(&p->d_win4, w4.size() * sizeof(f4)));
             FXC_HIP(p, hipMemcpy(p->d_win4, w4.data(), w4.size() * sizeof(f4), hipMemcpyHostToDevice));
         }
@@ -2841,7 +2978,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
     const size_t row_elems = mode == FXC_MODE_SPECTRUM ? (size_t)p->n_base * p->nchan * sizeof(cf) : (size_t)p->n_base * sizeof(cd);
     // chunks per pass: dc_sum_u8_kernel carries the stream index in grid.y (<= 65535 streams), and plans without the
     // fused ingest convert a pass into a complex64 staging buffer that stays within the workspace target
-    const bool fused_in = p->n_ant == 2 && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && p->tiled_ring));
+    const bool fused_in = p->n_ant == 2 && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && p->tiled_ring && !p->prefilter));
     int64_t per_pass = std::min<int64_t>(16384, 65535 / p->n_ant);
     if (!fused_in) per_pass = std::min<int64_t>(per_pass, kWorkspaceTarget / ((int64_t)p->n_ant * p->num_samp * (int64_t)sizeof(cf)));
     per_pass = std::max<int64_t>(1, per_pass);
