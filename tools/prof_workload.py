@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Developer aid: one named workload a few times, for rocprofv3 (kernel trace / PMC passes; tools/collect_profiles.sh).
+
+    python3 tools/prof_workload.py 8ant | stream1 | nfft2048 | taps32 [reps]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from effex_amd.plan import FxPlan, synth_fill
+
+WORKLOADS = {
+    # name: (n_ant, nchan, ntaps, num_samp, n_chunks, mode, rows)
+    "8ant": (8, 4096, 4, 2 ** 18, 512, "SPECTRUM", False),          # BASELINE configs[4]
+    "stream1": (2, 1, 4, 2 ** 20, 2048, "CONTINUUM", True),          # BASELINE configs[2](i)
+    "nfft2048": (2, 2048, 4, 2 ** 18, 10000, "SPECTRUM", False),     # --nfft 2048, tiled ring kernel
+    "taps32": (2, 2048, 32, 2 ** 18, 1024, "SPECTRUM", False),       # the reference test's taps = 32 shape
+}
+
+
+def main():
+    name = sys.argv[1]
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    n_ant, nchan, ntaps, num_samp, n_chunks, mode, rows = WORKLOADS[name]
+    x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")
+    synth_fill(x, 1234)
+    window = np.array([0.4, 0.3, 0.2, 0.1]) if nchan == 1 else None
+    with FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as plan:
+        for _ in range(reps):
+            if rows:
+                plan.fx_rows(x, mode, 2.4e6)
+            else:
+                plan.acc_reset()
+                plan.fx_accumulate(x)
+                plan.finalize(mode, 2.4e6)
+        plan.sync()
+    print(name, "bytes_in_per_call", n_chunks * n_ant * num_samp * 8)
+
+
+if __name__ == "__main__":
+    main()
