@@ -318,16 +318,16 @@ __global__ __launch_bounds__(256) void fused_reduce1_kernel(const cf* __restrict
     part[(int64_t)split * nchan + slot] = o;
 }
 
-// stage 2: acc[k] += sum_split part[split][slot(k)]; 16 bins x 16 threads per workgroup, each thread sums every 16th
-// split and the 16 sub-sums are combined in a fixed order
+// stage 2: acc[bin(slot)] += sum_split part[split][slot]; 16 slots x 16 threads per workgroup, each thread sums every
+// 16th split (reads in slot order: coalesced; only the 64 KiB of accumulator updates are scattered by the slot -> bin
+// permutation) and the 16 sub-sums are combined in a fixed order
 __global__ __launch_bounds__(256) void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict__ acc, int nchan,
                                                            int n_splits, int slots) {
     __shared__ cd sub[16][17];
     const int kl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int k = blockIdx.x * 16 + kl;
+    const int slot = blockIdx.x * 16 + kl;
     double ar = 0.0, ai = 0.0;
-    if (k < nchan) {
-        const int64_t slot = raw_index(k, slots);
+    if (slot < nchan) {
         for (int s = sl; s < n_splits; s += 16) {
             const cd v = part[(int64_t)s * nchan + slot];
             ar += v.x;
@@ -337,7 +337,9 @@ __global__ __launch_bounds__(256) void fused_reduce2_kernel(const cd* __restrict
     sub[sl][kl].x = ar;
     sub[sl][kl].y = ai;
     __syncthreads();
-    if (sl == 0 && k < nchan) {
+    if (sl == 0 && slot < nchan) {
+        // slots == 1: the fused kernel's order, slot = q * 512 + tid (fx_fused4096.h::bin_of); 0: natural order
+        const int k = slots == 1 ? fxc::fused::bin_of(slot % fxc::fused::kThreads, slot / fxc::fused::kThreads) : slot;
         cd a = acc[k];
         for (int j = 0; j < 16; ++j) {
             a.x += sub[j][kl].x;
@@ -352,6 +354,10 @@ __global__ __launch_bounds__(256) void fused_reduce2_kernel(const cd* __restrict
 // row per chunk; the integration takes float32 sums of up to 256 spectra, like the 2-antenna kernel's rows) and
 // reads every spectrum sample exactly once; raw[group][p][pos], baselines ordered (0,1),(0,2)..(A-2,A-1) --
 // effex.py:520 for A > 2
+#ifndef FXC_XENGINE_UNROLL
+#define FXC_XENGINE_UNROLL 2
+#endif
+constexpr int kXU = FXC_XENGINE_UNROLL;
 template <int A>
 __global__ __launch_bounds__(256) void xengine_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int64_t n_pts,
                                                      int nchan, int64_t n_chunks, int cg) {
@@ -364,25 +370,25 @@ __global__ __launch_bounds__(256) void xengine_kernel(const cf* __restrict__ spe
     const int64_t c_end = (grp + 1) * cg < n_chunks ? (grp + 1) * cg : n_chunks;
     for (int64_t c = grp * cg; c < c_end; ++c) {
         const cf* base = spec + (c * A * n_pts) * nchan + pos;
-        // two spectra per trip: 2A independent 8-byte loads in flight before the A(A-1) multiply-accumulates
+        // kXU spectra per trip: kXU * A independent 8-byte loads in flight before the multiply-accumulates
         int64_t i = 0;
-        for (; i + 1 < n_pts; i += 2) {
-            cf z0[A], z1[A];
+        for (; i + kXU <= n_pts; i += kXU) {
+            cf z[kXU][A];
 #pragma unroll
-            for (int a = 0; a < A; ++a) {
-                z0[a] = base[((int64_t)a * n_pts + i) * nchan];
-                z1[a] = base[((int64_t)a * n_pts + i + 1) * nchan];
+            for (int u = 0; u < kXU; ++u)
+#pragma unroll
+                for (int a = 0; a < A; ++a) z[u][a] = base[((int64_t)a * n_pts + i + u) * nchan];
+#pragma unroll
+            for (int u = 0; u < kXU; ++u) {
+                int p = 0;
+#pragma unroll
+                for (int a = 0; a < A; ++a)
+#pragma unroll
+                    for (int b = a + 1; b < A; ++b, ++p) {
+                        ar[p] += z[u][a].x * z[u][b].x + z[u][a].y * z[u][b].y;
+                        ai[p] += z[u][a].y * z[u][b].x - z[u][a].x * z[u][b].y;
+                    }
             }
-            int p = 0;
-#pragma unroll
-            for (int a = 0; a < A; ++a)
-#pragma unroll
-                for (int b = a + 1; b < A; ++b, ++p) {
-                    ar[p] += z0[a].x * z0[b].x + z0[a].y * z0[b].y;
-                    ai[p] += z0[a].y * z0[b].x - z0[a].x * z0[b].y;
-                    ar[p] += z1[a].x * z1[b].x + z1[a].y * z1[b].y;
-                    ai[p] += z1[a].y * z1[b].x - z1[a].x * z1[b].y;
-                }
         }
         for (; i < n_pts; ++i) {
             cf z[A];
