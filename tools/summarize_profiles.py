@@ -61,6 +61,8 @@ def main():
                 summary["kernels"][k] = {"launches": len(v), "first_launch_us": round(v[0], 1),
                                          "mean_us_excluding_first": round(sum(warm) / len(warm), 1),
                                          "min_us": round(min(v), 1), "max_us": round(max(v), 1)}
+                if len(v) <= 32:       # launch by launch: the first launches after idle run slower (clock ramp)
+                    summary["kernels"][k]["durations_us"] = [round(t, 1) for t in v]
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cc = find(os.path.join(raw, "%s_%s" % (name, counter)), "counter_collection.csv")
             if not cc:
@@ -77,6 +79,17 @@ def main():
             if "FETCH_SIZE_bytes_per_launch_raw" in d:
                 d["hbm_read_bytes_per_launch"] = 2 * d["FETCH_SIZE_bytes_per_launch_raw"]
                 d["hbm_traffic_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d.get("WRITE_SIZE_bytes_per_launch_raw", 0)
+        log = os.path.join(raw, name + "_trace.log")
+        if os.path.isfile(log):          # bench.py's own JSON line from the same profiled process (HIP-event timing)
+            for line in open(log):
+                if line.startswith("{") and "roofline" in line:
+                    try:
+                        d = json.loads(line)
+                        summary["bench_line_of_this_profiled_run"] = {
+                            "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "value": d["value"],
+                            "roofline": d["roofline"]}
+                    except ValueError:
+                        pass
         summary["note"] = ("durations: rocprofv3 --kernel-trace; traffic: separate --pmc passes, FETCH_SIZE x 2 (gfx950 wide "
                            "streaming reads), WRITE_SIZE exact; means exclude each kernel's first launch")
         with open(os.path.join(base, "summary_%s.json" % name), "w") as fh:
