@@ -47,7 +47,8 @@ CHECK_FRAMES = (0, 7777)       # frames of rank 0 whose rows are checked against
 # The same leg produces the oracle rows the GPU result is checked against after the timed region.
 # ----------------------------------------------------------------------------------------------
 def _cpu_worker(args):
-    seconds, seed_offset = args
+    seconds, seed_offset = args[:2]
+    c128 = len(args) > 2 and args[2]          # the reference's own precision (effex.py:109-110, 551), single core once
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, ROOT)
     os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -55,14 +56,16 @@ def _cpu_worker(args):
     import fx_oracle
     from effex_amd import synth
     from effex_amd.window import design_window
-    window = design_window(NTAPS, NCHAN).astype(np.float32)
+    window = design_window(NTAPS, NCHAN) if c128 else design_window(NTAPS, NCHAN).astype(np.float32)
+    dtype = np.complex128 if c128 else np.complex64
     x = synth.synth_iq(SEED + seed_offset, 1, 2, NUM_SAMP)[0]
-    fx_oracle.pfb_xcorr(x[0], x[1], NTAPS, NCHAN, window, BANDWIDTH, FREQUENCY, 0.0, "SPECTRUM", dtype=np.complex64)
+    if c128:
+        x = x.astype(np.complex128)
+    fx_oracle.pfb_xcorr(x[0], x[1], NTAPS, NCHAN, window, BANDWIDTH, FREQUENCY, 0.0, "SPECTRUM", dtype=dtype)
     frames = 0
     t0 = time.perf_counter()
     while True:
-        fx_oracle.pfb_xcorr(x[0], x[1], NTAPS, NCHAN, window, BANDWIDTH, FREQUENCY, 0.0, "SPECTRUM",
-                            dtype=np.complex64)
+        fx_oracle.pfb_xcorr(x[0], x[1], NTAPS, NCHAN, window, BANDWIDTH, FREQUENCY, 0.0, "SPECTRUM", dtype=dtype)
         frames += 1
         dt = time.perf_counter() - t0
         if dt >= seconds:
@@ -105,6 +108,8 @@ def cpu_baseline(seconds=8.0, frames=FRAMES):
     workers = max(1, usable)                 # one single-threaded worker per usable core, no cap
     frames1, dt1 = _cpu_worker((min(seconds, 4.0), 0))
     single = frames1 * NUM_SAMP / dt1 / 1e6
+    frames2, dt2 = _cpu_worker((2.0, 0, True))
+    single_c128 = frames2 * NUM_SAMP / dt2 / 1e6
     ctx = mp.get_context("spawn")
     with ctx.Pool(workers) as pool:
         res = pool.map(_cpu_worker, [(seconds, k) for k in range(workers)])
@@ -112,7 +117,8 @@ def cpu_baseline(seconds=8.0, frames=FRAMES):
     total_frames = sum(f for f, _ in res)
     check = _oracle_rows([f for f in CHECK_FRAMES if f < frames])
     return {"value": round(multi, 2), "unit": "Msamples/s", "cores": workers, "kind": "port",
-            "single_core_value": round(single, 2), "cpu_count_logical": logical, "cpu_count_usable": usable,
+            "single_core_value": round(single, 2), "single_core_complex128_value": round(single_c128, 2),
+            "cpu_count_logical": logical, "cpu_count_usable": usable,
             "cpu_model": cpu_model(),
             "sample": "%d frames of the same workload (S=%d, N=%d, T=%d, 2 ant, complex64 numpy/scipy oracle), "
                       "%d single-threaded worker processes (one per usable core) x %.0f s on independent frames"

@@ -1149,9 +1149,12 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
 // applied from registers.  HBM: stream in + stream out, then stream in again for the FFT/X kernel: 3 x algorithmic,
 // whatever ntaps is.
 // ------------------------------------------------------------------------------------------
+// outputs i0 .. i0 + TP - 1 from the block in flight (xn) and the one before it (xo), stored as they are formed
 template <int TP>
-__device__ __forceinline__ void prefilter_block(const cf (&xo)[TP], const cf (&xn)[TP], const float (&hc)[TP], cf* yp,
-                                                int64_t stride, int64_t i0, int64_t i_end) {
+__device__ __forceinline__ void prefilter_fir_store(const cf (&xo)[TP], const cf (&xn)[TP], const float (&hc)[TP],
+                                                    __amdgpu_buffer_rsrc_t rs, unsigned voff, int64_t i0, int64_t i_end,
+                                                    unsigned frame_bytes) {
+    const bool full = i0 + TP <= i_end;    // wave-uniform
 #pragma unroll
     for (int k = 0; k < TP; ++k) {
         float ar = 0.f, ai = 0.f;
@@ -1161,20 +1164,31 @@ __device__ __forceinline__ void prefilter_block(const cf (&xo)[TP], const cf (&x
             ar = fmaf(hc[t], v.x, ar);
             ai = fmaf(hc[t], v.y, ai);
         }
-        if (i0 + k < i_end) yp[(i0 + k) * stride] = fxc::mk(ar, ai);
+        if (full || i0 + k < i_end) {
+            v2u32 d = {__float_as_uint(ar), __float_as_uint(ai)};
+            __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, (unsigned)(i0 + k) * frame_bytes, 0);
+        }
     }
 }
 
+// frames i0 .. i0 + TP - 1 of this thread's sample position: buffer loads, one VGPR byte offset, scalar frame offsets.
+// Frames past the stream's last one are clamped to it (a later frame never feeds an earlier output, and outputs past
+// the end are not stored); frames before its first one read as zeros.
 template <int TP>
-__device__ __forceinline__ void prefilter_load(cf (&xr)[TP], const cf* xp, int64_t stride, int64_t i0, int64_t n_pts) {
+__device__ __forceinline__ void prefilter_load(cf (&xr)[TP], __amdgpu_buffer_rsrc_t rs, unsigned voff, int64_t i0, int64_t n_pts,
+                                               unsigned frame_bytes) {
 #pragma unroll
     for (int k = 0; k < TP; ++k) {
         const int64_t i = i0 + k;
-        xr[k] = (i >= 0 && i < n_pts) ? xp[i * stride] : fxc::mk(0.f, 0.f);
+        const int64_t ic = i < 0 ? 0 : (i < n_pts ? i : n_pts - 1);
+        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)ic * frame_bytes, 0);
+        const bool zero = i < 0;   // wave-uniform
+        xr[k] = fxc::mk(zero ? 0.f : __uint_as_float(d[0]), zero ? 0.f : __uint_as_float(d[1]));
     }
 }
 
 // hcoef[t][n] = h[t N + (N - 1 - n)] for t < ntaps, zero rows up to TP; grid (N / 256, streams, frame splits)
+// (asking for 3 waves per SIMD at TP = 32 makes the compiler spill and the pass 3 % slower: measured)
 template <int TP>
 __global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict__ x, cf* __restrict__ y,
                                                            const float* __restrict__ hcoef, int64_t num_samp, int nchan,
@@ -1187,19 +1201,19 @@ __global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict
     float hc[TP];
 #pragma unroll
     for (int t = 0; t < TP; ++t) hc[t] = hcoef[(int64_t)t * nchan + n];
-    const cf* xp = x + s * num_samp + n;
-    cf* yp = y + s * num_samp + n;
+    const unsigned stream_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf));       // num_samp <= 2^27
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x + s * num_samp), 0, (int)stream_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + s * num_samp, 0, (int)stream_bytes, 0x00020000);
+    const unsigned voff = (unsigned)n * (unsigned)sizeof(cf);
+    const unsigned frame_bytes = (unsigned)nchan * (unsigned)sizeof(cf);
     cf xa[TP], xb[TP];
-    prefilter_load<TP>(xa, xp, nchan, i_begin - TP, n_pts);       // history (zeros before the stream's start)
-    for (int64_t i0 = i_begin; i0 < i_end; i0 += 2 * TP) {        // two blocks per trip: the pair swaps roles, no copies
-        prefilter_load<TP>(xb, xp, nchan, i0, n_pts);
-        prefilter_block<TP>(xa, xb, hc, yp, nchan, i0, i_end);
-        if (i0 + TP < i_end) {
-            prefilter_load<TP>(xa, xp, nchan, i0 + TP, n_pts);
-            prefilter_block<TP>(xb, xa, hc, yp, nchan, i0 + TP, i_end);
-        } else {
-            break;
-        }
+    prefilter_load<TP>(xa, rx, voff, i_begin - TP, n_pts, frame_bytes);     // history (zeros before the stream's start)
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 2 * TP) {                  // two blocks per trip: the pair swaps roles, no copies
+        prefilter_load<TP>(xb, rx, voff, i0, n_pts, frame_bytes);
+        prefilter_fir_store<TP>(xa, xb, hc, ry, voff, i0, i_end, frame_bytes);
+        if (i0 + TP >= i_end) break;
+        prefilter_load<TP>(xa, rx, voff, i0 + TP, n_pts, frame_bytes);
+        prefilter_fir_store<TP>(xb, xa, hc, ry, voff, i0 + TP, i_end, frame_bytes);
     }
 }
 
