@@ -185,6 +185,8 @@ def rank_env(args):
 def max_over_ranks(seconds, world, device):
     import torch
     import torch.distributed as dist
+    if world > 1 and dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -331,6 +333,9 @@ def main():
                          "the per-kernel statistics)")
     ap.add_argument("--reduce", choices=("rccl", "torch"), default="rccl",
                     help="N > 1: fxc_reduce (libfxcorr calls RCCL on the plan's stream) or torch.distributed")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend for N > 1.  gloo + fewer GPUs than ranks (ranks share GPUs round-robin) "
+                         "runs the real multi-rank flow on a one-GPU box for testing; its timing means nothing")
     ap.add_argument("--dry-run-dist", action="store_true",
                     help="run the multi-rank control flow on gloo / CPU tensors with a stand-in plan (no GPU)")
     args = ap.parse_args()
@@ -358,10 +363,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and args.dist_backend == "nccl":
+        raise SystemExit("rank %d has no GPU of its own (%d visible): RCCL needs one GPU per rank" % (local_rank, n_dev))
+    gpu = local_rank % n_dev
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # --- synthetic input, device resident: `frames` distinct chunk pairs per rank if they fit --------
     frames = args.frames
@@ -372,16 +384,18 @@ def main():
     synth_fill(x, SEED, first_chunk=rank * frames)
     torch.cuda.synchronize(dev)
 
-    plan = FxPlan(N_ANT, NCHAN, NTAPS, NUM_SAMP, device=local_rank)
+    plan = FxPlan(N_ANT, NCHAN, NTAPS, NUM_SAMP, device=gpu)
     assert plan.path == "fused", "headline workload must run on the fused HIP kernel"
     plan.set_delay(BANDWIDTH, FREQUENCY, 0.0)
     comm, comm_note = None, None
     if world > 1 and args.reduce == "rccl":
         try:
-            comm = sharding.make_comm(local_rank, rank, world)
-        except Exception as exc:                  # RCCL not bindable: torch.distributed carries the reduce
-            comm, comm_note = None, "fxc_comm_create failed (%s)" % exc
-        ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            if n_dev < world:
+                raise RuntimeError("ranks share GPUs: RCCL wants one GPU per rank")
+            comm = sharding.make_comm(gpu, rank, world)
+        except Exception as exc:                  # RCCL not usable: torch.distributed carries the reduce
+            comm, comm_note = None, "no RCCL communicator (%s)" % exc
+        ok = torch.tensor([1 if comm is not None else 0], device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)           # all ranks or none
         if int(ok.item()) == 0 and comm is not None:
             comm.close()
@@ -428,8 +442,7 @@ def main():
             rows_sum += plan.fx_rows(x[lo:hi], "SPECTRUM")[:, 0].to(torch.complex128).sum(dim=0)
         done += n
     if world > 1:
-        flat = torch.view_as_real(rows_sum)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        sharding.reduce_sums(rows_sum, to_all=True)
     verify = None
     if rank == 0 and not args.no_verify:
         rows_mean = (rows_sum / (frames * world)).cpu().numpy()
@@ -478,7 +491,7 @@ def main():
                        "nchan": NCHAN, "ntaps": NTAPS, "n_ant": N_ANT, "path": plan.path,
                        "sample_definition": "one complex sample per antenna stream",
                        "parallelism": "frames sharded over %d GPU(s), one RCCL reduce of the cross-spectra "
-                                      "per integration" % world,
+                                      "per integration" % world, "dist_backend": args.dist_backend if world > 1 else None,
                        "reduce_transport": integ.transport if comm_note is None else integ.transport + "; " + comm_note,
                        "library": os.path.relpath(_lib.LIB_PATH, ROOT)},
             "roofline": {"bound": "hbm", "kernel": "fx_fused4096_kernel", "achieved": round(achieved, 1),

@@ -38,6 +38,14 @@ def reduce_sums(sums, root=0, group=None, to_all=False):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return sums
     flat = torch.view_as_real(sums) if sums.is_complex() else sums
+    if flat.is_cuda and dist.get_backend(group) == "gloo":      # test set-ups only: gloo reduces host tensors
+        host = flat.cpu()
+        if to_all:
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce(host, dst=root, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+        return sums
     if to_all:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     else:

@@ -880,3 +880,32 @@ def test_timers_and_kernel_profiling(plan_mod, torch):
         kms, n = p.kernel_time()
         assert n == 2 and 0 < kms <= ms * 1.05
         p.finalize("SPECTRUM")
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's real multi-rank flow (torch.distributed.run, per-rank frames of the synthetic stream, FxPlan +
+    ShardedIntegrator, barrier / max-over-ranks timing, the all-reduced float64 check after the timed region) with two
+    ranks on this one GPU over gloo.  RCCL wants a GPU per rank, so the run also takes bench.py's fall-back from
+    fxc_reduce to the torch.distributed transport.  Timing is meaningless here; the checks are not."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--frames", "600"]
+    proc = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["frames_per_gpu"] == 600 and line["config"]["path"] == "fused"
+    assert line["config"]["reduce_transport"].startswith("torch.distributed")
+    assert line["verify"]["frames"] == 1200 and line["verify"]["integration_vs_float64_mean_of_rows"] < 1e-6
+    assert line["value"] > 0 and line["roofline"]["launches"] == 2
