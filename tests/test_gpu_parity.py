@@ -355,6 +355,37 @@ def test_fused_frame_ranges_ignore_chunk_boundaries(plan_mod, torch, n_chunks, f
         assert rel_err(p.finalize("SPECTRUM")[0], rows_b[:, 0].astype(np.complex128).mean(axis=0)) < 1e-5
 
 
+def test_randomized_launch_shapes_fused_vs_generic(plan_mod, torch):
+    """60 random (chunk count, frames per chunk, ragged tail) draws on the headline kernel — launches that are all
+    tail (fewer chunks than CUs), whole rounds plus a tail, chunks of one frame, ranges shorter and longer than a chunk,
+    rows of 1 … 64 chunks in the integration — against the generic kernels, which share no code with it."""
+    rng = np.random.default_rng(20261003)
+    with plan_mod.FxPlan(2, 4096, 4, 4096) as probe:
+        n_cu = probe.info["cu_count"]
+    for case in range(60):
+        frames = int(rng.choice([1, 1, 2, 3, 5, 8, 13, 40]))
+        n_chunks = int(rng.choice([1, 2, 7, n_cu - 1, n_cu, n_cu + 1, 2 * n_cu + 3, int(rng.integers(1, 900))]))
+        if n_chunks * frames > 6000:
+            n_chunks = max(1, 6000 // frames)
+        num_samp = 4096 * frames + int(rng.integers(0, 4096))
+        x = torch.from_numpy(synth.synth_iq(3000 + case, n_chunks, 2, num_samp)).cuda()
+        tag = (case, n_chunks, frames, num_samp)
+        with plan_mod.FxPlan(2, 4096, 4, num_samp, path="fused") as f, \
+                plan_mod.FxPlan(2, 4096, 4, num_samp, path="generic") as g:
+            rf, rg = f.fx_rows(x).cpu().numpy(), g.fx_rows(x).cpu().numpy()
+            assert rel_err(rf, rg) < 4e-6, tag
+            f.fx_accumulate(x)
+            assert rel_err(f.finalize("SPECTRUM")[0], rf[:, 0].astype(np.complex128).mean(axis=0)) < 4e-6, tag
+            if case % 4 == 0:
+                u8 = torch.from_numpy(rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)).cuda()
+                assert rel_err(f.fx_rows_u8(u8).cpu().numpy(), g.fx_rows_u8(u8).cpu().numpy()) < TOL_VIS, tag
+            if case % 6 == 0 and n_chunks >= 2:                 # 4 antennas: the F-only variant walks the same ranges
+                x4 = x[: n_chunks // 2 * 2].reshape(n_chunks // 2, 4, num_samp).contiguous()
+                with plan_mod.FxPlan(4, 4096, 4, num_samp) as m, plan_mod.FxPlan(4, 4096, 4, num_samp, path="generic") as mg:
+                    assert m.path == "fused", tag
+                    assert rel_err(m.fx_rows(x4).cpu().numpy(), mg.fx_rows(x4).cpu().numpy()) < 4e-6, tag
+
+
 def test_ten_thousand_frame_accumulation(plan_mod, torch):
     """BASELINE configs[1] integrates 10 000 frames: float32 sums of up to 256 spectra per raw row, float64 across rows
     (fxcorr.hip::fused_unit, fused_reduce1/2_kernel).  A pool of 25 distinct chunk pairs cycled to 10 400 frames of 16
