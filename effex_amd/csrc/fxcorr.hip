@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256) void xmul_kernel(const cf* __restrict__ spec, 
 // finishing kernels (shared by all paths); `slots` = layout of the raw sums inside a row:
 //   0 natural bin order, 1 the 2-antenna fused kernel's slot order, 2 the F-only kernel's spectrum order
 // ------------------------------------------------------------------------------------------
+//   3 the 8192-channel split (§ pfb_split8192_kernel): two 4096-rows of the fused kernel side by side, even bins in
+//     the first, odd bins in the second
 __device__ __forceinline__ int64_t raw_index(int k, int slots) {
+    if (slots == 3) return (int64_t)(k & 1) * fxc::fused::kN + fxc::fused::slot_of_bin(k >> 1);
     return slots == 1 ? fxc::fused::slot_of_bin(k) : (slots == 2 ? fxc::fused::specpos_of_bin(k) : k);
 }
 
@@ -192,14 +195,19 @@ struct LeadRows {
     int grid;
 };
 
+// slots == 3: row `row` of the caller is the pair of fused-kernel chunks 2 row (even bins) and 2 row + 1 (odd bins)
 __device__ __forceinline__ void add_lead_rows(const cf* __restrict__ raw, const LeadRows& lr, int64_t row, int nchan,
-                                              int64_t ridx, float& ar, float& ai) {
-    if (lr.n_frames == 0 || row < lr.first_chunk) return;
-    const int64_t t = row - lr.first_chunk;   // chunk of the tail (fx_fused4096.h::range_walk_tail)
+                                              int k, int slots, float& ar, float& ai) {
+    if (lr.n_frames == 0) return;
+    const int64_t vrow = slots == 3 ? 2 * row + (k & 1) : row;
+    if (vrow < lr.first_chunk) return;
+    const int row_len = slots == 3 ? fxc::fused::kN : nchan;
+    const int64_t ridx = slots == 3 ? fxc::fused::slot_of_bin(k >> 1) : raw_index(k, slots);
+    const int64_t t = vrow - lr.first_chunk;   // chunk of the tail (fx_fused4096.h::range_walk_tail)
     const int64_t b_lo = fxc::range_owner(t * lr.n_pts, lr.n_frames, lr.grid);
     const int64_t b_hi = fxc::range_owner((t + 1) * lr.n_pts - 1, lr.n_frames, lr.grid);
-    for (int64_t b = b_lo + 1; b <= b_hi; ++b) {   // the workgroups that start strictly inside chunk `row`
-        const cf r = raw[lr.offset + b * nchan + ridx];
+    for (int64_t b = b_lo + 1; b <= b_hi; ++b) {   // the workgroups that start strictly inside that chunk
+        const cf r = raw[lr.offset + b * row_len + ridx];
         ar += r.x;
         ai += r.y;
     }
@@ -220,7 +228,7 @@ __global__ void rows_spectrum_kernel(const cf* __restrict__ raw, cf* __restrict_
             ar += r.x;
             ai += r.y;
         }
-        add_lead_rows(raw, lead, row, nchan, raw_index(k, slots), ar, ai);
+        add_lead_rows(raw, lead, row, nchan, k, slots, ar, ai);
         const float cr = (float)rot[k].x, ci = (float)rot[k].y;
         // (ar + i ai) * (cr - i ci)
         const float orr = (ar * cr + ai * ci) * inv_pts;
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256) void rows_continuum_kernel(const cf* __restric
                 xi += r.y;
             }
             float lr_re = 0.f, lr_im = 0.f;
-            add_lead_rows(raw, lead, row, nchan, raw_index(k, slots), lr_re, lr_im);
+            add_lead_rows(raw, lead, row, nchan, k, slots, lr_re, lr_im);
             xr += lr_re;
             xi += lr_im;
             const cd w = rot[k];
@@ -339,7 +347,13 @@ __global__ __launch_bounds__(256) void fused_reduce2_kernel(const cd* __restrict
     __syncthreads();
     if (sl == 0 && slot < nchan) {
         // slots == 1: the fused kernel's order, slot = q * 512 + tid (fx_fused4096.h::bin_of); 0: natural order
-        const int k = slots == 1 ? fxc::fused::bin_of(slot % fxc::fused::kThreads, slot / fxc::fused::kThreads) : slot;
+        // 3: the 8192-channel split, [even | odd] halves each in the fused kernel's order
+        int k = slot;
+        if (slots == 1) k = fxc::fused::bin_of(slot % fxc::fused::kThreads, slot / fxc::fused::kThreads);
+        if (slots == 3) {
+            const int sl = slot % fxc::fused::kN;
+            k = 2 * fxc::fused::bin_of(sl % fxc::fused::kThreads, sl / fxc::fused::kThreads) + slot / fxc::fused::kN;
+        }
         cd a = acc[k];
         for (int j = 0; j < 16; ++j) {
             a.x += sub[j][kl].x;
@@ -1218,6 +1232,111 @@ __global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// nchan = 8192 as two 4096-channel problems.  A frame ring does not fit 8192 channels (128 VGPRs per thread at 1024
+// threads, or 128 KiB of window + 136 KiB of exchange rows in LDS at 512), and the plain tiled kernel re-reads its
+// history (0.145 of the HBM roofline).  Decimation in frequency splits the transform of the FIR output v[m]:
+//     spec[2k']     = sum_{m < 4096} (v[m] + v[m + 4096])            w4096^(m k')
+//     spec[2k' + 1] = sum_{m < 4096} (v[m] - v[m + 4096]) w8192^m    w4096^(m k')
+// so the pre-filter pass (above) is extended: a thread owns the sample positions n' and n' + 4096 of a stream, forms
+// both FIR outputs y_lo, y_hi per frame from registers, and writes a = y_hi + y_lo and b = (y_hi - y_lo) w8192^(4095 - n')
+// at position n' of two half-size streams.  The headline kernel then runs on those as 2 n_chunks chunk pairs with a
+// single unit tap -- pair 2c gives the even bins of chunk c, pair 2c + 1 the odd ones (raw layout 3).
+// y = [chunk][even | odd][antenna][n_pts * 4096].  HBM: stream in + out, then in again: 3 x algorithmic.
+// ------------------------------------------------------------------------------------------
+template <int TP>
+__global__ __launch_bounds__(256) void pfb_split8192_kernel(const cf* __restrict__ x, cf* __restrict__ y,
+                                                           const float* __restrict__ hcoef, const cf* __restrict__ tw,
+                                                           int64_t num_samp, int64_t n_pts, int64_t per_split) {
+    constexpr int kHalf = 4096, kFull = 8192;
+    const int n = blockIdx.x * 256 + threadIdx.x;          // position inside the half frame
+    const int64_t s = blockIdx.y;                           // stream = chunk * 2 + antenna
+    const int64_t i_begin = (int64_t)blockIdx.z * per_split;
+    const int64_t i_end = (i_begin + per_split < n_pts) ? i_begin + per_split : n_pts;
+    if (i_begin >= i_end) return;
+    float hc[TP][2];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+        hc[t][0] = hcoef[(int64_t)t * kFull + n];
+        hc[t][1] = hcoef[(int64_t)t * kFull + n + kHalf];
+    }
+    const cf w = tw[n];
+    const int64_t half_samp = n_pts * kHalf;
+    const int64_t c = s >> 1, a = s & 1;
+    const unsigned in_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf)), out_bytes = (unsigned)(half_samp * (int64_t)sizeof(cf));
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x + s * num_samp), 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(y + ((c * 2 + 0) * 2 + a) * half_samp, 0, (int)out_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(y + ((c * 2 + 1) * 2 + a) * half_samp, 0, (int)out_bytes, 0x00020000);
+    const unsigned voff = (unsigned)n * (unsigned)sizeof(cf);
+    const unsigned in_frame = kFull * (unsigned)sizeof(cf), out_frame = kHalf * (unsigned)sizeof(cf), hi = kHalf * (unsigned)sizeof(cf);
+    cf xa[TP][2], xb[TP][2];
+    auto load = [&](cf (&xr)[TP][2], int64_t i0) {
+#pragma unroll
+        for (int k = 0; k < TP; ++k) {
+            const int64_t i = i0 + k;
+            const int64_t ic = i < 0 ? 0 : (i < n_pts ? i : n_pts - 1);      // see prefilter_load
+            const bool zero = i < 0;
+            const v2u32 d0 = __builtin_amdgcn_raw_buffer_load_b64(rx, voff, (unsigned)ic * in_frame, 0);
+            const v2u32 d1 = __builtin_amdgcn_raw_buffer_load_b64(rx, voff, (unsigned)ic * in_frame + hi, 0);
+            xr[k][0] = fxc::mk(zero ? 0.f : __uint_as_float(d0[0]), zero ? 0.f : __uint_as_float(d0[1]));
+            xr[k][1] = fxc::mk(zero ? 0.f : __uint_as_float(d1[0]), zero ? 0.f : __uint_as_float(d1[1]));
+        }
+    };
+    auto fir_store = [&](const cf (&xo)[TP][2], const cf (&xn)[TP][2], int64_t i0) {
+        const bool full = i0 + TP <= i_end;
+#pragma unroll
+        for (int k = 0; k < TP; ++k) {
+            cf yv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float ar = 0.f, ai = 0.f;
+#pragma unroll
+                for (int t = 0; t < TP; ++t) {
+                    const cf v = (k - t >= 0) ? xn[(k - t) >= 0 ? k - t : 0][h] : xo[(TP + k - t) < TP ? TP + k - t : 0][h];
+                    ar = fmaf(hc[t][h], v.x, ar);
+                    ai = fmaf(hc[t][h], v.y, ai);
+                }
+                yv[h] = fxc::mk(ar, ai);
+            }
+            if (full || i0 + k < i_end) {
+                const cf ea = fxc::cadd(yv[1], yv[0]), eb = fxc::cmul(fxc::csub(yv[1], yv[0]), w);
+                const unsigned soff = (unsigned)(i0 + k) * out_frame;
+                v2u32 da = {__float_as_uint(ea.x), __float_as_uint(ea.y)}, db = {__float_as_uint(eb.x), __float_as_uint(eb.y)};
+                __builtin_amdgcn_raw_buffer_store_b64(da, ra, voff, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(db, rb, voff, soff, 0);
+            }
+        }
+    };
+    load(xa, i_begin - TP);
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 2 * TP) {
+        load(xb, i0);
+        fir_store(xa, xb, i0);
+        if (i0 + TP >= i_end) break;
+        load(xa, i0 + TP);
+        fir_store(xb, xa, i0 + TP);
+    }
+}
+
+// acc[k] += the leading-part rows of the split launch that belong to bin k's half (even bins: fused chunks 2c, odd:
+// 2c + 1); the chunk rows themselves go through fused_reduce1/2_kernel in layout 3
+__global__ __launch_bounds__(256) void split_lead_acc_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, LeadRows lr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;    // 0 .. 8191
+    const int64_t slot = fxc::fused::slot_of_bin(k >> 1);
+    double ar = 0.0, ai = 0.0;
+    for (int b = 0; b < lr.grid; ++b) {
+        // the fused chunk workgroup b's range starts in (its leading part, if any, belongs to that chunk)
+        const int64_t vc = lr.first_chunk + fxc::range_begin(b, (int)lr.n_frames, lr.grid) / lr.n_pts;
+        if ((vc & 1) != (k & 1)) continue;
+        const cf r = raw[lr.offset + (int64_t)b * fxc::fused::kN + slot];
+        ar += r.x;
+        ai += r.y;
+    }
+    cd v = acc[k];
+    v.x += ar;
+    v.y += ai;
+    acc[k] = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // continuum streaming limit: nchan == 1, 2 antennas (BASELINE config 3(i))
 // The PFB degenerates to a T-tap FIR y_a[n] = sum_t h[t] x_a[n - t] (zero history per chunk), the FFT is
 // the identity and X is sum_n y_0[n] conj(y_1[n]).  One workgroup takes kStreamBlock consecutive
@@ -1650,6 +1769,8 @@ struct fxc_plan {
     float* d_ones = nullptr;       // [nchan] unit window of the plain tiled kernel behind the pre-filter
     void* d_pre = nullptr;         // pre-filtered streams of one pass
     size_t pre_bytes = 0;
+    bool split8192 = false;        // nchan 8192, 2 antennas: pfb_split8192_kernel + the 4096-channel fused kernel
+    cf* d_tw8192 = nullptr;        // [4096] w8192^(4095 - n')
     unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int fused_grid_max = 0;
     int64_t fused_seg = 1;         // chunks per round-robin segment of the fused kernel (fx_fused4096.h::RangeWalk)
@@ -1802,7 +1923,7 @@ int drain_kernel_events(fxc_plan* p) {
 }
 
 int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8 = nullptr,
-                 int64_t unit = 1, bool rows_are_chunks = true);
+                 int64_t unit = 1, bool rows_are_chunks = true, int64_t num_samp = 0);
 
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams);
@@ -1894,8 +2015,9 @@ const LeadRows kNoLead = {0, 0, 0, 0, 0};
 // dc_u8 != nullptr: x is the uint8 I,Q stream and dc_u8 its per-stream conversion offsets (2 antennas, X fused in)
 // unit / rows_are_chunks: the raw-row layout (fx_fused4096.h::RangeWalk)
 int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8, int64_t unit,
-                 bool rows_are_chunks) {
+                 bool rows_are_chunks, int64_t num_samp) {
     using namespace fxc::fused;
+    if (num_samp == 0) num_samp = p->num_samp;      // (the 8192-channel split runs on half-size streams)
     const int grid = fused_grid(p, n_pairs);
     const int seg = (int)p->fused_seg;
     if (n_pairs * p->n_pts >= (1ll << 31)) return fail(p, FXC_ERR_ARG, "more than 2^31 frames in one launch");
@@ -1909,15 +2031,15 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
     KernelTimer kt(p);
     if (dc_u8)
         hipLaunchKernelGGL((fx_fused4096_kernel<false, true>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, seg, (int)unit,
+                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, seg, (int)unit,
                            rows_are_chunks ? 1 : 0);
     else if (spec_out)
         hipLaunchKernelGGL((fx_fused4096_kernel<true, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
+                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
                            seg, 1, 1);
     else
         hipLaunchKernelGGL((fx_fused4096_kernel<false, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           p->num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
+                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
                            seg, (int)unit, rows_are_chunks ? 1 : 0);
     kt.stop();
     FXC_HIP(p, hipGetLastError());
@@ -2115,6 +2237,36 @@ int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
     return FXC_OK;
 }
 
+// ---- nchan 8192 as two 4096-channel problems (pfb_split8192_kernel) ---------------------------------
+int64_t split_chunks_per_pass(const fxc_plan* p, int64_t n_chunks) {
+    const int64_t per_chunk = 4 * p->n_pts * 4096 * (int64_t)sizeof(cf) + 2 * 4096 * (int64_t)sizeof(cf);   // y + two raw rows
+    return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, 32767), kWorkspaceTarget / per_chunk));
+}
+
+// raw = the fused kernel's rows over 2 nc chunk pairs (+ leading-part rows) for nc chunks of 8192-channel input
+int split_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* raw) {
+    const int64_t half_samp = p->n_pts * 4096;
+    int rc = grow(p, &p->d_pre, &p->pre_bytes, (size_t)nc * 4 * half_samp * sizeof(cf));
+    if (rc) return rc;
+    cf* y = static_cast<cf*>(p->d_pre);
+    const int tp = p->pre_tp;
+    const int64_t blocks = 16 * 2 * nc;
+    int64_t fs = std::max<int64_t>(1, (2 * (int64_t)p->cu_count + blocks - 1) / blocks);
+    fs = std::min<int64_t>(fs, std::max<int64_t>(1, p->n_pts / (4 * tp)));
+    const int64_t per = ((p->n_pts + fs - 1) / fs + 2 * tp - 1) / (2 * tp) * (2 * tp);
+    const dim3 grid(16, (unsigned)(2 * nc), (unsigned)((p->n_pts + per - 1) / per));
+    KernelTimer kt(p);
+    if (tp == 4)
+        hipLaunchKernelGGL(pfb_split8192_kernel<4>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, p->n_pts, per);
+    else if (tp == 8)
+        hipLaunchKernelGGL(pfb_split8192_kernel<8>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, p->n_pts, per);
+    else
+        hipLaunchKernelGGL(pfb_split8192_kernel<16>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, p->n_pts, per);
+    FXC_HIP(p, hipGetLastError());
+    kt.stop();
+    return launch_fused(p, y, 2 * nc, raw, false, nullptr, 1, true, half_samp);
+}
+
 // nchan == 1 streaming path: raw[block][chunk] partial sums for nc chunks
 bool stream_is_t4(const fxc_plan* p) { return p->ntaps <= 4 && (p->num_samp % 2) == 0; }
 
@@ -2186,6 +2338,27 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
                 hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream,
                                    raw, p->d_acc, p->nchan, p->n_base, (nc + unit - 1) / unit, 1, fused_layout(p));
             }
+            FXC_HIP(p, hipGetLastError());
+        }
+    } else if (p->split8192 && !dc_u8) {
+        const int N = p->nchan;
+        const int64_t cb = split_chunks_per_pass(p, n_chunks);
+        const int64_t row_bytes = (int64_t)fxc::fused::kN * (int64_t)sizeof(cf);
+        const int64_t raw_bytes = ((2 * cb + p->fused_grid_max) * row_bytes + 255) / 256 * 256;
+        const int64_t part_bytes = (int64_t)kFusedReduceSplits * N * (int64_t)sizeof(cd);
+        int rc = ensure_ws(p, raw_bytes + part_bytes);
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + raw_bytes);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = split_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
+            if (rc) return rc;
+            // the nc pairs of 4096-rows are nc rows of 8192 in layout 3; the leading-part rows are added by parity
+            const int splits = fused_reduce_splits(nc);
+            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(N / 256, splits), dim3(256), 0, p->stream, raw, part, N, nc, splits);
+            hipLaunchKernelGGL(fused_reduce2_kernel, dim3(N / 16), dim3(256), 0, p->stream, part, p->d_acc, N, splits, 3);
+            hipLaunchKernelGGL(split_lead_acc_kernel, dim3(N / 256), dim3(256), 0, p->stream, raw, p->d_acc, fused_lead(p, 2 * nc));
             FXC_HIP(p, hipGetLastError());
         }
     } else if (use_tiled(p, n_chunks)) {
@@ -2292,6 +2465,28 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
                                    dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot,
                                    p->nchan, rows, 1, (int64_t)0, cscale, fused_layout(p), lead);
+            FXC_HIP(p, hipGetLastError());
+        }
+        return FXC_OK;
+    }
+    if (p->split8192 && !dc_u8) {
+        const int N = p->nchan;
+        const int64_t cb = split_chunks_per_pass(p, n_chunks);
+        int rc = ensure_ws(p, (2 * cb + p->fused_grid_max) * (int64_t)fxc::fused::kN * (int64_t)sizeof(cf));
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = split_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
+            if (rc) return rc;
+            const LeadRows lead = fused_lead(p, 2 * nc);
+            if (mode == FXC_MODE_SPECTRUM)
+                hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc * N, 256, p->cu_count)), dim3(256), 0, p->stream,
+                                   raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, 1, (int64_t)0, inv_pts, 3, lead);
+            else
+                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
+                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, 1, (int64_t)0,
+                                   cscale, 3, lead);
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;
@@ -2424,7 +2619,7 @@ int fxc_plan_destroy(fxc_plan* p) {
     }
     void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_stamps,
                     p->d_acc, p->d_sums, p->d_out, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
-                    p->d_ones, p->d_pre};
+                    p->d_ones, p->d_pre, p->d_tw8192};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -2581,6 +2776,37 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             FXC_HIP(p, hipMemcpy(p->d_hpre, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
             FXC_HIP(p, hipMalloc(&p->d_ones, ones.size() * sizeof(float)));
             FXC_HIP(p, hipMemcpy(p->d_ones, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        // nchan 8192, two antennas, up to 16 taps: the split into two 4096-channel problems (FXC_SPLIT8192=0: off)
+        const char* split_env = std::getenv("FXC_SPLIT8192");
+        p->split8192 = (N == 8192 && p->n_ant == 2 && T <= 16 && p->path == FXC_PATH_TILED && p->num_samp <= (1ll << 27) &&
+                        !(split_env && std::atoi(split_env) == 0));
+        if (p->split8192) {
+            p->prefilter = false;
+            p->pre_tp = T <= 4 ? 4 : (T <= 8 ? 8 : 16);
+            std::vector<float> hp((size_t)p->pre_tp * N, 0.f);
+            for (int t = 0; t < T; ++t)
+                for (int n = 0; n < N; ++n) hp[(size_t)t * N + n] = wf[(size_t)t * N + (N - 1 - n)];
+            if (p->d_hpre) (void)hipFree(p->d_hpre);
+            FXC_HIP(p, hipMalloc(&p->d_hpre, hp.size() * sizeof(float)));
+            FXC_HIP(p, hipMemcpy(p->d_hpre, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
+            std::vector<cf> tw((size_t)4096);
+            for (int n = 0; n < 4096; ++n) {
+                const double ph = kTwoPi * (double)(4095 - n) / 8192.0;
+                tw[n] = fxc::mk((float)std::cos(ph), (float)std::sin(ph));
+            }
+            FXC_HIP(p, hipMalloc(&p->d_tw8192, tw.size() * sizeof(cf)));
+            FXC_HIP(p, hipMemcpy(p->d_tw8192, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+            std::vector<f4> unit_taps((size_t)fxc::fused::kN);
+            for (auto& q : unit_taps) {
+                q.x = 1.f;
+                q.y = q.z = q.w = 0.f;
+            }
+            FXC_HIP(p, hipMalloc(&p->d_win4, unit_taps.size() * sizeof(f4)));
+            FXC_HIP(p, hipMemcpy(p->d_win4, unit_taps.data(), unit_taps.size() * sizeof(f4), hipMemcpyHostToDevice));
+            p->fused_grid_max = p->cu_count;
+            FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, fxc::fused::kLdsBytes));
         }
         p->tiled_ring = ((T <= 4 || p->prefilter) && N <= 4096);
         if (p->tiled_ring && (!p->d_win4 || p->prefilter)) {

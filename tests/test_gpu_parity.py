@@ -457,7 +457,8 @@ def test_eight_antennas_full_size(plan_mod, torch):
     (512, 4, 7, 20, 5), (1024, 4, 3, 9, 0), (2048, 4, 5, 33, 100), (2048, 32, 2, 40, 0), (4096, 8, 2, 11, 7),
     (8192, 4, 3, 6, 1), (4096, 3, 2, 11, 7), (1024, 1, 4, 5, 0), (512, 7, 300, 3, 0), (2048, 4, 1, 128, 0),
     (512, 4, 1, 2049, 0),    # 256 frame ranges of 9 over 2049 frames: the last ranges are empty
-    (512, 7, 1, 700, 3), (512, 20, 1, 600, 0), (1024, 20, 2, 150, 5), (2048, 9, 1, 260, 0)])   # pre-filter pass, its frame splits
+    (512, 7, 1, 700, 3), (512, 20, 1, 600, 0), (1024, 20, 2, 150, 5), (2048, 9, 1, 260, 0),   # pre-filter pass, its frame splits
+    (8192, 4, 1, 70, 5), (8192, 9, 2, 40, 0), (8192, 16, 1, 130, 77), (8192, 17, 2, 9, 0)])    # 8192 as two 4096-channel problems (17 taps: plain)
 def test_tiled_path_matches_oracle(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
     """The other --nfft values (effex.py:778) on the tiled fused kernel: rows, ragged tails, frame splits
     (few chunks, many frames), integration in uneven calls, continuum."""
