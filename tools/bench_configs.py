@@ -69,7 +69,7 @@ def main():
     report("N=2048 T=32 (reference test shape), 2 antennas", 2, 2048, 32, 2 ** 18, 256, "SPECTRUM")
     for nfft in (512, 1024, 2048):   # the reference's --nfft at its fixed ntaps = 4 (effex.py:115,778)
         report("--nfft %d, integrate" % nfft, 2, nfft, 4, 2 ** 18, 4096, "SPECTRUM")
-    report("--nfft 8192, integrate", 2, 8192, 4, 2 ** 18, 1024, "SPECTRUM")
+    report("--nfft 8192, integrate (split into two 4096-channel problems)", 2, 8192, 4, 2 ** 18, 1024, "SPECTRUM")
     report("headline shape, one chunk pair per call (the reference's call pattern)", 2, 4096, 4, 2 ** 18, 1, "SPECTRUM",
            rows=True)
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "configs.json"), "w") as fh:
