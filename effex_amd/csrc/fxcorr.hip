@@ -1760,8 +1760,6 @@ struct fxc_plan {
     cf* d_tw0 = nullptr;           // tiled: pre-stage twiddles [16][nchan/16]
     int tiled_grid_max = 0, tiled_grid_max_f = 0;   // resident workgroups of the F+X / F-only tiled kernels
     bool tiled_f = false;          // the F-only tiled kernel serves fxc_channelize
-    bool small_tiled = false;      // fused shape, path chosen automatically: calls with few chunks split frames
-                                   // over workgroups through the tiled ring kernel
     bool tiled_ring = false;       // ntaps <= 4 and nchan <= 4096: VGPR frame ring + window in LDS
     bool prefilter = false;        // ntaps > 4: pfb_prefilter_kernel first, then the tiled kernels with one unit tap
     int pre_tp = 0;                // its register block: 8, 16 or 32 frames
@@ -2157,11 +2155,10 @@ void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, i
         default: return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for nchan=%d", (p)->nchan); \
     }
 
-// this call goes through the tiled kernel: the tiled path, or a fused-shape plan with too few chunks to fill the
-// chip one chunk per workgroup
-bool use_tiled(const fxc_plan* p, int64_t n_chunks) {
-    return p->path == FXC_PATH_TILED || (p->small_tiled && n_chunks * 2 <= p->cu_count);
-}
+// this call goes through the tiled kernels.  (Round 1 also sent few-chunk calls on the headline shape here to split a
+// chunk's frames over workgroups; the fused kernel's frame ranges do that themselves now, faster: one reference-sized
+// call 25 us against 56.)
+bool use_tiled(const fxc_plan* p, int64_t) { return p->path == FXC_PATH_TILED; }
 
 bool tiled_nchan(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
 
@@ -2733,9 +2730,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
-    p->small_tiled = (p->path == FXC_PATH_FUSED && p->n_ant == 2 && force_path == -1);
     p->tiled_f = (tiled_nchan(N) && p->num_samp <= (1ll << 27) && force_path != FXC_PATH_GENERIC);
-    if (p->path == FXC_PATH_TILED || p->small_tiled || p->tiled_f) {
+    if (p->path == FXC_PATH_TILED || p->tiled_f) {
         // pre-stage twiddles wN^((u + P g) k) at [g + G k][u]; stage tables as on the fused path
         const int P = N / 16, R0 = N >= 4096 ? N / 4096 : N / 256, G = 16 / R0;
         std::vector<cf> tw0((size_t)16 * P);

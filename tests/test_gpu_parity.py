@@ -419,7 +419,7 @@ def test_continuum_reference_semantics_full_size(plan_mod, torch):
         for q in (p, a):
             q.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-6)
         cont = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
-        cont_a = a.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()       # default plan: frame-split small call
+        cont_a = a.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()       # default plan
         spec = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
         p.fx_accumulate(xd)
         integ = p.finalize("CONTINUUM", gi.BANDWIDTH)
@@ -489,17 +489,19 @@ def test_tiled_path_matches_oracle(plan_mod, torch, nchan, ntaps, n_chunks, fram
 
 @pytest.mark.parametrize("n_chunks", [1, 2, 7])
 def test_headline_shape_small_calls_split_frames(plan_mod, torch, n_chunks):
-    """The reference hands over one chunk pair per call (effex.py:497-527): with too few chunks to give every CU
-    one, an automatically chosen plan splits the frames of a chunk over workgroups (tiled ring kernel); an
-    explicit "fused" plan keeps one workgroup per chunk.  Same rows either way."""
+    """The reference hands over one chunk pair per call (effex.py:497-527): with fewer chunks than CUs the headline
+    kernel splits the frames of a chunk over workgroups (frame ranges, leading-part rows); an automatically chosen plan
+    and an explicit "fused" plan are the same thing now, and the tiled kernel for 4096 channels must agree with both."""
     num_samp = 262144
     x = synth.synth_iq(77, n_chunks, 2, num_samp)
     xd = torch.from_numpy(x).cuda()
-    with plan_mod.FxPlan(2, 4096, 4, num_samp) as a, plan_mod.FxPlan(2, 4096, 4, num_samp, path="fused") as f:
-        assert a.path == "fused" and f.path == "fused"
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as a, plan_mod.FxPlan(2, 4096, 4, num_samp, path="fused") as f, \
+            plan_mod.FxPlan(2, 4096, 4, num_samp, path="tiled") as t:
+        assert a.path == "fused" and f.path == "fused" and t.path == "tiled"
         ra = a.fx_rows(xd).cpu().numpy()
         rf = f.fx_rows(xd).cpu().numpy()
-        assert rel_err(ra, rf) < 2e-6
+        np.testing.assert_array_equal(ra, rf)
+        assert rel_err(t.fx_rows(xd).cpu().numpy(), rf) < 2e-6
         ref = fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], 4, 4096, a.window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
         a.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 0.0)
         assert rel_err(a.fx_rows(xd).cpu().numpy()[0, 0], ref) < TOL_VIS
@@ -667,7 +669,7 @@ def test_empty_batches_and_errors(plan_mod, torch):
                                                  (2048, None, 4), (1024, None, 300), (8192, None, 3)])
 def test_linearity_and_conjugate_symmetry_full_size(plan_mod, torch, nchan, path, n_chunks):
     """BASELINE.json's num_samp through size-independent properties: the headline kernel (explicit "fused": one
-    workgroup per chunk pair, also with more chunk pairs than CUs), the default plan's small-call route, and the
+    workgroup per chunk pair, also with more chunk pairs than CUs), the default plan, and the
     tiled kernels."""
     num_samp = 2 ** 18
     x = torch.from_numpy(synth.synth_iq(77777, n_chunks, 2, num_samp)).cuda()
