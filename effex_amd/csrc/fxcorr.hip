@@ -652,10 +652,17 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
     FXC_STAMP(9);
     fxc::dft16(v);
     if (SPEC_OUT) {
-        // stream = 2 * (virtual chunk) + antenna; for a fixed q2 a half-wave stores 256 contiguous bytes
-        cf* dst = rows_raw + (((c * 2 + ((tid >> 5) & 1)) * n_pts + i) * kN + lane_specpos(tid));
+        // stream = 2 * (virtual chunk) + antenna; for a fixed q2 a half-wave stores 256 contiguous bytes.  Buffer
+        // stores from the row of antenna 0 of this frame: one VGPR byte offset per thread (antenna 1's row is n_pts
+        // rows further on), scalar offsets for q2 -- no per-store address arithmetic on the vector unit
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rows_raw + (c * 2 * n_pts + i) * kN, 0,
+                                                                       (int)((n_pts + 1) * kN * (int64_t)sizeof(cf)), 0x00020000);
+        const unsigned soff0 = (unsigned)(((tid >> 5) & 1) * n_pts * kN + lane_specpos(tid)) * (unsigned)sizeof(cf);
 #pragma unroll
-        for (int q2 = 0; q2 < 16; ++q2) dst[q2 * 256] = v[q2];
+        for (int q2 = 0; q2 < 16; ++q2) {
+            v2u32 d = {__float_as_uint(v[q2].x), __float_as_uint(v[q2].y)};
+            __builtin_amdgcn_raw_buffer_store_b64(d, rs, soff0, (unsigned)(q2 * 256 * sizeof(cf)), 0);
+        }
     } else {
         // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins: after the swap each lane has both
         // antennas for 8 of them (lanes 0-31: q2 = 0..7, lanes 32-63: q2 = 8..15) -- effex.py:520 without rot
