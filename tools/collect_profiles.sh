@@ -16,6 +16,7 @@ run() {   # name, program args...
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/${name}_$c" -o t -- python3 "$@" > "$out/${name}_$c.log" 2>&1
   done
 }
-run bench "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-power --no-other-configs --no-verify
+# the driver's own command line (20 timed steps after 5 warm-up steps), minus the CPU leg and the untimed extras
+run bench "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-power --no-other-configs --no-verify
 for w in 8ant stream1 nfft2048 taps32; do run $w "$root/tools/prof_workload.py" $w 3; done
 python3 "$root/tools/summarize_profiles.py" "$root/gpurun_out/$tag"

@@ -61,6 +61,7 @@ def main():
                 summary["kernels"][k] = {"launches": len(v), "first_launch_us": round(v[0], 1),
                                          "mean_us_excluding_first": round(sum(warm) / len(warm), 1),
                                          "min_us": round(min(v), 1), "max_us": round(max(v), 1)}
+                summary["kernels"][k]["mean_us_all_launches"] = round(sum(v) / len(v), 1)
                 if len(v) <= 32:       # launch by launch: the first launches after idle run slower (clock ramp)
                     summary["kernels"][k]["durations_us"] = [round(t, 1) for t in v]
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
