@@ -242,16 +242,16 @@ FXC_HD void phase1_fir(const State& s, const f4* win, int tid, cf (&v)[16]) {
     }
 }
 
-// phase 1b: twiddle w4096^(j*k1) fused per k1 with the exchange-1 store, so the stores trickle out between
-// the multiplies instead of a burst of sixteen after them
-FXC_HD void phase1_twiddle_store(const State& s, cf (&v)[16], cf* region, int tid) {
+// phase 1b: the second half of the radix-16 over r (dft16_b) with each output twiddled by w4096^(j*k1) and stored to
+// exchange 1 as soon as it exists -- the stores are bound by the LDS write path (64 KiB at ~85 B/clk per CU), and the
+// 72 + 60 vector instructions of the butterflies and twiddles run in its shadow instead of in front of barrier B0.
+// Call after dft16_a(v).
+FXC_HD void phase1_finish_store(const State& s, cf (&v)[16], cf* region, int tid) {
     cf* mine = region + (tid >> 8) * kRegion + (tid & 255);
-    mine[0] = v[0];
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) {
-        v[k1] = cmul(v[k1], s.tw1[k1]);
-        mine[k1 * kRowPitch] = v[k1];
-    }
+    dft16_b_stream(v, [&](int k1, cf val) {
+        if (k1 > 0) val = cmul(val, s.tw1[k1]);
+        mine[k1 * kRowPitch] = val;
+    });
 }
 
 // load this thread's twiddles from the [16][256] table w4096^(j*k1)

@@ -120,6 +120,24 @@ FXC_HD void dft16_b(cf (&v)[16]) {
         }
 }
 
+// Stage B with every butterfly's four outputs handed to sink(k, Y[k]) (k = c + 4 d) as soon as they exist, so that
+// a caller can let its stores trickle out between the remaining butterflies instead of after all of them
+template <class Sink>
+FXC_HD void dft16_b_stream(cf (&v)[16], Sink&& sink) {
+    dft4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) sink(4 * d, v[d]);
+    dft4_scaled_c_bd(v[4], v[5], v[6], v[7]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) sink(1 + 4 * d, v[4 + d]);
+    dft4_bd_scaled(v[8], v[9], v[10], v[11]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) sink(2 + 4 * d, v[8 + d]);
+    dft4_scaled_c_bd(v[12], v[13], v[14], v[15]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) sink(3 + 4 * d, v[12 + d]);
+}
+
 FXC_HD void dft16(cf (&v)[16]) {
     dft16_a(v);
     dft16_b(v);

@@ -617,7 +617,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
     const cf* nbase = x + (int64_t)pc * 2 * num_samp;
     cf (&nx)[16] = s.h[(PH + 1) & 3];
     FXC_PREFETCH(0);
-    fxc::dft16(v);
+    fxc::dft16_a(v);
     FXC_PREFETCH(4);
     FXC_STAMP(3);
 #if !(FXC_ABL & 1)
@@ -625,7 +625,10 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
 #endif
     FXC_STAMP(4);
 #if !(FXC_ABL & 4)
-    phase1_twiddle_store(s, v, region, tid);   // twiddle w4096^(j k1) fused with the exchange-1 stores
+    // second half of the radix-16 with the twiddle w4096^(j k1) and the exchange-1 store of every output as it forms:
+    // the stores are bound by the LDS write path, the butterflies and twiddles run in its shadow (B0 in front of the
+    // whole radix-16 instead: +7 %; exchange 2 streamed the same way: spills, +6 %)
+    phase1_finish_store(s, v, region, tid);
 #endif
     FXC_STAMP(5);
 #if !(FXC_ABL & 2)

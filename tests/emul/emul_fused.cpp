@@ -61,10 +61,10 @@ extern "C" int emul_fused4096(const float* x, int64_t num_samp, const double* wi
                 case 2: phase1_fir<2>(st[tid], win, tid, v); break;
                 default: phase1_fir<3>(st[tid], win, tid, v); break;
             }
-            dft16(v);
+            dft16_a(v);
         }
         for (int tid = 0; tid < kThreads; ++tid)
-            phase1_twiddle_store(st[tid], *reinterpret_cast<cf(*)[16]>(&vbuf[tid * 16]), region, tid);
+            phase1_finish_store(st[tid], *reinterpret_cast<cf(*)[16]>(&vbuf[tid * 16]), region, tid);
         // barrier; phase 2 (reads complete for a whole wave before its stores: emulate per wave)
         for (int wave = 0; wave < kThreads / 64; ++wave) {
             for (int l = 0; l < 64; ++l) {
