@@ -75,6 +75,42 @@ class ArraySource(IQSource):
         self.closed = True
 
 
+class FileSource(IQSource):
+    """Chunk pairs from two recordings, one per receiver (the reference only reads live RTL-SDR dongles,
+    effex.py:81-82, 630-664; recorded streams are how its path is fed without them).
+
+    ``fmt='u8'``: raw interleaved unsigned 8-bit I,Q as ``rtl_sdr`` writes them — handed over as bytes, so conversion,
+    DC removal and F+X happen in one device call (``fxc_fx_rows_u8``).  ``fmt='c64'``: raw complex64 samples.  The files
+    are memory-mapped and read chunk by chunk; a trailing partial chunk is dropped, as a short read ends the reference's
+    run."""
+
+    def __init__(self, path_0, path_1, fmt='u8', rs=None, fc=None, gain=None):
+        if fmt not in ('u8', 'c64'):
+            raise ValueError("fmt must be 'u8' or 'c64'")
+        self.fmt = fmt
+        self.rs, self.fc, self.gain = rs, fc, gain
+        dtype = np.uint8 if fmt == 'u8' else np.complex64
+        self._maps = [np.memmap(p, dtype=dtype, mode='r') for p in (path_0, path_1)]
+        per = 2 if fmt == 'u8' else 1
+        self.n_samples = min(len(m) for m in self._maps) // per
+        self._next = 0
+        self.closed = False
+
+    def read(self, num_samp):
+        num_samp = int(num_samp)
+        lo, hi = self._next, self._next + num_samp
+        if hi > self.n_samples:
+            return None
+        self._next = hi
+        if self.fmt == 'u8':
+            return tuple(np.asarray(m[2 * lo:2 * hi]).reshape(num_samp, 2) for m in self._maps)
+        return tuple(np.asarray(m[lo:hi]) for m in self._maps)
+
+    def close(self):
+        self._maps = []
+        self.closed = True
+
+
 def _without_mean(x):
     """x minus its complex mean (= the mean of the real parts and of the imaginary parts), in complex128."""
     z = np.asarray(x).astype(np.complex128)

@@ -263,6 +263,37 @@ def test_state_machine_on_a_byte_source(tmp_path, torch):
     assert rel_err(rows["bytes"][0], rows["samples"][0]) < TOL_VIS
 
 
+def test_state_machine_on_recorded_files(tmp_path, torch):
+    """FileSource: two rtl_sdr-style recordings (raw interleaved uint8 I,Q) and the same data as raw complex64 files
+    write the csv an in-memory source of the same chunk pairs writes; a trailing partial chunk is dropped."""
+    from effex_amd.correlator import ArraySource, Correlator, FileSource
+    n_chunks, num_samp, nbins = 4, 4096 * 5, 4096
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 256, size=(n_chunks * num_samp + 500 + 2, 2), dtype=np.uint8)
+    own = rng.integers(0, 256, size=(2, n_chunks * num_samp + 500, 2), dtype=np.uint8)
+    streams = [base[2:] // 2 + own[0] // 2, base[:-2] // 2 + own[1] // 2]          # antenna 1 two samples late, 500 spare samples
+    for a in range(2):
+        streams[a].tofile(str(tmp_path / ("rx%d.u8" % a)))
+        fx_oracle.u8_to_complex(streams[a][None, None])[0, 0].astype(np.complex64).tofile(str(tmp_path / ("rx%d.c64" % a)))
+    chunks = np.stack([s[: n_chunks * num_samp].reshape(n_chunks, num_samp, 2) for s in streams], axis=1)
+    rows = {}
+    sources = {"memory": lambda: ArraySource(chunks),
+               "u8": lambda: FileSource(str(tmp_path / "rx0.u8"), str(tmp_path / "rx1.u8"), fmt='u8'),
+               "c64": lambda: FileSource(str(tmp_path / "rx0.c64"), str(tmp_path / "rx1.c64"), fmt='c64')}
+    for name, make in sources.items():
+        path = str(tmp_path / (name + ".csv"))
+        src = make()
+        cor = Correlator(num_samp=num_samp, nbins=nbins, source=src, output_file=path)
+        assert cor.run_state_machine() == n_chunks - 1          # first pair calibrates; the 500 spare samples are dropped
+        assert src.closed
+        rows[name] = (np.loadtxt(path, dtype=np.complex128, delimiter=',', skiprows=2), cor.calibrated_delay)
+    np.testing.assert_array_equal(rows["u8"][0], rows["memory"][0])
+    assert rows["u8"][1] == rows["memory"][1] and abs(rows["u8"][1] * 2.4e6 - 2) < 0.5
+    # complex64 files: the float32-rounded samples move the calibrated delay by ~1e-14 s, i.e. the rot phase
+    # 2 pi f tau (f = 1.42 GHz) by ~1e-4 rad
+    assert abs(rows["c64"][1] - rows["memory"][1]) < 1e-12 and rel_err(rows["c64"][0], rows["memory"][0]) < 1e-3
+
+
 def test_delay_calibration_against_reference(plan_mod, torch, golden):
     """The reference's delay tests (tests/test_effex.py:92-121): 14 cases, |k - est*rate| < 0.5 sample and
     |k/rate - est| < 1e-6 s, plus agreement with the reference's own estimate (golden)."""

@@ -163,3 +163,30 @@ def test_csv_bytes_match_reference(tmp_path, golden, mode):
 def test_default_output_name():
     c = Correlator(source=SyntheticSource())
     assert c.output_file.startswith('visibilities_') and c.output_file.endswith('.csv')
+
+
+def test_file_source_reads_chunk_pairs(tmp_path):
+    """FileSource (recorded streams instead of the reference's live dongles, effex.py:81-82, 630-664): chunk by chunk,
+    bytes stay bytes, a trailing partial chunk is dropped."""
+    from effex_amd.correlator import FileSource
+    rng = np.random.default_rng(3)
+    raw = [rng.integers(0, 256, size=(1000 * 3 + 17, 2), dtype=np.uint8) for _ in range(2)]
+    for a in range(2):
+        raw[a].tofile(str(tmp_path / ("rx%d.u8" % a)))
+        (raw[a][:, 0] + 1j * raw[a][:, 1]).astype(np.complex64).tofile(str(tmp_path / ("rx%d.c64" % a)))
+    src = FileSource(str(tmp_path / "rx0.u8"), str(tmp_path / "rx1.u8"), fmt='u8', rs=2.4e6)
+    assert src.n_samples == 3017 and src.rs == 2.4e6
+    for c in range(3):
+        b0, b1 = src.read(1000)
+        assert b0.dtype == np.uint8 and b0.shape == (1000, 2)
+        np.testing.assert_array_equal(b0, raw[0][1000 * c:1000 * (c + 1)])
+        np.testing.assert_array_equal(b1, raw[1][1000 * c:1000 * (c + 1)])
+    assert src.read(1000) is None
+    src.close()
+    assert src.closed
+    src = FileSource(str(tmp_path / "rx0.c64"), str(tmp_path / "rx1.c64"), fmt='c64')
+    z0, z1 = src.read(2000)
+    assert z0.dtype == np.complex64 and len(z1) == 2000 and z1[5] == raw[1][5, 0] + 1j * raw[1][5, 1]
+    assert src.read(2000) is None
+    with pytest.raises(ValueError):
+        FileSource(str(tmp_path / "rx0.u8"), str(tmp_path / "rx1.u8"), fmt='s16')
