@@ -88,3 +88,38 @@ def test_bench_refuses_a_foreign_library(monkeypatch, tmp_path):
                           env=env, capture_output=True, text=True, timeout=120)
     assert proc.returncode != 0 and "in-tree library only" in proc.stderr
     assert _lib.is_in_tree()
+
+
+def test_header_and_library_from_plain_c(lib, tmp_path):
+    """include/fxcorr.h is a C header (C99, -pedantic) and libfxcorr.so links from a C program: what a cgo / JNI / FFI
+    binding of the reference's language would rely on."""
+    _run_c_program(tmp_path)
+
+
+@pytest.mark.gpu
+def test_plan_from_plain_c_on_the_gpu(lib, tmp_path):
+    """The same C program on a GPU box: creates a plan, reads its info, destroys it."""
+    _run_c_program(tmp_path)
+
+
+def _run_c_program(tmp_path):
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "use_fxcorr")
+    libdir = os.path.dirname(_lib.IN_TREE_LIB)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cabi", "use_fxcorr.c"), "-o", exe, "-L", libdir, "-lfxcorr",
+                    "-Wl,-rpath," + libdir], check=True)
+    env = dict(os.environ)
+    # the process needs a HIP runtime for libfxcorr's own dependency: torch's copy or ROCm's
+    try:
+        import torch
+        env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    except ImportError:
+        pass
+    proc = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, (proc.returncode, proc.stdout, proc.stderr)
+    assert "c-abi ok" in proc.stdout
