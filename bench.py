@@ -364,9 +364,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     n_dev = torch.cuda.device_count()
-    if local_rank >= n_dev and args.dist_backend == "nccl":
-        raise SystemExit("rank %d has no GPU of its own (%d visible): RCCL needs one GPU per rank" % (local_rank, n_dev))
-    gpu = local_rank % n_dev
+    gpu = local_rank % n_dev          # (a launcher may also show every rank just its own GPU: then this is device 0)
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
     if world > 1:
@@ -390,8 +388,8 @@ def main():
     comm, comm_note = None, None
     if world > 1 and args.reduce == "rccl":
         try:
-            if n_dev < world:
-                raise RuntimeError("ranks share GPUs: RCCL wants one GPU per rank")
+            if args.dist_backend != "nccl":
+                raise RuntimeError("ranks share GPUs in the gloo test set-up: RCCL wants one GPU per rank")
             comm = sharding.make_comm(gpu, rank, world)
         except Exception as exc:                  # RCCL not usable: torch.distributed carries the reduce
             comm, comm_note = None, "no RCCL communicator (%s)" % exc
