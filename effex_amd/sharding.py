@@ -60,8 +60,15 @@ def make_comm(device, rank, world_size, group=None):
         return None
     import torch.distributed as dist
     from .plan import RcclComm
-    box = [RcclComm.unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = RcclComm.unique_id()
+        except Exception as exc:        # librccl not bindable: tell every rank instead of leaving them in the broadcast
+            box[0] = exc
     dist.broadcast_object_list(box, src=0, group=group)
+    if isinstance(box[0], Exception):
+        raise RuntimeError("rank 0 could not draw an RCCL unique id: {}".format(box[0]))
     return RcclComm(device, rank, world_size, box[0])
 
 
