@@ -223,3 +223,46 @@ def test_bench_dry_run_dist_two_ranks():
     assert line["dry_run"] and line["n_gpus"] == 2 and line["steps"] == 3 and line["frames_per_rank"] == 100
     assert line["first_chunk_last_rank"] == 100 and line["transport"] == "torch.distributed"
     assert line["mean_chunk_index"] == 99.5      # mean over both ranks' chunk ranges: the reduce reached the root
+
+
+def _comm_worker(rank, world, port, queue):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from effex_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        try:
+            comm = sharding.make_comm(0, rank, world)
+            queue.put((rank, "comm", None))
+            comm.close()
+        except Exception as exc:          # no GPU here: every rank must come back with an error, none may hang
+            queue.put((rank, "error", str(exc)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_make_comm_fails_on_every_rank_without_a_gpu():
+    """sharding.make_comm without GPUs (this container): the unique id is drawn and broadcast, fxc_comm_create refuses on
+    every rank (no HIP device) — nobody is left waiting in a collective, which is what bench.py's fall-back to the
+    torch.distributed transport relies on."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: communicator creation would succeed or need one GPU per rank")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(queue.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == ["error", "error"], got
+    assert all("device" in g[2].lower() or "rccl" in g[2].lower() for g in got), got
