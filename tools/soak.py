@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Developer aid: randomized differential soak of every fast path against the generic kernels (which share no code with
+them) for a time budget — wider and longer than the randomized tests in tests/test_gpu_parity.py.
+
+    python tools/soak.py --seconds 240 [--seed 1]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def rel_err(a, b):
+    import numpy as np
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-30))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from effex_amd import synth
+    from effex_amd.plan import FxPlan
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    n = 0
+    worst = {}
+    while time.time() < t_end:
+        nchan = int(rng.choice([1, 64, 256, 512, 1024, 2048, 4096, 4096, 4096, 8192]))
+        ntaps = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8, 9, 16, 17, 32]))
+        n_ant = int(rng.choice([2, 2, 2, 2, 3, 4, 8]))
+        if nchan == 1:
+            n_ant, ntaps = 2, int(rng.choice([1, 3, 4, 7]))
+        frames = int(rng.integers(1, 80 if nchan <= 1024 else 30))
+        n_chunks = int(rng.choice([1, 2, 3, 5, 17, 64, 255, 257, 300, 600]))
+        budget = 3.0e7          # complex samples per case
+        num_samp = max(nchan, 1) * frames + int(rng.integers(0, max(nchan, 2)))
+        if nchan == 1:
+            num_samp = int(rng.integers(ntaps + 1, 70000))
+        n_chunks = max(1, min(n_chunks, int(budget // (n_ant * num_samp))))
+        x = torch.from_numpy(synth.synth_iq(int(rng.integers(1, 1 << 30)), n_chunks, n_ant, num_samp)).cuda()
+        window = np.linspace(0.4, 0.1, ntaps) if nchan == 1 else None
+        tag = dict(nchan=nchan, ntaps=ntaps, n_ant=n_ant, frames=frames, n_chunks=n_chunks, num_samp=num_samp)
+        try:
+            with FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as f, \
+                    FxPlan(n_ant, nchan, ntaps, num_samp, window=window, path="generic") as g:
+                rf, rg = f.fx_rows(x).cpu().numpy(), g.fx_rows(x).cpu().numpy()
+                e_rows = rel_err(rf, rg)
+                f.fx_accumulate(x[: n_chunks // 2])
+                f.fx_accumulate(x[n_chunks // 2:])
+                e_int = rel_err(f.finalize("SPECTRUM"), rg.astype(np.complex128).mean(axis=0))
+                cf_, cg_ = f.fx_rows(x, "CONTINUUM", 2.4e6).cpu().numpy(), g.fx_rows(x, "CONTINUUM", 2.4e6).cpu().numpy()
+                e_cont = rel_err(cf_, cg_)
+                path = f.path
+        except Exception as exc:
+            print(json.dumps({"FAILED": str(exc), **tag}), flush=True)
+            raise
+        tol = 2e-5 if nchan == 1 else 6e-6
+        key = (path, nchan if nchan in (1, 4096, 8192) else 0, ntaps > 4)
+        worst[key] = max(worst.get(key, 0.0), e_rows, e_int)
+        if not (e_rows < tol and e_int < tol and e_cont < 5e-5):
+            print(json.dumps({"MISMATCH": [e_rows, e_int, e_cont], "path": path, **tag}), flush=True)
+            raise SystemExit(1)
+        n += 1
+    print(json.dumps({"cases": n, "seconds": args.seconds, "seed": args.seed,
+                      "worst_rel_err_by_path": {str(k): v for k, v in sorted(worst.items())}}))
+
+
+if __name__ == "__main__":
+    main()
