@@ -7,7 +7,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libfxcorr.so")
-SOURCES = ["fxcorr.hip", "fx_math.h", "fx_fused4096.h", "fx_tiled.h", os.path.join("..", "..", "include", "fxcorr.h")]
+# one translation unit: fxcorr.hip (the C ABI) includes the kernel (k_*.h), phase (fx_*.h) and host (h_*.h) parts
+
+
+def sources():
+    parts = sorted(f for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".hip"))
+    return parts + [os.path.join("..", "..", "include", "fxcorr.h")]
+
+
+
 # -fno-slp-vectorize: packed f32 VALU runs at the scalar-f32 rate on gfx950 and the v_pk_* forms cost
 # operand-shuffling moves, so SLP packing of the butterflies is a net loss (MI355X_MICROARCH.md).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
@@ -24,7 +32,7 @@ def up_to_date():
     if not os.path.isfile(LIB):
         return False
     t = os.path.getmtime(LIB)
-    return all(os.path.getmtime(os.path.join(CSRC, s)) <= t for s in SOURCES)
+    return all(os.path.getmtime(os.path.join(CSRC, s)) <= t for s in sources())
 
 
 def build(force=False, verbose=False):

@@ -1,0 +1,376 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+// per-path launchers: which kernels a pass over a batch of chunks takes, and how the workspace is cut into passes
+
+namespace {
+
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8 = nullptr,
+                 int64_t unit = 1, bool rows_are_chunks = true, int64_t num_samp = 0);
+
+// F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
+int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams);
+
+int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
+    if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
+    // the F-only tiled kernel writes natural-order spectra straight to `spec` (no workspace): any caller may use it
+    if (p->tiled_f) return tiled_channelize(p, x, spec, n_streams);
+    const int64_t total = n_streams * p->n_pts * p->nchan;
+    hipLaunchKernelGGL(pfb_fir_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream, x, p->d_win,
+                       spec, p->num_samp, p->nchan, p->ntaps, p->n_pts, total);
+    const int64_t rows = n_streams * p->n_pts;
+    if (p->nchan > 1) {
+        const int grid = (int)std::min<int64_t>(rows, (int64_t)p->cu_count * 4);
+        const size_t lds = (size_t)std::max(p->nchan, p->pow2 ? 512 : 0) * sizeof(cf);   // small N: 512 / N rows per workgroup
+        if (p->pow2)
+            hipLaunchKernelGGL(fft_pow2_kernel, dim3(grid), dim3(256), lds, p->stream, spec, p->d_tw, p->nchan,
+                               p->lg2n, rows);
+        else
+            hipLaunchKernelGGL(dft_any_kernel, dim3(grid), dim3(256), lds, p->stream, spec, p->d_tw, p->nchan, rows);
+    }
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+struct XGeom {
+    int kx, n_splits;
+};
+
+XGeom x_geometry(const fxc_plan* p) {
+    XGeom g;
+    g.kx = 1;
+    while (g.kx < 256 && g.kx < p->nchan) g.kx <<= 1;
+    const int iy = 256 / g.kx;
+    int64_t splits = (p->n_pts + (int64_t)iy * 64 - 1) / ((int64_t)iy * 64);
+    if (splits < 1) splits = 1;
+    if (splits > 256) splits = 256;
+    g.n_splits = (int)splits;
+    return g;
+}
+
+// chunks per pass on the generic path so that spectra + raw sums fit the workspace target
+int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom& g, int64_t* spec_bytes,
+                                int64_t* raw_bytes) {
+    const int64_t spec_per_chunk = (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
+    const int64_t raw_per_chunk = (int64_t)g.n_splits * p->n_base * p->nchan * (int64_t)sizeof(cf);
+    int64_t cb = kWorkspaceTarget / std::max<int64_t>(1, spec_per_chunk + raw_per_chunk);
+    if (cb < 1) cb = 1;
+    if (cb > n_chunks) cb = n_chunks;
+    *spec_bytes = (cb * spec_per_chunk + 255) / 256 * 256;
+    *raw_bytes = cb * raw_per_chunk;
+    return cb;
+}
+
+constexpr int kFusedReduceSplits = 256;   // most splits of the two-stage reduce over raw rows (size of `part`)
+// splits that leave each thread of stage 1 about four rows to walk
+int fused_reduce_splits(int64_t n_rows) { return (int)std::max<int64_t>(16, std::min<int64_t>(kFusedReduceSplits, n_rows / 4)); }
+
+// workgroups of a fused launch over n_pairs chunk pairs: one per CU; a launch with fewer chunks than that is all
+// tail (frame ranges), on fewer workgroups when a range would be under four frames (each reloads up to three
+// frames of history)
+int fused_grid(const fxc_plan* p, int64_t n_pairs) {
+    if (n_pairs >= p->fused_grid_max) return p->fused_grid_max;
+    const int64_t frames = n_pairs * p->n_pts;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(frames / 4, p->fused_grid_max));
+}
+
+// chunks per raw row when only the integration is wanted: float32 sums of up to 256 spectra
+int64_t fused_unit(const fxc_plan* p) { return std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(1, p->n_pts), 64)); }
+
+// raw rows a 2-antenna fused launch over nc chunks writes (leading-part rows included)
+int64_t fused_rows(const fxc_plan* p, int64_t nc, int64_t unit, bool rows_are_chunks) {
+    return fxc::fused::range_split(fused_grid(p, nc), (int)nc, (int)p->fused_seg, (int)unit, rows_are_chunks).n_rows;
+}
+
+LeadRows fused_lead(const fxc_plan* p, int64_t nc) {
+    const fxc::fused::RangeSplit sp = fxc::fused::range_split(fused_grid(p, nc), (int)nc, (int)p->fused_seg, 1, true);
+    LeadRows lr;
+    lr.first_chunk = sp.n_full;
+    lr.n_frames = sp.n_tail * p->n_pts;
+    lr.n_pts = p->n_pts;
+    lr.offset = nc * (int64_t)fxc::fused::kN;
+    lr.grid = fused_grid(p, nc);
+    return lr;
+}
+const LeadRows kNoLead = {0, 0, 0, 0, 0};
+
+// n_pairs = pairs of consecutive antenna streams to channelise; spec_out: write spectra instead of X sums
+// dc_u8 != nullptr: x is the uint8 I,Q stream and dc_u8 its per-stream conversion offsets (2 antennas, X fused in)
+// unit / rows_are_chunks: the raw-row layout (fx_fused4096.h::RangeWalk)
+int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8, int64_t unit,
+                 bool rows_are_chunks, int64_t num_samp) {
+    using namespace fxc::fused;
+    if (num_samp == 0) num_samp = p->num_samp;      // (the 8192-channel split runs on half-size streams)
+    const int grid = fused_grid(p, n_pairs);
+    const int seg = (int)p->fused_seg;
+    if (n_pairs * p->n_pts >= (1ll << 31)) return fail(p, FXC_ERR_ARG, "more than 2^31 frames in one launch");
+    unsigned long long* stamps = nullptr;
+#if FXC_STAMPS
+    if (!p->d_stamps) FXC_HIP(p, hipMalloc(&p->d_stamps, (size_t)p->fused_grid_max * 8 * kStampSegs * 8));
+    FXC_HIP(p, hipMemsetAsync(p->d_stamps, 0, (size_t)p->fused_grid_max * 8 * kStampSegs * 8, p->stream));
+    stamps = p->d_stamps;
+    p->stamp_grid = grid;
+#endif
+    KernelTimer kt(p);
+    if (dc_u8)
+        hipLaunchKernelGGL((fx_fused4096_kernel<false, true>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
+                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, seg, (int)unit,
+                           rows_are_chunks ? 1 : 0);
+    else if (spec_out)
+        hipLaunchKernelGGL((fx_fused4096_kernel<true, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
+                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
+                           seg, 1, 1);
+    else
+        hipLaunchKernelGGL((fx_fused4096_kernel<false, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
+                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
+                           seg, (int)unit, rows_are_chunks ? 1 : 0);
+    kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+// layout of the raw per-chunk sums the fused paths produce (see raw_index)
+int fused_layout(const fxc_plan* p) { return p->n_ant == 2 ? 1 : (p->path == FXC_PATH_FUSED ? 2 : 0); }
+
+// chunks per pass on the fused paths: 2 antennas only need the raw rows; more antennas also the spectra
+int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec_bytes, int64_t* raw_bytes) {
+    const int64_t raw_per_chunk = (int64_t)p->n_base * p->nchan * (int64_t)sizeof(cf);
+    const int64_t spec_per_chunk = p->n_ant == 2 ? 0 : (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
+    int64_t cb = kWorkspaceTarget / (raw_per_chunk + spec_per_chunk);
+    if (cb < 1) cb = 1;
+    if (cb > n_chunks) cb = n_chunks;
+    if (p->n_ant > 2 && cb > 65535) cb = 65535;   // xengine_kernel carries the chunk in grid.y
+    *spec_bytes = (cb * spec_per_chunk + 255) / 256 * 256;
+    // 2 antennas: one leading-part row per workgroup after the chunk rows (fx_fused4096_kernel)
+    *raw_bytes = ((cb + (p->n_ant == 2 ? p->fused_grid_max : 0)) * raw_per_chunk + 255) / 256 * 256;
+    return cb;
+}
+
+// raw[c][p][layout] for nc chunks starting at x; spec = scratch for the multi-antenna path.  2 antennas: rows of
+// `unit` chunks + leading-part rows (fused_rows() of them in all)
+int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, const cf* dc_u8 = nullptr, int64_t unit = 1,
+                   bool rows_are_chunks = true) {
+    using namespace fxc::fused;
+    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8, unit, rows_are_chunks);
+    // 4 / 6 / 8 antennas: spectra to HBM (the F-only fused kernel in its own spectrum order at nchan 4096 / ntaps 4,
+    // the F-only tiled kernel in natural order otherwise), then the register-resident X-engine.  unit = chunks per
+    // raw row here too: ceil(nc / unit) rows come out
+    int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
+                                       : tiled_channelize(p, x, spec, nc * p->n_ant);
+    if (rc) return rc;
+    const int cg = (int)unit;
+    const dim3 grid(p->nchan / 256, (unsigned)((nc + cg - 1) / cg));
+    switch (p->n_ant) {
+        case 3: hipLaunchKernelGGL(xengine_kernel<3>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 4: hipLaunchKernelGGL(xengine_kernel<4>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 5: hipLaunchKernelGGL(xengine_kernel<5>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 6: hipLaunchKernelGGL(xengine_kernel<6>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 7: hipLaunchKernelGGL(xengine_kernel<7>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 8: hipLaunchKernelGGL(xengine_kernel<8>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        default: return fail(p, FXC_ERR_UNSUPPORTED, "no X-engine instantiation for n_ant=%d", p->n_ant);
+    }
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+// ---- tiled path -------------------------------------------------------------------------------------
+template <class G, bool SPEC>
+const void* tiled_fn(const fxc_plan* p, int* lds) {
+    *lds = G::kLdsBytes;
+    if constexpr (G::N <= 4096) {
+        if (p->tiled_ring) {
+            *lds = G::kLdsBytesRing;
+            return reinterpret_cast<const void*>(&fx_tiled_ring_kernel<G, SPEC, false>);
+        }
+    }
+    return reinterpret_cast<const void*>(&fx_tiled_kernel<G, SPEC>);
+}
+
+template <class G>
+int tiled_setup(fxc_plan* p) {
+    for (int spec = 0; spec < 2; ++spec) {
+        int lds = 0;
+        const void* fn = spec ? tiled_fn<G, true>(p, &lds) : tiled_fn<G, false>(p, &lds);
+        FXC_HIP(p, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int per_cu = 0;
+        FXC_HIP(p, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, G::kThreads, lds));
+        if (per_cu < 1) return fail(p, FXC_ERR_HIP, "tiled kernel for nchan=%d does not fit a CU", G::N);
+        (spec ? p->tiled_grid_max_f : p->tiled_grid_max) = per_cu * p->cu_count;
+    }
+    if constexpr (G::N <= 4096) {
+        if (p->tiled_ring)   // the uint8-ingest variant shares the F+X variant's launch geometry
+            FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_tiled_ring_kernel<G, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytesRing));
+    }
+    return FXC_OK;
+}
+
+// SPEC: x = n_streams consecutive streams, nc = pairs of them, raw = spectra [stream][i][k]
+template <class G, bool SPEC>
+void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, int64_t n_streams, const cf* dc_u8 = nullptr) {
+    const int grid = (int)std::min<int64_t>(nc * n_splits, SPEC ? p->tiled_grid_max_f : p->tiled_grid_max);
+    if constexpr (G::N <= 4096) {
+        if (p->tiled_ring) {
+            if constexpr (!SPEC) {
+                if (dc_u8) {   // uint8 ingest: x is the byte stream
+                    hipLaunchKernelGGL((fx_tiled_ring_kernel<G, false, true>), dim3(grid), dim3(G::kThreads), G::kLdsBytesRing,
+                                       p->stream, x, p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1,
+                                       p->d_tw2, raw, n_streams, dc_u8);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((fx_tiled_ring_kernel<G, SPEC, false>), dim3(grid), dim3(G::kThreads), G::kLdsBytesRing,
+                               p->stream, x, p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw,
+                               n_streams, (const cf*)nullptr);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((fx_tiled_kernel<G, SPEC>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, p->stream, x, p->num_samp,
+                       p->n_pts, nc, n_splits, p->prefilter ? 1 : p->ntaps, p->prefilter ? p->d_ones : p->d_win, p->d_tw0,
+                       p->d_tw1, p->d_tw2, raw, n_streams);
+}
+
+#define FXC_TILED_DISPATCH(p, CALL)                                                   \
+    switch ((p)->nchan) {                                                             \
+        case 512: { using G = fxc::tiled::Geo<2, false>; CALL; } break;               \
+        case 1024: { using G = fxc::tiled::Geo<4, false>; CALL; } break;              \
+        case 2048: { using G = fxc::tiled::Geo<8, false>; CALL; } break;              \
+        case 4096: { using G = fxc::tiled::Geo<1, true>; CALL; } break;               \
+        case 8192: { using G = fxc::tiled::Geo<2, true>; CALL; } break;               \
+        default: return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for nchan=%d", (p)->nchan); \
+    }
+
+// this call goes through the tiled kernels.  (Round 1 also sent few-chunk calls on the headline shape here to split a
+// chunk's frames over workgroups; the fused kernel's frame ranges do that themselves now, faster: one reference-sized
+// call 25 us against 56.)
+bool use_tiled(const fxc_plan* p, int64_t) { return p->path == FXC_PATH_TILED; }
+
+bool tiled_nchan(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
+
+// frame ranges per chunk so that a launch has at least ~2 work items per resident workgroup
+int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false) {
+    const int64_t cap = f_only ? p->tiled_grid_max_f : p->tiled_grid_max;
+    const int64_t want = (2 * cap + n_chunks - 1) / n_chunks;
+    const int64_t most = std::max<int64_t>(1, p->n_pts / 8);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 256));
+}
+
+// streams the pre-filter handles per pass (its output stays within the workspace target)
+int64_t prefilter_streams_per_pass(const fxc_plan* p) {
+    if (!p->prefilter) return INT64_MAX;
+    int64_t n = kWorkspaceTarget / (p->num_samp * (int64_t)sizeof(cf));
+    n = std::min<int64_t>(n, 65534) & ~(int64_t)1;      // grid.y carries the stream; whole pairs
+    return std::max<int64_t>(2, n);
+}
+
+// y = pre-filtered copy of n_streams streams (plan buffer, grown on demand)
+int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_out) {
+    const int rg = grow(p, &p->d_pre, &p->pre_bytes, (size_t)n_streams * p->num_samp * sizeof(cf));
+    if (rg) return rg;
+    cf* y = static_cast<cf*>(p->d_pre);
+    const int tp = p->pre_tp;
+    // frame splits so that a few-stream call still fills the chip; each split reloads one block of history
+    const int64_t blocks = (int64_t)(p->nchan / 256) * n_streams;
+    int64_t fs = std::max<int64_t>(1, (2 * (int64_t)p->cu_count + blocks - 1) / blocks);
+    fs = std::min<int64_t>(fs, std::max<int64_t>(1, p->n_pts / (4 * tp)));
+    const int64_t per = ((p->n_pts + fs - 1) / fs + 2 * tp - 1) / (2 * tp) * (2 * tp);
+    const dim3 grid((unsigned)(p->nchan / 256), (unsigned)n_streams, (unsigned)((p->n_pts + per - 1) / per));
+    if (tp == 8)
+        hipLaunchKernelGGL(pfb_prefilter_kernel<8>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, p->n_pts, per);
+    else if (tp == 16)
+        hipLaunchKernelGGL(pfb_prefilter_kernel<16>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, p->n_pts, per);
+    else
+        hipLaunchKernelGGL(pfb_prefilter_kernel<32>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, p->n_pts, per);
+    FXC_HIP(p, hipGetLastError());
+    *y_out = y;
+    return FXC_OK;
+}
+
+// raw[split][c][k] (natural bin order) for nc chunks starting at x (nc * 2 <= prefilter_streams_per_pass())
+int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
+    KernelTimer kt(p);
+    if (p->prefilter && !dc_u8) {
+        const int rc = tiled_prefilter(p, x, 2 * nc, &x);
+        if (rc) return rc;
+    }
+    FXC_TILED_DISPATCH(p, (tiled_launch<G, false>(p, x, nc, n_splits, raw, 2 * nc, dc_u8)));
+    kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+// F-stage only: n_streams consecutive streams -> spec[stream][i][k], pairs of streams per work item
+int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
+    KernelTimer kt(p);
+    const int64_t per_pass = prefilter_streams_per_pass(p);
+    for (int64_t s0 = 0; s0 < n_streams; s0 += per_pass) {
+        const int64_t ns = std::min(per_pass, n_streams - s0);
+        const cf* xs = x + s0 * p->num_samp;
+        if (p->prefilter) {
+            const int rc = tiled_prefilter(p, xs, ns, &xs);
+            if (rc) return rc;
+        }
+        const int64_t pairs = (ns + 1) / 2;
+        const int n_splits = tiled_splits(p, pairs, true);
+        FXC_TILED_DISPATCH(p, (tiled_launch<G, true>(p, xs, pairs, n_splits, spec + s0 * p->n_pts * p->nchan, ns)));
+    }
+    kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+// ---- nchan 8192 as two 4096-channel problems (pfb_split8192_kernel) ---------------------------------
+int64_t split_chunks_per_pass(const fxc_plan* p, int64_t n_chunks) {
+    const int64_t per_chunk = 4 * p->n_pts * 4096 * (int64_t)sizeof(cf) + 2 * 4096 * (int64_t)sizeof(cf);   // y + two raw rows
+    return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, 32767), kWorkspaceTarget / per_chunk));
+}
+
+// raw = the fused kernel's rows over 2 nc chunk pairs (+ leading-part rows) for nc chunks of 8192-channel input
+int split_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* raw) {
+    const int64_t half_samp = p->n_pts * 4096;
+    int rc = grow(p, &p->d_pre, &p->pre_bytes, (size_t)nc * 4 * half_samp * sizeof(cf));
+    if (rc) return rc;
+    cf* y = static_cast<cf*>(p->d_pre);
+    const int tp = p->pre_tp;
+    const int64_t blocks = 16 * 2 * nc;
+    int64_t fs = std::max<int64_t>(1, (2 * (int64_t)p->cu_count + blocks - 1) / blocks);
+    fs = std::min<int64_t>(fs, std::max<int64_t>(1, p->n_pts / (4 * tp)));
+    const int64_t per = ((p->n_pts + fs - 1) / fs + 2 * tp - 1) / (2 * tp) * (2 * tp);
+    const dim3 grid(16, (unsigned)(2 * nc), (unsigned)((p->n_pts + per - 1) / per));
+    KernelTimer kt(p);
+    if (tp == 4)
+        hipLaunchKernelGGL(pfb_split8192_kernel<4>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, p->n_pts, per);
+    else if (tp == 8)
+        hipLaunchKernelGGL(pfb_split8192_kernel<8>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, p->n_pts, per);
+    else
+        hipLaunchKernelGGL(pfb_split8192_kernel<16>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, p->n_pts, per);
+    FXC_HIP(p, hipGetLastError());
+    kt.stop();
+    return launch_fused(p, y, 2 * nc, raw, false, nullptr, 1, true, half_samp);
+}
+
+// nchan == 1 streaming path: raw[block][chunk] partial sums for nc chunks
+bool stream_is_t4(const fxc_plan* p) { return p->ntaps <= 4 && (p->num_samp % 2) == 0; }
+
+int64_t stream_blocks(const fxc_plan* p) {
+    return stream_is_t4(p) ? kStream4Blocks : (p->num_samp + kStreamBlock - 1) / kStreamBlock;
+}
+
+int stream_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* raw) {
+    const int blocks = (int)stream_blocks(p);
+    KernelTimer kt(p);
+    if (stream_is_t4(p)) {
+        // 16-byte loads need 16-byte aligned streams: x from hipMalloc / torch is, and num_samp is even
+        hipLaunchKernelGGL(stream1_t4_kernel, dim3(blocks, (unsigned)nc), dim3(256), 0, p->stream, x, raw, p->num_samp,
+                           p->taps.h[0], p->taps.h[1], p->taps.h[2], p->taps.h[3], nc);
+    } else {
+        const size_t lds = (size_t)2 * (kStreamBlock + p->ntaps - 1) * sizeof(cf);
+        hipLaunchKernelGGL(stream1_kernel, dim3(blocks, (unsigned)nc), dim3(256), lds, p->stream, x, raw, p->num_samp,
+                           p->ntaps, p->taps, nc);
+    }
+    kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+}  // namespace

@@ -1,0 +1,209 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_lib_error;
+
+}  // namespace
+
+
+// ------------------------------------------------------------------------------------------
+// host-fed front end: double-buffered pinned staging, H2D / compute / D2H on three
+// streams chained by events, so batch k+1 crosses PCIe while batch k is on the CUs.  Replaces the
+// reference's per-chunk blocking copies (effex/effex.py:391-392, 508-509, 693).
+// ------------------------------------------------------------------------------------------
+struct fxc_pipe_slot {
+    void* h_in = nullptr;    // pinned
+    void* h_out = nullptr;   // pinned
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    hipEvent_t ev_in = nullptr, ev_compute = nullptr, ev_out = nullptr;
+    bool busy = false;
+};
+
+struct fxc_plan {
+    int device = 0, cu_count = 0;
+    int n_ant = 0, n_base = 0, nchan = 0, ntaps = 0;
+    int64_t num_samp = 0, n_pts = 0;
+    int path = FXC_PATH_GENERIC;
+    bool pow2 = false;
+    int lg2n = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_order = nullptr;   // orders the old stream's work before the new one's (fxc_set_stream)
+    int live_pipes = 0;              // fxc_pipe objects that hold a pointer to this plan
+    // device tables
+    float* d_win = nullptr;        // [ntaps*nchan] float (generic)
+    cf* d_tw = nullptr;            // generic FFT twiddles
+    cd* d_rot = nullptr;           // [nchan]
+    f4* d_win4 = nullptr;          // fused
+    cf* d_tw1 = nullptr;
+    cf* d_tw2 = nullptr;
+    cf* d_tw0 = nullptr;           // tiled: pre-stage twiddles [16][nchan/16]
+    int tiled_grid_max = 0, tiled_grid_max_f = 0;   // resident workgroups of the F+X / F-only tiled kernels
+    bool tiled_f = false;          // the F-only tiled kernel serves fxc_channelize
+    bool tiled_ring = false;       // ntaps <= 4 and nchan <= 4096: VGPR frame ring + window in LDS
+    bool prefilter = false;        // ntaps > 4: pfb_prefilter_kernel first, then the tiled kernels with one unit tap
+    int pre_tp = 0;                // its register block: 8, 16 or 32 frames
+    float* d_hpre = nullptr;       // [pre_tp][nchan] reversed polyphase coefficients
+    float* d_ones = nullptr;       // [nchan] unit window of the plain tiled kernel behind the pre-filter
+    void* d_pre = nullptr;         // pre-filtered streams of one pass
+    size_t pre_bytes = 0;
+    bool split8192 = false;        // nchan 8192, 2 antennas: pfb_split8192_kernel + the 4096-channel fused kernel
+    cf* d_tw8192 = nullptr;        // [4096] w8192^(4095 - n')
+    unsigned long long* d_stamps = nullptr;   // diagnostic builds only
+    int fused_grid_max = 0;
+    int64_t fused_seg = 1;         // chunks per round-robin segment of the fused kernel (fx_fused4096.h::RangeWalk)
+    cd* d_acc = nullptr;           // [n_base*nchan]
+    cd* d_sums = nullptr;          // [n_base*nchan + 1]
+    cd* d_out = nullptr;           // finalize staging [n_base*nchan]
+    cd* h_out = nullptr;           // its pinned host mirror: a D2H copy into pageable memory costs ~30 us of staging
+    double spectra_count = 0.0;
+    // workspace (grown on demand)
+    void* d_ws = nullptr;
+    int64_t ws_bytes = 0;
+    void* d_stage[3] = {nullptr, nullptr, nullptr};   // host-buffer calls: device copies of x and out; uint8 calls on
+    size_t stage_bytes[3] = {0, 0, 0};                // plans without the fused ingest: the converted samples
+    void* d_dc = nullptr;                            // uint8 ingest: byte sums + conversion offsets per stream
+    size_t dc_bytes = 0;
+    // timing
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+    double kernel_ms = 0.0;
+    int64_t kernel_launches = 0;
+    int stamp_grid = 0;
+    StreamTaps taps;               // nchan == 1: the FIR taps by value
+    mutable std::string error;
+};
+
+struct fxc_pipe {
+    fxc_plan* plan = nullptr;
+    int64_t chunks = 0;
+    int depth = 0, mode = FXC_MODE_SPECTRUM;
+    double bandwidth = 1.0;
+    size_t in_bytes = 0, out_bytes = 0;
+    bool counted = false;      // registered in plan->live_pipes
+    bool u8 = false;           // batches are RTL-SDR byte pairs (fxc_pipe_create_u8)
+    int remove_dc = 0;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<fxc_pipe_slot> slots;
+    int64_t pushed = 0, popped = 0;
+};
+
+namespace {
+
+
+int fail(const fxc_plan* p, int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (p)
+        p->error = buf;
+    else
+        g_lib_error = buf;
+    return status;
+}
+
+// Every ABI entry runs on the plan's device and leaves the caller's current device as it found it (a process
+// that drives several GPUs, or torch's own notion of the current device, must not see it change).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false, ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) {
+            ok = hipSetDevice(device) == hipSuccess;
+            changed = ok && prev >= 0;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define FXC_DEVICE(p, device)                                                                  \
+    DeviceGuard device_guard__(device);                                                        \
+    if (!device_guard__.ok) return fail(p, FXC_ERR_HIP, "hipSetDevice(%d) failed", (int)(device))
+
+#define FXC_HIP(p, call)                                                                                       \
+    do {                                                                                                       \
+        hipError_t e__ = (call);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return fail(p, e__ == hipErrorOutOfMemory ? FXC_ERR_NOMEM : FXC_ERR_HIP, "%s failed: %s", #call,   \
+                        hipGetErrorString(e__));                                                               \
+    } while (0)
+
+int grid_for(int64_t work_items, int block, int cu_count) {
+    int64_t g = (work_items + block - 1) / block;
+    const int64_t cap = (int64_t)cu_count * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int ensure_ws(fxc_plan* p, int64_t bytes) {
+    if (bytes <= p->ws_bytes) return FXC_OK;
+    if (p->d_ws) {
+        FXC_HIP(p, hipStreamSynchronize(p->stream));
+        FXC_HIP(p, hipFree(p->d_ws));
+        p->d_ws = nullptr;
+        p->ws_bytes = 0;
+    }
+    FXC_HIP(p, hipMalloc(&p->d_ws, (size_t)bytes));
+    p->ws_bytes = bytes;
+    return FXC_OK;
+}
+
+// grow-only device buffer owned by the plan (staging, conversion offsets)
+int grow(fxc_plan* p, void** buf, size_t* have, size_t want) {
+    if (want <= *have) return FXC_OK;
+    FXC_HIP(p, hipStreamSynchronize(p->stream));
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    const hipError_t e = hipMalloc(buf, want);
+    if (e != hipSuccess) return fail(p, FXC_ERR_NOMEM, "allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+    *have = want;
+    return FXC_OK;
+}
+
+struct KernelTimer {
+    fxc_plan* p;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit KernelTimer(fxc_plan* plan) : p(plan) {
+        if (p->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+            (void)hipEventRecord(a, p->stream);
+        else
+            a = b = nullptr;
+    }
+    void stop() {
+        if (a) {
+            (void)hipEventRecord(b, p->stream);
+            p->kev.emplace_back(a, b);
+            a = b = nullptr;
+        }
+    }
+};
+
+int drain_kernel_events(fxc_plan* p) {
+    for (auto& e : p->kev) {
+        FXC_HIP(p, hipEventSynchronize(e.second));
+        float ms = 0.f;
+        FXC_HIP(p, hipEventElapsedTime(&ms, e.first, e.second));
+        p->kernel_ms += ms;
+        p->kernel_launches += 1;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    p->kev.clear();
+    return FXC_OK;
+}
+}  // namespace

@@ -1,0 +1,61 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU reduce: one RCCL sum of the exported accumulators over xGMI, enqueued on the plan's
+// stream.  librccl is bound at run time (the copy the process already has -- PyTorch ships one -- else ROCm's), so
+// single-GPU users need no RCCL at all.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string error;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return &api;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)   // a copy that is already mapped wins: one RCCL per process
+        if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    for (size_t k = 0; !api.handle && k < sizeof names / sizeof *names; ++k) api.handle = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL);
+    if (!api.handle) {
+        const char* why = dlerror();
+        api.error = std::string("librccl not found: ") + (why ? why : "dlopen failed");
+        return &api;
+    }
+    bool ok = true;
+    auto bind = [&](const char* sym) {
+        void* f = dlsym(api.handle, sym);
+        if (!f) {
+            ok = false;
+            api.error = std::string("librccl lacks ") + sym;
+        }
+        return f;
+    };
+    api.get_unique_id = reinterpret_cast<decltype(api.get_unique_id)>(bind("ncclGetUniqueId"));
+    api.comm_init_rank = reinterpret_cast<decltype(api.comm_init_rank)>(bind("ncclCommInitRank"));
+    api.comm_destroy = reinterpret_cast<decltype(api.comm_destroy)>(bind("ncclCommDestroy"));
+    api.reduce = reinterpret_cast<decltype(api.reduce)>(bind("ncclReduce"));
+    api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(bind("ncclAllReduce"));
+    api.error_string = reinterpret_cast<decltype(api.error_string)>(bind("ncclGetErrorString"));
+    if (!ok) {
+        api.handle = nullptr;
+    }
+    return &api;
+}
+
+int rccl_fail(const fxc_plan* p, const RcclApi* api, const char* what, ncclResult_t r) {
+    return fail(p, FXC_ERR_COMM, "%s failed: %s", what, api->error_string ? api->error_string(r) : "RCCL error");
+}
+
+}  // namespace

@@ -1,0 +1,288 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+namespace {
+
+// device-resident implementation of fx_accumulate
+// dc_u8 != nullptr (fused 2-antenna plans only): x is the uint8 I,Q stream [n_chunks][2][num_samp][2] and dc_u8 its
+// per-stream conversion offsets
+int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u8 = nullptr) {
+    if (n_chunks == 0) return FXC_OK;
+    if (p->path == FXC_PATH_STREAM) {
+        const int64_t blocks = stream_blocks(p);
+        const int64_t cb = std::min<int64_t>(n_chunks, 65535);
+        int rc = ensure_ws(p, cb * blocks * (int64_t)sizeof(cf));
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = stream_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
+            if (rc) return rc;
+            hipLaunchKernelGGL(stream1_acc_kernel, dim3(1), dim3(256), 0, p->stream, raw, p->d_acc, nc * blocks);
+            FXC_HIP(p, hipGetLastError());
+        }
+    } else if ((p->path == FXC_PATH_FUSED && (dc_u8 || !use_tiled(p, n_chunks))) || (p->path == FXC_PATH_TILED && p->n_ant > 2)) {
+        using namespace fxc::fused;
+        const int64_t in_bytes = (int64_t)p->n_ant * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
+        int64_t spec_bytes, raw_bytes;
+        const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
+        const int64_t part_bytes = (int64_t)kFusedReduceSplits * kN * (int64_t)sizeof(cd);
+        int rc = ensure_ws(p, spec_bytes + raw_bytes + part_bytes);
+        if (rc) return rc;
+        cf* spec = reinterpret_cast<cf*>(p->d_ws);
+        cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
+        cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + spec_bytes + raw_bytes);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            const int64_t unit = fused_unit(p);
+            rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
+                                dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit, false);
+            if (rc) return rc;
+            if (p->n_ant == 2) {   // one baseline: two-stage reduce over all the raw rows (leading parts included)
+                const int64_t n_rows = fused_rows(p, nc, unit, false);
+                const int splits = fused_reduce_splits(n_rows);
+                hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, splits), dim3(256), 0, p->stream, raw, part, kN,
+                                   n_rows, splits);
+                hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 16), dim3(256), 0, p->stream, part, p->d_acc, kN, splits,
+                                   fused_layout(p));
+            } else {   // raw rows of `unit` chunks each
+                const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
+                hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream,
+                                   raw, p->d_acc, p->nchan, p->n_base, (nc + unit - 1) / unit, 1, fused_layout(p));
+            }
+            FXC_HIP(p, hipGetLastError());
+        }
+    } else if (p->split8192 && !dc_u8) {
+        const int N = p->nchan;
+        const int64_t cb = split_chunks_per_pass(p, n_chunks);
+        const int64_t row_bytes = (int64_t)fxc::fused::kN * (int64_t)sizeof(cf);
+        const int64_t raw_bytes = ((2 * cb + p->fused_grid_max) * row_bytes + 255) / 256 * 256;
+        const int64_t part_bytes = (int64_t)kFusedReduceSplits * N * (int64_t)sizeof(cd);
+        int rc = ensure_ws(p, raw_bytes + part_bytes);
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + raw_bytes);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = split_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
+            if (rc) return rc;
+            // the nc pairs of 4096-rows are nc rows of 8192 in layout 3; the leading-part rows are added by parity
+            const int splits = fused_reduce_splits(nc);
+            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(N / 256, splits), dim3(256), 0, p->stream, raw, part, N, nc, splits);
+            hipLaunchKernelGGL(fused_reduce2_kernel, dim3(N / 16), dim3(256), 0, p->stream, part, p->d_acc, N, splits, 3);
+            hipLaunchKernelGGL(split_lead_acc_kernel, dim3(N / 256), dim3(256), 0, p->stream, raw, p->d_acc, fused_lead(p, 2 * nc));
+            FXC_HIP(p, hipGetLastError());
+        }
+    } else if (use_tiled(p, n_chunks)) {
+        const int N = p->nchan;
+        const int64_t in_bytes = (int64_t)2 * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
+        const int n_splits = tiled_splits(p, n_chunks);
+        const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
+        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, prefilter_streams_per_pass(p) / 2),
+                                                                  kWorkspaceTarget / (row_bytes * n_splits)));
+        const int64_t raw_bytes = (cb * n_splits * row_bytes + 255) / 256 * 256;
+        const int64_t part_bytes = (int64_t)kFusedReduceSplits * N * (int64_t)sizeof(cd);
+        int rc = ensure_ws(p, raw_bytes + part_bytes);
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + raw_bytes);
+        const int kb = (N + 255) / 256;
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = tiled_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, n_splits,
+                                raw, dc_u8 ? dc_u8 + c0 * 2 : nullptr);
+            if (rc) return rc;
+            const int splits = fused_reduce_splits(nc * n_splits);
+            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kb, splits), dim3(256), 0, p->stream, raw, part, N, nc * n_splits,
+                               splits);
+            hipLaunchKernelGGL(fused_reduce2_kernel, dim3((N + 15) / 16), dim3(256), 0, p->stream, part, p->d_acc, N, splits, 0);
+            FXC_HIP(p, hipGetLastError());
+        }
+    } else {
+        const XGeom g = x_geometry(p);
+        int64_t spec_bytes, raw_bytes;
+        const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes);
+        int rc = ensure_ws(p, spec_bytes + raw_bytes);
+        if (rc) return rc;
+        cf* spec = reinterpret_cast<cf*>(p->d_ws);
+        cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            KernelTimer kt(p);
+            rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);
+            if (rc) return rc;
+            const int kblocks = (p->nchan + g.kx - 1) / g.kx;
+            const int64_t wgs = nc * p->n_base * kblocks * g.n_splits;
+            hipLaunchKernelGGL(xmul_kernel, dim3((int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8)), dim3(256), 0,
+                               p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
+            const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
+            hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream, raw,
+                               p->d_acc, p->nchan, p->n_base, nc, g.n_splits, 0);
+            kt.stop();
+            FXC_HIP(p, hipGetLastError());
+        }
+    }
+    p->spectra_count += (double)n_chunks * (double)p->n_pts;
+    return FXC_OK;
+}
+
+// device-resident implementation of fx_rows; out = cf[n_chunks][n_base][nchan] or cd[n_chunks][n_base]
+int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode, double bandwidth,
+                const cf* dc_u8 = nullptr) {
+    if (n_chunks == 0) return FXC_OK;
+    const float inv_pts = (float)(1.0 / (double)p->n_pts);
+    const double cscale = 1.0 / ((double)p->n_pts * (double)p->nchan * bandwidth);
+    if (p->path == FXC_PATH_STREAM) {
+        const int nb = (int)stream_blocks(p);
+        const int64_t cb = std::min<int64_t>(n_chunks, 65535);
+        int rc = ensure_ws(p, cb * nb * (int64_t)sizeof(cf));
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = stream_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
+            if (rc) return rc;
+            // raw[block][chunk]: the blocks play the role of the generic path's splits (nchan = n_base = 1)
+            if (mode == FXC_MODE_SPECTRUM)
+                hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc, 256, p->cu_count)), dim3(256), 0, p->stream, raw,
+                                   static_cast<cf*>(out) + c0, p->d_rot, 1, nc, nb, nc, inv_pts, 0, kNoLead);
+            else
+                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
+                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, 1, nc, nb, nc,
+                                   cscale, 0, kNoLead);
+            FXC_HIP(p, hipGetLastError());
+        }
+        return FXC_OK;
+    }
+    if ((p->path == FXC_PATH_FUSED && (dc_u8 || !use_tiled(p, n_chunks))) || (p->path == FXC_PATH_TILED && p->n_ant > 2)) {
+        const int64_t in_bytes = (int64_t)p->n_ant * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
+        int64_t spec_bytes, raw_bytes;
+        const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
+        int rc = ensure_ws(p, spec_bytes + raw_bytes);
+        if (rc) return rc;
+        cf* spec = reinterpret_cast<cf*>(p->d_ws);
+        cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
+                                dc_u8 ? dc_u8 + c0 * 2 : nullptr);
+            if (rc) return rc;
+            const int64_t rows = nc * p->n_base;
+            const LeadRows lead = p->n_ant == 2 ? fused_lead(p, nc) : kNoLead;
+            if (mode == FXC_MODE_SPECTRUM)
+                hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(rows * p->nchan, 256, p->cu_count)), dim3(256), 0,
+                                   p->stream, raw, static_cast<cf*>(out) + c0 * p->n_base * p->nchan, p->d_rot, p->nchan,
+                                   rows, 1, (int64_t)0, inv_pts, fused_layout(p), lead);
+            else
+                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
+                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot,
+                                   p->nchan, rows, 1, (int64_t)0, cscale, fused_layout(p), lead);
+            FXC_HIP(p, hipGetLastError());
+        }
+        return FXC_OK;
+    }
+    if (p->split8192 && !dc_u8) {
+        const int N = p->nchan;
+        const int64_t cb = split_chunks_per_pass(p, n_chunks);
+        int rc = ensure_ws(p, (2 * cb + p->fused_grid_max) * (int64_t)fxc::fused::kN * (int64_t)sizeof(cf));
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = split_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
+            if (rc) return rc;
+            const LeadRows lead = fused_lead(p, 2 * nc);
+            if (mode == FXC_MODE_SPECTRUM)
+                hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc * N, 256, p->cu_count)), dim3(256), 0, p->stream,
+                                   raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, 1, (int64_t)0, inv_pts, 3, lead);
+            else
+                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
+                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, 1, (int64_t)0,
+                                   cscale, 3, lead);
+            FXC_HIP(p, hipGetLastError());
+        }
+        return FXC_OK;
+    }
+    if (use_tiled(p, n_chunks)) {
+        const int N = p->nchan;
+        const int64_t in_bytes = (int64_t)2 * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
+        const int n_splits = tiled_splits(p, n_chunks);
+        const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
+        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, prefilter_streams_per_pass(p) / 2),
+                                                                  kWorkspaceTarget / (row_bytes * n_splits)));
+        int rc = ensure_ws(p, cb * n_splits * row_bytes);
+        if (rc) return rc;
+        cf* raw = reinterpret_cast<cf*>(p->d_ws);
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+            const int64_t nc = std::min(cb, n_chunks - c0);
+            rc = tiled_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, n_splits,
+                                raw, dc_u8 ? dc_u8 + c0 * 2 : nullptr);
+            if (rc) return rc;
+            if (mode == FXC_MODE_SPECTRUM)
+                hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc * N, 256, p->cu_count)), dim3(256), 0, p->stream,
+                                   raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, n_splits, nc * N, inv_pts, 0, kNoLead);
+            else
+                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
+                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, n_splits,
+                                   nc * N, cscale, 0, kNoLead);
+            FXC_HIP(p, hipGetLastError());
+        }
+        return FXC_OK;
+    }
+    const XGeom g = x_geometry(p);
+    int64_t spec_bytes, raw_bytes;
+    const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes);
+    int rc = ensure_ws(p, spec_bytes + raw_bytes);
+    if (rc) return rc;
+    cf* spec = reinterpret_cast<cf*>(p->d_ws);
+    cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
+        const int64_t nc = std::min(cb, n_chunks - c0);
+        KernelTimer kt(p);
+        rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);
+        if (rc) return rc;
+        const int kblocks = (p->nchan + g.kx - 1) / g.kx;
+        const int64_t wgs = nc * p->n_base * kblocks * g.n_splits;
+        hipLaunchKernelGGL(xmul_kernel, dim3((int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8)), dim3(256), 0,
+                           p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
+        kt.stop();
+        const int64_t rows = nc * p->n_base;
+        const int64_t split_stride = rows * p->nchan;
+        if (mode == FXC_MODE_SPECTRUM)
+            hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(rows * p->nchan, 256, p->cu_count)), dim3(256), 0,
+                               p->stream, raw, static_cast<cf*>(out) + c0 * p->n_base * p->nchan, p->d_rot, p->nchan,
+                               rows, g.n_splits, split_stride, inv_pts, 0, kNoLead);
+        else
+            hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
+                               dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot, p->nchan,
+                               rows, g.n_splits, split_stride, cscale, 0, kNoLead);
+        FXC_HIP(p, hipGetLastError());
+    }
+    return FXC_OK;
+}
+
+// host-buffer helper: stage in, run, stage out (synchronous)
+template <class Fn>
+int with_host_staging(fxc_plan* p, const void* x, size_t x_bytes, void* out, size_t out_bytes, Fn fn) {
+    // staging buffers live in the plan and only grow: the reference calls once per chunk pair (effex.py:490-494),
+    // and a hipMalloc / hipFree pair per call costs more than the copy of one chunk
+    const size_t want[2] = {x_bytes ? x_bytes : 1, out_bytes};
+    for (int k = 0; k < 2; ++k) {
+        const int rg = grow(p, &p->d_stage[k], &p->stage_bytes[k], want[k]);
+        if (rg) return rg;
+    }
+    void* dx = p->d_stage[0];
+    void* dout = out_bytes ? p->d_stage[1] : nullptr;
+    int rc = FXC_OK;
+    hipError_t e = hipMemcpyAsync(dx, x, x_bytes, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) rc = fn(static_cast<const cf*>(dx), dout);
+    if (e == hipSuccess && rc == FXC_OK && out_bytes)
+        e = hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, p->stream);
+    hipError_t e2 = hipStreamSynchronize(p->stream);
+    if (rc != FXC_OK) return rc;
+    if (e != hipSuccess) return fail(p, FXC_ERR_HIP, "host staging copy failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(p, FXC_ERR_HIP, "stream sync failed: %s", hipGetErrorString(e2));
+    return FXC_OK;
+}
+
+}  // namespace

@@ -1,0 +1,154 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// input conditioning: RTL-SDR uint8 IQ -> complex64 and per-chunk DC removal
+//   reference: pyrtlsdr packed-bytes-to-samples (byte - 127.5) / 127.5 [third party], and
+//   effex/effex.py:394-395  x = (x.real - x.real.mean()) + 1j * (x.imag - x.imag.mean())  per chunk, per antenna
+// ------------------------------------------------------------------------------------------
+// sums[stream] = {sum re, sum im} in float64; one workgroup per (stream, slice), fixed-order two-level sum
+__global__ __launch_bounds__(256) void dc_sum_c64_kernel(const cf* __restrict__ x, double* __restrict__ part,
+                                                        int64_t num_samp, int n_slices) {
+    __shared__ double red[256];
+    const int64_t s = blockIdx.y;
+    const int slice = blockIdx.x;
+    const int64_t per = (num_samp + n_slices - 1) / n_slices;
+    const int64_t lo = slice * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
+    double ar = 0.0, ai = 0.0;
+    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+        const cf v = x[s * num_samp + n];
+        ar += v.x;
+        ai += v.y;
+    }
+    ar = block_sum(ar, red);
+    ai = block_sum(ai, red);
+    if (threadIdx.x == 0) {
+        part[(s * n_slices + slice) * 2] = ar;
+        part[(s * n_slices + slice) * 2 + 1] = ai;
+    }
+}
+
+__global__ __launch_bounds__(256) void dc_sum_u8_kernel(const unsigned char* __restrict__ x, double* __restrict__ part,
+                                                       int64_t num_samp, int n_slices) {
+    __shared__ double red[256];
+    const int64_t s = blockIdx.y;
+    const int slice = blockIdx.x;
+    const int64_t per = (num_samp + n_slices - 1) / n_slices;
+    const int64_t lo = slice * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
+    unsigned long long ar = 0, ai = 0;      // byte sums are exact
+    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+        const unsigned short v = reinterpret_cast<const unsigned short*>(x)[s * num_samp + n];
+        ar += v & 0xFF;
+        ai += v >> 8;
+    }
+    const double sr = block_sum((double)ar, red);
+    const double si = block_sum((double)ai, red);
+    if (threadIdx.x == 0) {
+        part[(s * n_slices + slice) * 2] = sr;
+        part[(s * n_slices + slice) * 2 + 1] = si;
+    }
+}
+
+// fused uint8 ingest: exact byte sums of whole streams, one workgroup per stream, 16-byte loads (8 samples per lane);
+// part[s * 2] = sum of I bytes, part[s * 2 + 1] = sum of Q bytes  (the n_slices = 1 layout of dc_sum_u8_kernel)
+__global__ __launch_bounds__(256) void dc_sum_u8_stream_kernel(const unsigned char* __restrict__ x, double* __restrict__ part,
+                                                              int64_t num_samp, int64_t n_streams) {
+    __shared__ double red[256];
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    for (int64_t s = blockIdx.x; s < n_streams; s += gridDim.x) {
+        const unsigned char* base = x + s * num_samp * 2;
+        // align to 16 bytes: head and tail bytes one sample at a time
+        const int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15) / 2);
+        const int64_t h = head < num_samp ? head : num_samp;
+        const int64_t n_vec = (num_samp - h) / 8;
+        const v4u* vp = reinterpret_cast<const v4u*>(base + h * 2);
+        unsigned long long ar = 0, ai = 0;
+        for (int64_t n = threadIdx.x; n < n_vec; n += 256) {
+            const v4u w = vp[n];
+            unsigned si = 0, sq = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                si = __builtin_amdgcn_sad_u8(w[k] & 0x00FF00FFu, 0u, si);
+                sq = __builtin_amdgcn_sad_u8((w[k] >> 8) & 0x00FF00FFu, 0u, sq);
+            }
+            ar += si;
+            ai += sq;
+        }
+        const unsigned short* sp = reinterpret_cast<const unsigned short*>(base);
+        for (int64_t n = threadIdx.x; n < h; n += 256) {
+            ar += sp[n] & 0xFF;
+            ai += sp[n] >> 8;
+        }
+        for (int64_t n = h + n_vec * 8 + threadIdx.x; n < num_samp; n += 256) {
+            ar += sp[n] & 0xFF;
+            ai += sp[n] >> 8;
+        }
+        const double sr = block_sum((double)ar, red);
+        const double si2 = block_sum((double)ai, red);
+        if (threadIdx.x == 0) {
+            part[s * 2] = sr;
+            part[s * 2 + 1] = si2;
+        }
+    }
+}
+
+// out = x - mean (complex64 in place or out of place)
+__global__ void dc_apply_c64_kernel(const cf* __restrict__ x, cf* __restrict__ out, const double* __restrict__ part,
+                                    int64_t num_samp, int n_slices, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t s = idx / num_samp;
+        double mr = 0.0, mi = 0.0;
+        for (int k = 0; k < n_slices; ++k) {
+            mr += part[(s * n_slices + k) * 2];
+            mi += part[(s * n_slices + k) * 2 + 1];
+        }
+        const cf v = x[idx];
+        out[idx] = fxc::mk((float)((double)v.x - mr / (double)num_samp), (float)((double)v.y - mi / (double)num_samp));
+    }
+}
+
+// out = (byte - 127.5) / 127.5 [- mean]; remove_dc == 0 keeps the mean
+__global__ void convert_u8_kernel(const unsigned char* __restrict__ x, cf* __restrict__ out, const double* __restrict__ part,
+                                  int64_t num_samp, int n_slices, int64_t total, int remove_dc) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t s = idx / num_samp;
+        double mr = 127.5, mi = 127.5;      // without DC removal only the format offset is subtracted
+        if (remove_dc) {
+            mr = mi = 0.0;
+            for (int k = 0; k < n_slices; ++k) {
+                mr += part[(s * n_slices + k) * 2];
+                mi += part[(s * n_slices + k) * 2 + 1];
+            }
+            mr /= (double)num_samp;
+            mi /= (double)num_samp;
+        }
+        const unsigned short v = reinterpret_cast<const unsigned short*>(x)[idx];
+        // ((b - 127.5) - (mean_b - 127.5)) / 127.5 = (b - mean_b) / 127.5, formed in float64, rounded once
+        out[idx] = fxc::mk((float)(((double)(v & 0xFF) - mr) / 127.5), (float)(((double)(v >> 8) - mi) / 127.5));
+    }
+}
+
+// conversion offsets of the fused uint8 ingest: dc[s] = -mean_byte / 127.5 per component (float64, rounded once), or
+// -1 when the mean is kept (only the format offset 127.5 is removed)
+__global__ void dc_offsets_u8_kernel(const double* __restrict__ part, cf* __restrict__ dc, int64_t n_streams, int n_slices,
+                                     int64_t num_samp, int remove_dc) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    double mr = 127.5, mi = 127.5;
+    if (remove_dc) {
+        mr = mi = 0.0;
+        for (int k = 0; k < n_slices; ++k) {
+            mr += part[(s * n_slices + k) * 2];
+            mi += part[(s * n_slices + k) * 2 + 1];
+        }
+        mr /= (double)num_samp;
+        mi /= (double)num_samp;
+    }
+    dc[s] = fxc::mk((float)(-mr / 127.5), (float)(-mi / 127.5));
+}
+
+}  // namespace

@@ -1,0 +1,310 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// finishing kernels (shared by all paths); `slots` = layout of the raw sums inside a row:
+//   0 natural bin order, 1 the 2-antenna fused kernel's slot order, 2 the F-only kernel's spectrum order
+// ------------------------------------------------------------------------------------------
+//   3 the 8192-channel split (§ pfb_split8192_kernel): two 4096-rows of the fused kernel side by side, even bins in
+//     the first, odd bins in the second
+__device__ __forceinline__ int64_t raw_index(int k, int slots) {
+    if (slots == 3) return (int64_t)(k & 1) * fxc::fused::kN + fxc::fused::slot_of_bin(k >> 1);
+    return slots == 1 ? fxc::fused::slot_of_bin(k) : (slots == 2 ? fxc::fused::specpos_of_bin(k) : k);
+}
+
+// The 2-antenna fused kernel splits the last chunks of a launch (its tail) over workgroups without regard to chunk
+// boundaries (fx_fused4096.h::RangeWalk): row c of such a chunk lacks the frames that later workgroups took over, which
+// sit in those workgroups' leading-part rows raw[offset + b * nchan ...].  n_frames == 0: every row is complete.
+struct LeadRows {
+    int64_t first_chunk, n_frames, n_pts, offset;   // the tail: chunks from first_chunk on, n_frames frames in all
+    int grid;
+};
+
+// slots == 3: row `row` of the caller is the pair of fused-kernel chunks 2 row (even bins) and 2 row + 1 (odd bins)
+__device__ __forceinline__ void add_lead_rows(const cf* __restrict__ raw, const LeadRows& lr, int64_t row, int nchan,
+                                              int k, int slots, float& ar, float& ai) {
+    if (lr.n_frames == 0) return;
+    const int64_t vrow = slots == 3 ? 2 * row + (k & 1) : row;
+    if (vrow < lr.first_chunk) return;
+    const int row_len = slots == 3 ? fxc::fused::kN : nchan;
+    const int64_t ridx = slots == 3 ? fxc::fused::slot_of_bin(k >> 1) : raw_index(k, slots);
+    const int64_t t = vrow - lr.first_chunk;   // chunk of the tail (fx_fused4096.h::range_walk_tail)
+    const int64_t b_lo = fxc::range_owner(t * lr.n_pts, lr.n_frames, lr.grid);
+    const int64_t b_hi = fxc::range_owner((t + 1) * lr.n_pts - 1, lr.n_frames, lr.grid);
+    for (int64_t b = b_lo + 1; b <= b_hi; ++b) {   // the workgroups that start strictly inside that chunk
+        const cf r = raw[lr.offset + b * row_len + ridx];
+        ar += r.x;
+        ai += r.y;
+    }
+}
+
+// SPECTRUM rows: out[c][p][(k + N/2) % N] = (sum_split raw) * conj(rot[k]) / n_pts   (effex.py:520-521)
+__global__ void rows_spectrum_kernel(const cf* __restrict__ raw, cf* __restrict__ out, const cd* __restrict__ rot,
+                                     int nchan, int64_t rows, int n_splits, int64_t split_stride, float inv_pts,
+                                     int slots, LeadRows lead) {
+    const int64_t total = rows * nchan;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int k = (int)(idx % nchan);
+        const int64_t row = idx / nchan;
+        float ar = 0.f, ai = 0.f;
+        for (int s = 0; s < n_splits; ++s) {
+            const cf r = raw[s * split_stride + row * nchan + raw_index(k, slots)];
+            ar += r.x;
+            ai += r.y;
+        }
+        add_lead_rows(raw, lead, row, nchan, k, slots, ar, ai);
+        const float cr = (float)rot[k].x, ci = (float)rot[k].y;
+        // (ar + i ai) * (cr - i ci)
+        const float orr = (ar * cr + ai * ci) * inv_pts;
+        const float oi = (ai * cr - ar * ci) * inv_pts;
+        int ks = k + nchan / 2;
+        if (ks >= nchan) ks -= nchan;
+        out[row * nchan + ks] = fxc::mk(orr, oi);
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// CONTINUUM rows: out[row] = mean_k( raw * conj(rot) / n_pts ) / bandwidth   (effex.py:523-524); one WG per row
+__global__ __launch_bounds__(256) void rows_continuum_kernel(const cf* __restrict__ raw, cd* __restrict__ out,
+                                                            const cd* __restrict__ rot, int nchan, int64_t rows,
+                                                            int n_splits, int64_t split_stride, double scale,
+                                                            int slots, LeadRows lead) {
+    __shared__ double red[256];
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        double ar = 0.0, ai = 0.0;
+        for (int k = threadIdx.x; k < nchan; k += blockDim.x) {
+            double xr = 0.0, xi = 0.0;
+            for (int s = 0; s < n_splits; ++s) {
+                const cf r = raw[s * split_stride + row * nchan + raw_index(k, slots)];
+                xr += r.x;
+                xi += r.y;
+            }
+            float lr_re = 0.f, lr_im = 0.f;
+            add_lead_rows(raw, lead, row, nchan, k, slots, lr_re, lr_im);
+            xr += lr_re;
+            xi += lr_im;
+            const cd w = rot[k];
+            ar += xr * w.x + xi * w.y;
+            ai += xi * w.x - xr * w.y;
+        }
+        ar = block_sum(ar, red);
+        ai = block_sum(ai, red);
+        if (threadIdx.x == 0) {
+            cd o;
+            o.x = ar * scale;
+            o.y = ai * scale;
+            out[row] = o;
+        }
+    }
+}
+
+// accumulate: acc[p][k] += sum_split sum_c raw[split][c][p][raw_index(k)]   (fixed order -> reproducible)
+__global__ void acc_add_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, int nchan, int n_base,
+                               int64_t n_chunks, int n_splits, int slots) {
+    const int64_t per_chunk = (int64_t)n_base * nchan;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per_chunk; idx += stride) {
+        const int k = (int)(idx % nchan);
+        const int64_t src = (idx / nchan) * nchan + raw_index(k, slots);
+        double ar = 0.0, ai = 0.0;
+        for (int64_t sc = 0; sc < n_chunks * n_splits; ++sc) {
+            const cf r = raw[sc * per_chunk + src];
+            ar += r.x;
+            ai += r.y;
+        }
+        cd a = acc[idx];
+        a.x += ar;
+        a.y += ai;
+        acc[idx] = a;
+    }
+}
+
+// accumulate over many chunks, stage 1: part[split][slot] = sum over this split's rows of the kernels' raw
+// float32 rows (slot order, coalesced); fixed order -> bit-reproducible.  Latency-bound (a thread walks its rows one
+// load after the other), so the launch uses as many splits as leave each a handful of rows (fused_reduce_splits)
+__global__ __launch_bounds__(256) void fused_reduce1_kernel(const cf* __restrict__ raw, cd* __restrict__ part, int nchan,
+                                                           int64_t n_rows, int n_splits) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int split = blockIdx.y;
+    if (slot >= nchan) return;
+    double ar = 0.0, ai = 0.0;
+    for (int64_t c = split; c < n_rows; c += n_splits) {
+        const cf r = raw[c * nchan + slot];
+        ar += r.x;
+        ai += r.y;
+    }
+    cd o;
+    o.x = ar;
+    o.y = ai;
+    part[(int64_t)split * nchan + slot] = o;
+}
+
+// stage 2: acc[bin(slot)] += sum_split part[split][slot]; 16 slots x 16 threads per workgroup, each thread sums every
+// 16th split (reads in slot order: coalesced; only the 64 KiB of accumulator updates are scattered by the slot -> bin
+// permutation) and the 16 sub-sums are combined in a fixed order
+__global__ __launch_bounds__(256) void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict__ acc, int nchan,
+                                                           int n_splits, int slots) {
+    __shared__ cd sub[16][17];
+    const int kl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int slot = blockIdx.x * 16 + kl;
+    double ar = 0.0, ai = 0.0;
+    if (slot < nchan) {
+        for (int s = sl; s < n_splits; s += 16) {
+            const cd v = part[(int64_t)s * nchan + slot];
+            ar += v.x;
+            ai += v.y;
+        }
+    }
+    sub[sl][kl].x = ar;
+    sub[sl][kl].y = ai;
+    __syncthreads();
+    if (sl == 0 && slot < nchan) {
+        // slots == 1: the fused kernel's order, slot = q * 512 + tid (fx_fused4096.h::bin_of); 0: natural order
+        // 3: the 8192-channel split, [even | odd] halves each in the fused kernel's order
+        int k = slot;
+        if (slots == 1) k = fxc::fused::bin_of(slot % fxc::fused::kThreads, slot / fxc::fused::kThreads);
+        if (slots == 3) {
+            const int sl = slot % fxc::fused::kN;
+            k = 2 * fxc::fused::bin_of(sl % fxc::fused::kThreads, sl / fxc::fused::kThreads) + slot / fxc::fused::kN;
+        }
+        cd a = acc[k];
+        for (int j = 0; j < 16; ++j) {
+            a.x += sub[j][kl].x;
+            a.y += sub[j][kl].y;
+        }
+        acc[k] = a;
+    }
+}
+
+// multi-antenna X-engine on the F-only kernel's spectra: spec[(c*A + a)*P + i][pos]; one thread per (chunk group,
+// pos) keeps all A(A-1)/2 accumulators in registers over the spectra of `cg` consecutive chunks (cg = 1: one raw
+// row per chunk; the integration takes float32 sums of up to 256 spectra, like the 2-antenna kernel's rows) and
+// reads every spectrum sample exactly once; raw[group][p][pos], baselines ordered (0,1),(0,2)..(A-2,A-1) --
+// effex.py:520 for A > 2
+#ifndef FXC_XENGINE_UNROLL
+#define FXC_XENGINE_UNROLL 2
+#endif
+constexpr int kXU = FXC_XENGINE_UNROLL;
+template <int A>
+__global__ __launch_bounds__(256) void xengine_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int64_t n_pts,
+                                                     int nchan, int64_t n_chunks, int cg) {
+    constexpr int NB = A * (A - 1) / 2;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t grp = blockIdx.y;
+    float ar[NB], ai[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) ar[p] = ai[p] = 0.f;
+    const int64_t c_end = (grp + 1) * cg < n_chunks ? (grp + 1) * cg : n_chunks;
+    for (int64_t c = grp * cg; c < c_end; ++c) {
+        const cf* base = spec + (c * A * n_pts) * nchan + pos;
+        // kXU spectra per trip: kXU * A independent 8-byte loads in flight before the multiply-accumulates
+        int64_t i = 0;
+        for (; i + kXU <= n_pts; i += kXU) {
+            cf z[kXU][A];
+#pragma unroll
+            for (int u = 0; u < kXU; ++u)
+#pragma unroll
+                for (int a = 0; a < A; ++a) z[u][a] = base[((int64_t)a * n_pts + i + u) * nchan];
+#pragma unroll
+            for (int u = 0; u < kXU; ++u) {
+                int p = 0;
+#pragma unroll
+                for (int a = 0; a < A; ++a)
+#pragma unroll
+                    for (int b = a + 1; b < A; ++b, ++p) {
+                        ar[p] += z[u][a].x * z[u][b].x + z[u][a].y * z[u][b].y;
+                        ai[p] += z[u][a].y * z[u][b].x - z[u][a].x * z[u][b].y;
+                    }
+            }
+        }
+        for (; i < n_pts; ++i) {
+            cf z[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * n_pts + i) * nchan];
+            int p = 0;
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+#pragma unroll
+                for (int b = a + 1; b < A; ++b, ++p) {
+                    ar[p] += z[a].x * z[b].x + z[a].y * z[b].y;
+                    ai[p] += z[a].y * z[b].x - z[a].x * z[b].y;
+                }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) raw[(grp * NB + p) * nchan + pos] = fxc::mk(ar[p], ai[p]);
+}
+
+// sums = [n_base*nchan] raw sums + [1] {count, 0}
+__global__ void export_kernel(const cd* __restrict__ acc, cd* __restrict__ sums, int64_t n, double count) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx <= n; idx += stride) {
+        cd v;
+        if (idx < n) {
+            v = acc[idx];
+        } else {
+            v.x = count;
+            v.y = 0.0;
+        }
+        sums[idx] = v;
+    }
+}
+
+// out[p][(k + N/2) % N] = sums[p][k] * conj(rot[k]) / count      (effex.py:520-521, integrated)
+__global__ void finalize_spectrum_kernel(const cd* __restrict__ sums, cd* __restrict__ out, const cd* __restrict__ rot,
+                                         int nchan, int n_base) {
+    const int64_t n = (int64_t)n_base * nchan;
+    const double inv = 1.0 / sums[n].x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        const int k = (int)(idx % nchan);
+        const int64_t p = idx / nchan;
+        const cd a = sums[idx], w = rot[k];
+        cd o;
+        o.x = (a.x * w.x + a.y * w.y) * inv;
+        o.y = (a.y * w.x - a.x * w.y) * inv;
+        int ks = k + nchan / 2;
+        if (ks >= nchan) ks -= nchan;
+        out[p * nchan + ks] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_continuum_kernel(const cd* __restrict__ sums, cd* __restrict__ out,
+                                                                const cd* __restrict__ rot, int nchan, int n_base,
+                                                                double inv_bw) {
+    __shared__ double red[256];
+    const int64_t n = (int64_t)n_base * nchan;
+    const double scale = inv_bw / (sums[n].x * (double)nchan);
+    for (int p = blockIdx.x; p < n_base; p += gridDim.x) {
+        double ar = 0.0, ai = 0.0;
+        for (int k = threadIdx.x; k < nchan; k += blockDim.x) {
+            const cd a = sums[(int64_t)p * nchan + k], w = rot[k];
+            ar += a.x * w.x + a.y * w.y;
+            ai += a.y * w.x - a.x * w.y;
+        }
+        ar = block_sum(ar, red);
+        ai = block_sum(ai, red);
+        if (threadIdx.x == 0) {
+            cd o;
+            o.x = ar * scale;
+            o.y = ai * scale;
+            out[p] = o;
+        }
+    }
+}
+
+}  // namespace

@@ -1,0 +1,142 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// generic path kernels (any ntaps <= 32, any n_ant, any nchan <= 16384)
+// ------------------------------------------------------------------------------------------
+
+// v[s][i][m] = sum_{t<T, i-t>=0} x[s][(i-t)N + N-1-m] * h[tN+m]      
+__global__ void pfb_fir_kernel(const cf* __restrict__ x, const float* __restrict__ h, cf* __restrict__ v,
+                               int64_t num_samp, int nchan, int ntaps, int64_t n_pts, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int m = (int)(idx % nchan);
+        const int64_t si = idx / nchan;
+        const int64_t i = si % n_pts;
+        const int64_t s = si / n_pts;
+        const cf* xs = x + s * num_samp + (nchan - 1 - m);
+        float ar = 0.f, ai = 0.f;
+        const int tmax = (i + 1 < (int64_t)ntaps) ? (int)(i + 1) : ntaps;
+        for (int t = 0; t < tmax; ++t) {
+            const cf xv = xs[(i - t) * nchan];
+            const float w = h[(int64_t)t * nchan + m];
+            ar = fmaf(w, xv.x, ar);
+            ai = fmaf(w, xv.y, ai);
+        }
+        v[idx] = fxc::mk(ar, ai);
+    }
+}
+
+__device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
+
+// in-place spec[k] = sum_m v[m] exp(+2 pi i k m / N) for each row; N = 2^lg2n <= 16384.  One workgroup per row, or
+// 512 / N rows per workgroup when N < 512 (N/2 threads per row, each row in its own LDS slice)
+__global__ __launch_bounds__(256) void fft_pow2_kernel(cf* __restrict__ data, const cf* __restrict__ tw /* [N/2] */,
+                                                      int nchan, int lg2n, int64_t n_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int half_n = nchan >> 1;
+    const int rpw = (nchan < 512 && nchan >= 2) ? 512 / nchan : 1;      // rows per workgroup
+    const int tpr = rpw > 1 ? half_n : (int)blockDim.x;                 // threads per row
+    const int sub = rpw > 1 ? (int)threadIdx.x / tpr : 0;
+    const int lt = rpw > 1 ? (int)threadIdx.x % tpr : (int)threadIdx.x;
+    cf* buf = reinterpret_cast<cf*>(smem) + (int64_t)sub * nchan;
+    for (int64_t rb = (int64_t)blockIdx.x * rpw; rb < n_rows; rb += (int64_t)gridDim.x * rpw) {
+        const bool active = rb + sub < n_rows;
+        cf* d = data + (rb + sub) * nchan;
+        if (active)
+            for (int n = lt; n < nchan; n += tpr) buf[bitrev((unsigned)n, lg2n)] = d[n];
+        __syncthreads();
+        for (int s = 0; s < lg2n; ++s) {
+            const int half = 1 << s;
+            const int tstep = nchan >> (s + 1);
+            if (active)
+                for (int b = lt; b < half_n; b += tpr) {
+                    const int pos = b & (half - 1);
+                    const int i0 = ((b >> s) << (s + 1)) + pos;
+                    const cf w = tw[pos * tstep];
+                    const cf a = buf[i0];
+                    const cf t = fxc::cmul(buf[i0 + half], w);
+                    buf[i0] = fxc::cadd(a, t);
+                    buf[i0 + half] = fxc::csub(a, t);
+                }
+            __syncthreads();
+        }
+        if (active)
+            for (int n = lt; n < nchan; n += tpr) d[n] = buf[n];
+        __syncthreads();
+    }
+}
+
+// same transform for any nchan <= 16384 (O(N^2) per row); tw = [N] table, exact index arithmetic
+__global__ __launch_bounds__(256) void dft_any_kernel(cf* __restrict__ data, const cf* __restrict__ tw, int nchan,
+                                                     int64_t n_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* buf = reinterpret_cast<cf*>(smem);
+    for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        cf* d = data + row * nchan;
+        for (int n = threadIdx.x; n < nchan; n += blockDim.x) buf[n] = d[n];
+        __syncthreads();
+        for (int k = threadIdx.x; k < nchan; k += blockDim.x) {
+            float ar = 0.f, ai = 0.f;
+            int idx = 0;
+            for (int m = 0; m < nchan; ++m) {
+                const cf w = tw[idx];
+                const cf a = buf[m];
+                ar += a.x * w.x - a.y * w.y;
+                ai += a.x * w.y + a.y * w.x;
+                idx += k;
+                if (idx >= nchan) idx -= nchan;
+            }
+            d[k] = fxc::mk(ar, ai);
+        }
+        __syncthreads();
+    }
+}
+
+// raw[split][c][p][k] = sum_{i in split} spec[c][a][i][k] * conj(spec[c][b][i][k]); block = kx x iy threads
+__global__ __launch_bounds__(256) void xmul_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int n_ant,
+                                                  int n_base, int nchan, int64_t n_pts, int kx, int n_splits,
+                                                  int64_t n_chunks) {
+    __shared__ cf red[256];
+    const int iy = 256 / kx;
+    const int tk = threadIdx.x % kx, ti = threadIdx.x / kx;
+    const int kblocks = (nchan + kx - 1) / kx;
+    const int64_t total = n_chunks * n_base * kblocks * n_splits;
+    for (int64_t wid = blockIdx.x; wid < total; wid += gridDim.x) {
+        const int split = (int)(wid % n_splits);
+        int64_t rest = wid / n_splits;
+        const int kb = (int)(rest % kblocks);
+        rest /= kblocks;
+        const int p = (int)(rest % n_base);
+        const int64_t c = rest / n_base;
+        // baseline p -> (a, b), ordered (0,1),(0,2),...,(A-2,A-1)
+        int a = 0, q = p;
+        while (q >= n_ant - 1 - a) { q -= n_ant - 1 - a; ++a; }
+        const int b = a + 1 + q;
+        const int k = kb * kx + tk;
+        float ar = 0.f, ai = 0.f;
+        if (k < nchan) {
+            const cf* sa = spec + ((c * n_ant + a) * n_pts) * nchan + k;
+            const cf* sb = spec + ((c * n_ant + b) * n_pts) * nchan + k;
+            for (int64_t i = (int64_t)split * iy + ti; i < n_pts; i += (int64_t)iy * n_splits) {
+                const cf u = sa[i * nchan], w = sb[i * nchan];
+                ar += u.x * w.x + u.y * w.y;
+                ai += u.y * w.x - u.x * w.y;
+            }
+        }
+        red[threadIdx.x] = fxc::mk(ar, ai);
+        __syncthreads();
+        if (ti == 0 && k < nchan) {
+            for (int j = 1; j < iy; ++j) {
+                ar += red[j * kx + tk].x;
+                ai += red[j * kx + tk].y;
+            }
+            raw[(((int64_t)split * n_chunks + c) * n_base + p) * nchan + k] = fxc::mk(ar, ai);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace

@@ -1,0 +1,191 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// PFB pre-filter for ntaps > 4 on the tiled channel counts (the reference's own test shape is taps = 32,
+// branches 2048 / 4096: /root/reference/tests/test_effex.py:62-66).  A register ring of four frames does not
+// stretch to 32 taps, and re-reading the history per spectrum costs (ntaps + 1) / 2 times the stream.  The FIR half of
+// channelize_poly (effex.py:553) works branch by branch, so it is applied in place of the samples first:
+//     y[i N + n] = sum_{t < T, i - t >= 0} h[t N + (N - 1 - n)] x[(i - t) N + n]
+// after which the tiled kernels run with a single unit tap on y (their branch m reads position N - 1 - m: exactly the
+// filtered branch).  A thread owns one sample position of one stream and walks its frames in blocks of TP: the block
+// in flight and the one before it sit in registers (2 TP complex), every sample is loaded once and every tap is
+// applied from registers.  HBM: stream in + stream out, then stream in again for the FFT/X kernel: 3 x algorithmic,
+// whatever ntaps is.
+// ------------------------------------------------------------------------------------------
+// outputs i0 .. i0 + TP - 1 from the block in flight (xn) and the one before it (xo), stored as they are formed
+template <int TP>
+__device__ __forceinline__ void prefilter_fir_store(const cf (&xo)[TP], const cf (&xn)[TP], const float (&hc)[TP],
+                                                    __amdgpu_buffer_rsrc_t rs, unsigned voff, int64_t i0, int64_t i_end,
+                                                    unsigned frame_bytes) {
+    const bool full = i0 + TP <= i_end;    // wave-uniform
+#pragma unroll
+    for (int k = 0; k < TP; ++k) {
+        float ar = 0.f, ai = 0.f;
+#pragma unroll
+        for (int t = 0; t < TP; ++t) {
+            const cf v = (k - t >= 0) ? xn[(k - t) >= 0 ? k - t : 0] : xo[(TP + k - t) < TP ? TP + k - t : 0];
+            ar = fmaf(hc[t], v.x, ar);
+            ai = fmaf(hc[t], v.y, ai);
+        }
+        if (full || i0 + k < i_end) {
+            v2u32 d = {__float_as_uint(ar), __float_as_uint(ai)};
+            __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, (unsigned)(i0 + k) * frame_bytes, 0);
+        }
+    }
+}
+
+// frames i0 .. i0 + TP - 1 of this thread's sample position: buffer loads, one VGPR byte offset, scalar frame offsets.
+// Frames past the stream's last one are clamped to it (a later frame never feeds an earlier output, and outputs past
+// the end are not stored); frames before its first one read as zeros.
+template <int TP>
+__device__ __forceinline__ void prefilter_load(cf (&xr)[TP], __amdgpu_buffer_rsrc_t rs, unsigned voff, int64_t i0, int64_t n_pts,
+                                               unsigned frame_bytes) {
+#pragma unroll
+    for (int k = 0; k < TP; ++k) {
+        const int64_t i = i0 + k;
+        const int64_t ic = i < 0 ? 0 : (i < n_pts ? i : n_pts - 1);
+        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)ic * frame_bytes, 0);
+        const bool zero = i < 0;   // wave-uniform
+        xr[k] = fxc::mk(zero ? 0.f : __uint_as_float(d[0]), zero ? 0.f : __uint_as_float(d[1]));
+    }
+}
+
+// hcoef[t][n] = h[t N + (N - 1 - n)] for t < ntaps, zero rows up to TP; grid (N / 256, streams, frame splits)
+// (asking for 3 waves per SIMD at TP = 32 makes the compiler spill and the pass 3 % slower: measured)
+template <int TP>
+__global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict__ x, cf* __restrict__ y,
+                                                           const float* __restrict__ hcoef, int64_t num_samp, int nchan,
+                                                           int64_t n_pts, int64_t per_split) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int64_t s = blockIdx.y;
+    const int64_t i_begin = (int64_t)blockIdx.z * per_split;
+    const int64_t i_end = (i_begin + per_split < n_pts) ? i_begin + per_split : n_pts;
+    if (i_begin >= i_end) return;
+    float hc[TP];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) hc[t] = hcoef[(int64_t)t * nchan + n];
+    const unsigned stream_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf));       // num_samp <= 2^27
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x + s * num_samp), 0, (int)stream_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + s * num_samp, 0, (int)stream_bytes, 0x00020000);
+    const unsigned voff = (unsigned)n * (unsigned)sizeof(cf);
+    const unsigned frame_bytes = (unsigned)nchan * (unsigned)sizeof(cf);
+    cf xa[TP], xb[TP];
+    prefilter_load<TP>(xa, rx, voff, i_begin - TP, n_pts, frame_bytes);     // history (zeros before the stream's start)
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 2 * TP) {                  // two blocks per trip: the pair swaps roles, no copies
+        prefilter_load<TP>(xb, rx, voff, i0, n_pts, frame_bytes);
+        prefilter_fir_store<TP>(xa, xb, hc, ry, voff, i0, i_end, frame_bytes);
+        if (i0 + TP >= i_end) break;
+        prefilter_load<TP>(xa, rx, voff, i0 + TP, n_pts, frame_bytes);
+        prefilter_fir_store<TP>(xb, xa, hc, ry, voff, i0 + TP, i_end, frame_bytes);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// nchan = 8192 as two 4096-channel problems.  A frame ring does not fit 8192 channels (128 VGPRs per thread at 1024
+// threads, or 128 KiB of window + 136 KiB of exchange rows in LDS at 512), and the plain tiled kernel re-reads its
+// history (0.145 of the HBM roofline).  Decimation in frequency splits the transform of the FIR output v[m]:
+//     spec[2k']     = sum_{m < 4096} (v[m] + v[m + 4096])            w4096^(m k')
+//     spec[2k' + 1] = sum_{m < 4096} (v[m] - v[m + 4096]) w8192^m    w4096^(m k')
+// so the pre-filter pass (above) is extended: a thread owns the sample positions n' and n' + 4096 of a stream, forms
+// both FIR outputs y_lo, y_hi per frame from registers, and writes a = y_hi + y_lo and b = (y_hi - y_lo) w8192^(4095 - n')
+// at position n' of two half-size streams.  The headline kernel then runs on those as 2 n_chunks chunk pairs with a
+// single unit tap -- pair 2c gives the even bins of chunk c, pair 2c + 1 the odd ones (raw layout 3).
+// y = [chunk][even | odd][antenna][n_pts * 4096].  HBM: stream in + out, then in again: 3 x algorithmic.
+// ------------------------------------------------------------------------------------------
+template <int TP>
+__global__ __launch_bounds__(256) void pfb_split8192_kernel(const cf* __restrict__ x, cf* __restrict__ y,
+                                                           const float* __restrict__ hcoef, const cf* __restrict__ tw,
+                                                           int64_t num_samp, int64_t n_pts, int64_t per_split) {
+    constexpr int kHalf = 4096, kFull = 8192;
+    const int n = blockIdx.x * 256 + threadIdx.x;          // position inside the half frame
+    const int64_t s = blockIdx.y;                           // stream = chunk * 2 + antenna
+    const int64_t i_begin = (int64_t)blockIdx.z * per_split;
+    const int64_t i_end = (i_begin + per_split < n_pts) ? i_begin + per_split : n_pts;
+    if (i_begin >= i_end) return;
+    float hc[TP][2];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+        hc[t][0] = hcoef[(int64_t)t * kFull + n];
+        hc[t][1] = hcoef[(int64_t)t * kFull + n + kHalf];
+    }
+    const cf w = tw[n];
+    const int64_t half_samp = n_pts * kHalf;
+    const int64_t c = s >> 1, a = s & 1;
+    const unsigned in_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf)), out_bytes = (unsigned)(half_samp * (int64_t)sizeof(cf));
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x + s * num_samp), 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(y + ((c * 2 + 0) * 2 + a) * half_samp, 0, (int)out_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(y + ((c * 2 + 1) * 2 + a) * half_samp, 0, (int)out_bytes, 0x00020000);
+    const unsigned voff = (unsigned)n * (unsigned)sizeof(cf);
+    const unsigned in_frame = kFull * (unsigned)sizeof(cf), out_frame = kHalf * (unsigned)sizeof(cf), hi = kHalf * (unsigned)sizeof(cf);
+    cf xa[TP][2], xb[TP][2];
+    auto load = [&](cf (&xr)[TP][2], int64_t i0) {
+#pragma unroll
+        for (int k = 0; k < TP; ++k) {
+            const int64_t i = i0 + k;
+            const int64_t ic = i < 0 ? 0 : (i < n_pts ? i : n_pts - 1);      // see prefilter_load
+            const bool zero = i < 0;
+            const v2u32 d0 = __builtin_amdgcn_raw_buffer_load_b64(rx, voff, (unsigned)ic * in_frame, 0);
+            const v2u32 d1 = __builtin_amdgcn_raw_buffer_load_b64(rx, voff, (unsigned)ic * in_frame + hi, 0);
+            xr[k][0] = fxc::mk(zero ? 0.f : __uint_as_float(d0[0]), zero ? 0.f : __uint_as_float(d0[1]));
+            xr[k][1] = fxc::mk(zero ? 0.f : __uint_as_float(d1[0]), zero ? 0.f : __uint_as_float(d1[1]));
+        }
+    };
+    auto fir_store = [&](const cf (&xo)[TP][2], const cf (&xn)[TP][2], int64_t i0) {
+        const bool full = i0 + TP <= i_end;
+#pragma unroll
+        for (int k = 0; k < TP; ++k) {
+            cf yv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float ar = 0.f, ai = 0.f;
+#pragma unroll
+                for (int t = 0; t < TP; ++t) {
+                    const cf v = (k - t >= 0) ? xn[(k - t) >= 0 ? k - t : 0][h] : xo[(TP + k - t) < TP ? TP + k - t : 0][h];
+                    ar = fmaf(hc[t][h], v.x, ar);
+                    ai = fmaf(hc[t][h], v.y, ai);
+                }
+                yv[h] = fxc::mk(ar, ai);
+            }
+            if (full || i0 + k < i_end) {
+                const cf ea = fxc::cadd(yv[1], yv[0]), eb = fxc::cmul(fxc::csub(yv[1], yv[0]), w);
+                const unsigned soff = (unsigned)(i0 + k) * out_frame;
+                v2u32 da = {__float_as_uint(ea.x), __float_as_uint(ea.y)}, db = {__float_as_uint(eb.x), __float_as_uint(eb.y)};
+                __builtin_amdgcn_raw_buffer_store_b64(da, ra, voff, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(db, rb, voff, soff, 0);
+            }
+        }
+    };
+    load(xa, i_begin - TP);
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 2 * TP) {
+        load(xb, i0);
+        fir_store(xa, xb, i0);
+        if (i0 + TP >= i_end) break;
+        load(xa, i0 + TP);
+        fir_store(xb, xa, i0 + TP);
+    }
+}
+
+// acc[k] += the leading-part rows of the split launch that belong to bin k's half (even bins: fused chunks 2c, odd:
+// 2c + 1); the chunk rows themselves go through fused_reduce1/2_kernel in layout 3
+__global__ __launch_bounds__(256) void split_lead_acc_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, LeadRows lr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;    // 0 .. 8191
+    const int64_t slot = fxc::fused::slot_of_bin(k >> 1);
+    double ar = 0.0, ai = 0.0;
+    for (int b = 0; b < lr.grid; ++b) {
+        // the fused chunk workgroup b's range starts in (its leading part, if any, belongs to that chunk)
+        const int64_t vc = lr.first_chunk + fxc::range_begin(b, (int)lr.n_frames, lr.grid) / lr.n_pts;
+        if ((vc & 1) != (k & 1)) continue;
+        const cf r = raw[lr.offset + (int64_t)b * fxc::fused::kN + slot];
+        ar += r.x;
+        ai += r.y;
+    }
+    cd v = acc[k];
+    v.x += ar;
+    v.y += ai;
+    acc[k] = v;
+}
+
+}  // namespace

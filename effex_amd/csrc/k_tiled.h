@@ -1,0 +1,377 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// tiled fused 2-antenna kernel for nchan in {512, 1024, 2048, 4096, 8192}, any ntaps (phases in fx_tiled.h)
+// ------------------------------------------------------------------------------------------
+// PFB FIR of frame i for butterfly u: buffer loads, one VGPR byte offset per thread (xoff into the chunk's
+// stream pair, hoff into the window), everything that varies with frame / tap / branch is scalar
+template <class G>
+__device__ __forceinline__ void tiled_fir(cf (&v)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned xoff,
+                                          const float* win, unsigned win_bytes, unsigned hoff, int64_t i, int ntaps) {
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(win), 0, (int)win_bytes, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fxc::mk(0.f, 0.f);
+    const int tmax = (int64_t)(ntaps - 1) < i ? ntaps - 1 : (int)i;
+    for (int t = 0; t <= tmax; ++t) {
+        const unsigned sx = (unsigned)((i - t) * G::N * (int64_t)sizeof(cf));
+        const unsigned sh = (unsigned)(t * G::N * (int)sizeof(float));
+        cf xv[16];
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rx, xoff, sx + (unsigned)(G::P * (15 - r) * sizeof(cf)), 0);
+            xv[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+            hv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, hoff, sh + (unsigned)(G::P * r * sizeof(float)), 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fxc::cfma(hv[r], xv[r], v[r]);
+    }
+}
+
+// Two frames per pass over the PFB history: v0 = FIR of frame i, v1 = FIR of frame i + 1 (computed only if
+// two == true).  At tap t the pass holds x[i + 1 - t] and x[i - t]; the next tap re-uses the older one and
+// loads one new frame, and every window coefficient is loaded once for both outputs: (ntaps + 1) frame loads
+// and ntaps window loads per two spectra instead of 2 ntaps of each.
+template <class G>
+__device__ __forceinline__ void tiled_fir2(cf (&v0)[16], cf (&v1)[16], bool two, const cf* chunk_base,
+                                           unsigned chunk_bytes, unsigned xoff, const float* win, unsigned win_bytes,
+                                           unsigned hoff, int64_t i, int ntaps) {
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(win), 0, (int)win_bytes, 0x00020000);
+    auto load_frame = [&](cf (&dst)[16], int64_t frame, bool present) {
+        if (present) {
+            const unsigned sx = (unsigned)(frame * G::N * (int64_t)sizeof(cf));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rx, xoff, sx + (unsigned)(G::P * (15 - r) * sizeof(cf)), 0);
+                dst[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r] = fxc::mk(0.f, 0.f);
+        }
+    };
+    auto tap = [&](int t, const cf (&xa)[16], const cf (&xb)[16]) {   // xa = x[i + 1 - t], xb = x[i - t]
+        const unsigned sh = (unsigned)(t * G::N * (int)sizeof(float));
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            hv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, hoff, sh + (unsigned)(G::P * r * sizeof(float)), 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v1[r] = fxc::cfma(hv[r], xa[r], v1[r]);
+            v0[r] = fxc::cfma(hv[r], xb[r], v0[r]);
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v0[r] = v1[r] = fxc::mk(0.f, 0.f);
+    cf xw[2][16];
+    load_frame(xw[0], i + 1, two);
+    load_frame(xw[1], i, true);
+    // taps in pairs so that the two-frame window rotates by renaming; a frame before the chunk start is zero
+    for (int t = 0; t < ntaps; t += 2) {
+        tap(t, xw[0], xw[1]);
+        load_frame(xw[0], i - t - 1, i - t - 1 >= 0);       // x[i - (t + 1)]: the older frame of tap t + 1
+        if (t + 1 < ntaps) {
+            tap(t + 1, xw[1], xw[0]);
+            load_frame(xw[1], i - t - 2, i - t - 2 >= 0);
+        }
+    }
+}
+
+// F-only tail of a tiled step: the two spectra of frame i leave in natural bin order.  Stage C leaves bin
+// bin_of(u, k2) in v[k2]; the exchange region serves as a transposition buffer (bin k at k + (k >> 4): the
+// 16 lanes of a group write 17 or R0 + 1/16 slots apart, conflict-free) and the rows go out 256 B per half-wave.
+// valid: this lane's stream exists (an odd stream count leaves the last pair half empty).
+template <class G>
+__device__ __forceinline__ void tiled_store_spectrum(const cf (&v)[16], cf* reg, int u, cf* out_row, bool valid) {
+    __syncthreads();   // every wave holds its stage-C outputs in registers: the rows can be overwritten
+    // bin_of(u, k2) = b0 + C k2 with C a multiple of 16, and P is one too: both index maps are one base + constants
+    constexpr int C = (G::A3 ? 256 : 16) * G::R0;
+    const int b0 = G::bin_of(u, 0);
+    cf* wr = reg + b0 + (b0 >> 4);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) wr[(C + C / 16) * k2] = v[k2];
+    __syncthreads();
+    if (valid) {
+        const cf* rd = reg + u + (u >> 4);
+        cf* dst = out_row + u;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) dst[G::P * n] = fxc::fused::lds_load(rd + (G::P + G::P / 16) * n);
+    }
+}
+
+// raw[(split * n_chunks + c) * N + k] = sum over the split's frames of spec0[i,k] * conj(spec1[i,k]), natural
+// bin order, float32.  Work item = (split, chunk); a split is a contiguous range of a chunk's frames (the
+// FIR reads its history from memory, so ranges are independent).
+// SPEC: F-only -- a "chunk" is a pair of consecutive streams (n_streams of them in all), raw is the spectra
+// buffer [stream][i][k] and n_chunks the number of pairs.
+template <class G, bool SPEC>
+__global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
+                                                               int64_t n_chunks, int n_splits, int ntaps,
+                                                               const float* __restrict__ win, const cf* __restrict__ tw0_g,
+                                                               const cf* __restrict__ twA_g, const cf* __restrict__ tw16_g,
+                                                               cf* __restrict__ raw, int64_t n_streams) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* region = reinterpret_cast<cf*>(smem + G::kLdsRegion);
+    cf* tw16 = reinterpret_cast<cf*>(smem + G::kLdsTw16);
+    const int tid = threadIdx.x;
+    const int u = G::u_of(tid), ant = G::ant_of(tid);
+    for (int idx = tid; idx < 256; idx += G::kThreads) tw16[idx] = tw16_g[idx];
+    cf tw0[16], twA[16];
+    if (G::R0 > 1) G::load_tw0(tw0, tw0_g, u);
+    if (G::A3) G::load_twA(twA, twA_g, u);
+    __syncthreads();
+    cf* reg = region + ant * G::kRegion;
+    const unsigned win_bytes = (unsigned)(ntaps * G::N * (int)sizeof(float));
+    const unsigned hoff = (unsigned)(u * (int)sizeof(float));
+    const int64_t per = (n_pts + n_splits - 1) / n_splits;
+    for (int64_t w = blockIdx.x; w < n_chunks * n_splits; w += gridDim.x) {
+        const int64_t c = w % n_chunks, split = w / n_chunks;
+        const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
+        const cf* chunk_base = x + c * 2 * num_samp;
+        // F-only with an odd stream count: the missing second stream of the last pair re-reads the first
+        const bool valid = !SPEC || (2 * c + ant) < n_streams;
+        const int ant_ld = valid ? ant : 0;
+        const unsigned chunk_bytes = (unsigned)((SPEC && 2 * c + 1 >= n_streams ? 1 : 2) * num_samp * (int64_t)sizeof(cf));
+        const unsigned xoff = (unsigned)((ant_ld * num_samp + (G::P - 1 - u)) * (int64_t)sizeof(cf));
+        cf acc[G::kAccPerThread];
+#pragma unroll
+        for (int q = 0; q < G::kAccPerThread; ++q) acc[q] = fxc::mk(0.f, 0.f);
+        // everything after the FIR for one frame
+        auto finish = [&](cf (&v)[16], int64_t i) {
+            if (G::R0 > 1) G::prestage(v, tw0);
+            if (G::A3) {
+                if (G::R0 > 1) {
+                    __syncthreads();   // every wave has finished reading the previous spectrum's exchange rows
+                    G::store0(v, reg, u);
+                    __syncthreads();
+                    G::loadA(reg, u, v);
+                }
+                fxc::dft16(v);
+                __syncthreads();
+                G::twiddleA_store(v, twA, reg, u);
+                __syncthreads();
+            } else {
+                __syncthreads();
+                G::store0(v, reg, u);
+                __syncthreads();
+            }
+            G::loadB(reg, u, v);
+            fxc::dft16(v);
+            G::twiddleB(v, tw16, u);
+            wave_sync();       // the 16x16 transpose stays inside each 16-lane group: no s_barrier
+            G::storeT(v, reg, u);
+            wave_sync();
+            G::loadC(reg, u, v);
+            fxc::dft16(v);
+            if (SPEC) {
+                tiled_store_spectrum<G>(v, reg, u, raw + ((2 * c + ant) * n_pts + i) * G::N, valid);
+                return;
+            }
+            // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins (see fused_step)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                cf a = v[q], b = v[q + 8];
+                permlane32_swap(a, b);
+                acc[q] = fxc::cadd(acc[q], fxc::cmulc(a, b));
+            }
+        };
+        if (G::kThreads <= 512) {   // two frames per pass over the history (the 1024-thread geometry has no registers for it)
+            for (int64_t i = i0; i < i1; i += 2) {
+                cf v0[16], v1[16];
+                const bool two = i + 1 < i1;
+                tiled_fir2<G>(v0, v1, two, chunk_base, chunk_bytes, xoff, win, win_bytes, hoff, i, ntaps);
+                finish(v0, i);
+                if (two) finish(v1, i + 1);
+            }
+        } else {
+            for (int64_t i = i0; i < i1; ++i) {
+                cf v[16];
+                tiled_fir<G>(v, chunk_base, chunk_bytes, xoff, win, win_bytes, hoff, i, ntaps);
+                finish(v, i);
+            }
+        }
+        if (SPEC) continue;
+        cf* row = raw + (split * n_chunks + c) * G::N;
+#pragma unroll
+        for (int q = 0; q < G::kAccPerThread; ++q) row[G::bin_of(u, q + 8 * ant)] = acc[q];
+    }
+}
+
+// ntaps <= 4, nchan <= 2048 variant of the tiled kernel: every IQ sample is fetched once into a VGPR ring of
+// four frames (as in fx_fused4096_kernel) and the window sits in LDS.
+template <class G, int R0, int CNT>
+__device__ __forceinline__ void tiled_load_part(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned xoff,
+                                                int64_t frame) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    const unsigned soff = (unsigned)(frame * G::N * (int64_t)sizeof(cf));
+#pragma unroll
+    for (int r = R0; r < R0 + CNT; ++r) {
+        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(cf)), 0);
+        xr[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+    }
+}
+
+// uint8 ingest (see load_frame_part_u8): chunk_base then points at byte pairs
+template <class G, int R0, int CNT>
+__device__ __forceinline__ void tiled_load_part_u8(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes,
+                                                   unsigned xoff, int64_t frame) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
+                                                                   0x00020000);
+    const unsigned soff = (unsigned)(frame * G::N * (int64_t)sizeof(unsigned short));
+#pragma unroll
+    for (int r = R0; r < R0 + CNT; ++r)
+        xr[r].x = __uint_as_float(
+            (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(unsigned short)), 0));
+}
+
+template <class G>
+struct TiledRing {
+    cf h[4][16];
+    cf tw0[16];   // pre-stage twiddles (R0 > 1)
+    cf twA[16];   // stage-A twiddles (nchan 4096)
+    cf acc[G::kAccPerThread];
+    U8State u8;   // uint8 ingest only
+};
+
+#define FXC_TILED_PREFETCH(R0)                                                                  \
+    do {                                                                                        \
+        FXC_SCHED_FENCE();                                                                      \
+        if (U8)                                                                                 \
+            tiled_load_part_u8<G, R0, 4>(nx, chunk_base, chunk_bytes, xoff, nframe);            \
+        else                                                                                    \
+            tiled_load_part<G, R0, 4>(nx, chunk_base, chunk_bytes, xoff, nframe);               \
+        FXC_SCHED_FENCE();                                                                      \
+    } while (0)
+
+// one spectrum of both antennas; frame i sits in ring slot PH, i1 = end of this work item's frame range
+template <class G, int PH, bool SPEC, bool U8>
+__device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, cf* reg, const cf* tw16, int u,
+                                                const cf* chunk_base, unsigned chunk_bytes, unsigned xoff, int64_t i,
+                                                int64_t i1, cf* out_row, bool valid) {
+    if (U8) convert_frame_u8(s.h[PH], s.u8.off);   // the byte pairs fetched a step ago become the samples of slot PH
+    cf v[16];
+    G::template fir_ring<PH>(s.h, win, u, v);
+    // the oldest slot is dead: refill it with the next frame of the range (the current one again at the end,
+    // never used) -- unconditional so that no branch guards a definition of ring registers
+    const int64_t nframe = (i + 1 < i1) ? i + 1 : i;
+    cf (&nx)[16] = s.h[(PH + 1) & 3];
+    FXC_TILED_PREFETCH(0);
+    if (G::A3) {
+        static_assert(!(G::A3 && G::R0 > 1), "ring variant: nchan <= 4096");
+        fxc::dft16(v);
+        FXC_TILED_PREFETCH(4);
+        __syncthreads();   // every wave has finished reading the previous spectrum's exchange rows
+        G::twiddleA_store(v, s.twA, reg, u);
+        __syncthreads();
+    } else {
+        G::prestage(v, s.tw0);
+        FXC_TILED_PREFETCH(4);
+        __syncthreads();
+        G::store0(v, reg, u);
+        __syncthreads();
+    }
+    G::loadB(reg, u, v);
+    FXC_TILED_PREFETCH(8);
+    fxc::dft16(v);
+    G::twiddleB(v, tw16, u);
+    wave_sync();
+    G::storeT(v, reg, u);
+    wave_sync();
+    FXC_TILED_PREFETCH(12);
+    G::loadC(reg, u, v);
+    fxc::dft16(v);
+    if (SPEC) {
+        tiled_store_spectrum<G>(v, reg, u, out_row + i * G::N, valid);
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        cf a = v[q], b = v[q + 8];
+        permlane32_swap(a, b);
+        s.acc[q] = fxc::cadd(s.acc[q], fxc::cmulc(a, b));
+    }
+}
+
+template <class G, bool SPEC, bool U8 = false>
+__global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf* __restrict__ x, int64_t num_samp,
+                                                                      int64_t n_pts, int64_t n_chunks, int n_splits,
+                                                                      const f4* __restrict__ win_g,
+                                                                      const cf* __restrict__ tw0_g,
+                                                                      const cf* __restrict__ twA_g,
+                                                                      const cf* __restrict__ tw16_g, cf* __restrict__ raw,
+                                                                      int64_t n_streams, const cf* __restrict__ dc) {
+    static_assert(!(SPEC && U8), "uint8 ingest: F+X only");
+    constexpr int64_t kSampleBytes = U8 ? sizeof(unsigned short) : sizeof(cf);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* region = reinterpret_cast<cf*>(smem + G::kLdsRegion);
+    cf* tw16 = reinterpret_cast<cf*>(smem + G::kLdsTw16);
+    f4* win = reinterpret_cast<f4*>(smem + G::kLdsWin);
+    const int tid = threadIdx.x;
+    const int u = G::u_of(tid), ant = G::ant_of(tid);
+    for (int idx = tid; idx < 256; idx += G::kThreads) tw16[idx] = tw16_g[idx];
+    for (int idx = tid; idx < G::N; idx += G::kThreads) win[idx] = win_g[idx];
+    TiledRing<G> s;
+    if (G::R0 > 1) G::load_tw0(s.tw0, tw0_g, u);
+    if (G::A3) G::load_twA(s.twA, twA_g, u);
+    __syncthreads();
+    cf* reg = region + ant * G::kRegion;
+    const int64_t per = (n_pts + n_splits - 1) / n_splits;
+    for (int64_t w = blockIdx.x; w < n_chunks * n_splits; w += gridDim.x) {
+        const int64_t c = w % n_chunks, split = w / n_chunks;
+        const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
+        const cf* chunk_base = reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c * 2 * num_samp * kSampleBytes);
+        const bool valid = !SPEC || (2 * c + ant) < n_streams;   // see fx_tiled_kernel
+        const int ant_ld = valid ? ant : 0;
+        const unsigned chunk_bytes = (unsigned)((SPEC && 2 * c + 1 >= n_streams ? 1 : 2) * num_samp * kSampleBytes);
+        const unsigned xoff = (unsigned)((ant_ld * num_samp + (G::P - 1 - u)) * kSampleBytes);
+        if (U8) s.u8.off = dc[c * 2 + ant];
+        cf* out_row = SPEC ? raw + (2 * c + ant) * n_pts * G::N : nullptr;
+#pragma unroll
+        for (int q = 0; q < G::kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
+        // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the chunk)
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+            if (i0 - d >= 0 && i0 < i1) {   // (an empty range at the end of a chunk loads nothing)
+                if (U8) {
+                    tiled_load_part_u8<G, 0, 16>(s.h[4 - d], chunk_base, chunk_bytes, xoff, i0 - d);
+                    convert_frame_u8(s.h[4 - d], s.u8.off);
+                } else {
+                    tiled_load_part<G, 0, 16>(s.h[4 - d], chunk_base, chunk_bytes, xoff, i0 - d);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s.h[4 - d][r] = fxc::mk(0.f, 0.f);
+            }
+        }
+        if (i0 < i1) {
+            if (U8)
+                tiled_load_part_u8<G, 0, 16>(s.h[0], chunk_base, chunk_bytes, xoff, i0);
+            else
+                tiled_load_part<G, 0, 16>(s.h[0], chunk_base, chunk_bytes, xoff, i0);
+        }
+        for (int64_t i = i0; i < i1; i += 4) {
+            tiled_ring_step<G, 0, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i, i1, out_row, valid);
+            if (i + 1 < i1)
+                tiled_ring_step<G, 1, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 1, i1, out_row, valid);
+            if (i + 2 < i1)
+                tiled_ring_step<G, 2, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 2, i1, out_row, valid);
+            if (i + 3 < i1)
+                tiled_ring_step<G, 3, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 3, i1, out_row, valid);
+        }
+        if (SPEC) continue;
+        cf* row = raw + (split * n_chunks + c) * G::N;
+#pragma unroll
+        for (int q = 0; q < G::kAccPerThread; ++q) row[G::bin_of(u, q + 8 * ant)] = s.acc[q];
+    }
+}
+
+}  // namespace

@@ -3,7 +3,7 @@
 The reference gets its samples from two RTL-SDR dongles (``/root/reference/effex/effex.py:81-82``,
 ``:652``); there is no hardware here, so benchmarks and parity tests use this counter-based
 generator instead.  The same arithmetic is implemented on the device by ``fxc_synth_fill``
-(``effex_amd/csrc/fxcorr.hip``) and the two are bit-identical (tests/test_gpu_parity.py), so a
+(``effex_amd/csrc/k_synth.h``) and the two are bit-identical (tests/test_gpu_parity.py), so a
 multi-GiB pool can be produced in HBM without a host copy.
 
 Model (all float32, RTL-SDR-like 8-bit quantised IQ, ``(byte - 127.5) / 127.5``):
