@@ -171,16 +171,23 @@ __global__ __launch_bounds__(256) void pfb_split8192_kernel(const cf* __restrict
 // acc[k] += the leading-part rows of the split launch that belong to bin k's half (even bins: fused chunks 2c, odd:
 // 2c + 1); the chunk rows themselves go through fused_reduce1/2_kernel in layout 3
 __global__ __launch_bounds__(256) void split_lead_acc_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, LeadRows lr) {
+    // the fused chunk workgroup b's range starts in (its leading part, if any, belongs to that chunk): parity per row,
+    // worked out once per block instead of one 64-bit division per row and thread
+    __shared__ unsigned char odd[1024];
+    for (int b = threadIdx.x; b < lr.grid; b += blockDim.x)
+        odd[b] = (unsigned char)((lr.first_chunk + fxc::range_begin(b, (int)lr.n_frames, lr.grid) / lr.n_pts) & 1);
+    __syncthreads();
     const int k = blockIdx.x * blockDim.x + threadIdx.x;    // 0 .. 8191
     const int64_t slot = fxc::fused::slot_of_bin(k >> 1);
+    const unsigned char mine = (unsigned char)(k & 1);
     double ar = 0.0, ai = 0.0;
+#pragma unroll 8
     for (int b = 0; b < lr.grid; ++b) {
-        // the fused chunk workgroup b's range starts in (its leading part, if any, belongs to that chunk)
-        const int64_t vc = lr.first_chunk + fxc::range_begin(b, (int)lr.n_frames, lr.grid) / lr.n_pts;
-        if ((vc & 1) != (k & 1)) continue;
         const cf r = raw[lr.offset + (int64_t)b * fxc::fused::kN + slot];
-        ar += r.x;
-        ai += r.y;
+        if (odd[b] == mine) {
+            ar += r.x;
+            ai += r.y;
+        }
     }
     cd v = acc[k];
     v.x += ar;
