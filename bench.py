@@ -176,7 +176,15 @@ def rank_env(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+            # started bare with --gpus N: launch the ranks ourselves (a child process, before anything here touches HIP)
+            import socket
+            import subprocess
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.call(cmd))
         args.gpus = world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     return rank, local_rank, world
