@@ -718,6 +718,40 @@ def test_linearity_and_conjugate_symmetry_full_size(plan_mod, torch, nchan, path
         assert auto.real.min() >= 0.0
 
 
+@pytest.mark.parametrize("nchan,ntaps,path", [(4096, 4, "fused"), (2048, 4, "tiled"), (2048, 32, "tiled"), (8192, 4, "tiled")])
+def test_largest_chunk_the_fast_paths_take(plan_mod, torch, nchan, ntaps, path):
+    """num_samp = 2^27 (1 GiB per stream): the 32-bit byte offsets of the fast kernels' buffer loads and stores at their
+    limit (fused kernel, tiled ring kernel, pre-filter pass, 8192 split), against the generic kernels (64-bit indexing,
+    no shared code); one frame more per stream and the plan leaves the fast path."""
+    from effex_amd.plan import synth_fill
+    num_samp = 2 ** 27
+    x = torch.empty((1, 2, num_samp), dtype=torch.complex64, device="cuda")
+    synth_fill(x, 31337)
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp) as f, plan_mod.FxPlan(2, nchan, ntaps, num_samp, path="generic") as g:
+        assert f.path == path and g.path == "generic"
+        rf, rg = f.fx_rows(x).cpu().numpy(), g.fx_rows(x).cpu().numpy()
+        assert rel_err(rf, rg) < TOL_VIS
+        f.fx_accumulate(x)
+        assert rel_err(f.finalize("SPECTRUM"), rg.astype(np.complex128)) < TOL_VIS
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp + nchan) as p:
+        assert p.path == "generic"
+
+
+@pytest.mark.parametrize("ntaps,num_samp", [(4, 2 ** 29 + 6), (7, 2 ** 29 + 5)])
+def test_streaming_path_on_streams_beyond_4_gib(plan_mod, torch, ntaps, num_samp):
+    """nchan = 1 has no size limit of its own: 4 GiB per stream (64-bit indexing in stream1_t4_kernel / stream1_kernel)
+    against the generic kernels."""
+    from effex_amd.plan import synth_fill
+    x = torch.empty((1, 2, num_samp), dtype=torch.complex64, device="cuda")
+    synth_fill(x, 99)
+    w = np.linspace(0.4, 0.1, ntaps)
+    with plan_mod.FxPlan(2, 1, ntaps, num_samp, window=w) as f, plan_mod.FxPlan(2, 1, ntaps, num_samp, window=w, path="generic") as g:
+        assert f.path == "stream" and g.path == "generic"
+        a = f.fx_rows(x, "CONTINUUM", 2.4e6).cpu().numpy()
+        b = g.fx_rows(x, "CONTINUUM", 2.4e6).cpu().numpy()
+    assert rel_err(a, b) < TOL_VIS
+
+
 def test_sharded_integration_equals_single_rank(plan_mod, torch):
     """SURVEY.md §8e on one GPU: two 'ranks' integrate disjoint chunk ranges, their exported sums are
     added (what the RCCL all-reduce does) and finalised once."""
