@@ -752,6 +752,30 @@ def test_streaming_path_on_streams_beyond_4_gib(plan_mod, torch, ntaps, num_samp
     assert rel_err(a, b) < TOL_VIS
 
 
+@pytest.mark.parametrize("nchan,ntaps,n_ant", [(4096, 4, 2), (2048, 4, 2), (2048, 32, 2), (8192, 4, 2), (4096, 4, 8), (64, 4, 2)])
+def test_nan_samples_poison_their_chunk_only(plan_mod, torch, nchan, ntaps, n_ant):
+    """numpy semantics of the reference (effex.py:508-527): one NaN sample makes every bin of its chunk's visibilities
+    NaN (FIR -> all bins of the frames it touches -> the mean over frames) and leaves the other chunks' rows alone; an
+    integration over the batch is NaN."""
+    num_samp = nchan * 40 + 7
+    x = torch.from_numpy(synth.synth_iq(4242, 5, n_ant, num_samp)).cuda()
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp) as p:
+        clean = p.fx_rows(x).cpu().numpy()
+        x[3, n_ant - 1, 17 * nchan + 5] = float("nan")
+        rows = p.fx_rows(x).cpu().numpy()
+        hit = [b for b in range(rows.shape[1])]              # baselines that include the last antenna are poisoned
+        last = [i for i, (a, b) in enumerate((a, b) for a in range(n_ant) for b in range(a + 1, n_ant)) if b == n_ant - 1]
+        assert np.isnan(rows[3][last]).all()
+        others = [c for c in range(5) if c != 3]
+        np.testing.assert_array_equal(rows[others], clean[others])
+        rest = [i for i in hit if i not in last]
+        if rest:
+            np.testing.assert_array_equal(rows[3][rest], clean[3][rest])
+        p.fx_accumulate(x)
+        integ = p.finalize("SPECTRUM")
+        assert np.isnan(integ[last]).all()
+
+
 def test_sharded_integration_equals_single_rank(plan_mod, torch):
     """SURVEY.md §8e on one GPU: two 'ranks' integrate disjoint chunk ranges, their exported sums are
     added (what the RCCL all-reduce does) and finalised once."""
