@@ -19,11 +19,7 @@ struct RcclApi {
     std::string error;
 };
 
-RcclApi* rccl_api() {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return &api;
-    tried = true;
+void rccl_bind(RcclApi& api) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names)   // a copy that is already mapped wins: one RCCL per process
         if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
@@ -31,7 +27,7 @@ RcclApi* rccl_api() {
     if (!api.handle) {
         const char* why = dlerror();
         api.error = std::string("librccl not found: ") + (why ? why : "dlopen failed");
-        return &api;
+        return;
     }
     bool ok = true;
     auto bind = [&](const char* sym) {
@@ -48,10 +44,17 @@ RcclApi* rccl_api() {
     api.reduce = reinterpret_cast<decltype(api.reduce)>(bind("ncclReduce"));
     api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(bind("ncclAllReduce"));
     api.error_string = reinterpret_cast<decltype(api.error_string)>(bind("ncclGetErrorString"));
-    if (!ok) {
-        api.handle = nullptr;
-    }
-    return &api;
+    if (!ok) api.handle = nullptr;
+}
+
+// bound once per process, on first use (a function-local static: initialised exactly once even with several caller threads)
+RcclApi* rccl_api() {
+    static RcclApi* api = [] {
+        RcclApi* a = new RcclApi;
+        rccl_bind(*a);
+        return a;
+    }();
+    return api;
 }
 
 int rccl_fail(const fxc_plan* p, const RcclApi* api, const char* what, ncclResult_t r) {

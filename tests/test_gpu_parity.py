@@ -776,6 +776,44 @@ def test_nan_samples_poison_their_chunk_only(plan_mod, torch, nchan, ntaps, n_an
         assert np.isnan(integ[last]).all()
 
 
+def test_caller_threads_with_a_plan_each(plan_mod, torch):
+    """include/fxcorr.h: one caller thread per plan.  Four threads drive a plan each (fused and tiled kernels, a torch
+    stream per thread) at the same time -- ctypes releases the GIL inside every fxc_* call -- and every result equals the one
+    the same plan gave alone."""
+    import threading
+    shapes = [(4096, 4, 37), (2048, 4, 29), (4096, 4, 5), (1024, 8, 11)]
+    jobs = []
+    for k, (nchan, ntaps, n_chunks) in enumerate(shapes):
+        num_samp = nchan * 24 + 3 * k
+        x = torch.from_numpy(synth.synth_iq(600 + k, n_chunks, 2, num_samp)).cuda()
+        plan = plan_mod.FxPlan(2, nchan, ntaps, num_samp)     # follows the calling thread's current torch stream
+        want = plan.fx_rows(x).cpu().numpy()
+        plan.fx_accumulate(x)
+        want_int = plan.finalize("SPECTRUM")
+        jobs.append((plan, x, want, want_int))
+    errors = []
+
+    def work(plan, x, want, want_int):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(25):
+                    got = plan.fx_rows(x).cpu().numpy()
+                    np.testing.assert_array_equal(got, want)
+                    plan.fx_accumulate(x)
+                    np.testing.assert_array_equal(plan.finalize("SPECTRUM"), want_int)
+        except Exception as exc:      # surfaced in the main thread below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=job) for job in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for plan, *_ in jobs:
+        plan.close()
+    assert not errors, errors
+
+
 def test_sharded_integration_equals_single_rank(plan_mod, torch):
     """SURVEY.md §8e on one GPU: two 'ranks' integrate disjoint chunk ranges, their exported sums are
     added (what the RCCL all-reduce does) and finalised once."""
