@@ -269,18 +269,29 @@ int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_ou
     if (rg) return rg;
     cf* y = static_cast<cf*>(p->d_pre);
     const int tp = p->pre_tp;
+    // two adjacent positions per thread (16-byte accesses) for the 8-frame block (1024 channels / 8 taps: -6 %; the 16-frame
+    // block would need 218 VGPRs: -2 % at 512 channels, +3 % at 2048; the 32-frame block has no registers to spare);
+    // streams of odd length are not 16-byte aligned one after the other.  FXC_PRE_W=1: developer knob, 8-byte accesses
+    static const bool narrow = [] { const char* e = std::getenv("FXC_PRE_W"); return e && std::atoi(e) == 1; }();
+    const int w = (!narrow && tp == 8 && (p->num_samp % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0) ? 2 : 1;
     // frame splits so that a few-stream call still fills the chip; each split reloads one block of history
-    const int64_t blocks = (int64_t)(p->nchan / 256) * n_streams;
+    const int64_t blocks = (int64_t)(p->nchan / (256 * w)) * n_streams;
     int64_t fs = std::max<int64_t>(1, (2 * (int64_t)p->cu_count + blocks - 1) / blocks);
     fs = std::min<int64_t>(fs, std::max<int64_t>(1, p->n_pts / (4 * tp)));
     const int64_t per = ((p->n_pts + fs - 1) / fs + 2 * tp - 1) / (2 * tp) * (2 * tp);
-    const dim3 grid((unsigned)(p->nchan / 256), (unsigned)n_streams, (unsigned)((p->n_pts + per - 1) / per));
-    if (tp == 8)
-        hipLaunchKernelGGL(pfb_prefilter_kernel<8>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, p->n_pts, per);
-    else if (tp == 16)
-        hipLaunchKernelGGL(pfb_prefilter_kernel<16>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, p->n_pts, per);
-    else
-        hipLaunchKernelGGL(pfb_prefilter_kernel<32>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, p->n_pts, per);
+    const dim3 grid((unsigned)(p->nchan / (256 * w)), (unsigned)n_streams, (unsigned)((p->n_pts + per - 1) / per));
+#define FXC_PRE_LAUNCH(TP, W)                                                                                             \
+    hipLaunchKernelGGL((pfb_prefilter_kernel<TP, W>), grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, \
+                       p->n_pts, per)
+    if (tp == 8) {
+        if (w == 2) FXC_PRE_LAUNCH(8, 2);
+        else FXC_PRE_LAUNCH(8, 1);
+    } else if (tp == 16) {
+        FXC_PRE_LAUNCH(16, 1);
+    } else {
+        FXC_PRE_LAUNCH(32, 1);
+    }
+#undef FXC_PRE_LAUNCH
     FXC_HIP(p, hipGetLastError());
     *y_out = y;
     return FXC_OK;

@@ -15,71 +15,99 @@ namespace {
 // applied from registers.  HBM: stream in + stream out, then stream in again for the FFT/X kernel: 3 x algorithmic,
 // whatever ntaps is.
 // ------------------------------------------------------------------------------------------
-// outputs i0 .. i0 + TP - 1 from the block in flight (xn) and the one before it (xo), stored as they are formed
-template <int TP>
-__device__ __forceinline__ void prefilter_fir_store(const cf (&xo)[TP], const cf (&xn)[TP], const float (&hc)[TP],
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+
+// outputs i0 .. i0 + TP - 1 from the block in flight (xn) and the one before it (xo), stored as they are formed.
+// W = adjacent sample positions per thread (1: 8-byte, 2: 16-byte accesses)
+template <int TP, int W>
+__device__ __forceinline__ void prefilter_fir_store(const cf (&xo)[TP][W], const cf (&xn)[TP][W], const float (&hc)[TP][W],
                                                     __amdgpu_buffer_rsrc_t rs, unsigned voff, int64_t i0, int64_t i_end,
                                                     unsigned frame_bytes) {
     const bool full = i0 + TP <= i_end;    // wave-uniform
 #pragma unroll
     for (int k = 0; k < TP; ++k) {
-        float ar = 0.f, ai = 0.f;
+        float ar[W], ai[W];
 #pragma unroll
-        for (int t = 0; t < TP; ++t) {
-            const cf v = (k - t >= 0) ? xn[(k - t) >= 0 ? k - t : 0] : xo[(TP + k - t) < TP ? TP + k - t : 0];
-            ar = fmaf(hc[t], v.x, ar);
-            ai = fmaf(hc[t], v.y, ai);
+        for (int w = 0; w < W; ++w) {
+            ar[w] = ai[w] = 0.f;
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                const cf v = (k - t >= 0) ? xn[(k - t) >= 0 ? k - t : 0][w] : xo[(TP + k - t) < TP ? TP + k - t : 0][w];
+                ar[w] = fmaf(hc[t][w], v.x, ar[w]);
+                ai[w] = fmaf(hc[t][w], v.y, ai[w]);
+            }
         }
         if (full || i0 + k < i_end) {
-            v2u32 d = {__float_as_uint(ar), __float_as_uint(ai)};
-            __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, (unsigned)(i0 + k) * frame_bytes, 0);
+            const unsigned soff = (unsigned)(i0 + k) * frame_bytes;
+            if constexpr (W == 2) {
+                // The frame offset rides in the VGPR offset here, not in the scalar one.  A 16-byte buffer store reads its data
+                // registers over more than one cycle; LLVM (ROCm 7.2) pads a following VALU write of those registers with
+                // s_nop only when the store has no SGPR offset (GCNHazardRecognizer: "this hazard only exists if the
+                // instruction is not using a register in the soffset field") -- on gfx950 the store with an SGPR offset needs
+                // the padding too: `buffer_store_dwordx4 v[0:3], ..., s0 offen` followed directly by `v_mov_b64 v[0:1], ...`
+                // stored the moved value in the workgroups that found the memory pipeline busy (wrong frames 7 / 13 of the
+                // streams of workgroups >= 256, `tools/prew_check.py`).
+                v4u32 d = {__float_as_uint(ar[0]), __float_as_uint(ai[0]), __float_as_uint(ar[1]), __float_as_uint(ai[1])};
+                __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff + soff, 0, 0);
+            } else {
+                v2u32 d = {__float_as_uint(ar[0]), __float_as_uint(ai[0])};
+                __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, soff, 0);
+            }
         }
     }
 }
 
-// frames i0 .. i0 + TP - 1 of this thread's sample position: buffer loads, one VGPR byte offset, scalar frame offsets.
+// frames i0 .. i0 + TP - 1 of this thread's sample positions: buffer loads, one VGPR byte offset, scalar frame offsets.
 // Frames past the stream's last one are clamped to it (a later frame never feeds an earlier output, and outputs past
 // the end are not stored); frames before its first one read as zeros.
-template <int TP>
-__device__ __forceinline__ void prefilter_load(cf (&xr)[TP], __amdgpu_buffer_rsrc_t rs, unsigned voff, int64_t i0, int64_t n_pts,
+template <int TP, int W>
+__device__ __forceinline__ void prefilter_load(cf (&xr)[TP][W], __amdgpu_buffer_rsrc_t rs, unsigned voff, int64_t i0, int64_t n_pts,
                                                unsigned frame_bytes) {
 #pragma unroll
     for (int k = 0; k < TP; ++k) {
         const int64_t i = i0 + k;
         const int64_t ic = i < 0 ? 0 : (i < n_pts ? i : n_pts - 1);
-        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)ic * frame_bytes, 0);
         const bool zero = i < 0;   // wave-uniform
-        xr[k] = fxc::mk(zero ? 0.f : __uint_as_float(d[0]), zero ? 0.f : __uint_as_float(d[1]));
+        if constexpr (W == 2) {
+            const v4u32 d = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)ic * frame_bytes, 0);
+            xr[k][0] = fxc::mk(zero ? 0.f : __uint_as_float(d[0]), zero ? 0.f : __uint_as_float(d[1]));
+            xr[k][1] = fxc::mk(zero ? 0.f : __uint_as_float(d[2]), zero ? 0.f : __uint_as_float(d[3]));
+        } else {
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)ic * frame_bytes, 0);
+            xr[k][0] = fxc::mk(zero ? 0.f : __uint_as_float(d[0]), zero ? 0.f : __uint_as_float(d[1]));
+        }
     }
 }
 
-// hcoef[t][n] = h[t N + (N - 1 - n)] for t < ntaps, zero rows up to TP; grid (N / 256, streams, frame splits)
+// hcoef[t][n] = h[t N + (N - 1 - n)] for t < ntaps, zero rows up to TP; grid (N / (256 W), streams, frame splits)
 // (asking for 3 waves per SIMD at TP = 32 makes the compiler spill and the pass 3 % slower: measured)
-template <int TP>
+template <int TP, int W>
 __global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict__ x, cf* __restrict__ y,
                                                            const float* __restrict__ hcoef, int64_t num_samp, int nchan,
                                                            int64_t n_pts, int64_t per_split) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int n = (blockIdx.x * 256 + threadIdx.x) * W;      // first of this thread's W adjacent positions
     const int64_t s = blockIdx.y;
     const int64_t i_begin = (int64_t)blockIdx.z * per_split;
     const int64_t i_end = (i_begin + per_split < n_pts) ? i_begin + per_split : n_pts;
     if (i_begin >= i_end) return;
-    float hc[TP];
+    float hc[TP][W];
 #pragma unroll
-    for (int t = 0; t < TP; ++t) hc[t] = hcoef[(int64_t)t * nchan + n];
+    for (int t = 0; t < TP; ++t)
+#pragma unroll
+        for (int w = 0; w < W; ++w) hc[t][w] = hcoef[(int64_t)t * nchan + n + w];
     const unsigned stream_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf));       // num_samp <= 2^27
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x + s * num_samp), 0, (int)stream_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + s * num_samp, 0, (int)stream_bytes, 0x00020000);
     const unsigned voff = (unsigned)n * (unsigned)sizeof(cf);
     const unsigned frame_bytes = (unsigned)nchan * (unsigned)sizeof(cf);
-    cf xa[TP], xb[TP];
-    prefilter_load<TP>(xa, rx, voff, i_begin - TP, n_pts, frame_bytes);     // history (zeros before the stream's start)
-    for (int64_t i0 = i_begin; i0 < i_end; i0 += 2 * TP) {                  // two blocks per trip: the pair swaps roles, no copies
-        prefilter_load<TP>(xb, rx, voff, i0, n_pts, frame_bytes);
-        prefilter_fir_store<TP>(xa, xb, hc, ry, voff, i0, i_end, frame_bytes);
+    cf xa[TP][W], xb[TP][W];
+    prefilter_load<TP, W>(xa, rx, voff, i_begin - TP, n_pts, frame_bytes);     // history (zeros before the stream's start)
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 2 * TP) {                     // two blocks per trip: the pair swaps roles, no copies
+        prefilter_load<TP, W>(xb, rx, voff, i0, n_pts, frame_bytes);
+        prefilter_fir_store<TP, W>(xa, xb, hc, ry, voff, i0, i_end, frame_bytes);
         if (i0 + TP >= i_end) break;
-        prefilter_load<TP>(xa, rx, voff, i0 + TP, n_pts, frame_bytes);
-        prefilter_fir_store<TP>(xb, xa, hc, ry, voff, i0 + TP, i_end, frame_bytes);
+        prefilter_load<TP, W>(xa, rx, voff, i0 + TP, n_pts, frame_bytes);
+        prefilter_fir_store<TP, W>(xb, xa, hc, ry, voff, i0 + TP, i_end, frame_bytes);
     }
 }
 

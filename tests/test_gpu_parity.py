@@ -814,6 +814,24 @@ def test_caller_threads_with_a_plan_each(plan_mod, torch):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [(4096, 8, 19, 23, 424), (1024, 8, 300, 24, 10), (512, 9, 600, 31, 0),
+                                                              (2048, 16, 5, 33, 100), (1024, 8, 7, 40, 1)])
+def test_prefilter_with_more_workgroups_than_cus(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
+    """The pre-filter pass with 16-byte accesses (even num_samp, 8-frame block) and 8-byte ones, on launches of more than
+    256 workgroups: the shapes on which a 16-byte buffer store with an SGPR offset lost its data to the next VALU write
+    (tests/test_isa_hazards.py) -- spectra of every stream and frame against the generic kernels, then the rows."""
+    num_samp = nchan * frames + extra
+    x = torch.from_numpy(synth.synth_iq(7, n_chunks, 2, num_samp)).cuda()
+    with plan_mod.FxPlan(1, nchan, ntaps, num_samp) as f, plan_mod.FxPlan(1, nchan, ntaps, num_samp, path="generic") as g:
+        xs = x.reshape(-1, num_samp)
+        sf, sg = f.channelize(xs).cpu().numpy(), g.channelize(xs).cpu().numpy()
+        worst = np.abs(sf - sg).max(axis=2) / np.abs(sg).max()
+        assert worst.max() < TOL_SPEC, np.argwhere(worst >= TOL_SPEC)[:10].tolist()
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp) as f, plan_mod.FxPlan(2, nchan, ntaps, num_samp, path="generic") as g:
+        assert f.path == "tiled"
+        assert rel_err(f.fx_rows(x).cpu().numpy(), g.fx_rows(x).cpu().numpy()) < TOL_VIS
+
+
 def test_sharded_integration_equals_single_rank(plan_mod, torch):
     """SURVEY.md §8e on one GPU: two 'ranks' integrate disjoint chunk ranges, their exported sums are
     added (what the RCCL all-reduce does) and finalised once."""

@@ -1,0 +1,31 @@
+"""Compiled-code check (no GPU): a hazard the ROCm 7.2 compiler does not pad on gfx950.
+
+A buffer store of more than 8 bytes reads its data registers over several cycles.  LLVM's hazard recognizer inserts
+`s_nop` in front of a VALU instruction that overwrites them — except when the store carries an SGPR offset
+("this hazard only exists if the instruction is not using a register in the soffset field").  On MI355X the exception
+does not hold: `buffer_store_dwordx4 v[0:3], v40, s[8:11], s0 offen` directly followed by `v_mov_b64 v[0:1], ...`
+stored the moved value in workgroups that found the memory pipeline busy (the pre-filter with 16-byte accesses:
+frames 7 and 13 of every stream of workgroups >= 256; k_prepass.h, profiles/r02/round2_experiments.md).  So the
+library must not contain such a store at all: wide buffer stores keep their offset in the VGPR."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from effex_amd import build as fx_build
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "effex_amd", "csrc")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not found")
+def test_no_wide_buffer_store_with_a_scalar_offset(tmp_path):
+    asm = tmp_path / "fxcorr.s"
+    flags = [f for f in fx_build.FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.run([fx_build.hipcc_path()] + flags + ["-S", "--cuda-device-only", "-o", str(asm), "fxcorr.hip"],
+                   cwd=CSRC, check=True, stderr=subprocess.DEVNULL)
+    wide = [line.strip() for line in open(asm) if re.search(r"\bbuffer_store_(dwordx3|dwordx4)\b", line)]
+    # operands: vdata, vaddr, srsrc, soffset [modifiers]
+    bad = [line for line in wide if re.match(r"s\d+|m0|s\[", line.split(",")[3].split()[0])]
+    assert not bad, "wide buffer stores with an SGPR offset:\n" + "\n".join(bad[:8])
