@@ -343,18 +343,28 @@ int split_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* raw) {
     if (rc) return rc;
     cf* y = static_cast<cf*>(p->d_pre);
     const int tp = p->pre_tp;
-    const int64_t blocks = 16 * 2 * nc;
+    // two adjacent positions per thread (16-byte accesses) for the 4- and 8-frame blocks (the 16-frame one has no registers left)
+    static const bool narrow = [] { const char* e = std::getenv("FXC_PRE_W"); return e && std::atoi(e) == 1; }();
+    const int w = (!narrow && tp <= 8 && (p->num_samp % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0) ? 2 : 1;
+    const int64_t blocks = (16 / w) * 2 * nc;
     int64_t fs = std::max<int64_t>(1, (2 * (int64_t)p->cu_count + blocks - 1) / blocks);
     fs = std::min<int64_t>(fs, std::max<int64_t>(1, p->n_pts / (4 * tp)));
     const int64_t per = ((p->n_pts + fs - 1) / fs + 2 * tp - 1) / (2 * tp) * (2 * tp);
-    const dim3 grid(16, (unsigned)(2 * nc), (unsigned)((p->n_pts + per - 1) / per));
+    const dim3 grid((unsigned)(16 / w), (unsigned)(2 * nc), (unsigned)((p->n_pts + per - 1) / per));
     KernelTimer kt(p);
-    if (tp == 4)
-        hipLaunchKernelGGL(pfb_split8192_kernel<4>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, p->n_pts, per);
-    else if (tp == 8)
-        hipLaunchKernelGGL(pfb_split8192_kernel<8>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, p->n_pts, per);
-    else
-        hipLaunchKernelGGL(pfb_split8192_kernel<16>, grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, p->n_pts, per);
+#define FXC_SPLIT_LAUNCH(TP, W)                                                                                             \
+    hipLaunchKernelGGL((pfb_split8192_kernel<TP, W>), grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->d_tw8192, p->num_samp, \
+                       p->n_pts, per)
+    if (tp == 4) {
+        if (w == 2) FXC_SPLIT_LAUNCH(4, 2);
+        else FXC_SPLIT_LAUNCH(4, 1);
+    } else if (tp == 8) {
+        if (w == 2) FXC_SPLIT_LAUNCH(8, 2);
+        else FXC_SPLIT_LAUNCH(8, 1);
+    } else {
+        FXC_SPLIT_LAUNCH(16, 1);
+    }
+#undef FXC_SPLIT_LAUNCH
     FXC_HIP(p, hipGetLastError());
     kt.stop();
     return launch_fused(p, y, 2 * nc, raw, false, nullptr, 1, true, half_samp);

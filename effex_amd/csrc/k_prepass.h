@@ -123,23 +123,29 @@ __global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict
 // single unit tap -- pair 2c gives the even bins of chunk c, pair 2c + 1 the odd ones (raw layout 3).
 // y = [chunk][even | odd][antenna][n_pts * 4096].  HBM: stream in + out, then in again: 3 x algorithmic.
 // ------------------------------------------------------------------------------------------
-template <int TP>
+// W = adjacent positions n', n' + 1 per thread (2: 16-byte accesses; the stores keep their frame offset in the VGPR,
+// see prefilter_fir_store)
+template <int TP, int W>
 __global__ __launch_bounds__(256) void pfb_split8192_kernel(const cf* __restrict__ x, cf* __restrict__ y,
                                                            const float* __restrict__ hcoef, const cf* __restrict__ tw,
                                                            int64_t num_samp, int64_t n_pts, int64_t per_split) {
     constexpr int kHalf = 4096, kFull = 8192;
-    const int n = blockIdx.x * 256 + threadIdx.x;          // position inside the half frame
+    const int n = (blockIdx.x * 256 + threadIdx.x) * W;    // first position inside the half frame
     const int64_t s = blockIdx.y;                           // stream = chunk * 2 + antenna
     const int64_t i_begin = (int64_t)blockIdx.z * per_split;
     const int64_t i_end = (i_begin + per_split < n_pts) ? i_begin + per_split : n_pts;
     if (i_begin >= i_end) return;
-    float hc[TP][2];
+    float hc[TP][2][W];
+    cf w[W];
 #pragma unroll
-    for (int t = 0; t < TP; ++t) {
-        hc[t][0] = hcoef[(int64_t)t * kFull + n];
-        hc[t][1] = hcoef[(int64_t)t * kFull + n + kHalf];
+    for (int q = 0; q < W; ++q) {
+#pragma unroll
+        for (int t = 0; t < TP; ++t) {
+            hc[t][0][q] = hcoef[(int64_t)t * kFull + n + q];
+            hc[t][1][q] = hcoef[(int64_t)t * kFull + n + q + kHalf];
+        }
+        w[q] = tw[n + q];
     }
-    const cf w = tw[n];
     const int64_t half_samp = n_pts * kHalf;
     const int64_t c = s >> 1, a = s & 1;
     const unsigned in_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf)), out_bytes = (unsigned)(half_samp * (int64_t)sizeof(cf));
@@ -148,41 +154,61 @@ __global__ __launch_bounds__(256) void pfb_split8192_kernel(const cf* __restrict
     __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(y + ((c * 2 + 1) * 2 + a) * half_samp, 0, (int)out_bytes, 0x00020000);
     const unsigned voff = (unsigned)n * (unsigned)sizeof(cf);
     const unsigned in_frame = kFull * (unsigned)sizeof(cf), out_frame = kHalf * (unsigned)sizeof(cf), hi = kHalf * (unsigned)sizeof(cf);
-    cf xa[TP][2], xb[TP][2];
-    auto load = [&](cf (&xr)[TP][2], int64_t i0) {
+    cf xa[TP][2][W], xb[TP][2][W];
+    auto load = [&](cf (&xr)[TP][2][W], int64_t i0) {
 #pragma unroll
         for (int k = 0; k < TP; ++k) {
             const int64_t i = i0 + k;
             const int64_t ic = i < 0 ? 0 : (i < n_pts ? i : n_pts - 1);      // see prefilter_load
             const bool zero = i < 0;
-            const v2u32 d0 = __builtin_amdgcn_raw_buffer_load_b64(rx, voff, (unsigned)ic * in_frame, 0);
-            const v2u32 d1 = __builtin_amdgcn_raw_buffer_load_b64(rx, voff, (unsigned)ic * in_frame + hi, 0);
-            xr[k][0] = fxc::mk(zero ? 0.f : __uint_as_float(d0[0]), zero ? 0.f : __uint_as_float(d0[1]));
-            xr[k][1] = fxc::mk(zero ? 0.f : __uint_as_float(d1[0]), zero ? 0.f : __uint_as_float(d1[1]));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned soff = (unsigned)ic * in_frame + (h ? hi : 0u);
+                if constexpr (W == 2) {
+                    const v4u32 d = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, soff, 0);
+                    xr[k][h][0] = fxc::mk(zero ? 0.f : __uint_as_float(d[0]), zero ? 0.f : __uint_as_float(d[1]));
+                    xr[k][h][1] = fxc::mk(zero ? 0.f : __uint_as_float(d[2]), zero ? 0.f : __uint_as_float(d[3]));
+                } else {
+                    const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rx, voff, soff, 0);
+                    xr[k][h][0] = fxc::mk(zero ? 0.f : __uint_as_float(d[0]), zero ? 0.f : __uint_as_float(d[1]));
+                }
+            }
         }
     };
-    auto fir_store = [&](const cf (&xo)[TP][2], const cf (&xn)[TP][2], int64_t i0) {
+    auto fir_store = [&](const cf (&xo)[TP][2][W], const cf (&xn)[TP][2][W], int64_t i0) {
         const bool full = i0 + TP <= i_end;
 #pragma unroll
         for (int k = 0; k < TP; ++k) {
-            cf yv[2];
+            cf ea[W], eb[W];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float ar = 0.f, ai = 0.f;
+            for (int q = 0; q < W; ++q) {
+                cf yv[2];
 #pragma unroll
-                for (int t = 0; t < TP; ++t) {
-                    const cf v = (k - t >= 0) ? xn[(k - t) >= 0 ? k - t : 0][h] : xo[(TP + k - t) < TP ? TP + k - t : 0][h];
-                    ar = fmaf(hc[t][h], v.x, ar);
-                    ai = fmaf(hc[t][h], v.y, ai);
+                for (int h = 0; h < 2; ++h) {
+                    float ar = 0.f, ai = 0.f;
+#pragma unroll
+                    for (int t = 0; t < TP; ++t) {
+                        const cf v = (k - t >= 0) ? xn[(k - t) >= 0 ? k - t : 0][h][q] : xo[(TP + k - t) < TP ? TP + k - t : 0][h][q];
+                        ar = fmaf(hc[t][h][q], v.x, ar);
+                        ai = fmaf(hc[t][h][q], v.y, ai);
+                    }
+                    yv[h] = fxc::mk(ar, ai);
                 }
-                yv[h] = fxc::mk(ar, ai);
+                ea[q] = fxc::cadd(yv[1], yv[0]);
+                eb[q] = fxc::cmul(fxc::csub(yv[1], yv[0]), w[q]);
             }
             if (full || i0 + k < i_end) {
-                const cf ea = fxc::cadd(yv[1], yv[0]), eb = fxc::cmul(fxc::csub(yv[1], yv[0]), w);
                 const unsigned soff = (unsigned)(i0 + k) * out_frame;
-                v2u32 da = {__float_as_uint(ea.x), __float_as_uint(ea.y)}, db = {__float_as_uint(eb.x), __float_as_uint(eb.y)};
-                __builtin_amdgcn_raw_buffer_store_b64(da, ra, voff, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(db, rb, voff, soff, 0);
+                if constexpr (W == 2) {
+                    v4u32 da = {__float_as_uint(ea[0].x), __float_as_uint(ea[0].y), __float_as_uint(ea[1].x), __float_as_uint(ea[1].y)};
+                    v4u32 db = {__float_as_uint(eb[0].x), __float_as_uint(eb[0].y), __float_as_uint(eb[1].x), __float_as_uint(eb[1].y)};
+                    __builtin_amdgcn_raw_buffer_store_b128(da, ra, voff + soff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(db, rb, voff + soff, 0, 0);
+                } else {
+                    v2u32 da = {__float_as_uint(ea[0].x), __float_as_uint(ea[0].y)}, db = {__float_as_uint(eb[0].x), __float_as_uint(eb[0].y)};
+                    __builtin_amdgcn_raw_buffer_store_b64(da, ra, voff, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(db, rb, voff, soff, 0);
+                }
             }
         }
     };
