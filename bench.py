@@ -285,18 +285,18 @@ def dry_run_dist(args):
 def other_configs(x, dev, reps=5):
     """Short, untimed-region runs of the other single-GPU BASELINE configs on the resident synthetic bytes (viewed with
     their own shapes): configs[2] continuum streaming limit (nchan = 1, num_samp = 2^20) and configs[4] (8 antennas,
-    28 baselines, nchan 4096).  HIP-event median of `reps` calls each."""
+    28 baselines, nchan 4096), plus two three-pass shapes (32 taps, 8192 channels).  HIP-event median of `reps` calls each."""
     import numpy as np
     from effex_amd.plan import FxPlan
     out = []
     flat = x.view(-1)
 
-    def run(name, n_ant, nchan, num_samp, n_chunks, window, mode, rows):
+    def run(name, n_ant, nchan, num_samp, n_chunks, window, mode, rows, ntaps=NTAPS):
         need = n_chunks * n_ant * num_samp
         if flat.numel() < need:
             return
         xv = flat[:need].view(n_chunks, n_ant, num_samp)
-        with FxPlan(n_ant, nchan, NTAPS, num_samp, window=window, device=dev.index) as plan:
+        with FxPlan(n_ant, nchan, ntaps, num_samp, window=window, device=dev.index) as plan:
             def call():
                 if rows:
                     plan.fx_rows(xv, mode, BANDWIDTH)
@@ -314,7 +314,7 @@ def other_configs(x, dev, reps=5):
             ms.sort()
             med = ms[len(ms) // 2]
             algo = need * 8
-            out.append({"config": name, "path": plan.path, "n_ant": n_ant, "nchan": nchan, "num_samp": num_samp,
+            out.append({"config": name, "path": plan.path, "n_ant": n_ant, "nchan": nchan, "ntaps": ntaps, "num_samp": num_samp,
                         "n_chunks": n_chunks, "mode": mode, "median_ms": round(med, 4),
                         "value": round(n_chunks * num_samp / med / 1e3, 1), "unit": "Msamples/s",
                         "algorithmic_GBps": round(algo / med / 1e6, 1), "frac_of_8TBs": round(algo / med / 1e6 / HBM_PEAK_GBS, 4)})
@@ -322,6 +322,12 @@ def other_configs(x, dev, reps=5):
     run("configs[2]: continuum streaming limit, nchan=1, num_samp=2^20, one scalar per chunk pair", 2, 1, 2 ** 20, 2048,
         np.array([0.4, 0.3, 0.2, 0.1]), "CONTINUUM", True)
     run("configs[4]: 8 antennas, 28 baselines, nchan=4096, num_samp=262144, integrated", 8, NCHAN, NUM_SAMP, 512, None,
+        "SPECTRUM", False)
+    # not BASELINE configs: the reference test's own shape (tests/test_effex.py:62-66) and the largest --nfft of its CLI
+    # examples; both are three-pass routes (3 x the algorithmic traffic by construction)
+    run("reference test shape: 2 antennas, nchan=2048, ntaps=32, num_samp=262144, integrated", 2, 2048, NUM_SAMP, 1024, None,
+        "SPECTRUM", False, ntaps=32)
+    run("--nfft 8192: 2 antennas, nchan=8192, ntaps=4, num_samp=262144, integrated", 2, 8192, NUM_SAMP, 1024, None,
         "SPECTRUM", False)
     return out
 
@@ -336,7 +342,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power sample after the timed region")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of configs[2] and configs[4]")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of configs[2], configs[4] and the two three-pass shapes")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check after the timed region (profiling runs: its fx_rows launches would mix into "
                          "the per-kernel statistics)")
