@@ -25,8 +25,9 @@ def _python_blocks():
 def _stub_namespace():
     """Module-level part of the first block (imports, CDLL, argtypes, _fxc) plus its method definitions; the two
     statements meant for Correlator.__init__ become `_init_plan(self)`."""
-    from effex_amd import build
-    build.build()                 # no-op when the in-tree library is current (the stub dlopens it)
+    if not os.path.isfile(_lib.LIB_PATH):     # a fresh checkout running this file alone (never rebuilt under a loaded library)
+        from effex_amd import build
+        build.build()
     blocks = _python_blocks()
     assert len(blocks) >= 3, "INTEGRATION.md lost its code blocks"
     first = blocks[0].replace('"/path/to/effex_amd/csrc/libfxcorr.so"', repr(_lib.LIB_PATH))
