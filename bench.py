@@ -415,28 +415,42 @@ def main():
             comm = None
     integ = sharding.ShardedIntegrator(plan, rank, world, comm=comm)
 
-    def step():
+    def issue():
+        """Queue one integration: the F+X launch(es) over this rank's frames, then reduce + finalize + reset (one
+        kernel on one GPU).  Nothing here waits for the device."""
         done = 0
         while done < frames:                      # one launch when the whole run is resident
             n = min(pool_frames, frames - done)
             plan.fx_accumulate(x[:n])
             done += n
-        return integ.finalize("SPECTRUM", BANDWIDTH, root=0)
+        integ.finalize_async("SPECTRUM", BANDWIDTH, root=0)
+
+    def run_steps(k):
+        """k integrations; every one is finalised to host memory and collected.  Integration j + 1 is queued before the
+        host waits for the result of j (two may be in flight), so the device never idles on the host's round trip."""
+        res = None
+        for j in range(k):
+            issue()
+            if j > 0:
+                res = integ.finalize_wait()
+        if k > 0:
+            res = integ.finalize_wait()
+        return res
+
+    def step():
+        return run_steps(1)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    out = None
-    for _ in range(args.warmup):
-        out = step()
+    out = run_steps(args.warmup)
     plan.kernel_profiling(True)
     plan.kernel_time(reset=True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = plan.kernel_time(reset=True)

@@ -67,6 +67,10 @@ SIGNATURES = {
     "fxc_acc_export": (_c.c_int, [_vp, _vp]),
     "fxc_finalize_sums": (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_double]),
     "fxc_finalize": (_c.c_int, [_vp, _vp, _c.c_int, _c.c_double, _c.c_int]),
+    "fxc_finalize_async": (_c.c_int, [_vp, _c.c_int, _c.c_double, _c.c_int]),
+    "fxc_finalize_sums_async": (_c.c_int, [_vp, _vp, _c.c_int, _c.c_double]),
+    "fxc_finalize_wait": (_c.c_int, [_vp, _vp]),
+    "fxc_finalize_pending": (_c.c_int, [_vp]),
     "fxc_comm_unique_id": (_c.c_int, [_vp]),
     "fxc_comm_create": (_c.c_int, [_c.POINTER(_vp), _c.c_int, _c.c_int, _c.c_int, _vp]),
     "fxc_comm_destroy": (_c.c_int, [_vp]),

@@ -22,7 +22,27 @@
 // No CPU fallback.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and prototypes only: the library itself is bound at run time (rccl_api)
+// RCCL: types and prototypes only -- the library itself is bound at run time (rccl_api), so a ROCm install without the
+// rccl headers still builds libfxcorr (single-GPU users need no RCCL at all)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char* ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, int root,
+                        ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
+                           ncclComm_t comm, hipStream_t stream);
+}
+#endif
 
 #include <cmath>
 #include <cstdarg>
@@ -107,14 +127,17 @@ int fxc_plan_destroy(fxc_plan* p) {
         (void)hipEventDestroy(e.second);
     }
     void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_stamps,
-                    p->d_acc, p->d_sums, p->d_out, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
+                    p->d_acc, p->d_sums, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
                     p->d_ones, p->d_pre, p->d_tw8192};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
     if (p->ev_t1) (void)hipEventDestroy(p->ev_t1);
     if (p->ev_order) (void)hipEventDestroy(p->ev_order);
-    if (p->h_out) (void)hipHostFree(p->h_out);
+    for (int k = 0; k < fxc_plan::kResSlots; ++k) {
+        if (p->ev_res[k]) (void)hipEventDestroy(p->ev_res[k]);
+        if (p->h_res[k]) (void)hipHostFree(p->h_res[k]);
+    }
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return FXC_OK;
@@ -180,8 +203,15 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     FXC_HIP(p, hipMalloc(&p->d_acc, acc_n * sizeof(cd)));
     FXC_HIP(p, hipMemset(p->d_acc, 0, acc_n * sizeof(cd)));
     FXC_HIP(p, hipMalloc(&p->d_sums, (acc_n + 1) * sizeof(cd)));
-    FXC_HIP(p, hipMalloc(&p->d_out, acc_n * sizeof(cd)));
-    FXC_HIP(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_out), acc_n * sizeof(cd), hipHostMallocDefault));
+    FXC_HIP(p, hipMemset(p->d_sums, 0, (acc_n + 1) * sizeof(cd)));
+    // finalize results: pinned host memory the finishing kernels write through the device's mapping of it (coherent,
+    // so the host sees the bytes once the slot's event has completed)
+    for (int k = 0; k < fxc_plan::kResSlots; ++k) {
+        FXC_HIP(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_res[k]), std::max<size_t>(acc_n, 16) * sizeof(cd),
+                                 hipHostMallocMapped | hipHostMallocCoherent));
+        FXC_HIP(p, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_res[k]), p->h_res[k], 0));
+        FXC_HIP(p, hipEventCreateWithFlags(&p->ev_res[k], hipEventDisableTiming | hipEventReleaseToSystem));
+    }
 
     if (p->path == FXC_PATH_FUSED) {
         using namespace fxc::fused;
@@ -464,32 +494,55 @@ int fxc_comm_create(void** rccl_comm_out, int device, int rank, int world_size, 
     ncclComm_t comm = nullptr;
     const ncclResult_t r = api->comm_init_rank(&comm, world_size, uid, rank);
     if (r != ncclSuccess) return rccl_fail(nullptr, api, "ncclCommInitRank", r);
-    *rccl_comm_out = comm;
+    fxc_comm* c = new (std::nothrow) fxc_comm();
+    if (!c) {
+        (void)api->comm_destroy(comm);
+        return fail(nullptr, FXC_ERR_NOMEM, "host allocation failed");
+    }
+    c->comm = comm;
+    c->device = device;
+    c->rank = rank;
+    c->world_size = world_size;
+    *rccl_comm_out = c;
     return FXC_OK;
 }
 
 int fxc_comm_destroy(void* rccl_comm) {
     if (!rccl_comm) return FXC_OK;
+    fxc_comm* c = static_cast<fxc_comm*>(rccl_comm);
+    if (c->magic != fxc_comm::kMagic) return fail(nullptr, FXC_ERR_ARG, "not a communicator made by fxc_comm_create");
     RcclApi* api = rccl_api();
     if (!api->handle) return fail(nullptr, FXC_ERR_COMM, "%s", api->error.c_str());
-    const ncclResult_t r = api->comm_destroy(static_cast<ncclComm_t>(rccl_comm));
+    DeviceGuard device_guard__(c->device);
+    const ncclResult_t r = api->comm_destroy(c->comm);
+    c->magic = 0;
+    delete c;
     if (r != ncclSuccess) return rccl_fail(nullptr, api, "ncclCommDestroy", r);
     return FXC_OK;
 }
 
 int fxc_reduce(fxc_plan* p, void* rccl_comm, int root) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    fxc_comm* c = static_cast<fxc_comm*>(rccl_comm);
+    if (c) {
+        // checked before anything is queued: a collective on the wrong device or with a root no rank has would leave
+        // the other ranks waiting in theirs
+        if (c->magic != fxc_comm::kMagic) return fail(p, FXC_ERR_ARG, "not a communicator made by fxc_comm_create");
+        if (c->device != p->device)
+            return fail(p, FXC_ERR_ARG, "the communicator was made on device %d, the plan is on device %d", c->device, p->device);
+        if (root >= c->world_size) return fail(p, FXC_ERR_ARG, "root %d outside the communicator's world of %d", root, c->world_size);
+    }
     FXC_DEVICE(p, p->device);
     int rc = fxc_acc_export(p, p->d_sums);
     if (rc) return rc;
-    if (!rccl_comm) return FXC_OK;          // single rank: the exported sums are the reduced sums
+    p->sums_valid = true;
+    if (!c) return FXC_OK;                  // single rank: the exported sums are the reduced sums
     RcclApi* api = rccl_api();
     if (!api->handle) return fail(p, FXC_ERR_COMM, "%s", api->error.c_str());
     // raw float64 sums + the spectra count, in place, ordered on the plan's stream behind the export
     const size_t count = 2 * ((size_t)p->n_base * p->nchan + 1);
-    ncclComm_t comm = static_cast<ncclComm_t>(rccl_comm);
-    const ncclResult_t r = root < 0 ? api->all_reduce(p->d_sums, p->d_sums, count, ncclFloat64, ncclSum, comm, p->stream)
-                                    : api->reduce(p->d_sums, p->d_sums, count, ncclFloat64, ncclSum, root, comm, p->stream);
+    const ncclResult_t r = root < 0 ? api->all_reduce(p->d_sums, p->d_sums, count, ncclFloat64, ncclSum, c->comm, p->stream)
+                                    : api->reduce(p->d_sums, p->d_sums, count, ncclFloat64, ncclSum, root, c->comm, p->stream);
     if (r != ncclSuccess) return rccl_fail(p, api, root < 0 ? "ncclAllReduce" : "ncclReduce", r);
     return FXC_OK;
 }
@@ -497,6 +550,8 @@ int fxc_reduce(fxc_plan* p, void* rccl_comm, int root) {
 int fxc_sync(fxc_plan* p) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     FXC_DEVICE(p, p->device);
+    const int rf = flush_pending(p);        // the fold of the last fx_accumulate pass belongs to "everything queued"
+    if (rf) return rf;
     FXC_HIP(p, hipStreamSynchronize(p->stream));
     return FXC_OK;
 }
@@ -553,6 +608,7 @@ int fxc_fx_rows(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mem
 int fxc_acc_reset(fxc_plan* p) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     FXC_DEVICE(p, p->device);
+    p->pend.valid = false;                  // rows not folded yet are simply dropped
     FXC_HIP(p, hipMemsetAsync(p->d_acc, 0, (size_t)p->n_base * p->nchan * sizeof(cd), p->stream));
     p->spectra_count = 0.0;
     return FXC_OK;
@@ -561,47 +617,98 @@ int fxc_acc_reset(fxc_plan* p) {
 int fxc_acc_export(fxc_plan* p, void* sums_dev) {
     if (!p || !sums_dev) return fail(p, FXC_ERR_ARG, "NULL argument");
     FXC_DEVICE(p, p->device);
+    const FoldFinish fin = {static_cast<cd*>(sums_dev), nullptr, p->d_rot, p->spectra_count, 0};
+    return flush_pending(p, &fin);
+}
+
+namespace {
+
+// Queue the finalize of `sums_src` (exported, possibly cross-rank reduced sums) or, sums_src == nullptr, of the plan's
+// accumulator -- then together with the fold of the rows still pending and with the reset, in one kernel -- into the
+// next result slot; the slot's event marks the host copy complete.
+int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth, int reset) {
+    if (mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
+    if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
+    if (p->res_head - p->res_tail >= fxc_plan::kResSlots)
+        return fail(p, FXC_ERR_STATE, "%d finalize results outstanding: collect one with fxc_finalize_wait first",
+                    fxc_plan::kResSlots);
+    if (!sums_src && !(p->spectra_count > 0.0)) return fail(p, FXC_ERR_STATE, "nothing accumulated");
+    const int slot = (int)(p->res_head % fxc_plan::kResSlots);
+    cd* out = p->d_res[slot];
     const int64_t n = (int64_t)p->n_base * p->nchan;
-    hipLaunchKernelGGL(export_kernel, dim3(grid_for(n + 1, 256, p->cu_count)), dim3(256), 0, p->stream, p->d_acc,
-                       static_cast<cd*>(sums_dev), n, p->spectra_count);
+    if (!sums_src) {
+        // SPECTRUM: one kernel.  CONTINUUM needs the mean over the bins of the finished accumulator: export, then reduce
+        FoldFinish fin = {nullptr, out, p->d_rot, p->spectra_count, reset ? 1 : 0};
+        if (mode == FXC_MODE_CONTINUUM) {
+            fin.sums = p->d_sums;
+            fin.out = nullptr;
+            p->sums_valid = true;
+            sums_src = p->d_sums;
+        }
+        const int rc = flush_pending(p, &fin);
+        if (rc) return rc;
+        if (reset) p->spectra_count = 0.0;
+    } else if (mode == FXC_MODE_SPECTRUM) {
+        const int rc = flush_pending(p);
+        if (rc) return rc;
+        hipLaunchKernelGGL(finalize_spectrum_kernel, dim3(grid_for(n, 256, p->cu_count)), dim3(256), 0, p->stream, sums_src,
+                           out, p->d_rot, p->nchan, p->n_base);
+    }
+    if (mode == FXC_MODE_CONTINUUM)
+        hipLaunchKernelGGL(finalize_continuum_kernel, dim3(p->n_base), dim3(256), 0, p->stream, sums_src, out, p->d_rot,
+                           p->nchan, p->n_base, 1.0 / bandwidth);
     FXC_HIP(p, hipGetLastError());
+    FXC_HIP(p, hipEventRecord(p->ev_res[slot], p->stream));
+    p->res_bytes[slot] = mode == FXC_MODE_SPECTRUM ? (size_t)n * sizeof(cd) : (size_t)p->n_base * sizeof(cd);
+    p->res_head += 1;
     return FXC_OK;
 }
 
+}  // namespace
+
+int fxc_finalize_async(fxc_plan* p, int mode, double bandwidth, int reset) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    FXC_DEVICE(p, p->device);
+    return finalize_enqueue(p, nullptr, mode, bandwidth, reset);
+}
+
+int fxc_finalize_sums_async(fxc_plan* p, const void* sums_dev, int mode, double bandwidth) {
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    if (!sums_dev) {                         // what fxc_reduce left in the plan
+        if (!p->sums_valid) return fail(p, FXC_ERR_STATE, "no reduced sums in the plan: call fxc_reduce first");
+        sums_dev = p->d_sums;
+    }
+    FXC_DEVICE(p, p->device);
+    return finalize_enqueue(p, static_cast<const cd*>(sums_dev), mode, bandwidth, 0);
+}
+
+int fxc_finalize_wait(fxc_plan* p, void* out_host) {
+    if (!p || !out_host) return fail(p, FXC_ERR_ARG, "NULL argument");
+    if (p->res_head == p->res_tail) return fail(p, FXC_ERR_STATE, "no finalize result outstanding");
+    FXC_DEVICE(p, p->device);
+    const int slot = (int)(p->res_tail % fxc_plan::kResSlots);
+    FXC_HIP(p, hipEventSynchronize(p->ev_res[slot]));
+    std::memcpy(out_host, p->h_res[slot], p->res_bytes[slot]);
+    p->res_tail += 1;
+    return FXC_OK;
+}
+
+int fxc_finalize_pending(const fxc_plan* p) { return p ? (int)(p->res_head - p->res_tail) : 0; }
+
 int fxc_finalize_sums(fxc_plan* p, const void* sums_dev, void* out_host, int mode, double bandwidth) {
     if (!p || !out_host) return fail(p, FXC_ERR_ARG, "NULL argument");
-    if (!sums_dev) sums_dev = p->d_sums;     // what fxc_reduce left in the plan
-    if (mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
-    if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
-    FXC_DEVICE(p, p->device);
-    const cd* sums = static_cast<const cd*>(sums_dev);
-    size_t out_bytes;
-    if (mode == FXC_MODE_SPECTRUM) {
-        const int64_t n = (int64_t)p->n_base * p->nchan;
-        hipLaunchKernelGGL(finalize_spectrum_kernel, dim3(grid_for(n, 256, p->cu_count)), dim3(256), 0, p->stream, sums,
-                           p->d_out, p->d_rot, p->nchan, p->n_base);
-        out_bytes = (size_t)n * sizeof(cd);
-    } else {
-        hipLaunchKernelGGL(finalize_continuum_kernel, dim3(p->n_base), dim3(256), 0, p->stream, sums, p->d_out,
-                           p->d_rot, p->nchan, p->n_base, 1.0 / bandwidth);
-        out_bytes = (size_t)p->n_base * sizeof(cd);
-    }
-    FXC_HIP(p, hipGetLastError());
-    FXC_HIP(p, hipMemcpyAsync(p->h_out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
-    FXC_HIP(p, hipStreamSynchronize(p->stream));
-    std::memcpy(out_host, p->h_out, out_bytes);
-    return FXC_OK;
+    if (p->res_head != p->res_tail) return fail(p, FXC_ERR_STATE, "asynchronous finalize results outstanding");
+    const int rc = fxc_finalize_sums_async(p, sums_dev, mode, bandwidth);
+    if (rc) return rc;
+    return fxc_finalize_wait(p, out_host);
 }
 
 int fxc_finalize(fxc_plan* p, void* out_host, int mode, double bandwidth, int reset) {
     if (!p || !out_host) return fail(p, FXC_ERR_ARG, "NULL argument");
-    if (!(p->spectra_count > 0.0)) return fail(p, FXC_ERR_STATE, "nothing accumulated");
-    int rc = fxc_acc_export(p, p->d_sums);
+    if (p->res_head != p->res_tail) return fail(p, FXC_ERR_STATE, "asynchronous finalize results outstanding");
+    const int rc = fxc_finalize_async(p, mode, bandwidth, reset);
     if (rc) return rc;
-    rc = fxc_finalize_sums(p, p->d_sums, out_host, mode, bandwidth);
-    if (rc) return rc;
-    if (reset) return fxc_acc_reset(p);
-    return FXC_OK;
+    return fxc_finalize_wait(p, out_host);
 }
 
 static int conditioning_common(fxc_plan* p, int64_t n_streams, const void* x, void* out) {

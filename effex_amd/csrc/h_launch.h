@@ -61,9 +61,56 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
     return cb;
 }
 
-constexpr int kFusedReduceSplits = 256;   // most splits of the two-stage reduce over raw rows (size of `part`)
-// splits that leave each thread of stage 1 about four rows to walk
-int fused_reduce_splits(int64_t n_rows) { return (int)std::max<int64_t>(16, std::min<int64_t>(kFusedReduceSplits, n_rows / 4)); }
+// fold_partial_kernel: splits that leave each of its threads about eight rows to walk; `part` holds kFoldMaxSplits rows
+int fold_splits(int64_t n_rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(kFoldMaxSplits, n_rows / (8 * kFoldPhases))); }
+int64_t fold_part_bytes(int nchan) { return (int64_t)kFoldMaxSplits * nchan * (int64_t)sizeof(cd); }
+
+const FoldFinish kNoFinish = {nullptr, nullptr, nullptr, 0.0, 0};
+
+// acc[bin] += sum of the raw rows (one baseline), and `fin` for every element: two launches, one when the rows are few
+int fold_rows(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int nchan, int layout, const FoldFinish& fin) {
+    const int cols = (nchan + 255) / 256;
+    if (n_rows <= kFoldMaxSplits) {
+        hipLaunchKernelGGL(fold_finish_kernel<cf>, dim3(cols), dim3(256 * kFoldPhases), 0, p->stream, raw, n_rows, p->d_acc, nchan,
+                           layout, fin);
+    } else {
+        const int splits = fold_splits(n_rows);
+        hipLaunchKernelGGL(fold_partial_kernel, dim3(cols, splits), dim3(256 * kFoldPhases), 0, p->stream, raw, part, nchan,
+                           n_rows, splits);
+        hipLaunchKernelGGL(fold_finish_kernel<cd>, dim3(cols), dim3(256 * kFoldPhases), 0, p->stream, part, (int64_t)splits,
+                           p->d_acc, nchan, layout, fin);
+    }
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
+// the fold of the last fx_accumulate pass, if it is still pending, with `fin` riding along; nothing pending: `fin`
+// alone on the accumulator as it stands
+int flush_pending(fxc_plan* p, const FoldFinish* fin) {
+    if (p->pend.valid) {
+        p->pend.valid = false;
+        return fold_rows(p, p->pend.raw, p->pend.part, p->pend.n_rows, p->pend.nchan, p->pend.layout, fin ? *fin : kNoFinish);
+    }
+    if (fin) {
+        const int64_t n = (int64_t)p->n_base * p->nchan;
+        hipLaunchKernelGGL(acc_finish_kernel, dim3(grid_for(n, 256, p->cu_count)), dim3(256), 0, p->stream, p->d_acc, p->nchan,
+                           p->n_base, *fin);
+        FXC_HIP(p, hipGetLastError());
+    }
+    return FXC_OK;
+}
+
+// the rows of an fx_accumulate pass: folded right away, or left pending when the pass is the call's last one
+int fold_or_defer(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int nchan, int layout, bool last_pass) {
+    if (!last_pass) return fold_rows(p, raw, part, n_rows, nchan, layout, kNoFinish);
+    p->pend.valid = true;
+    p->pend.raw = raw;
+    p->pend.part = part;
+    p->pend.n_rows = n_rows;
+    p->pend.nchan = nchan;
+    p->pend.layout = layout;
+    return FXC_OK;
+}
 
 // workgroups of a fused launch over n_pairs chunk pairs: one per CU; a launch with fewer chunks than that is all
 // tail (frame ranges), on fewer workgroups when a range would be under four frames (each reloads up to three
@@ -74,8 +121,12 @@ int fused_grid(const fxc_plan* p, int64_t n_pairs) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(frames / 4, p->fused_grid_max));
 }
 
-// chunks per raw row when only the integration is wanted: float32 sums of up to 256 spectra
-int64_t fused_unit(const fxc_plan* p) { return std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(1, p->n_pts), 64)); }
+// chunks per raw row when only the integration is wanted: float32 sums of up to kRowSpectra spectra (the rows
+// themselves are summed in float64).  Measured on 10 000 frames against the float64 mean of the per-frame rows
+// (profiles/r02/round2_experiments.md): 256 spectra per row 5.6e-9 of max|vis|, 1 024: 2.5e-8, 4 096: 6.3e-8 -- against
+// a tolerance of 1e-5; 1 024 leaves a quarter of the rows to fold (34 MB instead of 92 MB per 10 000 frames)
+constexpr int64_t kRowSpectra = 1024;
+int64_t fused_unit(const fxc_plan* p) { return std::max<int64_t>(1, std::min<int64_t>(kRowSpectra / std::max<int64_t>(1, p->n_pts), 64)); }
 
 // raw rows a 2-antenna fused launch over nc chunks writes (leading-part rows included)
 int64_t fused_rows(const fxc_plan* p, int64_t nc, int64_t unit, bool rows_are_chunks) {

@@ -60,8 +60,25 @@ struct fxc_plan {
     int64_t fused_seg = 1;         // chunks per round-robin segment of the fused kernel (fx_fused4096.h::RangeWalk)
     cd* d_acc = nullptr;           // [n_base*nchan]
     cd* d_sums = nullptr;          // [n_base*nchan + 1]
-    cd* d_out = nullptr;           // finalize staging [n_base*nchan]
-    cd* h_out = nullptr;           // its pinned host mirror: a D2H copy into pageable memory costs ~30 us of staging
+    bool sums_valid = false;       // d_sums holds exported sums (fxc_reduce): fxc_finalize_sums(plan, NULL, ...) may read it
+    // raw rows of the last fx_accumulate pass whose fold into the accumulator is still to be launched: it is launched
+    // by whatever needs the accumulator or the workspace next (flush_pending) -- by a finalize together with the
+    // export / finalize / reset of every element, in the same kernel
+    struct Pending {
+        bool valid = false;
+        const cf* raw = nullptr;
+        cd* part = nullptr;
+        int64_t n_rows = 0;
+        int nchan = 0, layout = 0;
+    } pend;
+    // finalize results: kResSlots pinned host buffers mapped into the device (the finishing kernel writes the
+    // visibilities straight into them: no staging copy), each with the event that marks it complete
+    static constexpr int kResSlots = 2;
+    cd* h_res[kResSlots] = {nullptr, nullptr};
+    cd* d_res[kResSlots] = {nullptr, nullptr};     // the same memory as the device sees it
+    hipEvent_t ev_res[kResSlots] = {nullptr, nullptr};
+    size_t res_bytes[kResSlots] = {0, 0};
+    int64_t res_head = 0, res_tail = 0;            // results queued / collected
     double spectra_count = 0.0;
     // workspace (grown on demand)
     void* d_ws = nullptr;
@@ -149,7 +166,12 @@ int grid_for(int64_t work_items, int block, int cu_count) {
     return (int)g;
 }
 
+// launches the fold of the pending raw rows (h_launch.h); every user of the workspace or the accumulator calls it first
+int flush_pending(fxc_plan* p, const FoldFinish* fin = nullptr);
+
 int ensure_ws(fxc_plan* p, int64_t bytes) {
+    const int rf = flush_pending(p);        // the pending rows (and their partials) live in the workspace
+    if (rf) return rf;
     if (bytes <= p->ws_bytes) return FXC_OK;
     if (p->d_ws) {
         FXC_HIP(p, hipStreamSynchronize(p->stream));

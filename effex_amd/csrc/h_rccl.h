@@ -6,6 +6,14 @@
 // stream.  librccl is bound at run time (the copy the process already has -- PyTorch ships one -- else ROCm's), so
 // single-GPU users need no RCCL at all.
 // ------------------------------------------------------------------------------------------
+// what fxc_comm_create hands out: the ncclComm_t and the device it lives on (fxc_reduce checks it against the plan's)
+struct fxc_comm {
+    static constexpr unsigned kMagic = 0x46584343u;   // "FXCC"
+    unsigned magic = kMagic;
+    ncclComm_t comm = nullptr;
+    int device = -1, rank = 0, world_size = 1;
+};
+
 namespace {
 
 struct RcclApi {

@@ -26,7 +26,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         const int64_t in_bytes = (int64_t)p->n_ant * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
-        const int64_t part_bytes = (int64_t)kFusedReduceSplits * kN * (int64_t)sizeof(cd);
+        const int64_t part_bytes = fold_part_bytes(kN);
         int rc = ensure_ws(p, spec_bytes + raw_bytes + part_bytes);
         if (rc) return rc;
         cf* spec = reinterpret_cast<cf*>(p->d_ws);
@@ -38,13 +38,9 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
                                 dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit, false);
             if (rc) return rc;
-            if (p->n_ant == 2) {   // one baseline: two-stage reduce over all the raw rows (leading parts included)
-                const int64_t n_rows = fused_rows(p, nc, unit, false);
-                const int splits = fused_reduce_splits(n_rows);
-                hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kN / 256, splits), dim3(256), 0, p->stream, raw, part, kN,
-                                   n_rows, splits);
-                hipLaunchKernelGGL(fused_reduce2_kernel, dim3(kN / 16), dim3(256), 0, p->stream, part, p->d_acc, kN, splits,
-                                   fused_layout(p));
+            if (p->n_ant == 2) {   // one baseline: fold all the raw rows (leading parts included) into the accumulator
+                rc = fold_or_defer(p, raw, part, fused_rows(p, nc, unit, false), kN, fused_layout(p), c0 + nc >= n_chunks);
+                if (rc) return rc;
             } else {   // raw rows of `unit` chunks each
                 const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
                 hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream,
@@ -57,7 +53,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         const int64_t cb = split_chunks_per_pass(p, n_chunks);
         const int64_t row_bytes = (int64_t)fxc::fused::kN * (int64_t)sizeof(cf);
         const int64_t raw_bytes = ((2 * cb + p->fused_grid_max) * row_bytes + 255) / 256 * 256;
-        const int64_t part_bytes = (int64_t)kFusedReduceSplits * N * (int64_t)sizeof(cd);
+        const int64_t part_bytes = fold_part_bytes(N);
         int rc = ensure_ws(p, raw_bytes + part_bytes);
         if (rc) return rc;
         cf* raw = reinterpret_cast<cf*>(p->d_ws);
@@ -67,9 +63,8 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             rc = split_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
             if (rc) return rc;
             // the nc pairs of 4096-rows are nc rows of 8192 in layout 3; the leading-part rows are added by parity
-            const int splits = fused_reduce_splits(nc);
-            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(N / 256, splits), dim3(256), 0, p->stream, raw, part, N, nc, splits);
-            hipLaunchKernelGGL(fused_reduce2_kernel, dim3(N / 16), dim3(256), 0, p->stream, part, p->d_acc, N, splits, 3);
+            rc = fold_rows(p, raw, part, nc, N, 3, kNoFinish);
+            if (rc) return rc;
             hipLaunchKernelGGL(split_lead_acc_kernel, dim3(N / 256), dim3(256), 0, p->stream, raw, p->d_acc, fused_lead(p, 2 * nc));
             FXC_HIP(p, hipGetLastError());
         }
@@ -81,22 +76,18 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, prefilter_streams_per_pass(p) / 2),
                                                                   kWorkspaceTarget / (row_bytes * n_splits)));
         const int64_t raw_bytes = (cb * n_splits * row_bytes + 255) / 256 * 256;
-        const int64_t part_bytes = (int64_t)kFusedReduceSplits * N * (int64_t)sizeof(cd);
+        const int64_t part_bytes = fold_part_bytes(N);
         int rc = ensure_ws(p, raw_bytes + part_bytes);
         if (rc) return rc;
         cf* raw = reinterpret_cast<cf*>(p->d_ws);
         cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + raw_bytes);
-        const int kb = (N + 255) / 256;
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
             rc = tiled_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, n_splits,
                                 raw, dc_u8 ? dc_u8 + c0 * 2 : nullptr);
             if (rc) return rc;
-            const int splits = fused_reduce_splits(nc * n_splits);
-            hipLaunchKernelGGL(fused_reduce1_kernel, dim3(kb, splits), dim3(256), 0, p->stream, raw, part, N, nc * n_splits,
-                               splits);
-            hipLaunchKernelGGL(fused_reduce2_kernel, dim3((N + 15) / 16), dim3(256), 0, p->stream, part, p->d_acc, N, splits, 0);
-            FXC_HIP(p, hipGetLastError());
+            rc = fold_or_defer(p, raw, part, nc * n_splits, N, 0, c0 + nc >= n_chunks);
+            if (rc) return rc;
         }
     } else {
         const XGeom g = x_geometry(p);

@@ -133,61 +133,138 @@ __global__ void acc_add_kernel(const cf* __restrict__ raw, cd* __restrict__ acc,
     }
 }
 
-// accumulate over many chunks, stage 1: part[split][slot] = sum over this split's rows of the kernels' raw
-// float32 rows (slot order, coalesced); fixed order -> bit-reproducible.  Latency-bound (a thread walks its rows one
-// load after the other), so the launch uses as many splits as leave each a handful of rows (fused_reduce_splits)
-__global__ __launch_bounds__(256) void fused_reduce1_kernel(const cf* __restrict__ raw, cd* __restrict__ part, int nchan,
-                                                           int64_t n_rows, int n_splits) {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const int split = blockIdx.y;
-    if (slot >= nchan) return;
-    double ar = 0.0, ai = 0.0;
-    for (int64_t c = split; c < n_rows; c += n_splits) {
-        const cf r = raw[c * nchan + slot];
-        ar += r.x;
-        ai += r.y;
+// What the kernel that finishes an integration does with an accumulator element besides updating it: export it for the
+// cross-rank reduce, finalise it, clear it -- in the same launch instead of export + finalize + device-to-host copy +
+// memset (round 2: four commands and 50 us of gaps per integration).
+struct FoldFinish {
+    cd* sums;         // != nullptr: sums[idx] = acc[idx] (raw float64 sums) and sums[n] = {count, 0} -- fxc_acc_export
+    cd* out;          // != nullptr: out[p][(k + N/2) % N] = acc * conj(rot[k]) / count (effex.py:520-521, integrated);
+                      //             device memory or host memory mapped into the device (the plan's pinned result
+                      //             slots).  Every kernel that fills it does so with consecutive lanes on consecutive
+                      //             bins: single 16-byte stores scattered over mapped host memory cost ~45 ns each
+                      //             (180 us per 4096-bin spectrum, measured), wave-wide runs go out at the copy rate
+    const cd* rot;
+    double count;     // spectra accumulated so far
+    int reset;        // clear the accumulator afterwards
+};
+
+__device__ __forceinline__ void finish_element(cd a, cd* __restrict__ acc, int64_t idx, int k, int nchan, int64_t n,
+                                               const FoldFinish& fin) {
+    if (fin.sums) {
+        fin.sums[idx] = a;
+        if (idx == 0) {
+            cd c;
+            c.x = fin.count;
+            c.y = 0.0;
+            fin.sums[n] = c;
+        }
     }
-    cd o;
-    o.x = ar;
-    o.y = ai;
-    part[(int64_t)split * nchan + slot] = o;
+    if (fin.out) {
+        const double inv = 1.0 / fin.count;
+        const cd w = fin.rot[k];
+        cd o;
+        o.x = (a.x * w.x + a.y * w.y) * inv;
+        o.y = (a.y * w.x - a.x * w.y) * inv;
+        int ks = k + nchan / 2;
+        if (ks >= nchan) ks -= nchan;
+        fin.out[idx - k + ks] = o;
+    }
+    if (fin.reset) a.x = a.y = 0.0;
+    acc[idx] = a;
 }
 
-// stage 2: acc[bin(slot)] += sum_split part[split][slot]; 16 slots x 16 threads per workgroup, each thread sums every
-// 16th split (reads in slot order: coalesced; only the 64 KiB of accumulator updates are scattered by the slot -> bin
-// permutation) and the 16 sub-sums are combined in a fixed order
-__global__ __launch_bounds__(256) void fused_reduce2_kernel(const cd* __restrict__ part, cd* __restrict__ acc, int nchan,
-                                                           int n_splits, int slots) {
-    __shared__ cd sub[16][17];
-    const int kl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int slot = blockIdx.x * 16 + kl;
+// Integration of the 2-antenna kernels' raw float32 rows (one baseline): acc[bin] += sum over all rows, in float64 and
+// in a fixed order (bit-reproducible), then FoldFinish.  Two launches back to back, no fences, no atomics (a single
+// kernel with a last-workgroup-done ticket per column was tried first: its agent-scope release / acquire fences write
+// back and invalidate the L2s once per workgroup and took 190 us):
+//   fold_partial_kernel  workgroup (column of 256 slots, split): thread (slot, phase) walks the rows
+//                        split * 4 + phase + 4 * n_splits * j (coalesced 8-byte loads, four in flight); the four phases
+//                        are combined through LDS in phase order -> part[split][slot]
+//   fold_finish_kernel   thread (bin, phase): sums every fourth of the n_rows rows it is given at raw_index(bin) -- the
+//                        n_splits partials, or the raw rows themselves when they are few (one launch then) -- phases
+//                        combined in order; acc[bin] += that; FoldFinish with consecutive lanes on consecutive bins
+// `slots`: layout of a row (raw_index): 0 natural order, 1 the fused kernel's slot order, 3 the 8192-channel split
+constexpr int kFoldPhases = 4;
+constexpr int kFoldMaxSplits = 32;
+__global__ __launch_bounds__(1024) void fold_partial_kernel(const cf* __restrict__ raw, cd* __restrict__ part, int nchan,
+                                                           int64_t n_rows, int n_splits) {
+    __shared__ cd sub[kFoldPhases][256];
+    const int kl = threadIdx.x & 255, ph = threadIdx.x >> 8;
+    const int slot = blockIdx.x * 256 + kl;
+    const int split = blockIdx.y;
+    const bool live = slot < nchan;
     double ar = 0.0, ai = 0.0;
-    if (slot < nchan) {
-        for (int s = sl; s < n_splits; s += 16) {
-            const cd v = part[(int64_t)s * nchan + slot];
+    if (live) {
+        const int64_t step = (int64_t)n_splits * kFoldPhases;
+        const cf* col = raw + slot;
+        int64_t c = (int64_t)split * kFoldPhases + ph;
+        for (; c + 3 * step < n_rows; c += 4 * step) {
+            const cf r0 = col[c * nchan], r1 = col[(c + step) * nchan], r2 = col[(c + 2 * step) * nchan],
+                     r3 = col[(c + 3 * step) * nchan];
+            ar += r0.x;
+            ai += r0.y;
+            ar += r1.x;
+            ai += r1.y;
+            ar += r2.x;
+            ai += r2.y;
+            ar += r3.x;
+            ai += r3.y;
+        }
+        for (; c < n_rows; c += step) {
+            const cf r = col[c * nchan];
+            ar += r.x;
+            ai += r.y;
+        }
+    }
+    sub[ph][kl].x = ar;
+    sub[ph][kl].y = ai;
+    __syncthreads();
+    if (ph == 0 && live) {
+        cd v = sub[0][kl];
+#pragma unroll
+        for (int q = 1; q < kFoldPhases; ++q) {
+            v.x += sub[q][kl].x;
+            v.y += sub[q][kl].y;
+        }
+        part[(int64_t)split * nchan + slot] = v;
+    }
+}
+
+template <class RowT>
+__global__ __launch_bounds__(1024) void fold_finish_kernel(const RowT* __restrict__ rows, int64_t n_rows, cd* __restrict__ acc,
+                                                          int nchan, int slots, FoldFinish fin) {
+    __shared__ cd sub[kFoldPhases][256];
+    const int kl = threadIdx.x & 255, ph = threadIdx.x >> 8;
+    const int k = blockIdx.x * 256 + kl;
+    const bool live = k < nchan;
+    double ar = 0.0, ai = 0.0;
+    if (live) {
+        const RowT* col = rows + raw_index(k, slots);
+        for (int64_t s = ph; s < n_rows; s += kFoldPhases) {
+            const RowT v = col[s * nchan];
             ar += v.x;
             ai += v.y;
         }
     }
-    sub[sl][kl].x = ar;
-    sub[sl][kl].y = ai;
+    sub[ph][kl].x = ar;
+    sub[ph][kl].y = ai;
     __syncthreads();
-    if (sl == 0 && slot < nchan) {
-        // slots == 1: the fused kernel's order, slot = q * 512 + tid (fx_fused4096.h::bin_of); 0: natural order
-        // 3: the 8192-channel split, [even | odd] halves each in the fused kernel's order
-        int k = slot;
-        if (slots == 1) k = fxc::fused::bin_of(slot % fxc::fused::kThreads, slot / fxc::fused::kThreads);
-        if (slots == 3) {
-            const int sl = slot % fxc::fused::kN;
-            k = 2 * fxc::fused::bin_of(sl % fxc::fused::kThreads, sl / fxc::fused::kThreads) + slot / fxc::fused::kN;
-        }
-        cd a = acc[k];
-        for (int j = 0; j < 16; ++j) {
-            a.x += sub[j][kl].x;
-            a.y += sub[j][kl].y;
-        }
-        acc[k] = a;
+    if (ph != 0 || !live) return;
+    cd a = acc[k];
+#pragma unroll
+    for (int q = 0; q < kFoldPhases; ++q) {
+        a.x += sub[q][kl].x;
+        a.y += sub[q][kl].y;
     }
+    finish_element(a, acc, k, k, nchan, nchan, fin);
+}
+
+// FoldFinish alone, on the accumulator as it stands (paths that update it themselves, or nothing pending)
+__global__ void acc_finish_kernel(cd* __restrict__ acc, int nchan, int n_base, FoldFinish fin) {
+    const int64_t n = (int64_t)n_base * nchan;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride)
+        finish_element(acc[idx], acc, idx, (int)(idx % nchan), nchan, n, fin);
 }
 
 // multi-antenna X-engine on the F-only kernel's spectra: spec[(c*A + a)*P + i][pos]; one thread per (chunk group,
@@ -247,21 +324,6 @@ __global__ __launch_bounds__(256) void xengine_kernel(const cf* __restrict__ spe
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) raw[(grp * NB + p) * nchan + pos] = fxc::mk(ar[p], ai[p]);
-}
-
-// sums = [n_base*nchan] raw sums + [1] {count, 0}
-__global__ void export_kernel(const cd* __restrict__ acc, cd* __restrict__ sums, int64_t n, double count) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx <= n; idx += stride) {
-        cd v;
-        if (idx < n) {
-            v = acc[idx];
-        } else {
-            v.x = count;
-            v.y = 0.0;
-        }
-        sums[idx] = v;
-    }
 }
 
 // out[p][(k + N/2) % N] = sums[p][k] * conj(rot[k]) / count      (effex.py:520-521, integrated)

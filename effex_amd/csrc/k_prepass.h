@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void pfb_split8192_kernel(const cf* __restrict
 }
 
 // acc[k] += the leading-part rows of the split launch that belong to bin k's half (even bins: fused chunks 2c, odd:
-// 2c + 1); the chunk rows themselves go through fused_reduce1/2_kernel in layout 3
+// 2c + 1); the chunk rows themselves go through fold_partial_kernel / fold_finish_kernel in layout 3
 __global__ __launch_bounds__(256) void split_lead_acc_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, LeadRows lr) {
     // the fused chunk workgroup b's range starts in (its leading part, if any, belongs to that chunk): parity per row,
     // worked out once per block instead of one 64-bit division per row and thread

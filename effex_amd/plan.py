@@ -53,6 +53,7 @@ class FxPlan(object):
             raise ValueError("window must have ntaps*nchan = {} taps, got {}".format(ntaps * nchan, window.shape))
         self.window = window
         self._pipes = []                                  # weak references to FxPipeline objects on this plan
+        self._queued = []                                 # modes of the finalize results queued and not yet collected
         # Work is issued on the caller's stream so it is ordered with torch's own copies / kernels.  stream=None
         # follows torch's *current* stream call by call (``_follow``): under ``with torch.cuda.stream(s)`` the plan moves
         # to ``s`` (fxc_set_stream orders the two streams with an event), so inputs, kernels and outputs stay ordered.
@@ -84,7 +85,9 @@ class FxPlan(object):
                 if pipe is not None:
                     pipe.close()
             self._pipes = []
-            self._lib.fxc_plan_destroy(self._h)
+            # FXC_ERR_STATE: a pipe made behind this object's back still uses the plan -- keep the handle (the plan and
+            # its device buffers stay valid for that pipe) and say so instead of leaking silently
+            self._check(self._lib.fxc_plan_destroy(self._h))
             self._h = ctypes.c_void_p()
 
     def _sync_stream(self):
@@ -236,6 +239,41 @@ class FxPlan(object):
         out = np.empty(shape, dtype=np.complex128)
         self._check(self._lib.fxc_finalize(self._h, out.ctypes.data, m, float(bandwidth), int(bool(reset))))
         return out
+
+    def _result(self, mode_code):
+        shape = (self.n_baselines, self.nchan) if mode_code == _lib.FXC_MODE_SPECTRUM else (self.n_baselines,)
+        return np.empty(shape, dtype=np.complex128)
+
+    def finalize_async(self, mode="SPECTRUM", bandwidth=1.0, reset=True):
+        """Queue ``finalize`` on the plan's stream and return at once (``fxc_finalize_async``): on the 2-antenna fast
+        paths the fold of the last ``fx_accumulate``'s partial sums, the finalize, the reset and the write into pinned
+        host memory are one kernel.  Collect with ``finalize_wait()``; up to two results may be outstanding, so the
+        next integration can be queued before the host waits for this one."""
+        self._sync_stream()
+        m = MODES[mode.upper()]
+        self._check(self._lib.fxc_finalize_async(self._h, m, float(bandwidth), int(bool(reset))))
+        self._queued.append(m)
+
+    def finalize_sums_async(self, sums=None, mode="SPECTRUM", bandwidth=1.0):
+        """``finalize_sums`` without the wait (``fxc_finalize_sums_async``); collect with ``finalize_wait()``."""
+        self._sync_stream()
+        m = MODES[mode.upper()]
+        ptr = sums.data_ptr() if sums is not None else None
+        self._check(self._lib.fxc_finalize_sums_async(self._h, ptr, m, float(bandwidth)))
+        self._queued.append(m)
+
+    def finalize_wait(self):
+        """The oldest queued finalize result as numpy complex128 (blocks on that result's event only)."""
+        if not self._queued:
+            raise _lib.FxcError(_lib.FXC_ERR_STATE, "no finalize result outstanding")
+        out = self._result(self._queued[0])
+        self._check(self._lib.fxc_finalize_wait(self._h, out.ctypes.data))
+        self._queued.pop(0)
+        return out
+
+    @property
+    def finalize_pending(self):
+        return int(self._lib.fxc_finalize_pending(self._h))
 
     def sync(self):
         self._check(self._lib.fxc_sync(self._h))
@@ -438,9 +476,15 @@ class RcclComm(object):
         return bytes(buf.raw)
 
     def close(self):
-        if self.handle:
+        if getattr(self, "handle", None):
             self._lib.fxc_comm_destroy(self.handle)
             self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self

@@ -81,6 +81,7 @@ class ShardedIntegrator(object):
     def __init__(self, plan, rank=0, world_size=1, group=None, comm=None):
         self.plan, self.rank, self.world_size, self.group, self.comm = plan, rank, world_size, group, comm
         self.sums = None if comm is not None else plan.new_sums()
+        self._waits = []
 
     @property
     def transport(self):
@@ -108,9 +109,32 @@ class ShardedIntegrator(object):
 
     def finalize(self, mode="SPECTRUM", bandwidth=1.0, root=0, to_all=False):
         """Returns the integrated visibilities on the root (every rank if ``to_all``), else None."""
+        self.finalize_async(mode, bandwidth, root=root, to_all=to_all)
+        return self.finalize_wait()
+
+    def finalize_async(self, mode="SPECTRUM", bandwidth=1.0, root=0, to_all=False):
+        """Queue reduce + finalize + reset on the device and return: the next integration can be queued before
+        ``finalize_wait()`` collects this one (the host never waits between the last F+X kernel of one integration and
+        the first of the next).  One rank: a single kernel (``fxc_finalize_async``)."""
+        mine = to_all or self.rank == root
+        if self.world_size == 1 and hasattr(self.plan, "finalize_async"):
+            self.plan.finalize_async(mode, bandwidth, reset=True)
+            self._waits.append(True)
+            return
         self.reduce(root=root, to_all=to_all)
-        out = None
-        if to_all or self.rank == root:
-            out = self.plan.finalize_sums(self.sums, mode, bandwidth)     # sums None: the plan's reduced copy
+        if mine:
+            if hasattr(self.plan, "finalize_sums_async"):
+                self.plan.finalize_sums_async(self.sums, mode, bandwidth)     # sums None: the plan's reduced copy
+                self._waits.append(True)
+            else:                                        # stand-in plans of the CPU tests
+                self._waits.append(self.plan.finalize_sums(self.sums, mode, bandwidth))
+        else:
+            self._waits.append(None)
         self.plan.acc_reset()
-        return out
+
+    def finalize_wait(self):
+        """The oldest queued integration: the visibilities on the root (every rank if ``to_all``), else None."""
+        item = self._waits.pop(0)
+        if item is True:
+            return self.plan.finalize_wait()
+        return item

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FXC_VERSION 102 /* 0.1.0 */
+#define FXC_VERSION 103 /* 0.1.0 */
 
 typedef struct fxc_plan fxc_plan; /* opaque; one per (device, configuration) */
 typedef struct fxc_pipe fxc_pipe; /* opaque; host-fed double-buffered front end on a plan */
@@ -115,16 +115,18 @@ int fxc_fx_rows(fxc_plan* plan, const void* x, void* out, int64_t n_chunks, int 
  * fxc_finalize_sums on the root. */
 int fxc_acc_reset(fxc_plan* plan);
 int fxc_acc_export(fxc_plan* plan, void* sums_dev);
-/* sums_dev == NULL: the plan's own copy, as fxc_reduce leaves it */
+/* sums_dev == NULL: the plan's own copy, as fxc_reduce leaves it (FXC_ERR_STATE if fxc_reduce has not run) */
 int fxc_finalize_sums(fxc_plan* plan, const void* sums_dev, void* out_host, int mode, double bandwidth);
 
 /* The reduce itself: export the plan's accumulator and sum it over the ranks of `rccl_comm`
- * (an ncclComm_t; NULL = single rank) with one ncclReduce to `root` (root < 0: ncclAllReduce), float64, in place, on
+ * (made by fxc_comm_create; NULL = single rank) with one ncclReduce to `root` (root < 0: ncclAllReduce), float64, in place, on
  * the plan's stream -- no host synchronisation between the F+X kernels, the collective and fxc_finalize_sums(plan,
  * NULL, ...) on the root.  64 KiB for two antennas; latency-bound over xGMI.
  * fxc_comm_*: the communicator for it.  Rank 0 calls fxc_comm_unique_id and hands the FXC_COMM_ID_BYTES bytes to
  * every rank by any channel (bench.py: torch.distributed broadcast); every rank then calls fxc_comm_create (blocking,
- * collective: ncclCommInitRank on `device`).  librccl is bound at run time; FXC_ERR_COMM if it cannot be. */
+ * collective: ncclCommInitRank on `device`).  librccl is bound at run time; FXC_ERR_COMM if it cannot be.
+ * fxc_reduce refuses (FXC_ERR_ARG, nothing queued) a communicator made on another device than the plan's, and a root
+ * outside its world: a collective entered on the wrong device leaves the other ranks waiting in theirs. */
 #define FXC_COMM_ID_BYTES 128
 int fxc_comm_unique_id(void* id_out);
 int fxc_comm_create(void** rccl_comm_out, int device, int rank, int world_size, const void* id);
@@ -133,8 +135,20 @@ int fxc_reduce(fxc_plan* plan, void* rccl_comm, int root);
 
 /* Single-GPU finalize: mean over everything accumulated, times conj(rot), fftshift; D2H.
  *   SPECTRUM : out_host = [n_baselines][nchan] complex128;  CONTINUUM: [n_baselines] complex128.
- * Synchronises the plan's stream.  reset != 0 clears the accumulator afterwards. */
+ * Waits for the result.  reset != 0 clears the accumulator afterwards.  = fxc_finalize_async + fxc_finalize_wait. */
 int fxc_finalize(fxc_plan* plan, void* out_host, int mode, double bandwidth, int reset);
+
+/* The same without the wait: the finalize is queued on the plan's stream -- on the 2-antenna fast paths as part of
+ * the kernel that folds the last fx_accumulate call's partial sums into the accumulator: fold, mean, conj(rot),
+ * fftshift, reset and the write into pinned host memory are one launch -- and the call returns.  The caller may queue
+ * the next integration (fxc_fx_accumulate ...) before it collects the result with fxc_finalize_wait, which blocks on
+ * that result's event only.  Up to two results may be outstanding (FXC_ERR_STATE beyond that, and from the blocking
+ * finalize calls while any is); they are collected in the order they were queued.
+ * fxc_finalize_sums_async: the multi-GPU form (sums as for fxc_finalize_sums; the accumulator is not touched). */
+int fxc_finalize_async(fxc_plan* plan, int mode, double bandwidth, int reset);
+int fxc_finalize_sums_async(fxc_plan* plan, const void* sums_dev, int mode, double bandwidth);
+int fxc_finalize_wait(fxc_plan* plan, void* out_host);
+int fxc_finalize_pending(const fxc_plan* plan); /* results queued and not yet collected */
 
 int fxc_sync(fxc_plan* plan);
 

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.fxc_version() == 102
+    assert lib.fxc_version() == 103
     assert lib.fxc_status_string(0) == b"ok"
     assert b"unsupported" in lib.fxc_status_string(_lib.FXC_ERR_UNSUPPORTED)
 

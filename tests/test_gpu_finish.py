@@ -1,0 +1,184 @@
+"""The end of an integration on the GPU: the fold of the kernels' raw rows into the accumulator, export, finalize and
+reset together (k_finish.h::fold_partial_kernel + fold_finish_kernel), the asynchronous finalize (include/fxcorr.h fxc_finalize_async /
+fxc_finalize_wait) and BASELINE configs[1] at its own size.
+
+Reference semantics: mean over all spectra of f0 * conj(f1 * rot), fft-shifted (effex/effex.py:516-521); CONTINUUM:
+mean over the bins / bandwidth (:523-524).  Tolerance as in test_gpu_parity.py: 1e-5 of max|vis| against the float64
+oracle; results that must be the same arithmetic in the same order are compared bit for bit.
+"""
+import numpy as np
+import pytest
+
+import fx_oracle
+import golden_inputs as gi
+from effex_amd import _lib, synth
+from effex_amd.window import design_window
+
+pytestmark = pytest.mark.gpu
+
+TOL_VIS = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def plan_mod(torch):
+    from effex_amd import plan
+    return plan
+
+
+def rel_err(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
+
+
+SHAPES = [  # n_ant, nchan, ntaps, num_samp, n_chunks, path
+    (2, 4096, 4, 4096 * 6, 7, "fused"), (2, 4096, 4, 4096 * 3, 300, "fused"), (2, 2048, 4, 2048 * 9 + 5, 11, "tiled"),
+    (2, 2048, 32, 2048 * 40, 3, "tiled"), (2, 8192, 4, 8192 * 5, 4, "tiled"), (8, 4096, 4, 4096 * 4, 3, "fused"),
+    (2, 1, 4, 5000, 6, "stream"), (3, 64, 4, 64 * 20, 5, "generic")]
+
+
+@pytest.mark.parametrize("n_ant,nchan,ntaps,num_samp,n_chunks,path", SHAPES)
+def test_async_finalize_equals_blocking_finalize(plan_mod, torch, n_ant, nchan, ntaps, num_samp, n_chunks, path):
+    """Every path, both modes: the queued finalize gives the bits of the blocking one, `reset=False` keeps integrating,
+    and the integration equals the float64 mean of the per-chunk rows."""
+    x = torch.from_numpy(synth.synth_iq(11, n_chunks, n_ant, num_samp)).cuda()
+    window = np.array([0.4, 0.3, 0.2, 0.1]) if nchan == 1 else None
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as p:
+        assert p.path == path
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-6)
+        rows = p.fx_rows(x, "SPECTRUM").cpu().numpy().astype(np.complex128)
+        for mode in ("SPECTRUM", "CONTINUUM"):
+            p.fx_accumulate(x)
+            blocking = p.finalize(mode, gi.BANDWIDTH, reset=False)
+            p.finalize_async(mode, gi.BANDWIDTH, reset=False)
+            assert p.finalize_pending == 1
+            np.testing.assert_array_equal(p.finalize_wait(), blocking)
+            p.fx_accumulate(x[: n_chunks // 2 + 1])             # integration goes on: 1.5 x the chunks now
+            p.finalize_async(mode, gi.BANDWIDTH, reset=True)
+            longer = p.finalize_wait()
+            both = np.concatenate([rows, rows[: n_chunks // 2 + 1]]).mean(axis=0)
+            want_b = rows.mean(axis=0) if mode == "SPECTRUM" else rows.mean(axis=0).mean(axis=-1) / gi.BANDWIDTH
+            want_l = both if mode == "SPECTRUM" else both.mean(axis=-1) / gi.BANDWIDTH
+            assert rel_err(blocking, want_b) < 2e-6, mode
+            assert rel_err(longer, want_l) < 2e-6, mode
+            with pytest.raises(_lib.FxcError):                   # reset: nothing accumulated any more
+                p.finalize(mode, gi.BANDWIDTH)
+
+
+def test_two_integrations_in_flight(plan_mod, torch):
+    """The next integration is queued before the host collects the previous one; results come back in order; a third
+    outstanding result, and a blocking finalize while any is outstanding, are refused."""
+    num_samp = 4096 * 5
+    xa = torch.from_numpy(synth.synth_iq(21, 260, 2, num_samp)).cuda()
+    xb = torch.from_numpy(synth.synth_iq(22, 9, 2, num_samp)).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        p.fx_accumulate(xa)
+        ref_a = p.finalize("SPECTRUM")
+        p.fx_accumulate(xb)
+        ref_b = p.finalize("SPECTRUM")
+        for _ in range(3):
+            p.fx_accumulate(xa)
+            p.finalize_async("SPECTRUM")
+            p.fx_accumulate(xb)
+            p.finalize_async("SPECTRUM")
+            assert p.finalize_pending == 2
+            p.fx_accumulate(xa)
+            with pytest.raises(_lib.FxcError):
+                p.finalize_async("SPECTRUM")
+            with pytest.raises(_lib.FxcError):
+                p.finalize("SPECTRUM")
+            np.testing.assert_array_equal(p.finalize_wait(), ref_a)
+            np.testing.assert_array_equal(p.finalize_wait(), ref_b)
+            np.testing.assert_array_equal(p.finalize("SPECTRUM"), ref_a)     # the third integration, queued above
+        with pytest.raises(_lib.FxcError):
+            p.finalize_wait()
+
+
+def test_fold_is_bit_reproducible(plan_mod, torch):
+    """The fold sums rows, phases and partials in a fixed order:
+    repeated integrations of the same frames are identical bit for bit (700 chunk pairs: every split in use)."""
+    num_samp = 4096 * 2
+    x = torch.from_numpy(synth.synth_iq(31, 700, 2, num_samp)).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        outs = []
+        for _ in range(6):
+            p.fx_accumulate(x)
+            outs.append(p.finalize("SPECTRUM"))
+        for o in outs[1:]:
+            np.testing.assert_array_equal(o, outs[0])
+        # a pass folded right away (export in between) and one folded together with the finalize: the same sums
+        p.fx_accumulate(x)
+        p.acc_export(p.new_sums())
+        np.testing.assert_array_equal(p.finalize("SPECTRUM"), outs[0])
+
+
+def test_finalize_sums_needs_reduced_sums(plan_mod, torch):
+    x = torch.from_numpy(synth.synth_iq(41, 3, 2, 4096 * 4)).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, 4096 * 4) as p:
+        p.fx_accumulate(x)
+        with pytest.raises(_lib.FxcError):
+            p.finalize_sums(None, "SPECTRUM")                    # nothing reduced into the plan yet
+        p.reduce(None, 0)
+        ref = p.finalize_sums(None, "SPECTRUM")
+        np.testing.assert_array_equal(p.finalize("SPECTRUM"), ref)
+
+
+def test_one_communicator_serves_several_plans(plan_mod, torch):
+    """fxc_reduce twice back to back, ncclAllReduce (root < 0) on one plan and ncclReduce to rank 0 on another, both on
+    the same communicator (a world of one here: what must hold is that the collectives run on each plan's stream and
+    leave the sums unchanged); a root no rank has is refused before anything is queued."""
+    num_samp = 4096 * 6
+    xa = torch.from_numpy(synth.synth_iq(51, 5, 2, num_samp)).cuda()
+    xb = torch.from_numpy(synth.synth_iq(52, 7, 2, num_samp)).cuda()
+    uid = plan_mod.RcclComm.unique_id()
+    with plan_mod.RcclComm(0, 0, 1, uid) as comm, plan_mod.FxPlan(2, 4096, 4, num_samp) as pa, \
+            plan_mod.FxPlan(2, 4096, 4, num_samp, stream="owned") as pb:
+        pa.fx_accumulate(xa)
+        pb.fx_accumulate(xb)
+        ref_a = pa.finalize("SPECTRUM", reset=False)
+        ref_b = pb.finalize("SPECTRUM", reset=False)
+        pa.reduce(comm, None)
+        pb.reduce(comm, 0)
+        pa.reduce(comm, 0)
+        pb.reduce(comm, None)
+        np.testing.assert_array_equal(pb.finalize_sums(None, "SPECTRUM"), ref_b)
+        np.testing.assert_array_equal(pa.finalize_sums(None, "SPECTRUM"), ref_a)
+        with pytest.raises(ValueError):
+            pa.reduce(comm, 1)
+        np.testing.assert_array_equal(pa.finalize("SPECTRUM"), ref_a)     # the refused call queued nothing
+
+
+def test_headline_config_at_full_size(plan_mod, torch):
+    """BASELINE.json configs[1] at its own size: 10 000 distinct integration frames of 2 x 262 144 samples resident in
+    HBM (41.9 GB), one fxc_fx_accumulate + finalize -- what bench.py times.  The integration must equal the float64 mean
+    of the 10 000 per-frame rows, and sampled frames the oracle (effex.py:490-527), to 1e-5 of max|vis|."""
+    frames, num_samp, seed = 10000, 262144, 1234
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < frames * 2 * num_samp * 8 * 1.05:
+        pytest.skip("needs 44 GB of free device memory")
+    x = torch.empty((frames, 2, num_samp), dtype=torch.complex64, device="cuda")
+    plan_mod.synth_fill(x, seed)
+    window = design_window(4, 4096)
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        assert p.path == "fused"
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 0.0)
+        p.fx_accumulate(x)
+        integ = p.finalize("SPECTRUM")[0]
+        rows_sum = torch.zeros(4096, dtype=torch.complex128, device="cuda")
+        for lo in range(0, frames, 2048):
+            rows_sum += p.fx_rows(x[lo:lo + 2048], "SPECTRUM")[:, 0].to(torch.complex128).sum(dim=0)
+        mean_rows = (rows_sum / frames).cpu().numpy()
+        assert rel_err(integ, mean_rows) < TOL_VIS
+        for f in (0, 7777):
+            xf = synth.synth_iq(seed, 1, 2, num_samp, first_chunk=f)[0]
+            np.testing.assert_array_equal(xf, x[f].cpu().numpy())
+            ref = fx_oracle.pfb_xcorr(xf[0], xf[1], 4, 4096, window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+            got = p.fx_rows(x[f:f + 1], "SPECTRUM")[0, 0].cpu().numpy()
+            assert rel_err(got, ref) < TOL_VIS, f
+    del x
+    torch.cuda.empty_cache()

@@ -418,8 +418,8 @@ def test_randomized_launch_shapes_fused_vs_generic(plan_mod, torch):
 
 
 def test_ten_thousand_frame_accumulation(plan_mod, torch):
-    """BASELINE configs[1] integrates 10 000 frames: float32 sums of up to 256 spectra per raw row, float64 across rows
-    (h_launch.h::fused_unit, k_finish.h::fused_reduce1/2_kernel).  A pool of 25 distinct chunk pairs cycled to 10 400 frames of 16
+    """BASELINE configs[1] integrates 10 000 frames: float32 sums of up to 1 024 spectra per raw row, float64 across rows
+    (h_launch.h::fused_unit, k_finish.h::fold_partial_kernel / fold_finish_kernel).  A pool of 25 distinct chunk pairs cycled to 10 400 frames of 16
     spectra must equal the float64 mean of the per-chunk rows, and the oracle's mean over the pool, to 1e-5 of max|vis|
     (SURVEY.md §8d 'parity tolerance to state')."""
     num_samp, pool_n, reps = 4096 * 16, 25, 416
