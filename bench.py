@@ -140,7 +140,7 @@ def pmc_traffic_per_frame():
     return best
 
 
-def power_sample(step, seconds=4.0):
+def power_sample(step, seconds=4.0, gpu_index=0):
     """Package power and shader clock read by rocm-smi while `step` keeps the GPU busy (untimed, after the timed
     region).  Evidence for DESIGN.md §6 (the kernel runs at the package power cap); None if rocm-smi is missing."""
     import re
@@ -158,9 +158,10 @@ def power_sample(step, seconds=4.0):
         while proc.poll() is None:
             step()
         text = proc.stdout.read()
-        watts = re.search(r"GPU\[0\]\s*:\s*(?:Current Socket|Average) Graphics Package Power \(W\):\s*([0-9.]+)", text)
-        cap = re.search(r"GPU\[0\].*?Max Graphics Package Power \(W\):\s*([0-9.]+)", text)
-        sclk = re.search(r"GPU\[0\].*?sclk clock level:.*?\((\d+)Mhz\)", text)
+        g = r"GPU\[%d\]" % int(gpu_index)
+        watts = re.search(g + r"\s*:\s*(?:Current Socket|Average) Graphics Package Power \(W\):\s*([0-9.]+)", text)
+        cap = re.search(g + r"[^\n]*?Max Graphics Package Power \(W\):\s*([0-9.]+)", text)
+        sclk = re.search(g + r"[^\n]*?sclk clock level:[^\n]*?\((\d+)Mhz\)", text)
         if not watts:
             return None
         return {"package_w": float(watts.group(1)), "cap_w": float(cap.group(1)) if cap else None,
@@ -246,35 +247,51 @@ def dry_run_dist(args):
     rank, local_rank, world = rank_env(args)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    frames = args.frames
-    first_chunk = rank * frames                       # weak scaling: every rank owns `frames` frames
+    if args.scaling == "weak":                        # every rank owns `frames` frames
+        first_chunk, frames = rank * args.frames, args.frames
+    else:                                             # `frames` in all, contiguous ranges
+        lo, hi = sharding.chunk_range(rank, world, args.frames)
+        first_chunk, frames = lo, hi - lo
+    total = args.frames * world if args.scaling == "weak" else args.frames
     plan = _DryPlan()
     integ = sharding.ShardedIntegrator(plan, rank, world)
 
-    def step():
+    def issue():
         plan.fx_accumulate(range(first_chunk, first_chunk + frames))
-        return integ.finalize("SPECTRUM", BANDWIDTH, root=0)
+        integ.finalize_async("SPECTRUM", BANDWIDTH, root=0)
+
+    def run_steps(k):                                 # the pipelined loop of main()
+        res = None
+        for j in range(k):
+            issue()
+            if j > 0:
+                res = integ.finalize_wait()
+        if k > 0:
+            res = integ.finalize_wait()
+        return res
 
     def fence():
         if world > 1:
             dist.barrier()
 
-    out = None
-    for _ in range(args.warmup):
-        out = step()
+    out = run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0, world, torch.device("cpu"))
+    elapsed_rank = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_rank, world, torch.device("cpu"))
+    ranks = gather_rank_stats({"rank": rank, "frames": frames, "first_frame": first_chunk,
+                               "ms_per_step_this_rank": round(elapsed_rank / max(args.steps, 1) * 1e3, 4)}, world)
     if rank == 0:
-        total = world * frames
         want = complex((total - 1) / 2.0, -(total - 1) / 2.0)      # mean of 0 .. total-1
         assert out is not None and np.allclose(out, want), (out, want)
-        print(json.dumps({"dry_run": True, "backend": "gloo", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "frames_per_rank": frames, "first_chunk_last_rank": (world - 1) * frames,
+        assert sum(r["frames"] for r in ranks) == total and [r["rank"] for r in ranks] == list(range(world))
+        print(json.dumps({"dry_run": True, "backend": "gloo", "n_gpus": world, "steps": args.steps, "scaling": args.scaling,
+                          "warmup": args.warmup, "frames_per_rank": [r["frames"] for r in ranks], "frames_total": total,
+                          "first_chunk_last_rank": ranks[-1]["first_frame"],
                           "transport": integ.transport, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+                          "ranks": {"per_rank": ranks, "ms_per_step_this_rank": spread(ranks, "ms_per_step_this_rank")},
                           "mean_chunk_index": want.real}))
     else:
         assert out is None
@@ -285,7 +302,8 @@ def dry_run_dist(args):
 def other_configs(x, dev, reps=5):
     """Short, untimed-region runs of the other single-GPU BASELINE configs on the resident synthetic bytes (viewed with
     their own shapes): configs[2] continuum streaming limit (nchan = 1, num_samp = 2^20) and configs[4] (8 antennas,
-    28 baselines, nchan 4096), plus two three-pass shapes (32 taps, 8192 channels).  HIP-event median of `reps` calls each."""
+    28 baselines, nchan 4096), plus two three-pass shapes (32 taps, 8192 channels).  HIP events around four calls back to
+    back (results collected one call behind, as the headline loop does), per call, median of `reps`."""
     import numpy as np
     from effex_amd.plan import FxPlan
     out = []
@@ -297,20 +315,25 @@ def other_configs(x, dev, reps=5):
             return
         xv = flat[:need].view(n_chunks, n_ant, num_samp)
         with FxPlan(n_ant, nchan, ntaps, num_samp, window=window, device=dev.index) as plan:
-            def call():
-                if rows:
-                    plan.fx_rows(xv, mode, BANDWIDTH)
-                else:
-                    plan.acc_reset()
-                    plan.fx_accumulate(xv)
-                    plan.finalize(mode, BANDWIDTH)
-            call()
+            def many(k):
+                """k calls back to back; an integration's result is collected while the next one runs, as in main()"""
+                for j in range(k):
+                    if rows:
+                        plan.fx_rows(xv, mode, BANDWIDTH)
+                    else:
+                        plan.fx_accumulate(xv)
+                        plan.finalize_async(mode, BANDWIDTH, reset=True)
+                        if j > 0:
+                            plan.finalize_wait()
+                if not rows and k > 0:
+                    plan.finalize_wait()
+            many(2)
             plan.sync()
             ms = []
             for _ in range(reps):
                 plan.timer_start()
-                call()
-                ms.append(plan.timer_stop())
+                many(4)
+                ms.append(plan.timer_stop() / 4)
             ms.sort()
             med = ms[len(ms) // 2]
             algo = need * 8
@@ -332,13 +355,100 @@ def other_configs(x, dev, reps=5):
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# RCCL preflight (N > 1, --reduce auto | rccl): fxc_comm_create / fxc_reduce in a fresh CHILD process per rank, under a
+# timeout.  A collective that hangs (one rank failing in ncclCommInitRank leaves the others waiting in theirs) then
+# costs the child, not the benchmark: the parent kills it and the run falls back to the torch.distributed transport
+# (or exits non-zero with --strict-rccl).  The child is started with subprocess (never an exec of this process, which
+# may already hold the GPU) and checks both forms of the reduce against the values every rank can predict.
+# ----------------------------------------------------------------------------------------------
+def _rccl_child(argv):
+    uid_hex, rank, world, gpu = argv[0], int(argv[1]), int(argv[2]), int(argv[3])
+    import numpy as np
+    import torch
+    from effex_amd import synth
+    from effex_amd.plan import FxPlan, RcclComm
+    num_samp, n_chunks = NCHAN * 4, 3
+    x = torch.from_numpy(synth.synth_iq(SEED, n_chunks, 2, num_samp)).cuda(gpu)     # the same frames on every rank
+    with FxPlan(N_ANT, NCHAN, NTAPS, num_samp, device=gpu) as plan, RcclComm(gpu, rank, world, bytes.fromhex(uid_hex)) as comm:
+        plan.fx_accumulate(x)
+        one = plan.finalize_sums(plan.acc_export(plan.new_sums()), "SPECTRUM")      # this rank's own integration
+        for root in (None, 0, world - 1):                # ncclAllReduce, ncclReduce to the first and to the last rank
+            plan.reduce(comm, root)
+            if root is None or root == rank:
+                got = plan.finalize_sums(None, "SPECTRUM")      # sums and spectra counts both scale by `world`
+                err = float(np.abs(got - one).max() / np.abs(one).max())
+                if not err < 1e-12:
+                    print("rccl preflight: rank %d root %s: reduced result off by %.3g" % (rank, root, err))
+                    return 4
+        plan.sync()
+    print("rccl preflight: rank %d of %d on GPU %d ok" % (rank, world, gpu))
+    return 0
+
+
+def rccl_preflight(gpu, rank, world, timeout_s):
+    """-> (ok on every rank, note).  Collective over torch.distributed (already initialised)."""
+    import subprocess
+    import torch
+    import torch.distributed as dist
+    from effex_amd.plan import RcclComm
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = RcclComm.unique_id().hex()
+        except Exception as exc:
+            box[0] = "error: %s" % exc
+    dist.broadcast_object_list(box, src=0)
+    note, ok = None, True
+    if box[0].startswith("error"):
+        ok, note = False, box[0]
+    else:
+        cmd = [sys.executable, os.path.abspath(__file__), "--rccl-child", box[0], str(rank), str(world), str(gpu)]
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        try:
+            out, _ = proc.communicate(timeout=timeout_s)
+            if proc.returncode != 0:
+                ok, note = False, "rank %d: child exited %s: %s" % (rank, proc.returncode, (out or "").strip()[-300:])
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.communicate()
+            ok, note = False, "rank %d: no answer within %.0f s (killed)" % (rank, timeout_s)
+    notes = [None] * world
+    dist.all_gather_object(notes, note)
+    bad = [n for n in notes if n]
+    return (not bad), ("; ".join(bad) if bad else None)
+
+
+def gather_rank_stats(stats, world):
+    """Every rank's dict on rank 0 (list indexed by rank)."""
+    if world == 1:
+        return [stats]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, stats)
+    return out
+
+
+def spread(rows, key):
+    vals = [r[key] for r in rows if r.get(key) is not None]
+    if not vals:
+        return None
+    return {"min": min(vals), "max": max(vals), "mean": round(sum(vals) / len(vals), 4), "argmax_rank": max(range(len(vals)), key=lambda i: vals[i])}
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--rccl-child":
+        raise SystemExit(_rccl_child(sys.argv[2:]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5,
                     help="untimed steps first; after idle the clock needs about five launches to settle")
-    ap.add_argument("--frames", type=int, default=FRAMES, help="integration frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=FRAMES,
+                    help="integration frames per step: per GPU (--scaling weak) or in all (--scaling strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --frames per GPU (SURVEY.md 8d config 4, the default the driver runs); strong: --frames in "
+                         "all, rank r integrates the contiguous range sharding.chunk_range(r, N, frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power sample after the timed region")
@@ -346,8 +456,12 @@ def main():
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check after the timed region (profiling runs: its fx_rows launches would mix into "
                          "the per-kernel statistics)")
-    ap.add_argument("--reduce", choices=("rccl", "torch"), default="rccl",
-                    help="N > 1: fxc_reduce (libfxcorr calls RCCL on the plan's stream) or torch.distributed")
+    ap.add_argument("--reduce", choices=("auto", "rccl", "torch"), default="auto",
+                    help="N > 1: the cross-rank reduce.  rccl: fxc_reduce (libfxcorr calls RCCL on the plan's stream); torch: "
+                         "torch.distributed (backend nccl = RCCL); auto: rccl if its preflight passes on every rank, else torch")
+    ap.add_argument("--strict-rccl", action="store_true",
+                    help="exit non-zero instead of falling back to torch.distributed when fxc_reduce cannot be used")
+    ap.add_argument("--rccl-timeout", type=float, default=120.0, help="seconds the RCCL preflight child of a rank may take")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend for N > 1.  gloo + fewer GPUs than ranks (ranks share GPUs round-robin) "
                          "runs the real multi-rank flow on a one-GPU box for testing; its timing means nothing")
@@ -388,31 +502,45 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    # --- synthetic input, device resident: `frames` distinct chunk pairs per rank if they fit --------
-    frames = args.frames
+    # --- this rank's frames of the synthetic stream, device resident if they fit ------------------------
+    if args.scaling == "weak":
+        first_frame, frames = rank * args.frames, args.frames
+    else:
+        lo, hi = sharding.chunk_range(rank, world, args.frames)
+        first_frame, frames = lo, hi - lo
+    total_frames = args.frames * world if args.scaling == "weak" else args.frames
+    if frames < 1:
+        raise SystemExit("rank %d has no frames: --frames %d over %d ranks" % (rank, args.frames, world))
     free_b, _total_b = torch.cuda.mem_get_info(dev)
     need = frames * BYTES_PER_FRAME
     pool_frames = frames if need < 0.8 * free_b else max(512, int(0.5 * free_b // BYTES_PER_FRAME))
     x = torch.empty((pool_frames, N_ANT, NUM_SAMP), dtype=torch.complex64, device=dev)
-    synth_fill(x, SEED, first_chunk=rank * frames)
+    synth_fill(x, SEED, first_chunk=first_frame)
     torch.cuda.synchronize(dev)
 
     plan = FxPlan(N_ANT, NCHAN, NTAPS, NUM_SAMP, device=gpu)
     assert plan.path == "fused", "headline workload must run on the fused HIP kernel"
     plan.set_delay(BANDWIDTH, FREQUENCY, 0.0)
     comm, comm_note = None, None
-    if world > 1 and args.reduce == "rccl":
-        try:
-            if args.dist_backend != "nccl":
-                raise RuntimeError("ranks share GPUs in the gloo test set-up: RCCL wants one GPU per rank")
-            comm = sharding.make_comm(gpu, rank, world)
-        except Exception as exc:                  # RCCL not usable: torch.distributed carries the reduce
-            comm, comm_note = None, "no RCCL communicator (%s)" % exc
-        ok = torch.tensor([1 if comm is not None else 0], device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)           # all ranks or none
-        if int(ok.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
+    if world > 1 and args.reduce != "torch":
+        if args.dist_backend != "nccl":
+            comm_note = "ranks share GPUs in the gloo test set-up: RCCL wants one GPU per rank"
+        else:
+            ok, why = rccl_preflight(gpu, rank, world, args.rccl_timeout)
+            if ok:
+                try:
+                    comm = sharding.make_comm(gpu, rank, world)
+                except Exception as exc:
+                    comm, why = None, "rank %d: %s" % (rank, exc)
+                flag = torch.tensor([1 if comm is not None else 0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)           # all ranks or none
+                if int(flag.item()) == 0 and comm is not None:
+                    comm.close()
+                    comm = None
+            if comm is None:
+                comm_note = "no RCCL communicator (%s)" % (why or "another rank failed")
+        if comm is None and args.strict_rccl:
+            raise SystemExit("bench.py --strict-rccl: fxc_reduce is not usable: %s" % comm_note)
     integ = sharding.ShardedIntegrator(plan, rank, world, comm=comm)
 
     def issue():
@@ -437,9 +565,6 @@ def main():
             res = integ.finalize_wait()
         return res
 
-    def step():
-        return run_steps(1)
-
     def fence():
         if world > 1:
             dist.barrier()
@@ -452,10 +577,24 @@ def main():
     t0 = time.perf_counter()
     out = run_steps(args.steps)
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed_rank = time.perf_counter() - t0
     kernel_ms, launches = plan.kernel_time(reset=True)
     plan.kernel_profiling(False)
-    elapsed = max_over_ranks(elapsed, world, dev)
+    elapsed = max_over_ranks(elapsed_rank, world, dev)
+
+    # --- untimed: latency of the reduce alone (export + collective, HIP events on the plan's stream) -----
+    reduce_us = None
+    if world > 1:
+        plan.fx_accumulate(x[:min(pool_frames, 64)])
+        lat = []
+        for _ in range(12):
+            fence()
+            plan.timer_start()
+            integ.reduce(root=0)
+            lat.append(plan.timer_stop() * 1e3)
+        plan.acc_reset()
+        lat.sort()
+        reduce_us = round(lat[len(lat) // 2], 1)
 
     # --- untimed: check what was timed -----------------------------------------------------------------
     # (i) the integration against the float64 mean of the per-frame rows over the same frames, summed over ranks;
@@ -472,7 +611,7 @@ def main():
         sharding.reduce_sums(rows_sum, to_all=True)
     verify = None
     if rank == 0 and not args.no_verify:
-        rows_mean = (rows_sum / (frames * world)).cpu().numpy()
+        rows_mean = (rows_sum / total_frames).cpu().numpy()
         err_rows = float(np.abs(out[0] - rows_mean).max() / np.abs(rows_mean).max())
         err_oracle = {}
         for f, ref in sorted(check_rows.items()):
@@ -480,18 +619,32 @@ def main():
                 got = plan.fx_rows(x[f:f + 1], "SPECTRUM")[0, 0].cpu().numpy()
                 err_oracle[str(f)] = float(np.abs(got - ref).max() / np.abs(ref).max())
         verify = {"integration_vs_float64_mean_of_rows": err_rows, "rows_vs_oracle": err_oracle, "tolerance": TOL_VIS,
-                  "frames": frames * world, "checked_after_timed_region": True}
+                  "frames": total_frames, "checked_after_timed_region": True}
         assert err_rows < TOL_VIS, verify
         assert all(e < TOL_VIS for e in err_oracle.values()), verify
 
     others = None
     if world == 1 and not args.no_other_configs:
         others = other_configs(x, dev)
-    power = power_sample(step) if (world == 1 and not args.no_power) else None
+
+    def busy():                                    # keeps this rank's GPU on the F+X kernel, no collective
+        plan.fx_accumulate(x[:min(pool_frames, frames)])
+        plan.acc_reset()
+        plan.sync()
+
+    power = power_sample(busy, gpu_index=gpu) if not args.no_power else None
+
+    # --- every rank's own numbers, for the reader of an efficiency < 1 ------------------------------------
+    my = {"rank": rank, "gpu": gpu, "frames": frames, "first_frame": first_frame,
+          "avg_kernel_ms": round(kernel_ms / max(launches, 1), 4), "launches": int(launches),
+          "ms_per_step_this_rank": round(elapsed_rank / max(args.steps, 1) * 1e3, 4),
+          "sclk_mhz": power["sclk_mhz"] if power else None, "package_w": power["package_w"] if power else None,
+          "reduce_us": reduce_us}
+    ranks = gather_rank_stats(my, world)
 
     if rank == 0:
         assert out is not None and np.isfinite(out).all() and np.abs(out).max() > 0
-        samples = float(frames) * NUM_SAMP * world * args.steps
+        samples = float(total_frames) * NUM_SAMP * args.steps
         value = samples / elapsed / 1e6
         frames_per_launch = frames * args.steps / max(launches, 1)
         algo_bytes = frames_per_launch * BYTES_PER_FRAME + NCHAN * 16        # + one cross-spectrum per integration
@@ -508,18 +661,21 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: 2-antenna FX, num_samp=262144, ntaps=4, nchan=4096, "
-                                   "%d integration frames per GPU per step" % frames,
-                       "frames_per_gpu": frames, "resident_frames": pool_frames, "num_samp": NUM_SAMP,
-                       "nchan": NCHAN, "ntaps": NTAPS, "n_ant": N_ANT, "path": plan.path,
+                                   "%d integration frames %s per step" % (args.frames, "per GPU" if args.scaling == "weak" else "in all"),
+                       "frames_per_gpu": frames, "frames_total": total_frames, "resident_frames": pool_frames,
+                       "num_samp": NUM_SAMP, "nchan": NCHAN, "ntaps": NTAPS, "n_ant": N_ANT, "path": plan.path,
                        "sample_definition": "one complex sample per antenna stream",
                        "parallelism": "frames sharded over %d GPU(s), one RCCL reduce of the cross-spectra "
                                       "per integration" % world, "dist_backend": args.dist_backend if world > 1 else None,
                        "reduce_transport": integ.transport if comm_note is None else integ.transport + "; " + comm_note,
+                       "steps_pipelined": "integration j + 1 is queued before the host collects the result of j "
+                                          "(fxc_finalize_async / fxc_finalize_wait); all %d results are collected inside the "
+                                          "timed region" % args.steps,
                        "library": os.path.relpath(_lib.LIB_PATH, ROOT)},
             "roofline": {"bound": "hbm", "kernel": "fx_fused4096_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -527,12 +683,23 @@ def main():
                          "bytes_per_launch": int(algo_bytes), "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                          "launches": int(launches),
                          "traffic": None if pmc is None else int(pmc[0] * frames_per_launch),
-                         "traffic_source": None if pmc is None else pmc[1]},
+                         "traffic_source": None if pmc is None else pmc[1],
+                         "rank": 0},
             "cpu_baseline": cpu,
             "verify": verify,
             "other_configs": others,
             "power": power,
         }
+        if world > 1:
+            # what an efficiency below 1 is made of: the slowest rank's kernel (clock under the power cap differs from
+            # GPU to GPU), the reduce, and what is left of the step outside the kernel
+            line["ranks"] = {"per_rank": ranks,
+                             "avg_kernel_ms": spread(ranks, "avg_kernel_ms"), "sclk_mhz": spread(ranks, "sclk_mhz"),
+                             "package_w": spread(ranks, "package_w"), "reduce_us": spread(ranks, "reduce_us"),
+                             "ms_per_step_this_rank": spread(ranks, "ms_per_step_this_rank"),
+                             "roofline_frac": spread([{"f": BYTES_PER_FRAME * r["frames"] / (r["avg_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                       if r["avg_kernel_ms"] else None} for r in ranks], "f"),
+                             "step_minus_slowest_kernel_ms": round(elapsed / args.steps * 1e3 - max(r["avg_kernel_ms"] for r in ranks), 4)}
         print(json.dumps(line))
     if comm is not None:
         comm.close()

@@ -330,15 +330,17 @@ FXC_HD int slot_of_bin(int k) {
     return (q2 & 7) * kThreads + tid;
 }
 
-// position of bin k inside a spectrum row written by the F-only variant of the kernel (multi-antenna path):
-// for a fixed q2 the 32 (k1, q1) lanes of the eight waves fill 256 consecutive samples
-FXC_HD int specpos_of_bin(int k) { return (k >> 8) * 256 + (k & 15) * 16 + ((k >> 4) & 15); }
-
-// this lane's position base for phase 3 (add q2 * 256)
+// this lane's index L among the 256 (k1, q1) combinations of phase 3
 FXC_HD int lane_specpos(int tid) {
     const int l = tid & 63, wave = tid >> 6;
     return (2 * wave + ((l >> 4) & 1)) * 16 + (l & 15);
 }
+
+// position inside a spectrum row written by the F-only variant of the kernel (multi-antenna path) of the lane's bin
+// q2: the lane's bins 2m and 2m + 1 sit side by side, so one 16-byte store takes both and the 32 lanes of a half-wave
+// fill 512 consecutive bytes
+FXC_HD int specpos(int lane_l, int q2) { return (q2 >> 1) * 512 + 2 * lane_l + (q2 & 1); }
+FXC_HD int specpos_of_bin(int k) { return specpos((k & 15) * 16 + ((k >> 4) & 15), k >> 8); }
 
 }  // namespace fused
 }  // namespace fxc

@@ -66,7 +66,8 @@ namespace {
 constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 channeliser kernels only
 constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
-constexpr int64_t kWorkspaceTarget = 8ll << 30;   // upper bound of the lazily grown workspace (288 GB of HBM per GPU)
+constexpr size_t kResDirectBytes = 256 << 10;      // finalize results up to this size are written to host memory by the kernel
+constexpr int64_t kWorkspaceTarget = 12ll << 30;  // upper bound of the lazily grown workspace (288 GB of HBM per GPU)
 
 }  // namespace
 
@@ -137,7 +138,13 @@ int fxc_plan_destroy(fxc_plan* p) {
     for (int k = 0; k < fxc_plan::kResSlots; ++k) {
         if (p->ev_res[k]) (void)hipEventDestroy(p->ev_res[k]);
         if (p->h_res[k]) (void)hipHostFree(p->h_res[k]);
+        if (p->d_res_big[k]) (void)hipFree(p->d_res_big[k]);
     }
+    if (p->s_copy) {
+        (void)hipStreamSynchronize(p->s_copy);
+        (void)hipStreamDestroy(p->s_copy);
+    }
+    if (p->ev_fin) (void)hipEventDestroy(p->ev_fin);
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return FXC_OK;
@@ -349,6 +356,27 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         int rc = FXC_OK;
         FXC_TILED_DISPATCH(p, rc = tiled_setup<G>(p));
         if (rc) return rc;
+    }
+    if (p->n_ant >= 3 && p->n_ant <= 8) {
+        const void* xfn = nullptr;
+        switch (p->n_ant) {
+            case 3: xfn = reinterpret_cast<const void*>(&xengine_kernel<3>); break;
+            case 4: xfn = reinterpret_cast<const void*>(&xengine_kernel<4>); break;
+            case 5: xfn = reinterpret_cast<const void*>(&xengine_kernel<5>); break;
+            case 6: xfn = reinterpret_cast<const void*>(&xengine_kernel<6>); break;
+            case 7: xfn = reinterpret_cast<const void*>(&xengine_kernel<7>); break;
+            default: xfn = reinterpret_cast<const void*>(&xengine_kernel<8>); break;
+        }
+        // one-wave workgroups resident per CU: the occupancy API, bounded by the register file (512 VGPRs per SIMD lane in
+        // granules of 8, at most 8 waves per SIMD) -- the API has been seen one block per CU high (MI355X_MICROARCH.md),
+        // and a launch sized one wave per CU too large would run a second round for that sliver
+        int per_cu = 0;
+        FXC_HIP(p, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xfn, kXThreads, 0));
+        hipFuncAttributes fa;
+        FXC_HIP(p, hipFuncGetAttributes(&fa, xfn));
+        const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8);
+        per_cu = std::min(per_cu, 4 * std::min(8, 512 / regs));
+        p->x_resident = (int64_t)std::max(per_cu, 1) * p->cu_count;
     }
     if (N > 1) {
         const int lds = N * (int)sizeof(cf);
@@ -634,8 +662,17 @@ int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth
                     fxc_plan::kResSlots);
     if (!sums_src && !(p->spectra_count > 0.0)) return fail(p, FXC_ERR_STATE, "nothing accumulated");
     const int slot = (int)(p->res_head % fxc_plan::kResSlots);
-    cd* out = p->d_res[slot];
     const int64_t n = (int64_t)p->n_base * p->nchan;
+    const size_t bytes = mode == FXC_MODE_SPECTRUM ? (size_t)n * sizeof(cd) : (size_t)p->n_base * sizeof(cd);
+    // small results are written into the pinned slot by the finishing kernel itself; large ones go through device
+    // memory and a copy on a side stream, off the F+X stream's critical path
+    const bool big = bytes > kResDirectBytes;
+    if (big && !p->s_copy) {
+        FXC_HIP(p, hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
+        FXC_HIP(p, hipEventCreateWithFlags(&p->ev_fin, hipEventDisableTiming));
+        for (int k = 0; k < fxc_plan::kResSlots; ++k) FXC_HIP(p, hipMalloc(&p->d_res_big[k], (size_t)n * sizeof(cd)));
+    }
+    cd* out = big ? p->d_res_big[slot] : p->d_res[slot];
     if (!sums_src) {
         // SPECTRUM: one kernel.  CONTINUUM needs the mean over the bins of the finished accumulator: export, then reduce
         FoldFinish fin = {nullptr, out, p->d_rot, p->spectra_count, reset ? 1 : 0};
@@ -658,8 +695,15 @@ int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth
         hipLaunchKernelGGL(finalize_continuum_kernel, dim3(p->n_base), dim3(256), 0, p->stream, sums_src, out, p->d_rot,
                            p->nchan, p->n_base, 1.0 / bandwidth);
     FXC_HIP(p, hipGetLastError());
-    FXC_HIP(p, hipEventRecord(p->ev_res[slot], p->stream));
-    p->res_bytes[slot] = mode == FXC_MODE_SPECTRUM ? (size_t)n * sizeof(cd) : (size_t)p->n_base * sizeof(cd);
+    if (big) {
+        FXC_HIP(p, hipEventRecord(p->ev_fin, p->stream));
+        FXC_HIP(p, hipStreamWaitEvent(p->s_copy, p->ev_fin, 0));
+        FXC_HIP(p, hipMemcpyAsync(p->h_res[slot], out, bytes, hipMemcpyDeviceToHost, p->s_copy));
+        FXC_HIP(p, hipEventRecord(p->ev_res[slot], p->s_copy));
+    } else {
+        FXC_HIP(p, hipEventRecord(p->ev_res[slot], p->stream));
+    }
+    p->res_bytes[slot] = bytes;
     p->res_head += 1;
     return FXC_OK;
 }

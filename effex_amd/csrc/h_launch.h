@@ -61,24 +61,30 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
     return cb;
 }
 
-// fold_partial_kernel: splits that leave each of its threads about eight rows to walk; `part` holds kFoldMaxSplits rows
-int fold_splits(int64_t n_rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(kFoldMaxSplits, n_rows / (8 * kFoldPhases))); }
-int64_t fold_part_bytes(int nchan) { return (int64_t)kFoldMaxSplits * nchan * (int64_t)sizeof(cd); }
+// fold_partial_kernel: splits that leave each of its threads about eight rows to walk, and the partials within 64 MiB
+// (long rows -- many baselines -- have the parallelism in the row itself)
+int fold_max_splits(int64_t row_len) { return (int)std::max<int64_t>(1, std::min<int64_t>(kFoldMaxSplits, (4ll << 20) / row_len)); }
+int fold_splits(int64_t n_rows, int64_t row_len) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(fold_max_splits(row_len), n_rows / (8 * kFoldPhases)));
+}
+int64_t fold_part_bytes(const fxc_plan* p) { return (int64_t)fold_max_splits((int64_t)p->n_base * p->nchan) * p->n_base * p->nchan * (int64_t)sizeof(cd); }
 
 const FoldFinish kNoFinish = {nullptr, nullptr, nullptr, 0.0, 0};
 
-// acc[bin] += sum of the raw rows (one baseline), and `fin` for every element: two launches, one when the rows are few
-int fold_rows(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int nchan, int layout, const FoldFinish& fin) {
-    const int cols = (nchan + 255) / 256;
-    if (n_rows <= kFoldMaxSplits) {
-        hipLaunchKernelGGL(fold_finish_kernel<cf>, dim3(cols), dim3(256 * kFoldPhases), 0, p->stream, raw, n_rows, p->d_acc, nchan,
-                           layout, fin);
+// acc[p][bin] += sum of the raw rows [n_base][nchan], and `fin` for every element: two launches, one when the rows are few
+int fold_rows(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int layout, const FoldFinish& fin) {
+    const int64_t row_len = (int64_t)p->n_base * p->nchan;
+    const unsigned cols = (unsigned)((row_len + 255) / 256);
+    const int splits = fold_splits(n_rows, row_len);
+    if (splits == 1) {
+        hipLaunchKernelGGL(fold_finish_kernel<cf>, dim3(cols), dim3(256 * kFoldPhases), 0, p->stream, raw, n_rows, p->d_acc,
+                           p->nchan, p->n_base, layout, fin);
     } else {
-        const int splits = fold_splits(n_rows);
-        hipLaunchKernelGGL(fold_partial_kernel, dim3(cols, splits), dim3(256 * kFoldPhases), 0, p->stream, raw, part, nchan,
+        hipLaunchKernelGGL(fold_partial_kernel, dim3(cols, splits), dim3(256 * kFoldPhases), 0, p->stream, raw, part, row_len,
                            n_rows, splits);
+        // the partials are in the rows' own layout
         hipLaunchKernelGGL(fold_finish_kernel<cd>, dim3(cols), dim3(256 * kFoldPhases), 0, p->stream, part, (int64_t)splits,
-                           p->d_acc, nchan, layout, fin);
+                           p->d_acc, p->nchan, p->n_base, layout, fin);
     }
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
@@ -89,7 +95,7 @@ int fold_rows(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int nchan, i
 int flush_pending(fxc_plan* p, const FoldFinish* fin) {
     if (p->pend.valid) {
         p->pend.valid = false;
-        return fold_rows(p, p->pend.raw, p->pend.part, p->pend.n_rows, p->pend.nchan, p->pend.layout, fin ? *fin : kNoFinish);
+        return fold_rows(p, p->pend.raw, p->pend.part, p->pend.n_rows, p->pend.layout, fin ? *fin : kNoFinish);
     }
     if (fin) {
         const int64_t n = (int64_t)p->n_base * p->nchan;
@@ -101,13 +107,12 @@ int flush_pending(fxc_plan* p, const FoldFinish* fin) {
 }
 
 // the rows of an fx_accumulate pass: folded right away, or left pending when the pass is the call's last one
-int fold_or_defer(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int nchan, int layout, bool last_pass) {
-    if (!last_pass) return fold_rows(p, raw, part, n_rows, nchan, layout, kNoFinish);
+int fold_or_defer(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int layout, bool last_pass) {
+    if (!last_pass) return fold_rows(p, raw, part, n_rows, layout, kNoFinish);
     p->pend.valid = true;
     p->pend.raw = raw;
     p->pend.part = part;
     p->pend.n_rows = n_rows;
-    p->pend.nchan = nchan;
     p->pend.layout = layout;
     return FXC_OK;
 }
@@ -170,7 +175,7 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
     else if (spec_out)
         hipLaunchKernelGGL((fx_fused4096_kernel<true, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
                            num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
-                           seg, 1, 1);
+                           seg, p->n_ant / 2, 1);   // (`unit` carries the stream pairs per chunk here)
     else
         hipLaunchKernelGGL((fx_fused4096_kernel<false, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
                            num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
@@ -178,6 +183,15 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
     kt.stop();
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
+}
+
+// chunks per X-engine workgroup (= per raw row) for an integration over nc chunks.  The kernel's one-wave workgroups
+// all do the same work, so the launch is cut into exactly as many as are resident at once (p->x_resident, from the
+// occupancy API: one round, no tail) unless a float32 row (fused_unit) allows fewer chunks than that: then many rounds
+int64_t xengine_group(const fxc_plan* p, int64_t nc, int64_t unit) {
+    const int64_t cols = std::max<int64_t>(1, p->nchan / kXThreads);
+    const int64_t groups = std::max<int64_t>(1, p->x_resident / cols);
+    return std::max<int64_t>(1, std::min<int64_t>(unit, (nc + groups - 1) / groups));
 }
 
 // layout of the raw per-chunk sums the fused paths produce (see raw_index)
@@ -209,17 +223,23 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
     int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
                                        : tiled_channelize(p, x, spec, nc * p->n_ant);
     if (rc) return rc;
+    // spectra layout: the fused F-only kernel writes [chunk][frame][antenna] rows, the tiled one [stream][frame]
+    const bool by_frame = p->path == FXC_PATH_FUSED;
+    const int64_t sa = by_frame ? 1 : p->n_pts, si = by_frame ? p->n_ant : 1;
     const int cg = (int)unit;
-    const dim3 grid(p->nchan / 256, (unsigned)((nc + cg - 1) / cg));
+    const dim3 grid(p->nchan / kXThreads, (unsigned)((nc + cg - 1) / cg));
+#define FXC_X_LAUNCH(A) \
+    hipLaunchKernelGGL(xengine_kernel<A>, grid, dim3(kXThreads), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg, sa, si)
     switch (p->n_ant) {
-        case 3: hipLaunchKernelGGL(xengine_kernel<3>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
-        case 4: hipLaunchKernelGGL(xengine_kernel<4>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
-        case 5: hipLaunchKernelGGL(xengine_kernel<5>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
-        case 6: hipLaunchKernelGGL(xengine_kernel<6>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
-        case 7: hipLaunchKernelGGL(xengine_kernel<7>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
-        case 8: hipLaunchKernelGGL(xengine_kernel<8>, grid, dim3(256), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg); break;
+        case 3: FXC_X_LAUNCH(3); break;
+        case 4: FXC_X_LAUNCH(4); break;
+        case 5: FXC_X_LAUNCH(5); break;
+        case 6: FXC_X_LAUNCH(6); break;
+        case 7: FXC_X_LAUNCH(7); break;
+        case 8: FXC_X_LAUNCH(8); break;
         default: return fail(p, FXC_ERR_UNSUPPORTED, "no X-engine instantiation for n_ant=%d", p->n_ant);
     }
+#undef FXC_X_LAUNCH
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
 }

@@ -57,6 +57,7 @@ struct fxc_plan {
     cf* d_tw8192 = nullptr;        // [4096] w8192^(4095 - n')
     unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int fused_grid_max = 0;
+    int64_t x_resident = 0;        // one-wave workgroups of xengine_kernel<n_ant> the device holds at once
     int64_t fused_seg = 1;         // chunks per round-robin segment of the fused kernel (fx_fused4096.h::RangeWalk)
     cd* d_acc = nullptr;           // [n_base*nchan]
     cd* d_sums = nullptr;          // [n_base*nchan + 1]
@@ -69,7 +70,7 @@ struct fxc_plan {
         const cf* raw = nullptr;
         cd* part = nullptr;
         int64_t n_rows = 0;
-        int nchan = 0, layout = 0;
+        int layout = 0;
     } pend;
     // finalize results: kResSlots pinned host buffers mapped into the device (the finishing kernel writes the
     // visibilities straight into them: no staging copy), each with the event that marks it complete
@@ -79,6 +80,11 @@ struct fxc_plan {
     hipEvent_t ev_res[kResSlots] = {nullptr, nullptr};
     size_t res_bytes[kResSlots] = {0, 0};
     int64_t res_head = 0, res_tail = 0;            // results queued / collected
+    // results too large to be worth a kernel's time on PCIe (28 baselines: 1.8 MB, 35 us inside the finishing kernel):
+    // the kernel writes device memory and a copy on a side stream carries it to the slot while the next F+X runs
+    cd* d_res_big[kResSlots] = {nullptr, nullptr};
+    hipStream_t s_copy = nullptr;
+    hipEvent_t ev_fin = nullptr;
     double spectra_count = 0.0;
     // workspace (grown on demand)
     void* d_ws = nullptr;

@@ -26,7 +26,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         const int64_t in_bytes = (int64_t)p->n_ant * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = fused_chunks_per_pass(p, n_chunks, &spec_bytes, &raw_bytes);
-        const int64_t part_bytes = fold_part_bytes(kN);
+        const int64_t part_bytes = fold_part_bytes(p);
         int rc = ensure_ws(p, spec_bytes + raw_bytes + part_bytes);
         if (rc) return rc;
         cf* spec = reinterpret_cast<cf*>(p->d_ws);
@@ -34,26 +34,22 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + spec_bytes + raw_bytes);
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
-            const int64_t unit = fused_unit(p);
+            // chunks per raw row: 2 antennas, rows of up to kRowSpectra spectra; more, the X-engine's chunk groups
+            const int64_t unit = p->n_ant == 2 ? fused_unit(p) : xengine_group(p, nc, fused_unit(p));
             rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
                                 dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit, false);
             if (rc) return rc;
-            if (p->n_ant == 2) {   // one baseline: fold all the raw rows (leading parts included) into the accumulator
-                rc = fold_or_defer(p, raw, part, fused_rows(p, nc, unit, false), kN, fused_layout(p), c0 + nc >= n_chunks);
-                if (rc) return rc;
-            } else {   // raw rows of `unit` chunks each
-                const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
-                hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream,
-                                   raw, p->d_acc, p->nchan, p->n_base, (nc + unit - 1) / unit, 1, fused_layout(p));
-            }
-            FXC_HIP(p, hipGetLastError());
+            // 2 antennas: all the raw rows, leading parts included; more: one row [n_base][nchan] per chunk group
+            const int64_t n_rows = p->n_ant == 2 ? fused_rows(p, nc, unit, false) : (nc + unit - 1) / unit;
+            rc = fold_or_defer(p, raw, part, n_rows, fused_layout(p), c0 + nc >= n_chunks);
+            if (rc) return rc;
         }
     } else if (p->split8192 && !dc_u8) {
         const int N = p->nchan;
         const int64_t cb = split_chunks_per_pass(p, n_chunks);
         const int64_t row_bytes = (int64_t)fxc::fused::kN * (int64_t)sizeof(cf);
         const int64_t raw_bytes = ((2 * cb + p->fused_grid_max) * row_bytes + 255) / 256 * 256;
-        const int64_t part_bytes = fold_part_bytes(N);
+        const int64_t part_bytes = fold_part_bytes(p);
         int rc = ensure_ws(p, raw_bytes + part_bytes);
         if (rc) return rc;
         cf* raw = reinterpret_cast<cf*>(p->d_ws);
@@ -63,7 +59,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             rc = split_raw_sums(p, x + c0 * 2 * p->num_samp, nc, raw);
             if (rc) return rc;
             // the nc pairs of 4096-rows are nc rows of 8192 in layout 3; the leading-part rows are added by parity
-            rc = fold_rows(p, raw, part, nc, N, 3, kNoFinish);
+            rc = fold_rows(p, raw, part, nc, 3, kNoFinish);
             if (rc) return rc;
             hipLaunchKernelGGL(split_lead_acc_kernel, dim3(N / 256), dim3(256), 0, p->stream, raw, p->d_acc, fused_lead(p, 2 * nc));
             FXC_HIP(p, hipGetLastError());
@@ -76,7 +72,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, prefilter_streams_per_pass(p) / 2),
                                                                   kWorkspaceTarget / (row_bytes * n_splits)));
         const int64_t raw_bytes = (cb * n_splits * row_bytes + 255) / 256 * 256;
-        const int64_t part_bytes = fold_part_bytes(N);
+        const int64_t part_bytes = fold_part_bytes(p);
         int rc = ensure_ws(p, raw_bytes + part_bytes);
         if (rc) return rc;
         cf* raw = reinterpret_cast<cf*>(p->d_ws);
@@ -86,17 +82,19 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             rc = tiled_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, n_splits,
                                 raw, dc_u8 ? dc_u8 + c0 * 2 : nullptr);
             if (rc) return rc;
-            rc = fold_or_defer(p, raw, part, nc * n_splits, N, 0, c0 + nc >= n_chunks);
+            rc = fold_or_defer(p, raw, part, nc * n_splits, 0, c0 + nc >= n_chunks);
             if (rc) return rc;
         }
     } else {
         const XGeom g = x_geometry(p);
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes);
-        int rc = ensure_ws(p, spec_bytes + raw_bytes);
+        raw_bytes = (raw_bytes + 255) / 256 * 256;
+        int rc = ensure_ws(p, spec_bytes + raw_bytes + fold_part_bytes(p));
         if (rc) return rc;
         cf* spec = reinterpret_cast<cf*>(p->d_ws);
         cf* raw = reinterpret_cast<cf*>(static_cast<char*>(p->d_ws) + spec_bytes);
+        cd* part = reinterpret_cast<cd*>(static_cast<char*>(p->d_ws) + spec_bytes + raw_bytes);
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
             KernelTimer kt(p);
@@ -106,11 +104,11 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             const int64_t wgs = nc * p->n_base * kblocks * g.n_splits;
             hipLaunchKernelGGL(xmul_kernel, dim3((int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8)), dim3(256), 0,
                                p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
-            const int64_t per_chunk = (int64_t)p->n_base * p->nchan;
-            hipLaunchKernelGGL(acc_add_kernel, dim3(grid_for(per_chunk, 256, p->cu_count)), dim3(256), 0, p->stream, raw,
-                               p->d_acc, p->nchan, p->n_base, nc, g.n_splits, 0);
             kt.stop();
             FXC_HIP(p, hipGetLastError());
+            // raw[split][chunk] = nc * n_splits rows of [n_base][nchan], natural bin order
+            rc = fold_or_defer(p, raw, part, nc * g.n_splits, 0, c0 + nc >= n_chunks);
+            if (rc) return rc;
         }
     }
     p->spectra_count += (double)n_chunks * (double)p->n_pts;

@@ -112,27 +112,6 @@ __global__ __launch_bounds__(256) void rows_continuum_kernel(const cf* __restric
     }
 }
 
-// accumulate: acc[p][k] += sum_split sum_c raw[split][c][p][raw_index(k)]   (fixed order -> reproducible)
-__global__ void acc_add_kernel(const cf* __restrict__ raw, cd* __restrict__ acc, int nchan, int n_base,
-                               int64_t n_chunks, int n_splits, int slots) {
-    const int64_t per_chunk = (int64_t)n_base * nchan;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per_chunk; idx += stride) {
-        const int k = (int)(idx % nchan);
-        const int64_t src = (idx / nchan) * nchan + raw_index(k, slots);
-        double ar = 0.0, ai = 0.0;
-        for (int64_t sc = 0; sc < n_chunks * n_splits; ++sc) {
-            const cf r = raw[sc * per_chunk + src];
-            ar += r.x;
-            ai += r.y;
-        }
-        cd a = acc[idx];
-        a.x += ar;
-        a.y += ai;
-        acc[idx] = a;
-    }
-}
-
 // What the kernel that finishes an integration does with an accumulator element besides updating it: export it for the
 // cross-rank reduce, finalise it, clear it -- in the same launch instead of export + finalize + device-to-host copy +
 // memset (round 2: four commands and 50 us of gaps per integration).
@@ -173,8 +152,8 @@ __device__ __forceinline__ void finish_element(cd a, cd* __restrict__ acc, int64
     acc[idx] = a;
 }
 
-// Integration of the 2-antenna kernels' raw float32 rows (one baseline): acc[bin] += sum over all rows, in float64 and
-// in a fixed order (bit-reproducible), then FoldFinish.  Two launches back to back, no fences, no atomics (a single
+// Integration of the kernels' raw float32 rows (row = [n_base][nchan] sums of spectrum products, each baseline in the
+// layout `slots`): acc[p][bin] += sum over all rows, in float64 and in a fixed order (bit-reproducible), then FoldFinish.  Two launches back to back, no fences, no atomics (a single
 // kernel with a last-workgroup-done ticket per column was tried first: its agent-scope release / acquire fences write
 // back and invalidate the L2s once per workgroup and took 190 us):
 //   fold_partial_kernel  workgroup (column of 256 slots, split): thread (slot, phase) walks the rows
@@ -186,11 +165,11 @@ __device__ __forceinline__ void finish_element(cd a, cd* __restrict__ acc, int64
 // `slots`: layout of a row (raw_index): 0 natural order, 1 the fused kernel's slot order, 3 the 8192-channel split
 constexpr int kFoldPhases = 4;
 constexpr int kFoldMaxSplits = 32;
-__global__ __launch_bounds__(1024) void fold_partial_kernel(const cf* __restrict__ raw, cd* __restrict__ part, int nchan,
-                                                           int64_t n_rows, int n_splits) {
+__global__ __launch_bounds__(1024) void fold_partial_kernel(const cf* __restrict__ raw, cd* __restrict__ part, int64_t nchan,
+                                                           int64_t n_rows, int n_splits) {   // (nchan: the row length)
     __shared__ cd sub[kFoldPhases][256];
     const int kl = threadIdx.x & 255, ph = threadIdx.x >> 8;
-    const int slot = blockIdx.x * 256 + kl;
+    const int64_t slot = (int64_t)blockIdx.x * 256 + kl;
     const int split = blockIdx.y;
     const bool live = slot < nchan;
     double ar = 0.0, ai = 0.0;
@@ -232,16 +211,31 @@ __global__ __launch_bounds__(1024) void fold_partial_kernel(const cf* __restrict
 
 template <class RowT>
 __global__ __launch_bounds__(1024) void fold_finish_kernel(const RowT* __restrict__ rows, int64_t n_rows, cd* __restrict__ acc,
-                                                          int nchan, int slots, FoldFinish fin) {
+                                                          int nchan, int n_base, int slots, FoldFinish fin) {
     __shared__ cd sub[kFoldPhases][256];
     const int kl = threadIdx.x & 255, ph = threadIdx.x >> 8;
-    const int k = blockIdx.x * 256 + kl;
-    const bool live = k < nchan;
+    const int64_t n = (int64_t)n_base * nchan;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + kl;
+    const bool live = idx < n;
+    const int k = (int)(idx % nchan);
     double ar = 0.0, ai = 0.0;
     if (live) {
-        const RowT* col = rows + raw_index(k, slots);
-        for (int64_t s = ph; s < n_rows; s += kFoldPhases) {
-            const RowT v = col[s * nchan];
+        const RowT* col = rows + (idx - k) + raw_index(k, slots);
+        int64_t s = ph;
+        for (; s + 3 * kFoldPhases < n_rows; s += 4 * kFoldPhases) {      // four loads in flight; summed in row order
+            const RowT v0 = col[s * n], v1 = col[(s + kFoldPhases) * n], v2 = col[(s + 2 * kFoldPhases) * n],
+                       v3 = col[(s + 3 * kFoldPhases) * n];
+            ar += v0.x;
+            ai += v0.y;
+            ar += v1.x;
+            ai += v1.y;
+            ar += v2.x;
+            ai += v2.y;
+            ar += v3.x;
+            ai += v3.y;
+        }
+        for (; s < n_rows; s += kFoldPhases) {
+            const RowT v = col[s * n];
             ar += v.x;
             ai += v.y;
         }
@@ -250,13 +244,13 @@ __global__ __launch_bounds__(1024) void fold_finish_kernel(const RowT* __restric
     sub[ph][kl].y = ai;
     __syncthreads();
     if (ph != 0 || !live) return;
-    cd a = acc[k];
+    cd a = acc[idx];
 #pragma unroll
     for (int q = 0; q < kFoldPhases; ++q) {
         a.x += sub[q][kl].x;
         a.y += sub[q][kl].y;
     }
-    finish_element(a, acc, k, k, nchan, nchan, fin);
+    finish_element(a, acc, idx, k, nchan, n, fin);
 }
 
 // FoldFinish alone, on the accumulator as it stands (paths that update it themselves, or nothing pending)
@@ -267,18 +261,21 @@ __global__ void acc_finish_kernel(cd* __restrict__ acc, int nchan, int n_base, F
         finish_element(acc[idx], acc, idx, (int)(idx % nchan), nchan, n, fin);
 }
 
-// multi-antenna X-engine on the F-only kernel's spectra: spec[(c*A + a)*P + i][pos]; one thread per (chunk group,
-// pos) keeps all A(A-1)/2 accumulators in registers over the spectra of `cg` consecutive chunks (cg = 1: one raw
-// row per chunk; the integration takes float32 sums of up to 256 spectra, like the 2-antenna kernel's rows) and
-// reads every spectrum sample exactly once; raw[group][p][pos], baselines ordered (0,1),(0,2)..(A-2,A-1) --
-// effex.py:520 for A > 2
-#ifndef FXC_XENGINE_UNROLL
-#define FXC_XENGINE_UNROLL 2
-#endif
-constexpr int kXU = FXC_XENGINE_UNROLL;
+// multi-antenna X-engine on the F-only kernels' spectra: spectrum (chunk c, antenna a, frame i) is row
+// c * A * n_pts + a * sa + i * si of `spec` (rows of nchan samples; sa = n_pts, si = 1: [stream][frame], what the tiled
+// F-only kernel and fxc_channelize write; sa = 1, si = A: [frame][antenna], what the fused F-only kernel writes -- the A
+// rows a thread needs for one frame then lie inside one block of A rows instead of 2 MiB apart: 8 antennas 1.64 -> 1.51 ms
+// per 512 chunks, 5.4 TB/s).  One wave per workgroup; a thread keeps all A(A-1)/2 accumulators of one position in
+// registers over the spectra of `cg` consecutive chunks (cg = 1: one raw row per chunk; integrations take float32 sums
+// of up to kRowSpectra spectra, like the 2-antenna kernel's rows) and reads every spectrum sample exactly once;
+// raw[group][p][pos], baselines ordered (0,1),(0,2)..(A-2,A-1) -- effex.py:520 for A > 2.
+// Measured and dropped (profiles/r03/experiments.md): two positions per thread with 16-byte loads (+10 %), 1 or 4
+// spectra per trip instead of 2 (+-0.5 %).
+constexpr int kXU = 2;           // spectra per trip: kXU * A independent 8-byte loads in flight before the multiply-accumulates
+constexpr int kXThreads = 64;
 template <int A>
-__global__ __launch_bounds__(256) void xengine_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int64_t n_pts,
-                                                     int nchan, int64_t n_chunks, int cg) {
+__global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int64_t n_pts,
+                                                           int nchan, int64_t n_chunks, int cg, int64_t sa, int64_t si) {
     constexpr int NB = A * (A - 1) / 2;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t grp = blockIdx.y;
@@ -288,14 +285,13 @@ __global__ __launch_bounds__(256) void xengine_kernel(const cf* __restrict__ spe
     const int64_t c_end = (grp + 1) * cg < n_chunks ? (grp + 1) * cg : n_chunks;
     for (int64_t c = grp * cg; c < c_end; ++c) {
         const cf* base = spec + (c * A * n_pts) * nchan + pos;
-        // kXU spectra per trip: kXU * A independent 8-byte loads in flight before the multiply-accumulates
         int64_t i = 0;
         for (; i + kXU <= n_pts; i += kXU) {
             cf z[kXU][A];
 #pragma unroll
             for (int u = 0; u < kXU; ++u)
 #pragma unroll
-                for (int a = 0; a < A; ++a) z[u][a] = base[((int64_t)a * n_pts + i + u) * nchan];
+                for (int a = 0; a < A; ++a) z[u][a] = base[((int64_t)a * sa + (i + u) * si) * nchan];
 #pragma unroll
             for (int u = 0; u < kXU; ++u) {
                 int p = 0;
@@ -311,7 +307,7 @@ __global__ __launch_bounds__(256) void xengine_kernel(const cf* __restrict__ spe
         for (; i < n_pts; ++i) {
             cf z[A];
 #pragma unroll
-            for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * n_pts + i) * nchan];
+            for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * sa + i * si) * nchan];
             int p = 0;
 #pragma unroll
             for (int a = 0; a < A; ++a)

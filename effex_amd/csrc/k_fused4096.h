@@ -23,6 +23,7 @@ __device__ __forceinline__ void permlane32_swap(cf& a, cf& b) {
 // this thread's 16 branch samples of frame i: element (255 - j) + 256 (15 - r); loads r = R0 .. R0+CNT-1.
 // Buffer loads: one VGPR byte offset per thread, everything that varies with chunk / frame / r is scalar.
 typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 #ifndef FXC_LOAD_AUX
 #define FXC_LOAD_AUX 0   // cache policy of the IQ stream loads: bit 0 sc0, bit 1 nt, bit 4 sc1
 #endif
@@ -108,7 +109,7 @@ constexpr int kStampSegs = 12;
 // wave-uniform and none of it guards a *definition* of ring registers (the prefetch is unconditional),
 // which keeps the register allocator from doubling live ranges at merge points.
 // SPEC_OUT: the multi-antenna variant -- the pair of streams is only channelised and both spectra go to
-// HBM for xengine_kernel (rows_raw then is the spectra buffer [stream][i][specpos]).
+// HBM for xengine_kernel (rows_raw then is the spectra buffer [chunk][i][stream][specpos]).
 // uint8 ingest state: this chunk's conversion offsets
 struct U8State {
     cf off;
@@ -117,7 +118,7 @@ struct U8State {
 template <int PH, bool SPEC_OUT, bool U8>
 __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, const cf* dc, const f4* win, cf* region,
                                            const cf* tw2, int tid, const cf* x, int64_t num_samp, unsigned chunk_bytes,
-                                           unsigned voff, fxc::fused::RangeWalk& pos, cf* rows_raw,
+                                           unsigned voff, fxc::fused::RangeWalk& pos, cf* rows_raw, int hp,
                                            unsigned long long (&seg)[kStampSegs], unsigned long long& t_prev) {
     using namespace fxc::fused;
     const int64_t c = pos.c, i = pos.i, n_pts = pos.n_pts;   // (the walk itself is 32-bit: scalar registers are scarce)
@@ -181,13 +182,22 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
         // stream = 2 * (virtual chunk) + antenna; for a fixed q2 a half-wave stores 256 contiguous bytes.  Buffer
         // stores from the row of antenna 0 of this frame: one VGPR byte offset per thread (antenna 1's row is n_pts
         // rows further on), scalar offsets for q2 -- no per-store address arithmetic on the vector unit
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rows_raw + (c * 2 * n_pts + i) * kN, 0,
-                                                                       (int)((n_pts + 1) * kN * (int64_t)sizeof(cf)), 0x00020000);
-        const unsigned soff0 = (unsigned)(((tid >> 5) & 1) * n_pts * kN + lane_specpos(tid)) * (unsigned)sizeof(cf);
+        // rows [chunk][frame][antenna], hp = stream pairs per chunk (c counts pairs): both antennas of the pair side by
+        // side, all antennas of a frame in one block for the X-engine
+        const unsigned cu = (unsigned)c;
+        const unsigned cr = hp == 1 ? cu : (hp == 2 ? cu >> 1 : (hp == 4 ? cu >> 2 : (unsigned)(((unsigned long long)cu * 0xAAAAAAABull) >> 33)));
+        const int64_t row0 = ((int64_t)cr * n_pts + i) * (2 * hp) + 2 * (cu - cr * hp);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rows_raw + row0 * kN, 0, (int)(2 * kN * (int64_t)sizeof(cf)), 0x00020000);
+        // the lane's bins 2m, 2m + 1 go out together (fx_fused4096.h::specpos): eight 16-byte stores, 512 contiguous
+        // bytes per half-wave.  The offset of m stays in the VGPR: gfx950 needs wait states between a store of more
+        // than 8 bytes with an SGPR offset and a VALU write of its data registers that the compiler omits
+        // (tests/test_isa_hazards.py)
+        const unsigned voff0 = (unsigned)(((tid >> 5) & 1) * kN + specpos(lane_specpos(tid), 0)) * (unsigned)sizeof(cf);
 #pragma unroll
-        for (int q2 = 0; q2 < 16; ++q2) {
-            v2u32 d = {__float_as_uint(v[q2].x), __float_as_uint(v[q2].y)};
-            __builtin_amdgcn_raw_buffer_store_b64(d, rs, soff0, (unsigned)(q2 * 256 * sizeof(cf)), 0);
+        for (int m = 0; m < 8; ++m) {
+            v4u32 d = {__float_as_uint(v[2 * m].x), __float_as_uint(v[2 * m].y), __float_as_uint(v[2 * m + 1].x),
+                       __float_as_uint(v[2 * m + 1].y)};
+            __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff0 + (unsigned)(m * 512 * sizeof(cf)), 0, 0);
         }
     } else {
         // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins: after the swap each lane has both
@@ -219,7 +229,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
 // SPEC_OUT == false: rows_raw = range_rows() raw rows, float32, slot order (fx_fused4096.h::slot_of_bin);
 // rows_are_chunks: row c = chunk c (+ leading-part rows for tail chunks shared by several workgroups), else rows of
 // `unit` chunks whose total is the integration.
-// SPEC_OUT == true: rows_raw[(2c + ant) * n_pts + i][specpos] = the spectra themselves.  A "chunk" here is a pair
+// SPEC_OUT == true: rows_raw[(chunk * n_pts + i) * n_ant + stream][specpos] = the spectra themselves (`unit` = n_ant / 2).  A "chunk" here is a pair
 // of consecutive antenna streams, so an even number of antennas [n_chunks][A][S] is simply n_chunks * A/2 pairs.
 // U8: x points at interleaved uint8 I,Q ([chunk][antenna][num_samp] byte pairs) and dc[chunk * 2 + antenna] holds the
 // conversion offsets (-mean_byte / 127.5, or -1 without DC removal) of each stream.  stamps: diagnostic builds only.
@@ -257,11 +267,12 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
 #endif
 #pragma unroll 1
     for (int part = 0; part < 2; ++part) {   // 0: whole chunks, round-robin; 1: this workgroup's range of the tail
-        RangeWalk pos = part == 0 ? range_walk_rounds(blockIdx.x, gridDim.x, (int)n_chunks, (int)n_pts, seg, unit, rows_are_chunks != 0)
-                                  : range_walk_tail(blockIdx.x, gridDim.x, (int)n_chunks, (int)n_pts, seg, unit, rows_are_chunks != 0);
+        const int walk_unit = SPEC_OUT ? 1 : unit;      // (SPEC_OUT: `unit` carries the stream pairs per chunk)
+        RangeWalk pos = part == 0 ? range_walk_rounds(blockIdx.x, gridDim.x, (int)n_chunks, (int)n_pts, seg, walk_unit, rows_are_chunks != 0)
+                                  : range_walk_tail(blockIdx.x, gridDim.x, (int)n_chunks, (int)n_pts, seg, walk_unit, rows_are_chunks != 0);
         const int total = pos.left;
         if (!SPEC_OUT && part == 1 && (!pos.lead || total == 0)) {   // no leading part: its row reads as zeros
-            const RangeSplit sp = range_split(gridDim.x, (int)n_chunks, seg, unit, rows_are_chunks != 0);
+            const RangeSplit sp = range_split(gridDim.x, (int)n_chunks, seg, walk_unit, rows_are_chunks != 0);
             cf* lead_row = rows_raw + (int64_t)(sp.rows_rounds + sp.n_tail + blockIdx.x) * kN + tid;
 #pragma unroll
             for (int q = 0; q < kAccPerThread; ++q) lead_row[q * kThreads] = fxc::mk(0.f, 0.f);
@@ -291,13 +302,13 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
         // frame g of the part sits in ring slot g & 3: unrolled by four so the ring rotates by register renaming
 #pragma unroll 1
         for (int g = 0; g < total; g += 4) {
-            fused_step<0, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg_t, t_prev);
+            fused_step<0, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, seg_t, t_prev);
             if (g + 1 < total)
-                fused_step<1, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg_t, t_prev);
+                fused_step<1, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, seg_t, t_prev);
             if (g + 2 < total)
-                fused_step<2, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg_t, t_prev);
+                fused_step<2, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, seg_t, t_prev);
             if (g + 3 < total)
-                fused_step<3, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, seg_t, t_prev);
+                fused_step<3, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, seg_t, t_prev);
         }
         frames_done += total;
     }

@@ -113,7 +113,7 @@ extern "C" int emul_layout_check(void) {
         const int k1 = 2 * wave + ((l >> 4) & 1), q1 = l & 15;
         for (int q2 = 0; q2 < 16; ++q2) {
             const int k = k1 + 16 * q1 + 256 * q2;
-            if (specpos_of_bin(k) != q2 * 256 + lane_specpos(tid)) return -1;
+            if (specpos_of_bin(k) != specpos(lane_specpos(tid), q2)) return -1;
         }
         for (int q = 0; q < kAccPerThread; ++q)
             if (slot_of_bin(bin_of(tid, q)) != q * kThreads + tid) return -2;

@@ -208,21 +208,36 @@ def test_sharded_integrator_finalize_over_gloo(world, to_all):
                 assert out is None
 
 
-def test_bench_dry_run_dist_two_ranks():
-    """bench.py's world > 1 control flow (rank env, first_chunk per rank, ShardedIntegrator, barrier, max-over-ranks
-    timing) under torch.distributed.run --nproc-per-node 2 on gloo / CPU tensors."""
+def _dry_run(n_ranks, *extra):
     import json
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--dry-run-dist"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--steps", "3",
+           "--warmup", "1", "--dry-run-dist"] + list(extra)
     proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                       # rank 0 alone prints the line
-    line = json.loads(lines[0])
-    assert line["dry_run"] and line["n_gpus"] == 2 and line["steps"] == 3 and line["frames_per_rank"] == 100
+    return json.loads(lines[0])
+
+
+def test_bench_dry_run_dist_two_ranks():
+    """bench.py's world > 1 control flow (rank env, first frame per rank, ShardedIntegrator's queued finalize with two
+    integrations in flight, barrier, max-over-ranks timing, the per-rank table) under torch.distributed.run
+    --nproc-per-node 2 on gloo / CPU tensors: weak scaling, the default."""
+    line = _dry_run(2)
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["steps"] == 3 and line["frames_per_rank"] == [100, 100]
+    assert line["scaling"] == "weak" and line["frames_total"] == 200
     assert line["first_chunk_last_rank"] == 100 and line["transport"] == "torch.distributed"
     assert line["mean_chunk_index"] == 99.5      # mean over both ranks' chunk ranges: the reduce reached the root
+    assert [r["rank"] for r in line["ranks"]["per_rank"]] == [0, 1]
+    assert line["ranks"]["ms_per_step_this_rank"]["max"] <= line["ms_per_step"] * 1.5 + 1.0
+
+
+def test_bench_dry_run_dist_strong_scaling_three_ranks():
+    """--scaling strong ('10 000 total'): --frames in all, contiguous uneven ranges."""
+    line = _dry_run(3, "--scaling", "strong", "--frames", "100")
+    assert line["scaling"] == "strong" and line["frames_total"] == 100 and line["frames_per_rank"] == [33, 33, 34]
+    assert line["first_chunk_last_rank"] == 66 and line["mean_chunk_index"] == 49.5
 
 
 def _comm_worker(rank, world, port, queue):

@@ -1085,6 +1085,9 @@ def test_bench_two_ranks_share_one_gpu():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["frames_per_gpu"] == 600 and line["config"]["path"] == "fused"
-    assert line["config"]["reduce_transport"].startswith("torch.distributed; no RCCL communicator")
+    assert line["config"]["reduce_transport"].startswith("torch.distributed; ranks share GPUs")
     assert line["verify"]["frames"] == 1200 and line["verify"]["integration_vs_float64_mean_of_rows"] < 1e-6
-    assert line["value"] > 0 and line["roofline"]["launches"] == 2
+    assert line["value"] > 0 and line["roofline"]["launches"] == 2 and line["scaling"] == "weak"
+    ranks = line["ranks"]
+    assert [r["rank"] for r in ranks["per_rank"]] == [0, 1] and [r["first_frame"] for r in ranks["per_rank"]] == [0, 600]
+    assert ranks["avg_kernel_ms"]["min"] > 0 and ranks["reduce_us"]["max"] > 0
