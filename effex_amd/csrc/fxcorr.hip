@@ -258,6 +258,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + kDckLdsBytes));
     }
     p->tiled_f = (tiled_nchan(N) && p->num_samp <= (1ll << 27) && force_path != FXC_PATH_GENERIC);
     if (p->path == FXC_PATH_TILED || p->tiled_f) {
@@ -824,18 +826,40 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
         double* part = static_cast<double*>(p->d_dc);
         cf* dc = reinterpret_cast<cf*>(static_cast<char*>(p->d_dc) + part_bytes);
         const bool fused_ingest = fused_in;
-        if (remove_dc && fused_ingest)
-            hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(n_streams, (int64_t)p->cu_count * 16)),
-                               dim3(256), 0, p->stream, xb, part, p->num_samp, n_streams);
-        else if (remove_dc)
+        // The fused 4096-channel kernel can sum the bytes of a workgroup's next chunk while it channelises the current one
+        // (k_fused4096.h, DCK): the pre-pass then only covers the first chunk of every workgroup's round-robin share and
+        // the tail chunks -- 272 of 10 000 chunk pairs.  Needs whole frames (num_samp % 4096 == 0), 16-byte aligned
+        // streams, the default work split, one launch for the pass and at least two rounds of chunks.
+        int64_t spec_b, raw_b;
+        const int64_t g = p->fused_grid_max;
+        const bool dck = remove_dc && fused_ingest && p->path == FXC_PATH_FUSED && p->fused_seg == 1 &&
+                         (p->num_samp % fxc::fused::kN) == 0 && (reinterpret_cast<uintptr_t>(xb) % 16) == 0 &&
+                         fused_chunks_per_pass(p, nc, &spec_b, &raw_b) >= nc && nc >= 2 * g;
+        if (remove_dc && fused_ingest) {
+            const int64_t n_full = dck ? nc / g * g : nc;
+            // chunk ranges the pre-pass sums: everything, or [0, g) and [n_full, nc)
+            const int64_t lo[2] = {0, n_full}, hi[2] = {dck ? g : nc, dck ? nc : n_full};
+            for (int r = 0; r < 2; ++r) {
+                const int64_t ns = (hi[r] - lo[r]) * p->n_ant;
+                if (ns <= 0) continue;
+                hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(ns, (int64_t)p->cu_count * 16)), dim3(256),
+                                   0, p->stream, xb + lo[r] * p->n_ant * p->num_samp * 2, part + lo[r] * p->n_ant * 2, p->num_samp, ns);
+                hipLaunchKernelGGL(dc_offsets_u8_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, p->stream,
+                                   part + lo[r] * p->n_ant * 2, dc + lo[r] * p->n_ant, ns, 1, p->num_samp, 1);
+            }
+        } else if (remove_dc) {
             hipLaunchKernelGGL(dc_sum_u8_kernel, dim3(kSlices, (unsigned)n_streams), dim3(256), 0, p->stream, xb, part,
                                p->num_samp, kSlices);
+        }
         if (fused_ingest) {
-            hipLaunchKernelGGL(dc_offsets_u8_kernel, dim3((unsigned)((n_streams + 255) / 256)), dim3(256), 0, p->stream, part,
-                               dc, n_streams, 1, p->num_samp, remove_dc ? 1 : 0);
+            if (!remove_dc)
+                hipLaunchKernelGGL(dc_offsets_u8_kernel, dim3((unsigned)((n_streams + 255) / 256)), dim3(256), 0, p->stream, part,
+                                   dc, n_streams, 1, p->num_samp, 0);
             FXC_HIP(p, hipGetLastError());
+            p->u8_dck = dck;
             rc = rows ? fx_rows_dev(p, reinterpret_cast<const cf*>(xb), ob, nc, mode, bandwidth, dc)
                       : fx_accumulate_dev(p, reinterpret_cast<const cf*>(xb), nc, dc);
+            p->u8_dck = false;
         } else {
             const int64_t total = n_streams * p->num_samp;
             rc = grow(p, &p->d_stage[2], &p->stage_bytes[2], (size_t)total * sizeof(cf));

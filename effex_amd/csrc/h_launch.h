@@ -6,7 +6,7 @@
 namespace {
 
 int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8 = nullptr,
-                 int64_t unit = 1, bool rows_are_chunks = true, int64_t num_samp = 0);
+                 int64_t unit = 1, bool rows_are_chunks = true, int64_t num_samp = 0, bool dck = false);
 
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams);
@@ -154,7 +154,7 @@ const LeadRows kNoLead = {0, 0, 0, 0, 0};
 // dc_u8 != nullptr: x is the uint8 I,Q stream and dc_u8 its per-stream conversion offsets (2 antennas, X fused in)
 // unit / rows_are_chunks: the raw-row layout (fx_fused4096.h::RangeWalk)
 int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_out, const cf* dc_u8, int64_t unit,
-                 bool rows_are_chunks, int64_t num_samp) {
+                 bool rows_are_chunks, int64_t num_samp, bool dck) {
     using namespace fxc::fused;
     if (num_samp == 0) num_samp = p->num_samp;      // (the 8192-channel split runs on half-size streams)
     const int grid = fused_grid(p, n_pairs);
@@ -168,7 +168,11 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
     p->stamp_grid = grid;
 #endif
     KernelTimer kt(p);
-    if (dc_u8)
+    if (dc_u8 && dck)
+        hipLaunchKernelGGL((fx_fused4096_kernel<false, true, true>), dim3(grid), dim3(kThreads), kLdsBytes + kDckLdsBytes, p->stream, x,
+                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, seg, (int)unit,
+                           rows_are_chunks ? 1 : 0);
+    else if (dc_u8)
         hipLaunchKernelGGL((fx_fused4096_kernel<false, true>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
                            num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, seg, (int)unit,
                            rows_are_chunks ? 1 : 0);
@@ -214,9 +218,9 @@ int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec
 // raw[c][p][layout] for nc chunks starting at x; spec = scratch for the multi-antenna path.  2 antennas: rows of
 // `unit` chunks + leading-part rows (fused_rows() of them in all)
 int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, const cf* dc_u8 = nullptr, int64_t unit = 1,
-                   bool rows_are_chunks = true) {
+                   bool rows_are_chunks = true, bool dck = false) {
     using namespace fxc::fused;
-    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8, unit, rows_are_chunks);
+    if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8, unit, rows_are_chunks, 0, dck);
     // 4 / 6 / 8 antennas: spectra to HBM (the F-only fused kernel in its own spectrum order at nchan 4096 / ntaps 4,
     // the F-only tiled kernel in natural order otherwise), then the register-resident X-engine.  unit = chunks per
     // raw row here too: ceil(nc / unit) rows come out

@@ -37,7 +37,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             // chunks per raw row: 2 antennas, rows of up to kRowSpectra spectra; more, the X-engine's chunk groups
             const int64_t unit = p->n_ant == 2 ? fused_unit(p) : xengine_group(p, nc, fused_unit(p));
             rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
-                                dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit, false);
+                                dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit, false, dc_u8 && p->u8_dck);
             if (rc) return rc;
             // 2 antennas: all the raw rows, leading parts included; more: one row [n_base][nchan] per chunk group
             const int64_t n_rows = p->n_ant == 2 ? fused_rows(p, nc, unit, false) : (nc + unit - 1) / unit;
@@ -154,7 +154,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
             rc = fused_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * in_bytes), nc, spec, raw,
-                                dc_u8 ? dc_u8 + c0 * 2 : nullptr);
+                                dc_u8 ? dc_u8 + c0 * 2 : nullptr, 1, true, dc_u8 && p->u8_dck);
             if (rc) return rc;
             const int64_t rows = nc * p->n_base;
             const LeadRows lead = p->n_ant == 2 ? fused_lead(p, nc) : kNoLead;

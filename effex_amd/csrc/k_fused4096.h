@@ -77,6 +77,7 @@ __device__ __forceinline__ void convert_frame_u8(cf (&h)[16], cf off) {
 #define FXC_STAMPS 0
 #endif
 constexpr int kStampSegs = 12;
+constexpr int kDckLdsBytes = 64;       // DCK launches: the waves' byte sums, behind the carve
 #if FXC_STAMPS
 #define FXC_STAMP(k)                                                              \
     do {                                                                          \
@@ -113,12 +114,102 @@ constexpr int kStampSegs = 12;
 // uint8 ingest state: this chunk's conversion offsets
 struct U8State {
     cf off;
+    bool have_next;      // DCK: the byte sums of the chunk that starts now are in LDS (this workgroup channelised a chunk before it)
+    bool rounds;         // this part of the walk is the round-robin one (whole chunks, the next one gridDim.x further on)
 };
 
-template <int PH, bool SPEC_OUT, bool U8>
+// DC removal inside the kernel (template flag DCK, uint8 ingest only): while a workgroup channelises chunk c of its
+// round-robin share it also sums the bytes of its next chunk, c + gridDim.x, so that chunk's conversion offset exists
+// when its first frame is converted and the pre-pass over the bytes (dc_sum_u8_stream_kernel: 1.7 of 9.7 ms per 10 000
+// chunk pairs) only has to cover each workgroup's first chunk and the tail.  The kernel has one VGPR to spare, so
+// nothing of this lives in registers across a step: every step each thread fetches 32 bytes of its own antenna's stream
+// straight into LDS (global_load_lds_dwordx4, issued behind barrier B1 so that no barrier finds it in flight), adds
+// their v_dot4 byte sums to its two counters in LDS at the end of the step, and the chunk-start branch -- where the
+// ring's history registers are dead -- turns the 256 counters of an antenna into the offset.  Exact integer sums and
+// the float64 formula of dc_offsets_u8_kernel: bit-identical to the pre-pass.  Straight-line code except in that
+// branch: a workgroup without a next chunk sums its current one again and nobody reads the result.
+typedef unsigned v4u32_t __attribute__((ext_vector_type(4)));
+constexpr int kDckStageVecs = 2 * fxc::fused::kThreads;     // two 16-byte vectors per thread and step
+
+__device__ __forceinline__ void dck_fetch(const unsigned char* pair_base, int64_t num_samp, int64_t i, int tid, v4u32_t* stage) {
+    // vectors i * 512 + j and i * 512 + 256 + j of stream (tid >> 8): num_samp is a whole number of 4096-sample frames.
+    // The two fetches are written in assembly so that the compiler does not know of them.  If it does, it guards every LDS
+    // access that might touch bytes in flight -- without alias information for the dynamic LDS array that is every
+    // exchange store of the step -- with s_waitcnt vmcnt(0), which also waits for every IQ load issued since; and it hoists
+    // the loop-invariant lane address out of the frame loop, spills it, and reloads it behind another vmcnt(0).  Unknown
+    // loads in the queue only make the compiler's own vmcnt(N) waits stricter, never weaker (loads return in order).
+    // LDS address of a lane's 16 bytes: M0 + lane * 16.
+    typedef __attribute__((address_space(3))) v4u32_t* lptr_t;
+    unsigned t = (unsigned)tid;
+    asm volatile("" : "+v"(t));           // the lane offsets are formed here and now: a handful of instructions, no live range
+    const unsigned lane_off = ((t >> 8) & 1u) * (unsigned)(2 * num_samp) + (t & 255u) * 16u;
+    const unsigned char* base = pair_base + i * (fxc::fused::kThreads * 16);      // uniform
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)(stage + (t >> 6) * 128));   // this wave's 2 x 64 vectors
+    unsigned m0_saved;
+    asm volatile(
+        "s_mov_b32 %[sv], m0\n\t"
+        "s_mov_b32 m0, %[l0]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o0], %[base]\n\t"
+        "s_add_u32 m0, %[l0], 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o1], %[base]\n\t"
+        "s_mov_b32 m0, %[sv]\n\t"
+        : [sv] "=&s"(m0_saved)
+        : [l0] "s"(lds_wave), [o0] "v"(lane_off), [o1] "v"(lane_off + 4096u), [base] "s"(base)
+        : "memory", "scc");
+}
+
+// the step's two fetches have landed: of the vector-memory operations issued after them only the last four IQ loads of the
+// step (FXC_PREFETCH(12)) may still be in flight
+__device__ __forceinline__ void dck_wait() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+
+__device__ __forceinline__ void dck_add(const v4u32_t* stage, unsigned* acc, int tid) {
+    unsigned si = 0u, sq = 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const v4u32_t w = stage[(tid >> 6) * 128 + h * 64 + (tid & 63)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            si = __builtin_amdgcn_udot4(w[k], 0x00010001u, si, false);     // bytes 0, 2: I
+            sq = __builtin_amdgcn_udot4(w[k], 0x01000100u, sq, false);     // bytes 1, 3: Q
+        }
+    }
+    acc[2 * tid] += si;
+    acc[2 * tid + 1] += sq;
+}
+
+// chunk start: the 256 threads' counters of this thread's antenna -> its conversion offset; counters cleared
+__device__ __forceinline__ cf dck_offset(unsigned* acc, unsigned* red, int tid, int64_t num_samp) {
+    unsigned v[2] = {acc[2 * tid], acc[2 * tid + 1]};
+    acc[2 * tid] = acc[2 * tid + 1] = 0u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d, 64);
+    }
+    __syncthreads();                       // every wave is done with the previous chunk's `red`
+    if ((tid & 63) == 0) {
+        red[(tid >> 6) * 2] = v[0];
+        red[(tid >> 6) * 2 + 1] = v[1];
+    }
+    __syncthreads();
+    const int ant = (tid >> 8) & 1;        // waves 0-3 summed antenna 0, waves 4-7 antenna 1
+    unsigned long long ti = 0, tq = 0;     // exact: at most 2^27 samples of 255
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+        ti += red[(4 * ant + wv) * 2];
+        tq += red[(4 * ant + wv) * 2 + 1];
+    }
+    const double mr = (double)ti / (double)num_samp, mi = (double)tq / (double)num_samp;
+    return fxc::mk((float)(-mr / 127.5), (float)(-mi / 127.5));
+}
+
+template <int PH, bool SPEC_OUT, bool U8, bool DCK>
 __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, const cf* dc, const f4* win, cf* region,
                                            const cf* tw2, int tid, const cf* x, int64_t num_samp, unsigned chunk_bytes,
-                                           unsigned voff, fxc::fused::RangeWalk& pos, cf* rows_raw, int hp,
+                                           unsigned voff, fxc::fused::RangeWalk& pos, cf* rows_raw, int hp, v4u32_t* dck_stage,
+                                           unsigned* dck_acc, unsigned* dck_red,
                                            unsigned long long (&seg)[kStampSegs], unsigned long long& t_prev) {
     using namespace fxc::fused;
     const int64_t c = pos.c, i = pos.i, n_pts = pos.n_pts;   // (the walk itself is 32-bit: scalar registers are scarce)
@@ -126,8 +217,15 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
     if (i == 0) {    // zero PFB history at the start of every chunk
         asm volatile("" ::: "memory");   // keep this a (rarely taken) uniform branch, not 96 v_cndmask per frame
         state_reset_history<PH>(s);
-        if (U8) u8.off = dc[c * 2 + ((tid >> 8) & 1)];
+        if (U8) {
+            if (DCK && u8.have_next) u8.off = dck_offset(dck_acc, dck_red, tid, num_samp);
+            else u8.off = dc[c * 2 + ((tid >> 8) & 1)];
+        }
     }
+    // DCK: the chunk whose bytes this step helps to sum: this workgroup's next one, or (none left in this part: the sums
+    // are never read) the current one again
+    const bool dck_next = DCK && u8.rounds && pos.left > n_pts - i;
+    const unsigned char* dck_base = reinterpret_cast<const unsigned char*>(x) + (int64_t)(c + (dck_next ? 1 + pos.seg_jump : 0)) * 4 * num_samp;
     if (U8) convert_frame_u8(s.h[PH], u8.off);   // the byte pairs fetched a step ago become the samples of slot PH
     cf v[16];
     phase1_fir<PH>(s, win, tid, v);      // first use of this frame: waits for its loads (issued a step ago)
@@ -158,6 +256,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
 #if !(FXC_ABL & 2)
     __syncthreads();   // B1: exchange-1 rows complete
 #endif
+    if (DCK) dck_fetch(dck_base, num_samp, i, tid, dck_stage);
     FXC_STAMP(6);
 #if !(FXC_ABL & 4)
     phase2_load(region, tid, v);
@@ -210,6 +309,11 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
         }
         FXC_STAMP(10);
     }
+    if (DCK) {
+        dck_wait();
+        dck_add(dck_stage, dck_acc, tid);
+        u8.have_next = dck_next;          // (read by the next chunk's first step only)
+    }
     // a raw row ends with the last frame of every `unit`-th chunk, of the last chunk and of this workgroup's
     // range: store this lane's 8 bins (fire and forget)
     const bool row_ends = !SPEC_OUT && range_walk_row_ends(pos);
@@ -232,8 +336,10 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
 // SPEC_OUT == true: rows_raw[(chunk * n_pts + i) * n_ant + stream][specpos] = the spectra themselves (`unit` = n_ant / 2).  A "chunk" here is a pair
 // of consecutive antenna streams, so an even number of antennas [n_chunks][A][S] is simply n_chunks * A/2 pairs.
 // U8: x points at interleaved uint8 I,Q ([chunk][antenna][num_samp] byte pairs) and dc[chunk * 2 + antenna] holds the
-// conversion offsets (-mean_byte / 127.5, or -1 without DC removal) of each stream.  stamps: diagnostic builds only.
-template <bool SPEC_OUT, bool U8 = false>
+// conversion offsets (-mean_byte / 127.5, or -1 without DC removal) of each stream; DCK: of the first chunk of every
+// workgroup's round-robin share and of the tail chunks only, the kernel sums the others itself.  stamps: diagnostic
+// builds only.
+template <bool SPEC_OUT, bool U8 = false, bool DCK = false>
 __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     const cf* __restrict__ x, int64_t num_samp, int64_t n_pts, int64_t n_chunks, const f4* __restrict__ win_g,
     const cf* __restrict__ tw1_g, const cf* __restrict__ tw2_g, cf* __restrict__ rows_raw,
@@ -257,8 +363,18 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     constexpr int64_t kSampleBytes = U8 ? sizeof(unsigned short) : sizeof(cf);
     const unsigned voff = (unsigned)((ant * num_samp + (255 - j)) * kSampleBytes);
     const unsigned chunk_bytes = (unsigned)(2 * num_samp * kSampleBytes);
+    static_assert(!DCK || (U8 && !SPEC_OUT), "in-kernel DC removal: uint8 ingest only");
     U8State u8;
     u8.off = fxc::mk(0.f, 0.f);
+    u8.have_next = u8.rounds = false;
+    // DCK: landing area of the byte fetches and the threads' counters -- LDS objects of their own, so that the compiler
+    // can tell the kernel's other LDS reads from reads of bytes still in flight -- and 64 bytes behind the carve
+    __shared__ v4u32_t dck_stage_mem[DCK ? kDckStageVecs : 1];
+    __shared__ unsigned dck_acc_mem[DCK ? 2 * kThreads : 1];
+    v4u32_t* dck_stage = dck_stage_mem;
+    unsigned* dck_acc = dck_acc_mem;
+    unsigned* dck_red = reinterpret_cast<unsigned*>(smem + kLdsBytes);
+    if (DCK) dck_acc[2 * tid] = dck_acc[2 * tid + 1] = 0u;
     unsigned long long seg_t[kStampSegs] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
     int64_t frames_done = 0;
@@ -279,6 +395,8 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
         }
         if (total == 0) continue;
         if (U8) u8.off = dc[(int64_t)pos.c * 2 + ant];
+        u8.have_next = false;      // a part's first chunk and every tail chunk: offsets from dc[]
+        u8.rounds = part == 0;
         // ring prologue: frame i -> slot 0, its history i-1, i-2, i-3 -> slots 3, 2, 1 (zeros before the chunk start)
         const cf* cbase = reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + (int64_t)pos.c * 2 * num_samp * kSampleBytes);
 #pragma unroll
@@ -302,13 +420,13 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
         // frame g of the part sits in ring slot g & 3: unrolled by four so the ring rotates by register renaming
 #pragma unroll 1
         for (int g = 0; g < total; g += 4) {
-            fused_step<0, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, seg_t, t_prev);
+            fused_step<0, SPEC_OUT, U8, DCK>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, dck_stage, dck_acc, dck_red, seg_t, t_prev);
             if (g + 1 < total)
-                fused_step<1, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, seg_t, t_prev);
+                fused_step<1, SPEC_OUT, U8, DCK>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, dck_stage, dck_acc, dck_red, seg_t, t_prev);
             if (g + 2 < total)
-                fused_step<2, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, seg_t, t_prev);
+                fused_step<2, SPEC_OUT, U8, DCK>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, dck_stage, dck_acc, dck_red, seg_t, t_prev);
             if (g + 3 < total)
-                fused_step<3, SPEC_OUT, U8>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, seg_t, t_prev);
+                fused_step<3, SPEC_OUT, U8, DCK>(s, u8, dc, win, region, tw2, tid, x, num_samp, chunk_bytes, voff, pos, rows_raw, SPEC_OUT ? unit : 0, dck_stage, dck_acc, dck_red, seg_t, t_prev);
         }
         frames_done += total;
     }

@@ -182,3 +182,38 @@ def test_headline_config_at_full_size(plan_mod, torch):
             assert rel_err(got, ref) < TOL_VIS, f
     del x
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("frames,extra,n_chunks", [(2, 0, 700), (3, 8 * 37, 600), (1, 4096 - 8, 1030)])
+def test_dc_removal_inside_the_fused_kernel(plan_mod, torch, frames, extra, n_chunks):
+    """fxc_fx_*_u8 with remove_dc on launches of at least two rounds of chunks per workgroup: the fused kernel sums the
+    bytes of a workgroup's next chunk itself (k_fused4096.h::U8State) and the pre-pass covers only the first round and
+    the tail.  Exact integer sums and the pre-pass's float64 formula, so the rows of the whole chunks must equal -- bit
+    for bit -- the rows of calls of one round each, whose chunks all get their offsets from the pre-pass (the tail chunks,
+    cut into frame ranges differently by the two launches, agree to rounding); sampled rows against the oracle chain (pyrtlsdr
+    conversion behind effex.py:652, DC removal effex.py:394-395, then effex.py:490-527).  Sizes that are not whole frames
+    keep the pre-pass for every chunk."""
+    num_samp = 4096 * frames + extra
+    rng = np.random.default_rng(77 + frames)
+    u8 = rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)
+    u8[:, 0, :, 0] = np.clip(u8[:, 0, :, 0].astype(int) // 2 + (np.arange(n_chunks) % 97)[:, None], 0, 255)   # DC differs chunk to chunk
+    u8[:, 1, 3:, :] = (u8[:, 0, :-3, :] // 2 + u8[:, 1, 3:, :] // 2)
+    ud = torch.from_numpy(u8).cuda()
+    window = design_window(4, 4096)
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        assert p.path == "fused"
+        rows = p.fx_rows_u8(ud, "SPECTRUM", remove_dc=True).cpu().numpy()
+        g = p.info["cu_count"]                   # calls of exactly one round of whole chunks: every offset from the pre-pass
+        small = np.concatenate([p.fx_rows_u8(ud[lo:lo + g], "SPECTRUM", remove_dc=True).cpu().numpy()
+                                for lo in range(0, n_chunks, g)])
+        n_full = n_chunks // g * g               # whole chunks, dealt round-robin; the rest is the tail
+        np.testing.assert_array_equal(rows[:n_full], small[:n_full])
+        assert rel_err(rows[n_full:], small[n_full:]) < 1e-6
+        for c in (0, 255, 256, 300, n_chunks - 1):
+            z = fx_oracle.u8_to_complex(u8[c:c + 1])[0]
+            ref = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(z[0]), fx_oracle.remove_dc(z[1]), 4, 4096, window, gi.BANDWIDTH,
+                                      gi.FREQUENCY, 0.0, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        p.fx_accumulate_u8(ud, remove_dc=True)
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ[0], rows[:, 0].astype(np.complex128).mean(axis=0)) < 2e-6
