@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-from . import synth
+from . import rowsink, synth
 from .plan import FxPlan, rot_table
 from .window import design_window
 
@@ -142,7 +142,8 @@ class Correlator(object):
 
     def __init__(self, run_time=1, bandwidth=2.4e6, frequency=1.4204e9, num_samp=2 ** 18, nbins=2 ** 12,
                  gain=49.6, mode='SPECTRUM', loglevel='INFO',
-                 source=None, device=0, max_num_samp=None, output_file=None, remove_dc=True, calibrate=True):
+                 source=None, device=0, max_num_samp=None, output_file=None, remove_dc=True, calibrate=True,
+                 output_format='csv'):
         self.logger = logging.getLogger(__name__)
         self.logger.setLevel(getattr(logging, loglevel))
         self._max_num_samp = int(max_num_samp) if max_num_samp else Correlator._MAX_NUM_SAMP
@@ -178,7 +179,13 @@ class Correlator(object):
         self.window = design_window(self.ntaps, self.nbins)      # effex.py:126-127
 
         self.calibrated_delay = 0                                # effex.py:132
-        self.output_file = output_file or (time.strftime('visibilities_%Y%m%d-%H%M%S') + '.csv')
+        # 'csv': the reference's file (effex.py:136, 667-696).  'bin': the binary sidecar of effex_amd.rowsink (same header
+        # line, rows as the device produced them; tools/rows_to_csv.py turns it into the reference's csv byte for byte)
+        if output_format not in ('csv', 'bin'):
+            raise ValueError("output_format must be 'csv' or 'bin'")
+        self.output_format = output_format
+        self.output_file = output_file or (time.strftime('visibilities_%Y%m%d-%H%M%S') +
+                                           ('.csv' if output_format == 'csv' else '.fxb'))
         crit_delay = 1 / self.frequency                          # effex.py:151-155
         self.test_delay_sweep_step = crit_delay / 2
         self.test_delay_offset = self.test_delay_sweep_step * 1600
@@ -381,14 +388,21 @@ class Correlator(object):
         return out[0]
 
     # -- output (effex.py:667-696) ----------------------------------------------------------
+    def _header_line(self):
+        return rowsink.header_line(self.run_time, self.bandwidth, self.frequency, self.num_samp, self.nbins, self.gain,
+                                   self.mode)
+
     def _write_metadata(self):
-        fields = (('run_time', self.run_time), ('bandwidth', self.bandwidth), ('frequency', self.frequency),
-                  ('num_samp', self.num_samp), ('resolution', self.nbins), ('gain', self.gain), ('mode', self.mode))
         with open(self.output_file, 'w') as fh:
-            fh.write(','.join('{}:{}'.format(k, v) for k, v in fields) + '\n')
+            fh.write(self._header_line() + '\n')
             if 'SPECTRUM' == self.mode:
-                freqs = np.fft.fftshift(np.fft.fftfreq(int(self.nbins), d=1 / self.bandwidth)) + self.frequency
-                np.savetxt(fh, [freqs], delimiter=',')
+                np.savetxt(fh, [rowsink.spectrum_freqs(self.nbins, self.bandwidth, self.frequency)], delimiter=',')
+
+    def _open_bin_sink(self):
+        spectrum = 'SPECTRUM' == self.mode
+        return rowsink.BinSink(self.output_file, self._header_line(),
+                               rowsink.spectrum_freqs(self.nbins, self.bandwidth, self.frequency) if spectrum else None,
+                               int(self.nbins) if spectrum else 1, np.complex64 if spectrum else np.complex128)
 
     def _write_row(self, fh, vis):
         np.savetxt(fh, [np.asarray(vis, dtype=np.complex128)], delimiter=',')
@@ -417,14 +431,17 @@ class Correlator(object):
         """OFF -> STARTUP -> CALIBRATE -> RUN ... -> SHUTDOWN -> OFF over the source's chunk pairs; the first
         pair calibrates the delay (unless ``calibrate=False``), every further pair writes one csv row."""
         rows = 0
-        fh = None
+        fh = sink = None
         try:
             while True:
                 if 'OFF' == self.state:
                     self.state = 'STARTUP'
                 elif 'STARTUP' == self.state:
-                    self._write_metadata()
-                    fh = open(self.output_file, 'a')
+                    if 'bin' == self.output_format:
+                        sink = self._open_bin_sink()
+                    else:
+                        self._write_metadata()
+                        fh = open(self.output_file, 'a')
                     self.start_time = time.time()
                     self.state = 'CALIBRATE' if self.calibrate else 'RUN'
                 elif self.state in ('CALIBRATE', 'RUN'):
@@ -439,7 +456,10 @@ class Correlator(object):
                         continue
                     if self.mode in ['TEST']:
                         self.calibrated_delay += self.test_delay_sweep_step      # effex.py:403-404
-                    self._write_row(fh, self._run_task())
+                    if sink is not None:
+                        sink.write(self._run_task())
+                    else:
+                        self._write_row(fh, self._run_task())
                     rows += 1
                 elif 'SHUTDOWN' == self.state:
                     self.close()
@@ -448,4 +468,6 @@ class Correlator(object):
         finally:
             if fh is not None:
                 fh.close()
+            if sink is not None:
+                sink.close()
         return rows

@@ -422,11 +422,18 @@ class FxPipeline(object):
     def submit(self):
         self.plan._check(self.plan._lib.fxc_pipe_submit(self._h))
 
-    def pop(self):
+    def pop(self, out=None):
+        """The oldest batch's rows.  ``out``: a C-contiguous array of the batch's shape and dtype to receive them in place --
+        e.g. a window of a memory-mapped row file (``effex_amd.rowsink.BinSink.reserve``): the rows then go from the pinned
+        result slot straight into the page cache."""
         if self.mode == _lib.FXC_MODE_SPECTRUM:
-            out = np.empty((self.chunks, self.plan.n_baselines, self.plan.nchan), dtype=np.complex64)
+            shape, dtype = (self.chunks, self.plan.n_baselines, self.plan.nchan), np.complex64
         else:
-            out = np.empty((self.chunks, self.plan.n_baselines), dtype=np.complex128)
+            shape, dtype = (self.chunks, self.plan.n_baselines), np.complex128
+        if out is None:
+            out = np.empty(shape, dtype=dtype)
+        elif out.dtype != dtype or out.size != int(np.prod(shape)) or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("out must be a writable C-contiguous {} array of {} elements".format(np.dtype(dtype).name, int(np.prod(shape))))
         self.plan._check(self.plan._lib.fxc_pipe_pop(self._h, out.ctypes.data))
         return out
 

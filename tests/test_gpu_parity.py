@@ -240,6 +240,49 @@ def test_state_machine_writes_reference_csv(tmp_path, torch, golden, calibrate):
         assert rel_err(data[c - first], ref) < TOL_VIS
 
 
+@pytest.mark.parametrize("mode", ["SPECTRUM", "CONTINUUM"])
+def test_state_machine_binary_sidecar_equals_csv(tmp_path, torch, mode):
+    """Correlator(output_format='bin'): the same run written as a binary sidecar and turned into text
+    by rowsink.to_csv gives the bytes of the csv run (effex.py:667-696) -- the rows are the same device results."""
+    from effex_amd import rowsink
+    from effex_amd.correlator import ArraySource, Correlator
+    x = gi.small_input()
+    paths = {fmt: str(tmp_path / ("vis." + ext)) for fmt, ext in (("csv", "csv"), ("bin", "fxb"))}
+    for fmt in ("csv", "bin"):
+        cor = Correlator(num_samp=gi.SMALL_S, nbins=gi.SMALL_N, source=ArraySource(x), output_file=paths[fmt], mode=mode,
+                         output_format=fmt)
+        assert cor.run_state_machine() == gi.SMALL_CHUNKS - 1
+    side = rowsink.RowFile(paths["bin"])
+    assert side.rows.shape == (gi.SMALL_CHUNKS - 1, gi.SMALL_N if mode == "SPECTRUM" else 1)
+    assert side.row_dtype == (np.complex64 if mode == "SPECTRUM" else np.complex128)
+    back = str(tmp_path / "back.csv")
+    assert rowsink.to_csv(paths["bin"], back) == gi.SMALL_CHUNKS - 1
+    assert open(back, "rb").read() == open(paths["csv"], "rb").read()
+
+
+def test_pipeline_pops_into_a_mapped_row_file(tmp_path, torch):
+    """FxPipeline.pop(out=...) into a window of the sidecar (BinSink.reserve / commit): rows as the blocking path gives."""
+    from effex_amd import rowsink
+    num_samp, chunks, n_batches = 4096 * 4, 3, 4
+    x = synth.synth_iq(18, chunks * n_batches, 2, num_samp).reshape(n_batches, chunks, 2, num_samp)
+    from effex_amd import plan as plan_mod
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        ref = np.concatenate([p.fx_rows(x[b], "SPECTRUM") for b in range(n_batches)])[:, 0]
+        path = str(tmp_path / "rows.fxb")
+        with rowsink.BinSink(path, "run_time:1", None, 4096, np.complex64) as sink, \
+                plan_mod.FxPipeline(p, chunks, depth=2, mode="SPECTRUM") as pipe:
+            view = sink.reserve(chunks * n_batches)
+            pipe.push(x[0])
+            for b in range(n_batches):
+                if b + 1 < n_batches:
+                    pipe.push(x[b + 1])
+                pipe.pop(out=view[b * chunks:(b + 1) * chunks])
+                sink.commit(chunks)
+            with pytest.raises(ValueError):
+                pipe.pop(out=np.empty((chunks, 1, 4095), dtype=np.complex64))
+    np.testing.assert_array_equal(np.asarray(rowsink.RowFile(path).rows), ref)
+
+
 def test_state_machine_on_a_byte_source(tmp_path, torch):
     """A source that hands over the receivers' bytes (pyrtlsdr format='bytes') writes the same csv as the same data
     handed over as samples: calibration on the first pair, then one fused convert + de-mean + F+X call per pair."""

@@ -190,3 +190,52 @@ def test_file_source_reads_chunk_pairs(tmp_path):
     assert src.read(2000) is None
     with pytest.raises(ValueError):
         FileSource(str(tmp_path / "rx0.u8"), str(tmp_path / "rx1.u8"), fmt='s16')
+
+
+# --- binary row sink and its way back to the reference's csv ------------------------
+@pytest.mark.parametrize("mode", ["SPECTRUM", "CONTINUUM"])
+def test_binary_sidecar_round_trips_to_the_reference_csv(tmp_path, golden, mode):
+    """rowsink.BinSink holds the csv's header line, the frequency row and the rows; tools/rows_to_csv.py must give back the
+    bytes the reference's own writer produced (tests/golden csv, effex.py:667-696) -- rows kept as complex128 here because
+    the golden row is; and, rows kept as the device's complex64, the bytes the csv sink writes for those rows."""
+    import subprocess
+    import sys
+    from effex_amd import rowsink
+    meta, _ = golden
+    c = Correlator(mode=mode, nbins=gi.CSV_NBINS, num_samp=gi.CSV_S, source=SyntheticSource(), output_file=str(tmp_path / "x.csv"))
+    freqs = rowsink.spectrum_freqs(c.nbins, c.bandwidth, c.frequency) if mode == "SPECTRUM" else None
+    row = gi.csv_row(mode)
+    fxb = str(tmp_path / "vis128.fxb")
+    with rowsink.BinSink(fxb, c._header_line(), freqs, len(row), np.complex128) as sink:
+        sink.write(row)
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rows_to_csv.py")
+    out = str(tmp_path / "back.csv")
+    subprocess.run([sys.executable, tool, fxb, out], check=True, capture_output=True)
+    assert open(out).read() == meta["csv"][mode]
+    # complex64 rows, several of them, three ways of writing: one by one, a batch, in place through a mapped window
+    rows = np.stack([(row * (k + 1)).astype(np.complex64) for k in range(7)])
+    fxb64, ref_csv = str(tmp_path / "vis64.fxb"), str(tmp_path / "ref.csv")
+    with rowsink.BinSink(fxb64, c._header_line(), freqs, rows.shape[1], np.complex64) as sink:
+        sink.write(rows[0])
+        sink.write_rows(rows[1:3])
+        view = sink.reserve(10)                     # more than will be committed: close() drops the rest
+        view[:4] = rows[3:7]
+        sink.commit(4)
+        assert sink.rows == 7
+    back = rowsink.RowFile(fxb64)
+    assert back.header == c._header_line() and back.fields["mode"] == mode and back.rows.shape == rows.shape
+    np.testing.assert_array_equal(np.asarray(back.rows), rows)
+    if mode == "SPECTRUM":
+        np.testing.assert_array_equal(back.freqs, freqs)
+    with rowsink.CsvSink(ref_csv, c._header_line(), freqs) as sink:
+        sink.write_rows(rows)
+    assert rowsink.to_csv(fxb64, out) == 7
+    assert open(out, 'rb').read() == open(ref_csv, 'rb').read()
+
+
+def test_binary_sidecar_rejects_other_files(tmp_path):
+    from effex_amd import rowsink
+    p = tmp_path / "not.fxb"
+    p.write_text("run_time:1\n" + "x" * 100)
+    with pytest.raises(ValueError):
+        rowsink.RowFile(str(p))

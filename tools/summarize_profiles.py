@@ -76,6 +76,20 @@ def main():
                 if k in summary["kernels"]:
                     warm = v[1:] if len(v) > 1 else v
                     summary["kernels"][k][counter + "_bytes_per_launch_raw"] = round(sum(warm) / len(warm))
+        # effective shader clock per kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the duration of the same dispatch
+        # in the same pass -- under 2.4 GHz means the chip is holding its clock down under load (power cap)
+        gdir = os.path.join(raw, name + "_GRBM_GUI_ACTIVE")
+        cc, tr = find(gdir, "counter_collection.csv"), find(gdir, "kernel_trace.csv")
+        if cc and tr:
+            dur = {row["Dispatch_Id"]: (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) for row in read_csv(tr)}
+            per = defaultdict(list)
+            for row in read_csv(cc):
+                if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and dur.get(row["Dispatch_Id"], 0) > 0:
+                    per[short(row["Kernel_Name"])].append(float(row["Counter_Value"]) / 8.0 / dur[row["Dispatch_Id"]])
+            for k, v in per.items():
+                if k in summary["kernels"]:
+                    warm = v[1:] if len(v) > 1 else v
+                    summary["kernels"][k]["effective_clock_GHz_under_pmc"] = round(sum(warm) / len(warm), 3)
         for k, d in summary["kernels"].items():
             if "FETCH_SIZE_bytes_per_launch_raw" in d:
                 d["hbm_read_bytes_per_launch"] = 2 * d["FETCH_SIZE_bytes_per_launch_raw"]
@@ -95,6 +109,24 @@ def main():
                            "streaming reads), WRITE_SIZE exact; means exclude each kernel's first launch")
         with open(os.path.join(base, "summary_%s.json" % name), "w") as fh:
             json.dump(summary, fh, indent=1)
+        if name == "bench":      # what bench.py reports as roofline.traffic (profiles/*/pmc_hbm_traffic.json)
+            for k, d in summary["kernels"].items():
+                if k.startswith("fx_fused4096_kernel") and "hbm_traffic_bytes_per_launch" in d:
+                    frames, algo = 10000, 10000 * 2 * 262144 * 8
+                    with open(os.path.join(base, "pmc_hbm_traffic.json"), "w") as fh:
+                        json.dump({"command": "bash tools/collect_profiles.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate "
+                                              "passes, --kernel-trace, on python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "
+                                              "--no-power --no-other-configs --no-verify)",
+                                   "head": head, "kernel": k, "frames_per_launch": frames, "algorithmic_bytes_per_launch": algo,
+                                   "FETCH_SIZE_bytes_raw": d["FETCH_SIZE_bytes_per_launch_raw"],
+                                   "FETCH_SIZE_bytes_corrected_x2": d["hbm_read_bytes_per_launch"],
+                                   "WRITE_SIZE_bytes": d.get("WRITE_SIZE_bytes_per_launch_raw", 0),
+                                   "hbm_traffic_bytes_per_launch": d["hbm_traffic_bytes_per_launch"],
+                                   "traffic_over_algorithmic": d["hbm_traffic_bytes_per_launch"] / algo,
+                                   "note": "gfx950: FETCH_SIZE counts 64 B per 128 B request for wide streaming reads -> doubled "
+                                           "(MI355X_MICROARCH.md HBM section); WRITE_SIZE exact.  Writes: one 32 KiB float32 raw row "
+                                           "per 16 chunk pairs + one leading-part row per workgroup (fx_fused4096.h::RangeWalk)."},
+                                  fh, indent=1)
         print(name, json.dumps(summary["kernels"])[:600])
 
 
