@@ -111,6 +111,67 @@ class FileSource(IQSource):
         self.closed = True
 
 
+class SocketSource(IQSource):
+    """Chunk pairs from two byte streams over TCP, one per receiver (the reference's producers are live
+    streams, ``sdr.stream()`` in two processes, effex.py:630-664; a network stream is how a remote or shared receiver --
+    ``rtl_tcp``, a recorder replaying a capture -- is fed to the path).
+
+    ``endpoints``: two ``(host, port)`` pairs to connect to, or two already connected sockets.  ``fmt='u8'``: interleaved
+    unsigned 8-bit I,Q, ``rtl_tcp``'s sample format, handed over as bytes (conversion, DC removal and F+X in one device
+    call); ``fmt='c64'``: raw little-endian complex64.  ``skip`` bytes are dropped from each stream first (``rtl_tcp``
+    greets with a 12-byte header).  A stream that ends inside a chunk ends the run, as a short read ends the reference's
+    (``read`` returns None).  Reads block; ``timeout`` seconds without data raise ``socket.timeout``."""
+
+    def __init__(self, endpoints, fmt='u8', rs=None, fc=None, gain=None, skip=0, timeout=None):
+        import socket
+        if fmt not in ('u8', 'c64'):
+            raise ValueError("fmt must be 'u8' or 'c64'")
+        if len(endpoints) != 2:
+            raise ValueError("two endpoints, one per receiver")
+        self.fmt = fmt
+        self.rs, self.fc, self.gain = rs, fc, gain
+        self._socks = []
+        for ep in endpoints:
+            sock = ep if hasattr(ep, "recv_into") else socket.create_connection(tuple(ep), timeout=timeout)
+            sock.settimeout(timeout)
+            self._socks.append(sock)
+        self.closed = False
+        for sock in self._socks:
+            if skip and self._recv_exact(sock, bytearray(int(skip))) is None:
+                raise EOFError("stream ended inside its {}-byte greeting".format(skip))
+
+    @staticmethod
+    def _recv_exact(sock, buf):
+        view, got = memoryview(buf), 0
+        while got < len(buf):
+            n = sock.recv_into(view[got:])
+            if n == 0:
+                return None
+            got += n
+        return buf
+
+    def read(self, num_samp):
+        num_samp = int(num_samp)
+        per = 2 if self.fmt == 'u8' else 8
+        out = []
+        for sock in self._socks:          # the two receivers' chunks, one after the other (kernel socket buffers decouple them)
+            buf = self._recv_exact(sock, bytearray(num_samp * per))
+            if buf is None:
+                return None
+            out.append(np.frombuffer(buf, dtype=np.uint8).reshape(num_samp, 2) if self.fmt == 'u8'
+                       else np.frombuffer(buf, dtype='<c8'))
+        return tuple(out)
+
+    def close(self):
+        for sock in self._socks:
+            try:
+                sock.close()
+            except OSError:
+                pass
+        self._socks = []
+        self.closed = True
+
+
 def _without_mean(x):
     """x minus its complex mean (= the mean of the real parts and of the imaginary parts), in complex128."""
     z = np.asarray(x).astype(np.complex128)

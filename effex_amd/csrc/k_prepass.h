@@ -40,13 +40,13 @@ __device__ __forceinline__ void prefilter_fir_store(const cf (&xo)[TP][W], const
         if (full || i0 + k < i_end) {
             const unsigned soff = (unsigned)(i0 + k) * frame_bytes;
             if constexpr (W == 2) {
-                // The frame offset rides in the VGPR offset here, not in the scalar one.  A 16-byte buffer store reads its data
-                // registers over more than one cycle; LLVM (ROCm 7.2) pads a following VALU write of those registers with
-                // s_nop only when the store has no SGPR offset (GCNHazardRecognizer: "this hazard only exists if the
-                // instruction is not using a register in the soffset field") -- on gfx950 the store with an SGPR offset needs
-                // the padding too: `buffer_store_dwordx4 v[0:3], ..., s0 offen` followed directly by `v_mov_b64 v[0:1], ...`
-                // stored the moved value in the workgroups that found the memory pipeline busy (wrong frames 7 / 13 of the
-                // streams of workgroups >= 256, `tools/prew_check.py`).
+                // The frame offset rides in the VGPR offset here, not in the scalar one.  With the scalar offset the compiled
+                // kernel had `buffer_store_dwordx4 v[0:3], ..., s0 offen` directly followed by `v_mov_b64 v[0:1], ...` (LLVM
+                // pads a VALU write of a wide store's data registers only for stores without an soffset register) and stored
+                // wrong frames 7 / 13 in the streams of workgroups >= 256, deterministically; in this form the compiler emits
+                // the `s_nop 1` and every shape is right.  The instruction pair alone does not fail
+                // (tools/ubench/store_hazard.hip, profiles/r03/gfx950_store_hazard.md), so what exactly went wrong in that
+                // schedule is not known; the rule stays (tests/test_isa_hazards.py).
                 v4u32 d = {__float_as_uint(ar[0]), __float_as_uint(ai[0]), __float_as_uint(ar[1]), __float_as_uint(ai[1])};
                 __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff + soff, 0, 0);
             } else {

@@ -121,6 +121,13 @@ def main():
         nfft_meta.append({"nbins": nbins, "num_samp": num_samp, "chunks": chunks, "delay": delay, "key": key})
     meta["nfft"] = nfft_meta
 
+    # (what pins these cases: the reference's lines around the call run unmodified, but channelize_poly is the stand-in)
+    STALE_PINNED_BY = (
+        "the reference's own lines around the call (effex.py:126-127, 287-294, 497-527) executed unmodified; the tap count "
+        "int(len(h) / n_chans) and the use of the first ntaps * n_chans coefficients only (also for nbins = 1000, which does not "
+        "divide the 16384-tap window) come from this repository's restatement of cusignal.filtering.channelize_poly "
+        "(oracle/ref_standins.py), not from cusignal itself, which is not in the image: on those two facts the case is pinned "
+        "by the restatement only")
     # (4d) nbins changed after construction (tests/test_effex.py:142-144; effex.py:287-294 only stores the value): the
     #      4 * 4096-tap window of the constructor stays (effex.py:126-127) and _run_task channelises with it
     stale_meta = []
@@ -140,7 +147,8 @@ def main():
         key = "stale_nbins_%d_rows" % nbins
         arrays[key] = np.stack(rows_s)
         stale_meta.append({"nbins": nbins, "num_samp": num_samp, "chunks": chunks, "delay": delay, "key": key,
-                           "window_len": int(len(cors.window)), "ntaps_effective": int(len(cors.window) / nbins)})
+                           "window_len": int(len(cors.window)), "ntaps_effective": int(len(cors.window) / nbins),
+                           "pinned_by": STALE_PINNED_BY})
     meta["stale_nbins"] = stale_meta
 
     # (5) csv bytes: _write_metadata + savetxt rows as _write_data does (effex.py:667-696)

@@ -192,6 +192,61 @@ def test_file_source_reads_chunk_pairs(tmp_path):
         FileSource(str(tmp_path / "rx0.u8"), str(tmp_path / "rx1.u8"), fmt='s16')
 
 
+def test_socket_source_reads_chunk_pairs_from_two_streams():
+    """SocketSource (a network stream in place of effex.py:630-664's live dongles): two TCP streams of
+    rtl_tcp-style bytes -- a 12-byte greeting, then interleaved uint8 I,Q -- read chunk pair by chunk pair whatever the
+    senders' packet sizes; a stream that ends inside a chunk ends the run."""
+    import socket
+    import threading
+    from effex_amd.correlator import SocketSource
+    rng = np.random.default_rng(5)
+    raw = [rng.integers(0, 256, size=(700 * 3 + 123, 2), dtype=np.uint8) for _ in range(2)]
+    servers = []
+    for a in range(2):
+        srv = socket.socket()
+        srv.bind(("127.0.0.1", 0))
+        srv.listen(1)
+        servers.append(srv)
+
+    def serve(srv, data, piece):
+        conn, _ = srv.accept()
+        payload = b"RTL0" + bytes(8) + data.tobytes()
+        for lo in range(0, len(payload), piece):       # odd-sized pieces: chunk boundaries fall inside packets
+            conn.sendall(payload[lo:lo + piece])
+        conn.close()
+        srv.close()
+
+    threads = [threading.Thread(target=serve, args=(servers[a], raw[a], 977 + 500 * a)) for a in range(2)]
+    for t in threads:
+        t.start()
+    src = SocketSource([srv.getsockname() for srv in servers], fmt='u8', rs=2.4e6, skip=12, timeout=20)
+    assert src.rs == 2.4e6
+    for c in range(3):
+        b0, b1 = src.read(700)
+        assert b0.dtype == np.uint8 and b0.shape == (700, 2)
+        np.testing.assert_array_equal(b0, raw[0][700 * c:700 * (c + 1)])
+        np.testing.assert_array_equal(b1, raw[1][700 * c:700 * (c + 1)])
+    assert src.read(700) is None                         # 123 samples left: a short stream ends the run
+    src.close()
+    assert src.closed
+    for t in threads:
+        t.join()
+    a, b = socket.socketpair()                           # connected sockets handed over; complex64 samples
+    c, d = socket.socketpair()
+    z = (rng.standard_normal(64) + 1j * rng.standard_normal(64)).astype('<c8')
+    b.sendall(z.tobytes())
+    d.sendall((2 * z).tobytes())
+    src = SocketSource([a, c], fmt='c64')
+    z0, z1 = src.read(64)
+    np.testing.assert_array_equal(z0, z)
+    np.testing.assert_array_equal(z1, 2 * z)
+    src.close()
+    b.close()
+    d.close()
+    with pytest.raises(ValueError):
+        SocketSource([("127.0.0.1", 1)], fmt='u8')
+
+
 # --- binary row sink (SURVEY.md §8f #3) and its way back to the reference's csv ------------------------
 @pytest.mark.parametrize("mode", ["SPECTRUM", "CONTINUUM"])
 def test_binary_sidecar_round_trips_to_the_reference_csv(tmp_path, golden, mode):

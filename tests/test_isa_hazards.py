@@ -1,12 +1,15 @@
-"""Compiled-code check (no GPU): a hazard the ROCm 7.2 compiler does not pad on gfx950.
+"""Compiled-code check (no GPU): no wide buffer store with a scalar offset in the library.
 
-A buffer store of more than 8 bytes reads its data registers over several cycles.  LLVM's hazard recognizer inserts
-`s_nop` in front of a VALU instruction that overwrites them — except when the store carries an SGPR offset
-("this hazard only exists if the instruction is not using a register in the soffset field").  On MI355X the exception
-does not hold: `buffer_store_dwordx4 v[0:3], v40, s[8:11], s0 offen` directly followed by `v_mov_b64 v[0:1], ...`
-stored the moved value in workgroups that found the memory pipeline busy (the pre-filter with 16-byte accesses:
-frames 7 and 13 of every stream of workgroups >= 256; k_prepass.h, profiles/r02/round2_experiments.md).  So the
-library must not contain such a store at all: wide buffer stores keep their offset in the VGPR."""
+A buffer store of more than 8 bytes reads its data registers over several cycles, and a VALU instruction that overwrites
+them needs wait states in between.  LLVM's hazard recognizer inserts the `s_nop` -- except when the store carries an SGPR
+offset ("this hazard only exists if the instruction is not using a register in the soffset field").  Round 2's pre-filter
+kernel with 16-byte accesses compiled to `buffer_store_dwordx4 v[0:3], v40, s[8:11], s0 offen` directly followed by
+`v_mov_b64 v[0:1], ...` and stored wrong frames (7 and 13 of every stream of workgroups >= 256), deterministically; with the
+offset in the VGPR the compiler pads the pair and every shape is right (k_prepass.h, profiles/r02/round2_experiments.md).
+Round 3's stand-alone reproducer (tools/ubench/store_hazard.hip, profiles/r03/gfx950_store_hazard.md) shows the hazard
+itself on MI355X -- the un-padded pair WITHOUT a scalar offset corrupts a quarter of the records -- but the pair WITH a
+scalar offset stores correctly there, as LLVM assumes: the root cause of round 2's failure is therefore not pinned down, and
+the defensive rule stays: wide buffer stores keep their offset in the VGPR."""
 import os
 import re
 import shutil
