@@ -9,7 +9,7 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
                  int64_t unit = 1, bool rows_are_chunks = true, int64_t num_samp = 0, bool dck = false);
 
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
-int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams);
+int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a = 0);
 
 int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
     if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
@@ -225,11 +225,10 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
     // the F-only tiled kernel in natural order otherwise), then the register-resident X-engine.  unit = chunks per
     // raw row here too: ceil(nc / unit) rows come out
     int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
-                                       : tiled_channelize(p, x, spec, nc * p->n_ant);
+                                       : tiled_channelize(p, x, spec, nc * p->n_ant, p->n_ant);
     if (rc) return rc;
-    // spectra layout: the fused F-only kernel writes [chunk][frame][antenna] rows, the tiled one [stream][frame]
-    const bool by_frame = p->path == FXC_PATH_FUSED;
-    const int64_t sa = by_frame ? 1 : p->n_pts, si = by_frame ? p->n_ant : 1;
+    // spectra layout of both F-only kernels here: [chunk][frame][antenna] rows
+    const int64_t sa = 1, si = p->n_ant;
     const int cg = (int)unit;
     const dim3 grid(p->nchan / kXThreads, (unsigned)((nc + cg - 1) / cg));
 #define FXC_X_LAUNCH(A) \
@@ -282,7 +281,8 @@ int tiled_setup(fxc_plan* p) {
 
 // SPEC: x = n_streams consecutive streams, nc = pairs of them, raw = spectra [stream][i][k]
 template <class G, bool SPEC>
-void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, int64_t n_streams, const cf* dc_u8 = nullptr) {
+void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, int64_t n_streams, const cf* dc_u8 = nullptr,
+                  int spec_a = 0, int64_t s_base = 0) {
     const int grid = (int)std::min<int64_t>(nc * n_splits, SPEC ? p->tiled_grid_max_f : p->tiled_grid_max);
     if constexpr (G::N <= 4096) {
         if (p->tiled_ring) {
@@ -290,19 +290,19 @@ void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, i
                 if (dc_u8) {   // uint8 ingest: x is the byte stream
                     hipLaunchKernelGGL((fx_tiled_ring_kernel<G, false, true>), dim3(grid), dim3(G::kThreads), G::kLdsBytesRing,
                                        p->stream, x, p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1,
-                                       p->d_tw2, raw, n_streams, dc_u8);
+                                       p->d_tw2, raw, n_streams, dc_u8, 0, (int64_t)0);
                     return;
                 }
             }
             hipLaunchKernelGGL((fx_tiled_ring_kernel<G, SPEC, false>), dim3(grid), dim3(G::kThreads), G::kLdsBytesRing,
                                p->stream, x, p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw,
-                               n_streams, (const cf*)nullptr);
+                               n_streams, (const cf*)nullptr, spec_a, s_base);
             return;
         }
     }
     hipLaunchKernelGGL((fx_tiled_kernel<G, SPEC>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, p->stream, x, p->num_samp,
                        p->n_pts, nc, n_splits, p->prefilter ? 1 : p->ntaps, p->prefilter ? p->d_ones : p->d_win, p->d_tw0,
-                       p->d_tw1, p->d_tw2, raw, n_streams);
+                       p->d_tw1, p->d_tw2, raw, n_streams, spec_a, s_base);
 }
 
 #define FXC_TILED_DISPATCH(p, CALL)                                                   \
@@ -386,7 +386,7 @@ int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, 
 }
 
 // F-stage only: n_streams consecutive streams -> spec[stream][i][k], pairs of streams per work item
-int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
+int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a) {
     KernelTimer kt(p);
     const int64_t per_pass = prefilter_streams_per_pass(p);
     for (int64_t s0 = 0; s0 < n_streams; s0 += per_pass) {
@@ -398,7 +398,9 @@ int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
         }
         const int64_t pairs = (ns + 1) / 2;
         const int n_splits = tiled_splits(p, pairs, true);
-        FXC_TILED_DISPATCH(p, (tiled_launch<G, true>(p, xs, pairs, n_splits, spec + s0 * p->n_pts * p->nchan, ns)));
+        // spec_a == 0: this pass's streams start at row s0 * n_pts; by frame: the kernel places rows from the global stream index
+        FXC_TILED_DISPATCH(p, (tiled_launch<G, true>(p, xs, pairs, n_splits, spec_a ? spec : spec + s0 * p->n_pts * p->nchan, ns,
+                                                     nullptr, spec_a, spec_a ? s0 : 0)));
     }
     kt.stop();
     FXC_HIP(p, hipGetLastError());

@@ -110,6 +110,15 @@ __device__ __forceinline__ void tiled_store_spectrum(const cf (&v)[16], cf* reg,
 // raw[(split * n_chunks + c) * N + k] = sum over the split's frames of spec0[i,k] * conj(spec1[i,k]), natural
 // bin order, float32.  Work item = (split, chunk); a split is a contiguous range of a chunk's frames (the
 // FIR reads its history from memory, so ranges are independent).
+// row of (stream s, frame i) in the spectra the F-only kernels write: spec_a == 0: [stream][frame] (fxc_channelize's
+// output); spec_a = antennas per chunk: [chunk][frame][antenna] -- the rows an X-engine thread needs for one frame side
+// by side (k_finish.h::xengine_kernel)
+__device__ __forceinline__ int64_t spec_row(int64_t s, int64_t i, int64_t n_pts, int spec_a) {
+    if (spec_a <= 0) return s * n_pts + i;
+    const int64_t chunk = s / spec_a;
+    return (chunk * n_pts + i) * spec_a + (s - chunk * spec_a);
+}
+
 // SPEC: F-only -- a "chunk" is a pair of consecutive streams (n_streams of them in all), raw is the spectra
 // buffer [stream][i][k] and n_chunks the number of pairs.
 template <class G, bool SPEC>
@@ -117,7 +126,8 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
                                                                int64_t n_chunks, int n_splits, int ntaps,
                                                                const float* __restrict__ win, const cf* __restrict__ tw0_g,
                                                                const cf* __restrict__ twA_g, const cf* __restrict__ tw16_g,
-                                                               cf* __restrict__ raw, int64_t n_streams) {
+                                                               cf* __restrict__ raw, int64_t n_streams, int spec_a,
+                                                               int64_t s_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* region = reinterpret_cast<cf*>(smem + G::kLdsRegion);
     cf* tw16 = reinterpret_cast<cf*>(smem + G::kLdsTw16);
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
             G::loadC(reg, u, v);
             fxc::dft16(v);
             if (SPEC) {
-                tiled_store_spectrum<G>(v, reg, u, raw + ((2 * c + ant) * n_pts + i) * G::N, valid);
+                tiled_store_spectrum<G>(v, reg, u, raw + spec_row(s_base + 2 * c + ant, i, n_pts, spec_a) * G::N, valid);
                 return;
             }
             // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins (see fused_step)
@@ -256,7 +266,7 @@ struct TiledRing {
 template <class G, int PH, bool SPEC, bool U8>
 __device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, cf* reg, const cf* tw16, int u,
                                                 const cf* chunk_base, unsigned chunk_bytes, unsigned xoff, int64_t i,
-                                                int64_t i1, cf* out_row, bool valid) {
+                                                int64_t i1, cf* out_row, int64_t out_step, bool valid) {
     if (U8) convert_frame_u8(s.h[PH], s.u8.off);   // the byte pairs fetched a step ago become the samples of slot PH
     cf v[16];
     G::template fir_ring<PH>(s.h, win, u, v);
@@ -290,7 +300,7 @@ __device__ __forceinline__ void tiled_ring_step(TiledRing<G>& s, const f4* win, 
     G::loadC(reg, u, v);
     fxc::dft16(v);
     if (SPEC) {
-        tiled_store_spectrum<G>(v, reg, u, out_row + i * G::N, valid);
+        tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, valid);
         return;
     }
 #pragma unroll
@@ -308,7 +318,8 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
                                                                       const cf* __restrict__ tw0_g,
                                                                       const cf* __restrict__ twA_g,
                                                                       const cf* __restrict__ tw16_g, cf* __restrict__ raw,
-                                                                      int64_t n_streams, const cf* __restrict__ dc) {
+                                                                      int64_t n_streams, const cf* __restrict__ dc, int spec_a,
+                                                                      int64_t s_base) {
     static_assert(!(SPEC && U8), "uint8 ingest: F+X only");
     constexpr int64_t kSampleBytes = U8 ? sizeof(unsigned short) : sizeof(cf);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -334,7 +345,9 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
         const unsigned chunk_bytes = (unsigned)((SPEC && 2 * c + 1 >= n_streams ? 1 : 2) * num_samp * kSampleBytes);
         const unsigned xoff = (unsigned)((ant_ld * num_samp + (G::P - 1 - u)) * kSampleBytes);
         if (U8) s.u8.off = dc[c * 2 + ant];
-        cf* out_row = SPEC ? raw + (2 * c + ant) * n_pts * G::N : nullptr;
+        // SPEC: row of this stream's frame 0 and the rows from frame to frame (spec_row)
+        cf* out_row = SPEC ? raw + spec_row(s_base + 2 * c + ant, 0, n_pts, spec_a) * G::N : nullptr;
+        const int64_t out_step = (int64_t)(spec_a > 0 ? spec_a : 1) * G::N;
 #pragma unroll
         for (int q = 0; q < G::kAccPerThread; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
         // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the chunk)
@@ -359,13 +372,13 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
                 tiled_load_part<G, 0, 16>(s.h[0], chunk_base, chunk_bytes, xoff, i0);
         }
         for (int64_t i = i0; i < i1; i += 4) {
-            tiled_ring_step<G, 0, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i, i1, out_row, valid);
+            tiled_ring_step<G, 0, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i, i1, out_row, out_step, valid);
             if (i + 1 < i1)
-                tiled_ring_step<G, 1, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 1, i1, out_row, valid);
+                tiled_ring_step<G, 1, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 1, i1, out_row, out_step, valid);
             if (i + 2 < i1)
-                tiled_ring_step<G, 2, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 2, i1, out_row, valid);
+                tiled_ring_step<G, 2, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 2, i1, out_row, out_step, valid);
             if (i + 3 < i1)
-                tiled_ring_step<G, 3, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 3, i1, out_row, valid);
+                tiled_ring_step<G, 3, SPEC, U8>(s, win, reg, tw16, u, chunk_base, chunk_bytes, xoff, i + 3, i1, out_row, out_step, valid);
         }
         if (SPEC) continue;
         cf* row = raw + (split * n_chunks + c) * G::N;

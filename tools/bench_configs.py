@@ -13,14 +13,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def timed(plan, fn, reps):
-    fn()
+def timed(plan, fn, reps, calls=4):
+    """fn(k) = k calls back to back (an integration's result is collected while the next one runs, as bench.py does);
+    HIP events around them, per call."""
+    fn(2)
     plan.sync()
     best = []
     for _ in range(reps):
         plan.timer_start()
-        fn()
-        best.append(plan.timer_stop())
+        fn(calls)
+        best.append(plan.timer_stop() / calls)
     best.sort()
     return best[len(best) // 2], best[0]
 
@@ -41,12 +43,17 @@ def main():
         synth_fill(x, 1234)
         plan = FxPlan(n_ant, nchan, ntaps, num_samp, window=window)
         if rows:
-            fn = lambda: plan.fx_rows(x, mode, bw)
+            def fn(k):
+                for _ in range(k):
+                    plan.fx_rows(x, mode, bw)
         else:
-            def fn():
-                plan.acc_reset()
-                plan.fx_accumulate(x)
-                plan.finalize(mode, bw)
+            def fn(k):
+                for j in range(k):
+                    plan.fx_accumulate(x)
+                    plan.finalize_async(mode, bw, reset=True)
+                    if j > 0:
+                        plan.finalize_wait()
+                plan.finalize_wait()
         med, best = timed(plan, fn, args.reps)
         samples = n_chunks * num_samp
         algo = n_chunks * n_ant * num_samp * 8
@@ -65,7 +72,10 @@ def main():
     report("configs[2](ii) continuum, reference semantics N=4096, S=2^20", 2, 4096, 4, 2 ** 20, 1024, "CONTINUUM", rows=True)
     report("configs[2](i) continuum streaming limit nchan=1, S=2^20", 2, 1, 4, 2 ** 20, 2048, "CONTINUUM",
            window=np.array([0.4, 0.3, 0.2, 0.1]), rows=True)
-    report("configs[4] 8 antennas, 28 baselines, N=4096", 8, 4096, 4, 2 ** 18, 256, "SPECTRUM")
+    report("configs[4] 8 antennas, 28 baselines, N=4096", 8, 4096, 4, 2 ** 18, 512, "SPECTRUM")
+    report("8 antennas, 28 baselines, N=2048 (tiled F-only kernel + X-engine)", 8, 2048, 4, 2 ** 18, 512, "SPECTRUM")
+    report("8 antennas, 28 baselines, N=1024 (tiled F-only kernel + X-engine)", 8, 1024, 4, 2 ** 18, 512, "SPECTRUM")
+    report("4 antennas, 6 baselines, N=4096", 4, 4096, 4, 2 ** 18, 1024, "SPECTRUM")
     report("N=2048 T=32 (reference test shape), 2 antennas", 2, 2048, 32, 2 ** 18, 256, "SPECTRUM")
     for nfft in (512, 1024, 2048):   # the reference's --nfft at its fixed ntaps = 4 (effex.py:115,778)
         report("--nfft %d, integrate" % nfft, 2, nfft, 4, 2 ** 18, 4096, "SPECTRUM")
