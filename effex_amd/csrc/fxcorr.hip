@@ -21,6 +21,7 @@
 // nchan 512..8192, any ntaps: the fused design generalised, fx_tiled.h), stream (nchan 1), generic (everything else).  Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap, buffer loads.
 // No CPU fallback.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 // RCCL: types and prototypes only -- the library itself is bound at run time (rccl_api), so a ROCm install without the
 // rccl headers still builds libfxcorr (single-GPU users need no RCCL at all)
@@ -67,7 +68,16 @@ constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 channeliser kernels only
 constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
 constexpr size_t kResDirectBytes = 256 << 10;      // finalize results up to this size are written to host memory by the kernel
-constexpr int64_t kWorkspaceTarget = 12ll << 30;  // upper bound of the lazily grown workspace (288 GB of HBM per GPU)
+// upper bound of the lazily grown workspace (288 GB of HBM per GPU): a call over more chunks than fit runs in passes.
+// FXC_WS_MB: developer / test knob, the bound in MiB (tests/test_gpu_finish.py forces many passes with it)
+int64_t ws_target() {
+    static const int64_t v = [] {
+        const char* e = std::getenv("FXC_WS_MB");
+        const long long mb = e ? std::atoll(e) : 0;
+        return mb > 0 ? (int64_t)mb << 20 : (int64_t)12 << 30;
+    }();
+    return v;
+}
 
 }  // namespace
 
@@ -217,7 +227,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_res[k]), std::max<size_t>(acc_n, 16) * sizeof(cd),
                                  hipHostMallocMapped | hipHostMallocCoherent));
         FXC_HIP(p, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_res[k]), p->h_res[k], 0));
-        FXC_HIP(p, hipEventCreateWithFlags(&p->ev_res[k], hipEventDisableTiming | hipEventReleaseToSystem));
+        FXC_HIP(p, hipEventCreateWithFlags(&p->ev_res[k], hipEventReleaseToSystem));
     }
 
     if (p->path == FXC_PATH_FUSED) {
@@ -684,26 +694,26 @@ int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth
             p->sums_valid = true;
             sums_src = p->d_sums;
         }
-        const int rc = flush_pending(p, &fin);
+        // the slot's event rides on the last kernel's own completion (hipExtLaunchKernelGGL): an event recorded behind it is
+        // a packet of its own in the stream, and the next F+X kernel starts 11 us later for it
+        const int rc = flush_pending(p, &fin, (mode == FXC_MODE_SPECTRUM && !big) ? p->ev_res[slot] : nullptr);
         if (rc) return rc;
         if (reset) p->spectra_count = 0.0;
     } else if (mode == FXC_MODE_SPECTRUM) {
         const int rc = flush_pending(p);
         if (rc) return rc;
-        hipLaunchKernelGGL(finalize_spectrum_kernel, dim3(grid_for(n, 256, p->cu_count)), dim3(256), 0, p->stream, sums_src,
-                           out, p->d_rot, p->nchan, p->n_base);
+        hipExtLaunchKernelGGL(finalize_spectrum_kernel, dim3(grid_for(n, 256, p->cu_count)), dim3(256), 0, p->stream, nullptr,
+                              big ? nullptr : p->ev_res[slot], 0, sums_src, out, p->d_rot, p->nchan, p->n_base);
     }
     if (mode == FXC_MODE_CONTINUUM)
-        hipLaunchKernelGGL(finalize_continuum_kernel, dim3(p->n_base), dim3(256), 0, p->stream, sums_src, out, p->d_rot,
-                           p->nchan, p->n_base, 1.0 / bandwidth);
+        hipExtLaunchKernelGGL(finalize_continuum_kernel, dim3(p->n_base), dim3(256), 0, p->stream, nullptr,
+                              big ? nullptr : p->ev_res[slot], 0, sums_src, out, p->d_rot, p->nchan, p->n_base, 1.0 / bandwidth);
     FXC_HIP(p, hipGetLastError());
     if (big) {
         FXC_HIP(p, hipEventRecord(p->ev_fin, p->stream));
         FXC_HIP(p, hipStreamWaitEvent(p->s_copy, p->ev_fin, 0));
         FXC_HIP(p, hipMemcpyAsync(p->h_res[slot], out, bytes, hipMemcpyDeviceToHost, p->s_copy));
         FXC_HIP(p, hipEventRecord(p->ev_res[slot], p->s_copy));
-    } else {
-        FXC_HIP(p, hipEventRecord(p->ev_res[slot], p->stream));
     }
     p->res_bytes[slot] = bytes;
     p->res_head += 1;
@@ -813,7 +823,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
     // fused ingest convert a pass into a complex64 staging buffer that stays within the workspace target
     const bool fused_in = p->n_ant == 2 && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && p->tiled_ring && !p->prefilter));
     int64_t per_pass = std::min<int64_t>(16384, 65535 / p->n_ant);
-    if (!fused_in) per_pass = std::min<int64_t>(per_pass, kWorkspaceTarget / ((int64_t)p->n_ant * p->num_samp * (int64_t)sizeof(cf)));
+    if (!fused_in) per_pass = std::min<int64_t>(per_pass, ws_target() / ((int64_t)p->n_ant * p->num_samp * (int64_t)sizeof(cf)));
     per_pass = std::max<int64_t>(1, per_pass);
     for (int64_t c0 = 0; c0 < n_chunks; c0 += per_pass) {
         const int64_t nc = std::min<int64_t>(per_pass, n_chunks - c0);

@@ -53,7 +53,7 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
                                 int64_t* raw_bytes) {
     const int64_t spec_per_chunk = (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
     const int64_t raw_per_chunk = (int64_t)g.n_splits * p->n_base * p->nchan * (int64_t)sizeof(cf);
-    int64_t cb = kWorkspaceTarget / std::max<int64_t>(1, spec_per_chunk + raw_per_chunk);
+    int64_t cb = ws_target() / std::max<int64_t>(1, spec_per_chunk + raw_per_chunk);
     if (cb < 1) cb = 1;
     if (cb > n_chunks) cb = n_chunks;
     *spec_bytes = (cb * spec_per_chunk + 255) / 256 * 256;
@@ -72,19 +72,20 @@ int64_t fold_part_bytes(const fxc_plan* p) { return (int64_t)fold_max_splits((in
 const FoldFinish kNoFinish = {nullptr, nullptr, nullptr, 0.0, 0};
 
 // acc[p][bin] += sum of the raw rows [n_base][nchan], and `fin` for every element: two launches, one when the rows are few
-int fold_rows(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int layout, const FoldFinish& fin) {
+// `done`: an event to complete with the last kernel (it rides on that dispatch: no packet of its own in the stream)
+int fold_rows(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int layout, const FoldFinish& fin, hipEvent_t done = nullptr) {
     const int64_t row_len = (int64_t)p->n_base * p->nchan;
     const unsigned cols = (unsigned)((row_len + 255) / 256);
     const int splits = fold_splits(n_rows, row_len);
     if (splits == 1) {
-        hipLaunchKernelGGL(fold_finish_kernel<cf>, dim3(cols), dim3(256 * kFoldPhases), 0, p->stream, raw, n_rows, p->d_acc,
-                           p->nchan, p->n_base, layout, fin);
+        hipExtLaunchKernelGGL(fold_finish_kernel<cf>, dim3(cols), dim3(256 * kFoldPhases), 0, p->stream, nullptr, done, 0, raw,
+                              n_rows, p->d_acc, p->nchan, p->n_base, layout, fin);
     } else {
         hipLaunchKernelGGL(fold_partial_kernel, dim3(cols, splits), dim3(256 * kFoldPhases), 0, p->stream, raw, part, row_len,
                            n_rows, splits);
         // the partials are in the rows' own layout
-        hipLaunchKernelGGL(fold_finish_kernel<cd>, dim3(cols), dim3(256 * kFoldPhases), 0, p->stream, part, (int64_t)splits,
-                           p->d_acc, p->nchan, p->n_base, layout, fin);
+        hipExtLaunchKernelGGL(fold_finish_kernel<cd>, dim3(cols), dim3(256 * kFoldPhases), 0, p->stream, nullptr, done, 0,
+                              (const cd*)part, (int64_t)splits, p->d_acc, p->nchan, p->n_base, layout, fin);
     }
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
@@ -92,16 +93,18 @@ int fold_rows(fxc_plan* p, const cf* raw, cd* part, int64_t n_rows, int layout, 
 
 // the fold of the last fx_accumulate pass, if it is still pending, with `fin` riding along; nothing pending: `fin`
 // alone on the accumulator as it stands
-int flush_pending(fxc_plan* p, const FoldFinish* fin) {
+int flush_pending(fxc_plan* p, const FoldFinish* fin, hipEvent_t done) {
     if (p->pend.valid) {
         p->pend.valid = false;
-        return fold_rows(p, p->pend.raw, p->pend.part, p->pend.n_rows, p->pend.layout, fin ? *fin : kNoFinish);
+        return fold_rows(p, p->pend.raw, p->pend.part, p->pend.n_rows, p->pend.layout, fin ? *fin : kNoFinish, done);
     }
     if (fin) {
         const int64_t n = (int64_t)p->n_base * p->nchan;
-        hipLaunchKernelGGL(acc_finish_kernel, dim3(grid_for(n, 256, p->cu_count)), dim3(256), 0, p->stream, p->d_acc, p->nchan,
-                           p->n_base, *fin);
+        hipExtLaunchKernelGGL(acc_finish_kernel, dim3(grid_for(n, 256, p->cu_count)), dim3(256), 0, p->stream, nullptr, done, 0,
+                              p->d_acc, p->nchan, p->n_base, *fin);
         FXC_HIP(p, hipGetLastError());
+    } else if (done) {
+        FXC_HIP(p, hipEventRecord(done, p->stream));
     }
     return FXC_OK;
 }
@@ -167,24 +170,27 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
     stamps = p->d_stamps;
     p->stamp_grid = grid;
 #endif
-    KernelTimer kt(p);
+    // kernel profiling (bench.py): the two events ride on the dispatch itself (hipExtLaunchKernelGGL: start and stop
+    // time of this kernel, no barrier packets of their own in the stream -- events recorded around the launch cost 6 + 11 us
+    // of stream time per launch, profiles/r03/experiments.md)
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (p->profiling && (hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess)) ev_a = ev_b = nullptr;
+#define FXC_FUSED_LAUNCH(KERNEL, LDS, ...) \
+    hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(kThreads), LDS, p->stream, ev_a, ev_b, 0, __VA_ARGS__)
     if (dc_u8 && dck)
-        hipLaunchKernelGGL((fx_fused4096_kernel<false, true, true>), dim3(grid), dim3(kThreads), kLdsBytes + kDckLdsBytes, p->stream, x,
-                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, seg, (int)unit,
-                           rows_are_chunks ? 1 : 0);
+        FXC_FUSED_LAUNCH((fx_fused4096_kernel<false, true, true>), kLdsBytes + kDckLdsBytes, x, num_samp, p->n_pts, n_pairs,
+                         p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, seg, (int)unit, rows_are_chunks ? 1 : 0);
     else if (dc_u8)
-        hipLaunchKernelGGL((fx_fused4096_kernel<false, true>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, dc_u8, seg, (int)unit,
-                           rows_are_chunks ? 1 : 0);
-    else if (spec_out)
-        hipLaunchKernelGGL((fx_fused4096_kernel<true, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
-                           seg, p->n_ant / 2, 1);   // (`unit` carries the stream pairs per chunk here)
+        FXC_FUSED_LAUNCH((fx_fused4096_kernel<false, true>), kLdsBytes, x, num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1,
+                         p->d_tw2, out, stamps, dc_u8, seg, (int)unit, rows_are_chunks ? 1 : 0);
+    else if (spec_out)      // (`unit` carries the stream pairs per chunk here)
+        FXC_FUSED_LAUNCH((fx_fused4096_kernel<true, false>), kLdsBytes, x, num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1,
+                         p->d_tw2, out, stamps, (const cf*)nullptr, seg, p->n_ant / 2, 1);
     else
-        hipLaunchKernelGGL((fx_fused4096_kernel<false, false>), dim3(grid), dim3(kThreads), kLdsBytes, p->stream, x,
-                           num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1, p->d_tw2, out, stamps, (const cf*)nullptr,
-                           seg, (int)unit, rows_are_chunks ? 1 : 0);
-    kt.stop();
+        FXC_FUSED_LAUNCH((fx_fused4096_kernel<false, false>), kLdsBytes, x, num_samp, p->n_pts, n_pairs, p->d_win4, p->d_tw1,
+                         p->d_tw2, out, stamps, (const cf*)nullptr, seg, (int)unit, rows_are_chunks ? 1 : 0);
+#undef FXC_FUSED_LAUNCH
+    if (ev_a) p->kev.emplace_back(ev_a, ev_b);
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
 }
@@ -205,7 +211,7 @@ int fused_layout(const fxc_plan* p) { return p->n_ant == 2 ? 1 : (p->path == FXC
 int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec_bytes, int64_t* raw_bytes) {
     const int64_t raw_per_chunk = (int64_t)p->n_base * p->nchan * (int64_t)sizeof(cf);
     const int64_t spec_per_chunk = p->n_ant == 2 ? 0 : (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
-    int64_t cb = kWorkspaceTarget / (raw_per_chunk + spec_per_chunk);
+    int64_t cb = ws_target() / (raw_per_chunk + spec_per_chunk);
     if (cb < 1) cb = 1;
     if (cb > n_chunks) cb = n_chunks;
     if (p->n_ant > 2 && cb > 65535) cb = 65535;   // xengine_kernel carries the chunk in grid.y
@@ -333,7 +339,7 @@ int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false) {
 // streams the pre-filter handles per pass (its output stays within the workspace target)
 int64_t prefilter_streams_per_pass(const fxc_plan* p) {
     if (!p->prefilter) return INT64_MAX;
-    int64_t n = kWorkspaceTarget / (p->num_samp * (int64_t)sizeof(cf));
+    int64_t n = ws_target() / (p->num_samp * (int64_t)sizeof(cf));
     n = std::min<int64_t>(n, 65534) & ~(int64_t)1;      // grid.y carries the stream; whole pairs
     return std::max<int64_t>(2, n);
 }
@@ -410,7 +416,7 @@ int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int 
 // ---- nchan 8192 as two 4096-channel problems (pfb_split8192_kernel) ---------------------------------
 int64_t split_chunks_per_pass(const fxc_plan* p, int64_t n_chunks) {
     const int64_t per_chunk = 4 * p->n_pts * 4096 * (int64_t)sizeof(cf) + 2 * 4096 * (int64_t)sizeof(cf);   // y + two raw rows
-    return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, 32767), kWorkspaceTarget / per_chunk));
+    return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, 32767), ws_target() / per_chunk));
 }
 
 // raw = the fused kernel's rows over 2 nc chunk pairs (+ leading-part rows) for nc chunks of 8192-channel input

@@ -174,7 +174,7 @@ int grid_for(int64_t work_items, int block, int cu_count) {
 }
 
 // launches the fold of the pending raw rows (h_launch.h); every user of the workspace or the accumulator calls it first
-int flush_pending(fxc_plan* p, const FoldFinish* fin = nullptr);
+int flush_pending(fxc_plan* p, const FoldFinish* fin = nullptr, hipEvent_t done = nullptr);
 
 int ensure_ws(fxc_plan* p, int64_t bytes) {
     const int rf = flush_pending(p);        // the pending rows (and their partials) live in the workspace

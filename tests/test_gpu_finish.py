@@ -217,3 +217,56 @@ def test_dc_removal_inside_the_fused_kernel(plan_mod, torch, frames, extra, n_ch
         p.fx_accumulate_u8(ud, remove_dc=True)
         integ = p.finalize("SPECTRUM")
         assert rel_err(integ[0], rows[:, 0].astype(np.complex128).mean(axis=0)) < 2e-6
+
+
+def test_integration_in_many_workspace_passes():
+    """A call over more chunks than the workspace holds runs in passes: all but the last fold their raw rows right away, the
+    last one's fold waits for whatever comes next (h_run.h::fold_or_defer).  With the workspace bound forced down to 8 MiB
+    (FXC_WS_MB, read once per process: a child process) the integrations of the 2-antenna, 8-antenna, tiled and generic
+    routes must equal the float64 mean of their per-chunk rows, as they do in one pass."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from effex_amd import synth
+from effex_amd.plan import FxPlan
+for n_ant, nchan, num_samp, n_chunks, path in ((2, 4096, 4096 * 8, 700, "fused"), (8, 4096, 4096 * 4, 40, "fused"),
+                                               (2, 1024, 1024 * 16, 300, "tiled"), (3, 64, 64 * 40, 200, "generic")):
+    x = torch.from_numpy(synth.synth_iq(7, n_chunks, n_ant, num_samp)).cuda()
+    with FxPlan(n_ant, nchan, 4, num_samp) as p:
+        assert p.path == path, (p.path, path)
+        rows = p.fx_rows(x, "SPECTRUM").cpu().numpy().astype(np.complex128)
+        p.fx_accumulate(x[: n_chunks // 2])
+        p.fx_accumulate(x[n_chunks // 2:])
+        p.finalize_async("SPECTRUM")
+        integ = p.finalize_wait()
+        ws = p.info["workspace_bytes"]
+    err = np.abs(integ - rows.mean(axis=0)).max() / np.abs(rows.mean(axis=0)).max()
+    print(path, n_ant, "workspace", ws, "err", err)
+    assert ws <= (80 << 20), ws            # the bound held (plus the fold's partials, up to 58 MB for 28 baselines)
+    assert err < 2e-6, err
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FXC_WS_MB="8")
+    proc = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and proc.stdout.strip().endswith("ok"), proc.stdout[-2000:] + proc.stderr[-2000:]
+
+
+def test_reduce_between_two_gpus():
+    """fxc_comm_create / fxc_reduce with a world of two, one process per GPU (what bench.py's RCCL preflight runs): needs
+    two GPUs, skipped on the one-GPU boxes this repository is built on."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from effex_amd.plan import RcclComm
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    uid = RcclComm.unique_id().hex()
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--rccl-child", uid, str(r), "2", str(r)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
