@@ -123,8 +123,8 @@ struct U8State {
 // when its first frame is converted and the pre-pass over the bytes (dc_sum_u8_stream_kernel: 1.7 of 9.7 ms per 10 000
 // chunk pairs) only has to cover each workgroup's first chunk and the tail.  The kernel has one VGPR to spare, so
 // nothing of this lives in registers across a step: every step each thread fetches 32 bytes of its own antenna's stream
-// straight into LDS (global_load_lds_dwordx4, issued behind barrier B1 so that no barrier finds it in flight), adds
-// their v_dot4 byte sums to its two counters in LDS at the end of the step, and the chunk-start branch -- where the
+// straight into LDS (global_load_lds_dwordx4), adds their v_dot4 byte sums to its two counters in LDS a step later,
+// and the chunk-start branch -- where the
 // ring's history registers are dead -- turns the 256 counters of an antenna into the offset.  Exact integer sums and
 // the float64 formula of dc_offsets_u8_kernel: bit-identical to the pre-pass.  Straight-line code except in that
 // branch: a workgroup without a next chunk sums its current one again and nobody reads the result.
@@ -160,9 +160,22 @@ __device__ __forceinline__ void dck_fetch(const unsigned char* pair_base, int64_
         : "memory", "scc");
 }
 
-// the step's two fetches have landed: of the vector-memory operations issued after them only the last four IQ loads of the
-// step (FXC_PREFETCH(12)) may still be in flight
-__device__ __forceinline__ void dck_wait() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+// The fetches of a step are summed a step later, just before the next ones go out (a whole step for them to land: summed
+// at the end of their own step, 45 % of a step after their issue, the kernel waited for HBM).  Between the two points the
+// wave issues the IQ loads FXC_PREFETCH(8), (12) of the old step and (0), (4) of the new one -- sixteen, and at a row
+// end eight stores more: once at most sixteen vector-memory operations are outstanding the fetches have landed (loads
+// return in order).  The last step of a chunk sums its own fetches as well, behind the four loads of FXC_PREFETCH(12).
+__device__ __forceinline__ void dck_wait_prev() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+__device__ __forceinline__ void dck_wait_own() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+
+// this thread's two landing slots cleared: the next unconditional dck_add then adds nothing
+__device__ __forceinline__ void dck_clear(v4u32_t* stage, int tid) {
+    unsigned z0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z0));      // made here: the compiler otherwise keeps a zero quad in scratch for this
+    const v4u32_t z = {z0, z0, z0, z0};
+    stage[(tid >> 6) * 128 + (tid & 63)] = z;
+    stage[(tid >> 6) * 128 + 64 + (tid & 63)] = z;
+}
 
 __device__ __forceinline__ void dck_add(const v4u32_t* stage, unsigned* acc, int tid) {
     unsigned si = 0u, sq = 0u;
@@ -256,7 +269,11 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
 #if !(FXC_ABL & 2)
     __syncthreads();   // B1: exchange-1 rows complete
 #endif
-    if (DCK) dck_fetch(dck_base, num_samp, i, tid, dck_stage);
+    if (DCK) {      // straight-line: what the previous step fetched (nothing at a chunk's first step: slots cleared), then fetch
+        dck_wait_prev();
+        dck_add(dck_stage, dck_acc, tid);
+        dck_fetch(dck_base, num_samp, i, tid, dck_stage);
+    }
     FXC_STAMP(6);
 #if !(FXC_ABL & 4)
     phase2_load(region, tid, v);
@@ -309,8 +326,11 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
         FXC_STAMP(10);
     }
     if (DCK) {
-        dck_wait();
-        dck_add(dck_stage, dck_acc, tid);
+        if (i + 1 == n_pts) {             // the chunk's last fetches are summed here, for the chunk-start branch of the next step
+            dck_wait_own();
+            dck_add(dck_stage, dck_acc, tid);
+            dck_clear(dck_stage, tid);
+        }
         u8.have_next = dck_next;          // (read by the next chunk's first step only)
     }
     // a raw row ends with the last frame of every `unit`-th chunk, of the last chunk and of this workgroup's
@@ -373,7 +393,10 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
     v4u32_t* dck_stage = dck_stage_mem;
     unsigned* dck_acc = dck_acc_mem;
     unsigned* dck_red = reinterpret_cast<unsigned*>(smem + kLdsBytes);
-    if (DCK) dck_acc[2 * tid] = dck_acc[2 * tid + 1] = 0u;
+    if (DCK) {
+        dck_acc[2 * tid] = dck_acc[2 * tid + 1] = 0u;
+        dck_clear(dck_stage, tid);
+    }
     unsigned long long seg_t[kStampSegs] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
     int64_t frames_done = 0;
