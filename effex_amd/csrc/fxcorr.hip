@@ -67,7 +67,10 @@ namespace {
 constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 channeliser kernels only
 constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
-constexpr size_t kResDirectBytes = 256 << 10;      // finalize results up to this size are written to host memory by the kernel
+size_t res_direct_bytes() {      // finalize results up to this size are written to host memory by the kernel (FXC_RES_DIRECT: developer knob, bytes)
+    static const size_t v = [] { const char* e = std::getenv("FXC_RES_DIRECT"); return e ? (size_t)std::atoll(e) : (size_t)(256 << 10); }();
+    return v;
+}
 // upper bound of the lazily grown workspace (288 GB of HBM per GPU): a call over more chunks than fit runs in passes.
 // FXC_WS_MB: developer / test knob, the bound in MiB (tests/test_gpu_finish.py forces many passes with it)
 int64_t ws_target() {
@@ -678,7 +681,7 @@ int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth
     const size_t bytes = mode == FXC_MODE_SPECTRUM ? (size_t)n * sizeof(cd) : (size_t)p->n_base * sizeof(cd);
     // small results are written into the pinned slot by the finishing kernel itself; large ones go through device
     // memory and a copy on a side stream, off the F+X stream's critical path
-    const bool big = bytes > kResDirectBytes;
+    const bool big = bytes > res_direct_bytes();
     if (big && !p->s_copy) {
         FXC_HIP(p, hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
         FXC_HIP(p, hipEventCreateWithFlags(&p->ev_fin, hipEventDisableTiming));
