@@ -61,6 +61,24 @@ def main():
         except Exception as exc:
             print(json.dumps({"FAILED": str(exc), **tag}), flush=True)
             raise
+        # byte ingest on the headline shape (fused uint8 kernels, with the in-kernel DC removal when the launch has two rounds of
+        # whole-frame chunks) against the two-step device path: convert + de-mean to complex64, then the same F+X
+        if nchan == 4096 and n_ant == 2 and ntaps == 4 and rng.random() < 0.5:
+            nb = int(rng.choice([3, 300, 520, 700, 1100]))
+            fb = int(rng.integers(1, 5))
+            nsb = 4096 * fb + (0 if rng.random() < 0.6 else int(rng.integers(1, 4096)))
+            nb = max(1, min(nb, int(2.0e7 // (2 * nsb))))
+            u8 = torch.randint(0, 256, (nb, 2, nsb, 2), dtype=torch.uint8, device="cuda")
+            u8[:, 0, :, 0] = (u8[:, 0, :, 0] // 2) + (torch.arange(nb, device="cuda") % 101)[:, None].to(torch.uint8)
+            with FxPlan(2, 4096, 4, nsb) as b:
+                rb = b.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()
+                r2 = b.fx_rows(b.convert_u8(u8, remove_dc=True)).cpu().numpy()
+                b.fx_accumulate_u8(u8, remove_dc=True)
+                e_b = max(rel_err(rb, r2), rel_err(b.finalize("SPECTRUM"), r2.astype(np.complex128).mean(axis=0)))
+            worst[("bytes", 4096, False)] = max(worst.get(("bytes", 4096, False), 0.0), e_b)
+            if not e_b < 1e-5:
+                print(json.dumps({"MISMATCH_BYTES": e_b, "n_chunks": nb, "num_samp": nsb}), flush=True)
+                raise SystemExit(1)
         tol = 2e-5 if nchan == 1 else 6e-6
         key = (path, nchan if nchan in (1, 4096, 8192) else 0, ntaps > 4)
         worst[key] = max(worst.get(key, 0.0), e_rows, e_int)
