@@ -227,18 +227,16 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
                    bool rows_are_chunks = true, bool dck = false) {
     using namespace fxc::fused;
     if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8, unit, rows_are_chunks, 0, dck);
-    // 4 / 6 / 8 antennas: spectra to HBM (the F-only fused kernel in its own spectrum order at nchan 4096 / ntaps 4,
-    // the F-only tiled kernel in natural order otherwise), then the register-resident X-engine.  unit = chunks per
-    // raw row here too: ceil(nc / unit) rows come out
+    // 3 .. 8 antennas: spectra to HBM as [chunk][frame][antenna] rows (the F-only fused kernel in its own position order
+    // at nchan 4096 / ntaps 4, the F-only tiled kernel in natural order otherwise), then the register-resident X-engine.
+    // unit = chunks per raw row here too: ceil(nc / unit) rows come out
     int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
                                        : tiled_channelize(p, x, spec, nc * p->n_ant, p->n_ant);
     if (rc) return rc;
-    // spectra layout of both F-only kernels here: [chunk][frame][antenna] rows
-    const int64_t sa = 1, si = p->n_ant;
     const int cg = (int)unit;
     const dim3 grid(p->nchan / kXThreads, (unsigned)((nc + cg - 1) / cg));
 #define FXC_X_LAUNCH(A) \
-    hipLaunchKernelGGL(xengine_kernel<A>, grid, dim3(kXThreads), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg, sa, si)
+    hipLaunchKernelGGL(xengine_kernel<A>, grid, dim3(kXThreads), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg)
     switch (p->n_ant) {
         case 3: FXC_X_LAUNCH(3); break;
         case 4: FXC_X_LAUNCH(4); break;

@@ -261,21 +261,20 @@ __global__ void acc_finish_kernel(cd* __restrict__ acc, int nchan, int n_base, F
         finish_element(acc[idx], acc, idx, (int)(idx % nchan), nchan, n, fin);
 }
 
-// multi-antenna X-engine on the F-only kernels' spectra: spectrum (chunk c, antenna a, frame i) is row
-// c * A * n_pts + a * sa + i * si of `spec` (rows of nchan samples; sa = n_pts, si = 1: [stream][frame], what the tiled
-// F-only kernel and fxc_channelize write; sa = 1, si = A: [frame][antenna], what the fused F-only kernel writes -- the A
-// rows a thread needs for one frame then lie inside one block of A rows instead of 2 MiB apart: 8 antennas 1.64 -> 1.51 ms
-// per 512 chunks, 5.4 TB/s).  One wave per workgroup; a thread keeps all A(A-1)/2 accumulators of one position in
-// registers over the spectra of `cg` consecutive chunks (cg = 1: one raw row per chunk; integrations take float32 sums
-// of up to kRowSpectra spectra, like the 2-antenna kernel's rows) and reads every spectrum sample exactly once;
-// raw[group][p][pos], baselines ordered (0,1),(0,2)..(A-2,A-1) -- effex.py:520 for A > 2.
+// multi-antenna X-engine on the F-only kernels' spectra: spectrum (chunk c, frame i, antenna a) is row
+// (c * n_pts + i) * A + a of `spec` (rows of nchan samples) -- the A rows a thread needs for one frame lie inside one block
+// of A rows (as [stream][frame] rows, 2 MiB apart, the kernel read 8 % slower: 8 antennas 1.64 -> 1.51 ms per 512 chunks).
+// One wave per workgroup; a thread keeps all A(A-1)/2 accumulators of one position in registers over the spectra of `cg`
+// consecutive chunks (cg = 1: one raw row per chunk; integrations take float32 sums of up to kRowSpectra spectra, like the
+// 2-antenna kernel's rows) and reads every spectrum sample exactly once; raw[group][p][pos], baselines ordered
+// (0,1),(0,2)..(A-2,A-1) -- effex.py:520 for A > 2.
 // Measured and dropped (profiles/r03/experiments.md): two positions per thread with 16-byte loads (+10 %), 1 or 4
 // spectra per trip instead of 2 (+-0.5 %).
 constexpr int kXU = 2;           // spectra per trip: kXU * A independent 8-byte loads in flight before the multiply-accumulates
 constexpr int kXThreads = 64;
 template <int A>
 __global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int64_t n_pts,
-                                                           int nchan, int64_t n_chunks, int cg, int64_t sa, int64_t si) {
+                                                           int nchan, int64_t n_chunks, int cg) {
     constexpr int NB = A * (A - 1) / 2;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t grp = blockIdx.y;
@@ -291,7 +290,7 @@ __global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict
 #pragma unroll
             for (int u = 0; u < kXU; ++u)
 #pragma unroll
-                for (int a = 0; a < A; ++a) z[u][a] = base[((int64_t)a * sa + (i + u) * si) * nchan];
+                for (int a = 0; a < A; ++a) z[u][a] = base[((i + u) * A + a) * nchan];
 #pragma unroll
             for (int u = 0; u < kXU; ++u) {
                 int p = 0;
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict
         for (; i < n_pts; ++i) {
             cf z[A];
 #pragma unroll
-            for (int a = 0; a < A; ++a) z[a] = base[((int64_t)a * sa + i * si) * nchan];
+            for (int a = 0; a < A; ++a) z[a] = base[(i * A + a) * nchan];
             int p = 0;
 #pragma unroll
             for (int a = 0; a < A; ++a)
