@@ -1,5 +1,5 @@
 // Developer micro-benchmark: run ONE kind of work for ~8 s so rocm-smi can sample package power and sclk.
-//   power_modes <mode>   mode: fma | add | read | lds | fma_read
+//   power_modes <mode>   mode: fma | add | read | read8 | read_fx | read_lin8 | lds | fma_read
 // hipcc --offload-arch=gfx950 -O3 -o power_modes power_modes.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -72,6 +72,40 @@ __global__ __launch_bounds__(512) void read8_k(const float2* __restrict__ in, fl
     out[(blockIdx.x & 255) * 512 + threadIdx.x] = acc.x + acc.y;
 }
 
+// the fused F+X kernel's read pattern without its arithmetic: one persistent block per CU walks chunk pairs b, b + 256, ...
+// (4 MiB each: two 2 MiB streams); per step (one 4096-sample frame of both streams, 64 KiB) thread (ant, j) loads its 16
+// branch samples with 8-byte loads, 512 contiguous bytes per wave-load, frame after frame
+__global__ __launch_bounds__(512) void read_fx_k(const float2* __restrict__ in, float* out, int n_chunks) {
+    const int ant = threadIdx.x >> 8, j = threadIdx.x & 255;
+    float2 acc = {0, 0};
+    for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const float2* base = in + (size_t)c * 2 * 262144 + (size_t)ant * 262144 + (255 - j);
+        for (int i = 0; i < 64; ++i) {
+            float2 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = base[(size_t)i * 4096 + 256 * (15 - r)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc.x += v[r].x; acc.y += v[r].y; }
+        }
+    }
+    out[(blockIdx.x & 255) * 512 + threadIdx.x] = acc.x + acc.y;
+}
+
+// the same bytes as one linear walk: block b reads the b-th 1/256 of the buffer front to back, 8-byte loads
+__global__ __launch_bounds__(512) void read_lin8_k(const float2* __restrict__ in, float* out, size_t n_vec) {
+    float2 acc = {0, 0};
+    const size_t per_block = n_vec / gridDim.x;
+    const float2* p = in + (size_t)blockIdx.x * per_block;
+    for (size_t i = threadIdx.x; i < per_block; i += 512 * 16) {
+        float2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = p[i + 512 * k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc.x += v[k].x; acc.y += v[k].y; }
+    }
+    out[(blockIdx.x & 255) * 512 + threadIdx.x] = acc.x + acc.y;
+}
+
 __global__ __launch_bounds__(512) void sleep_k(float* out, int iters, int mode) {
     float s = threadIdx.x;
     for (int it = 0; it < iters; ++it) {
@@ -107,6 +141,8 @@ static void pin() { hipFuncSetAttribute((const void*)valu_k<M>, hipFuncAttribute
 
 int main(int argc, char** argv) {
     pin<0>(); pin<1>(); pin<2>(); pin<3>(); pin<4>(); pin<5>(); pin<6>();
+    hipFuncSetAttribute((const void*)read_fx_k, hipFuncAttributeMaxDynamicSharedMemorySize, kPin);
+    hipFuncSetAttribute((const void*)read_lin8_k, hipFuncAttributeMaxDynamicSharedMemorySize, kPin);
     const char* mode = argc > 1 ? argv[1] : "fma";
     const double seconds = argc > 2 ? atof(argv[2]) : 8.0;
     float* out; hipMalloc(&out, 256 * 512 * 4);
@@ -127,6 +163,8 @@ int main(int argc, char** argv) {
         else if (!strcmp(mode, "mov")) hipLaunchKernelGGL(valu_k<6>, dim3(256), dim3(512), kPin, 0, out, 200000);
         else if (!strcmp(mode, "read")) hipLaunchKernelGGL(read_k, dim3(2048), dim3(512), 0, 0, in, out, n_vec, 0);
         else if (!strcmp(mode, "read8")) hipLaunchKernelGGL(read8_k, dim3(2048), dim3(512), 0, 0, (const float2*)in, out, n_vec * 2);
+        else if (!strcmp(mode, "read_fx")) hipLaunchKernelGGL(read_fx_k, dim3(256), dim3(512), kPin, 0, (const float2*)in, out, 2048);
+        else if (!strcmp(mode, "read_lin8")) hipLaunchKernelGGL(read_lin8_k, dim3(256), dim3(512), kPin, 0, (const float2*)in, out, n_vec * 2);
         else if (!strcmp(mode, "fma_read")) hipLaunchKernelGGL(read_k, dim3(2048), dim3(512), 0, 0, in, out, n_vec, 6);
         else if (!strcmp(mode, "lds")) hipLaunchKernelGGL(lds_k, dim3(256), dim3(512), 0, 0, out, 100000);
         else if (!strcmp(mode, "sleep")) hipLaunchKernelGGL(sleep_k, dim3(256), dim3(512), 0, 0, out, 100000, 0);
