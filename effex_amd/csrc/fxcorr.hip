@@ -949,20 +949,29 @@ int fxc_estimate_delay(fxc_plan* p, const void* iq0, const void* iq1, int64_t n,
     }
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + 4 * buf_bytes + stage_bytes);
     cf* out3 = reinterpret_cast<cf*>(ws + 4 * buf_bytes + stage_bytes + 16);
-    const int g_len = grid_for(len, 256, p->cu_count), g_half = grid_for(len / 2, 256, p->cu_count);
+    const int g_len = grid_for(len, 256, p->cu_count);
     hipLaunchKernelGGL(delay_pad_kernel, dim3(g_len), dim3(256), 0, p->stream, x0, a[0], n, len);
     hipLaunchKernelGGL(delay_pad_kernel, dim3(g_len), dim3(256), 0, p->stream, x1, b[0], n, len);
-    int cur = 0;
-    for (int s = 0; s < lg; ++s, cur ^= 1) {   // forward transforms, kernel exp(-2 pi i ...) like cp.fft.fft
-        hipLaunchKernelGGL(stockham_stage_kernel, dim3(g_half), dim3(256), 0, p->stream, a[cur], a[cur ^ 1], len / 2,
-                           1ll << s, -1.0);
-        hipLaunchKernelGGL(stockham_stage_kernel, dim3(g_half), dim3(256), 0, p->stream, b[cur], b[cur ^ 1], len / 2,
-                           1ll << s, -1.0);
-    }
-    hipLaunchKernelGGL(mul_conj_kernel, dim3(g_len), dim3(256), 0, p->stream, a[cur], b[cur], len);   // f0 * conj(f1)
-    for (int s = 0; s < lg; ++s, cur ^= 1)     // inverse transform (un-normalised: the peak fit is scale free)
-        hipLaunchKernelGGL(stockham_stage_kernel, dim3(g_half), dim3(256), 0, p->stream, a[cur], a[cur ^ 1], len / 2,
-                           1ll << s, 1.0);
+    // one transform = radix-16 passes, then one radix-8 / 4 / 2 pass for the remaining bits of lg
+    auto transform = [&](cf* (&buf)[2], int& cur, double sign) {
+        int64_t pp = 1;
+        for (int bits = lg; bits > 0;) {
+            const int r = bits >= 4 ? 4 : bits;
+            const int grid = grid_for(len >> r, 256, p->cu_count);
+            if (r == 4) hipLaunchKernelGGL(stockham_stage_kernel<16>, dim3(grid), dim3(256), 0, p->stream, buf[cur], buf[cur ^ 1], len, pp, sign);
+            else if (r == 3) hipLaunchKernelGGL(stockham_stage_kernel<8>, dim3(grid), dim3(256), 0, p->stream, buf[cur], buf[cur ^ 1], len, pp, sign);
+            else if (r == 2) hipLaunchKernelGGL(stockham_stage_kernel<4>, dim3(grid), dim3(256), 0, p->stream, buf[cur], buf[cur ^ 1], len, pp, sign);
+            else hipLaunchKernelGGL(stockham_stage_kernel<2>, dim3(grid), dim3(256), 0, p->stream, buf[cur], buf[cur ^ 1], len, pp, sign);
+            pp <<= r;
+            bits -= r;
+            cur ^= 1;
+        }
+    };
+    int cur = 0, cur_b = 0;
+    transform(a, cur, -1.0);       // forward transforms, kernel exp(-2 pi i ...) like cp.fft.fft
+    transform(b, cur_b, -1.0);
+    hipLaunchKernelGGL(mul_conj_kernel, dim3(g_len), dim3(256), 0, p->stream, a[cur], b[cur_b], len);   // f0 * conj(f1)
+    transform(a, cur, 1.0);        // inverse transform (un-normalised: the peak fit is scale free)
     FXC_HIP(p, hipMemsetAsync(best, 0, 8, p->stream));
     hipLaunchKernelGGL(delay_argmax_kernel, dim3(grid_for(2 * n, 256, p->cu_count)), dim3(256), 0, p->stream, a[cur], best,
                        n, len);

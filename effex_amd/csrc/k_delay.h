@@ -5,9 +5,11 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 // delay calibration — effex/effex.py:583-627: zero-padded FFT cross-correlation,
-// arg-max of |xcorr|, 3-point log-Gaussian peak.  Runs once per calibration, so the FFT is a plain
-// global-memory radix-2 Stockham (log2 L passes); the linear correlation is the same for any padded
-// length L >= 2n, so L is the next power of two and lags are re-indexed to the reference's 2n layout.
+// arg-max of |xcorr|, 3-point log-Gaussian peak.  Runs once per calibration: the FFT is a global-memory
+// Stockham autosort with radix-16 passes (the DFT-16 of fx_math.h in registers, twiddles formed in float64)
+// and one radix-8 / 4 / 2 pass for what is left of log2 L -- 5 passes for the reference's 2 x 262144 points
+// (19 with the radix-2 passes of rounds 1-2); the linear correlation is the same for any padded length
+// L >= 2n, so L is the next power of two and lags are re-indexed to the reference's 2n layout.
 // ------------------------------------------------------------------------------------------
 __global__ void delay_pad_kernel(const cf* __restrict__ x, cf* __restrict__ out, int64_t n, int64_t len) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -15,20 +17,39 @@ __global__ void delay_pad_kernel(const cf* __restrict__ x, cf* __restrict__ out,
         out[idx] = idx < n ? x[idx] : fxc::mk(0.f, 0.f);
 }
 
-// one radix-2 Stockham stage: natural order in, natural order out after log2(len) stages
-__global__ void stockham_stage_kernel(const cf* __restrict__ in, cf* __restrict__ out, int64_t half_len, int64_t p,
-                                      double sign) {
+// one radix-R Stockham stage (R = 16, 8, 4, 2): thread j of len / R takes in[j + q len / R], q = 0 .. R-1, multiplies by
+// exp(sign 2 pi i q k / (p R)) with k = j mod p (p = the product of the radices of the stages before), transforms, and
+// writes Y_q to out[(j - k) R + k + q p]: natural order in, natural order out after the last stage.  The butterflies have
+// the kernel exp(+2 pi i ..) (fx_math.h, fx_tiled.h); the forward transform (sign = -1) runs them on conjugated data.
+template <int R>
+__global__ void stockham_stage_kernel(const cf* __restrict__ in, cf* __restrict__ out, int64_t len, int64_t p, double sign) {
+    const int64_t sub = len / R;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < half_len; j += stride) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < sub; j += stride) {
         const int64_t k = j & (p - 1);
-        double sn, cs;
-        sincospi(sign * (double)k / (double)p, &sn, &cs);
-        const cf u0 = in[j], u1 = in[j + half_len];
-        const float tr = (float)((double)u1.x * cs - (double)u1.y * sn);
-        const float ti = (float)((double)u1.x * sn + (double)u1.y * cs);
-        const int64_t jj = ((j - k) << 1) + k;
-        out[jj] = fxc::mk(u0.x + tr, u0.y + ti);
-        out[jj + p] = fxc::mk(u0.x - tr, u0.y - ti);
+        cf v[16];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const cf u = in[j + q * sub];
+            double sn = 0.0, cs = 1.0;
+            if (q > 0) sincospi(2.0 * (double)q * (double)k / ((double)p * (double)R), &sn, &cs);
+            // u exp(sign i angle) in float64, conjugated for the forward transform
+            const double re = (double)u.x * cs - sign * (double)u.y * sn;
+            const double im = sign * (double)u.x * sn + (double)u.y * cs;
+            v[q] = fxc::mk((float)re, (float)(sign < 0.0 ? -im : im));
+        }
+        if (R == 16) {
+            fxc::dft16(v);
+        } else if (R == 8) {
+            fxc::tiled::dft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        } else if (R == 4) {
+            fxc::dft4(v[0], v[1], v[2], v[3]);
+        } else {
+            fxc::tiled::dft2(v[0], v[1]);
+        }
+        const int64_t base = (j - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) out[base + q * p] = fxc::mk(v[q].x, sign < 0.0 ? -v[q].y : v[q].y);
     }
 }
 

@@ -361,6 +361,22 @@ def test_delay_calibration_against_reference(plan_mod, torch, golden):
         cor.close()
 
 
+@pytest.mark.parametrize("n", [3, 100, 2048, 4096, 5000, 8192, 16384, 40000, 1 << 17])
+def test_delay_transform_every_pass_mix(plan_mod, n):
+    """log2 of the padded length runs through 3 .. 18: every mix of radix-16 passes and a radix-8 / 4 / 2 tail
+    (k_delay.h), against the oracle's float64 estimate of the same streams."""
+    rng = np.random.default_rng(n)
+    iq_0 = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    shift = 1 if n < 8 else 1 + n // 7 % 11
+    iq_1 = np.roll(iq_0, shift) + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    ref = fx_oracle.estimate_delay_gaussian(iq_0.astype(np.complex128), iq_1.astype(np.complex128), gi.DELAY_RATE)
+    with plan_mod.FxPlan(2, 512, 4, 4096) as p:
+        est = p.estimate_delay(iq_0, iq_1, gi.DELAY_RATE)
+    assert abs(est - ref) * gi.DELAY_RATE < 2e-3, (n, est * gi.DELAY_RATE, ref * gi.DELAY_RATE)
+    if n >= 100:
+        assert abs(est * gi.DELAY_RATE - shift) < 0.5
+
+
 # --------------------------------------------------------------------------------------------
 # batches, ragged sizes, multi-antenna, continuum streaming limit
 # --------------------------------------------------------------------------------------------
