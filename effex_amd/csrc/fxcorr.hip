@@ -852,13 +852,16 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
             const int64_t n_full = dck ? nc / g * g : nc;
             // chunk ranges the pre-pass sums: everything, or [0, g) and [n_full, nc)
             const int64_t lo[2] = {0, n_full}, hi[2] = {dck ? g : nc, dck ? nc : n_full};
+            // a call of a few streams (one chunk pair: the reference's own call) is cut into slices to fill the chip
+            const int sl = dck ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(kSlices, (int64_t)p->cu_count * 2 / n_streams));
             for (int r = 0; r < 2; ++r) {
                 const int64_t ns = (hi[r] - lo[r]) * p->n_ant;
                 if (ns <= 0) continue;
-                hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(ns, (int64_t)p->cu_count * 16)), dim3(256),
-                                   0, p->stream, xb + lo[r] * p->n_ant * p->num_samp * 2, part + lo[r] * p->n_ant * 2, p->num_samp, ns);
+                hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(ns * sl, (int64_t)p->cu_count * 16)),
+                                   dim3(256), 0, p->stream, xb + lo[r] * p->n_ant * p->num_samp * 2,
+                                   part + lo[r] * p->n_ant * 2 * sl, p->num_samp, ns, sl);
                 hipLaunchKernelGGL(dc_offsets_u8_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, p->stream,
-                                   part + lo[r] * p->n_ant * 2, dc + lo[r] * p->n_ant, ns, 1, p->num_samp, 1);
+                                   part + lo[r] * p->n_ant * 2 * sl, dc + lo[r] * p->n_ant, ns, sl, p->num_samp, 1);
             }
         } else if (remove_dc) {
             hipLaunchKernelGGL(dc_sum_u8_kernel, dim3(kSlices, (unsigned)n_streams), dim3(256), 0, p->stream, xb, part,

@@ -137,7 +137,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
                                    static_cast<cf*>(out) + c0, p->d_rot, 1, nc, nb, nc, inv_pts, 0, kNoLead);
             else
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
-                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, 1, nc, nb, nc,
+                                   dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, 1, nc, nb, nc,
                                    cscale, 0, kNoLead);
             FXC_HIP(p, hipGetLastError());
         }
@@ -164,7 +164,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
                                    rows, 1, (int64_t)0, inv_pts, fused_layout(p), lead);
             else
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
-                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot,
+                                   dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot,
                                    p->nchan, rows, 1, (int64_t)0, cscale, fused_layout(p), lead);
             FXC_HIP(p, hipGetLastError());
         }
@@ -186,7 +186,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
                                    raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, 1, (int64_t)0, inv_pts, 3, lead);
             else
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
-                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, 1, (int64_t)0,
+                                   dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, 1, (int64_t)0,
                                    cscale, 3, lead);
             FXC_HIP(p, hipGetLastError());
         }
@@ -212,7 +212,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
                                    raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, n_splits, nc * N, inv_pts, 0, kNoLead);
             else
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
-                                   dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, n_splits,
+                                   dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, n_splits,
                                    nc * N, cscale, 0, kNoLead);
             FXC_HIP(p, hipGetLastError());
         }
@@ -243,7 +243,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
                                rows, g.n_splits, split_stride, inv_pts, 0, kNoLead);
         else
             hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
-                               dim3(256), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot, p->nchan,
+                               dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot, p->nchan,
                                rows, g.n_splits, split_stride, cscale, 0, kNoLead);
         FXC_HIP(p, hipGetLastError());
     }

@@ -51,45 +51,53 @@ __global__ __launch_bounds__(256) void dc_sum_u8_kernel(const unsigned char* __r
     }
 }
 
-// fused uint8 ingest: exact byte sums of whole streams, one workgroup per stream, 16-byte loads (8 samples per lane);
-// part[s * 2] = sum of I bytes, part[s * 2 + 1] = sum of Q bytes  (the n_slices = 1 layout of dc_sum_u8_kernel)
+// fused uint8 ingest: exact byte sums of streams, 16-byte loads (8 samples per lane).  n_slices == 1: one workgroup per
+// stream, part[s * 2] = sum of I bytes, part[s * 2 + 1] = sum of Q bytes.  n_slices > 1 (calls of a few streams -- the
+// reference hands over one chunk pair at a time, effex.py:490-494 -- would leave a stream of 512 KiB to one workgroup):
+// workgroup w sums slice w % n_slices of stream w / n_slices into part[(s n_slices + slice) * 2]; the sums are integers,
+// so dc_offsets_u8_kernel's total over the slices is the same number whatever the split.
 __global__ __launch_bounds__(256) void dc_sum_u8_stream_kernel(const unsigned char* __restrict__ x, double* __restrict__ part,
-                                                              int64_t num_samp, int64_t n_streams) {
+                                                              int64_t num_samp, int64_t n_streams, int n_slices) {
     __shared__ double red[256];
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    for (int64_t s = blockIdx.x; s < n_streams; s += gridDim.x) {
+    for (int64_t w = blockIdx.x; w < n_streams * n_slices; w += gridDim.x) {
+        const int64_t s = w / n_slices;
+        const int slice = (int)(w - s * n_slices);
         const unsigned char* base = x + s * num_samp * 2;
-        // align to 16 bytes: head and tail bytes one sample at a time
+        // align to 16 bytes: head and tail bytes one sample at a time (slice 0)
         const int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15) / 2);
         const int64_t h = head < num_samp ? head : num_samp;
         const int64_t n_vec = (num_samp - h) / 8;
+        const int64_t v_lo = n_vec * slice / n_slices, v_hi = n_vec * (slice + 1) / n_slices;
         const v4u* vp = reinterpret_cast<const v4u*>(base + h * 2);
         unsigned long long ar = 0, ai = 0;
-        for (int64_t n = threadIdx.x; n < n_vec; n += 256) {
-            const v4u w = vp[n];
+        for (int64_t n = v_lo + threadIdx.x; n < v_hi; n += 256) {
+            const v4u w4 = vp[n];
             unsigned si = 0, sq = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                si = __builtin_amdgcn_sad_u8(w[k] & 0x00FF00FFu, 0u, si);
-                sq = __builtin_amdgcn_sad_u8((w[k] >> 8) & 0x00FF00FFu, 0u, sq);
+                si = __builtin_amdgcn_sad_u8(w4[k] & 0x00FF00FFu, 0u, si);
+                sq = __builtin_amdgcn_sad_u8((w4[k] >> 8) & 0x00FF00FFu, 0u, sq);
             }
             ar += si;
             ai += sq;
         }
-        const unsigned short* sp = reinterpret_cast<const unsigned short*>(base);
-        for (int64_t n = threadIdx.x; n < h; n += 256) {
-            ar += sp[n] & 0xFF;
-            ai += sp[n] >> 8;
-        }
-        for (int64_t n = h + n_vec * 8 + threadIdx.x; n < num_samp; n += 256) {
-            ar += sp[n] & 0xFF;
-            ai += sp[n] >> 8;
+        if (slice == 0) {
+            const unsigned short* sp = reinterpret_cast<const unsigned short*>(base);
+            for (int64_t n = threadIdx.x; n < h; n += 256) {
+                ar += sp[n] & 0xFF;
+                ai += sp[n] >> 8;
+            }
+            for (int64_t n = h + n_vec * 8 + threadIdx.x; n < num_samp; n += 256) {
+                ar += sp[n] & 0xFF;
+                ai += sp[n] >> 8;
+            }
         }
         const double sr = block_sum((double)ar, red);
         const double si2 = block_sum((double)ai, red);
         if (threadIdx.x == 0) {
-            part[s * 2] = sr;
-            part[s * 2 + 1] = si2;
+            part[w * 2] = sr;
+            part[w * 2 + 1] = si2;
         }
     }
 }

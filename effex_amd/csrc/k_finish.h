@@ -33,8 +33,17 @@ __device__ __forceinline__ void add_lead_rows(const cf* __restrict__ raw, const 
     const int64_t t = vrow - lr.first_chunk;   // chunk of the tail (fx_fused4096.h::range_walk_tail)
     const int64_t b_lo = fxc::range_owner(t * lr.n_pts, lr.n_frames, lr.grid);
     const int64_t b_hi = fxc::range_owner((t + 1) * lr.n_pts - 1, lr.n_frames, lr.grid);
-    for (int64_t b = b_lo + 1; b <= b_hi; ++b) {   // the workgroups that start strictly inside that chunk
-        const cf r = raw[lr.offset + b * row_len + ridx];
+    // the workgroups that start strictly inside that chunk (up to grid - 1 of them when one chunk pair is the whole call,
+    // effex.py:490-494): four loads in flight, added in the order of the plain loop
+    const cf* __restrict__ src = raw + lr.offset + ridx;
+    int64_t b = b_lo + 1;
+    for (; b + 3 <= b_hi; b += 4) {
+        const cf r0 = src[b * row_len], r1 = src[(b + 1) * row_len], r2 = src[(b + 2) * row_len], r3 = src[(b + 3) * row_len];
+        ar = ((ar + r0.x) + r1.x) + r2.x + r3.x;
+        ai = ((ai + r0.y) + r1.y) + r2.y + r3.y;
+    }
+    for (; b <= b_hi; ++b) {
+        const cf r = src[b * row_len];
         ar += r.x;
         ai += r.y;
     }
@@ -78,12 +87,16 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return r;
 }
 
-// CONTINUUM rows: out[row] = mean_k( raw * conj(rot) / n_pts ) / bandwidth   (effex.py:523-524); one WG per row
-__global__ __launch_bounds__(256) void rows_continuum_kernel(const cf* __restrict__ raw, cd* __restrict__ out,
+// CONTINUUM rows: out[row] = mean_k( raw * conj(rot) / n_pts ) / bandwidth   (effex.py:523-524); one WG per row, of
+// kContinuumThreads threads: a reference-sized call is a single row whose frames the F+X kernel spread over the whole grid,
+// so each bin gathers up to grid - 1 leading-part rows -- 72 us with 256 threads, the largest item of that call
+constexpr int kContinuumThreads = 1024;
+inline int continuum_threads(int nchan) { return nchan >= kContinuumThreads ? kContinuumThreads : 256; }
+__global__ __launch_bounds__(kContinuumThreads) void rows_continuum_kernel(const cf* __restrict__ raw, cd* __restrict__ out,
                                                             const cd* __restrict__ rot, int nchan, int64_t rows,
                                                             int n_splits, int64_t split_stride, double scale,
                                                             int slots, LeadRows lead) {
-    __shared__ double red[256];
+    __shared__ double red[kContinuumThreads];
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         double ar = 0.0, ai = 0.0;
         for (int k = threadIdx.x; k < nchan; k += blockDim.x) {
