@@ -33,6 +33,25 @@ class IQSource(object):
         I,Q (pyrtlsdr's ``format='bytes'``): conversion, DC removal and F+X then happen in one device call."""
         raise NotImplementedError
 
+    def read_into(self, num_samp, out_0, out_1):
+        """Fill ``out_0`` / ``out_1`` (uint8 [num_samp, 2] for a byte source, complex64 [num_samp] otherwise) with the next
+        chunk pair; False when the stream ends.  The batched run (``Correlator(batch=...)``) hands over windows of a pinned
+        staging slot, so a source that overrides this writes its data where the device copies it from."""
+        pair = self.read(num_samp)
+        if pair is None:
+            return False
+        out_0[...] = np.asarray(pair[0]).reshape(out_0.shape)
+        out_1[...] = np.asarray(pair[1]).reshape(out_1.shape)
+        return True
+
+    def read_many_into(self, num_samp, out):
+        """Fill ``out[k, a]`` (a batch window [K, 2, num_samp(, 2)]) with up to K consecutive chunk pairs; returns how many
+        were filled (fewer than K: the stream has ended)."""
+        k = 0
+        while k < len(out) and self.read_into(num_samp, out[k, 0], out[k, 1]):
+            k += 1
+        return k
+
     def close(self):
         pass
 
@@ -84,16 +103,21 @@ class FileSource(IQSource):
     are memory-mapped and read chunk by chunk; a trailing partial chunk is dropped, as a short read ends the reference's
     run."""
 
+    _READERS = 4        # read_many_into: threads per receiver
+
     def __init__(self, path_0, path_1, fmt='u8', rs=None, fc=None, gain=None):
         if fmt not in ('u8', 'c64'):
             raise ValueError("fmt must be 'u8' or 'c64'")
         self.fmt = fmt
         self.rs, self.fc, self.gain = rs, fc, gain
         dtype = np.uint8 if fmt == 'u8' else np.complex64
+        self._paths = (path_0, path_1)
+        self._fds = None            # file descriptors of read_many_into, opened on first use
         self._maps = [np.memmap(p, dtype=dtype, mode='r') for p in (path_0, path_1)]
         per = 2 if fmt == 'u8' else 1
         self.n_samples = min(len(m) for m in self._maps) // per
         self._next = 0
+        self._pool = None           # copy threads of read_many_into, made on first use
         self.closed = False
 
     def read(self, num_samp):
@@ -106,7 +130,63 @@ class FileSource(IQSource):
             return tuple(np.asarray(m[2 * lo:2 * hi]).reshape(num_samp, 2) for m in self._maps)
         return tuple(np.asarray(m[lo:hi]) for m in self._maps)
 
+    def read_into(self, num_samp, out_0, out_1):
+        num_samp = int(num_samp)
+        lo, hi = self._next, self._next + num_samp
+        if hi > self.n_samples:
+            return False
+        self._next = hi
+        per = 2 if self.fmt == 'u8' else 1
+        for m, out in zip(self._maps, (out_0, out_1)):       # page cache -> staging slot, one copy
+            out.reshape(-1)[...] = m[per * lo:per * hi]
+        return True
+
+    def read_many_into(self, num_samp, out):
+        """Scatter reads (``os.preadv``), ``_READERS`` per receiver in parallel: the kernel copies from the page cache
+        straight into the batch window (through the memory map, with its page faults, eight threads moved 13 GB/s)."""
+        import os
+        num_samp = int(num_samp)
+        k = min(len(out), (self.n_samples - self._next) // num_samp)
+        if k <= 0:
+            return 0
+        bytes_per = 2 if self.fmt == 'u8' else 8
+        lo = self._next
+        self._next += k * num_samp
+        if self._fds is None:
+            self._fds = [os.open(path, os.O_RDONLY) for path in self._paths]
+
+        def fill(job):
+            a, c_lo, c_hi = job
+            bufs = [out[c, a].reshape(-1).view(np.uint8) for c in range(c_lo, c_hi)]
+            per_chunk = num_samp * bytes_per
+            offset, want = (lo + c_lo * num_samp) * bytes_per, (c_hi - c_lo) * per_chunk
+            # preadv takes at most IOV_MAX buffers and may return short: continue from where it stopped
+            done = 0
+            while done < want:
+                c0, skip = divmod(done, per_chunk)
+                iov = [bufs[c0][skip:]] + bufs[c0 + 1:c0 + 512]
+                got = os.preadv(self._fds[a], iov, offset + done)
+                if got <= 0:
+                    raise EOFError("recording {} shrank while it was read".format(self._paths[a]))
+                done += got
+
+        if self._pool is None:
+            import concurrent.futures
+            self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=2 * self._READERS)
+        parts = min(self._READERS, k)
+        jobs = [(a, k * i // parts, k * (i + 1) // parts) for a in range(2) for i in range(parts)]
+        list(self._pool.map(fill, jobs))
+        return k
+
     def close(self):
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
+        if self._fds is not None:
+            import os
+            for fd in self._fds:
+                os.close(fd)
+            self._fds = None
         self._maps = []
         self.closed = True
 
@@ -162,6 +242,12 @@ class SocketSource(IQSource):
                        else np.frombuffer(buf, dtype='<c8'))
         return tuple(out)
 
+    def read_into(self, num_samp, out_0, out_1):
+        for sock, out in zip(self._socks, (out_0, out_1)):   # socket -> staging slot, no copy in between
+            if self._recv_exact(sock, out.reshape(-1).view(np.uint8)) is None:
+                return False
+        return True
+
     def close(self):
         for sock in self._socks:
             try:
@@ -204,7 +290,7 @@ class Correlator(object):
     def __init__(self, run_time=1, bandwidth=2.4e6, frequency=1.4204e9, num_samp=2 ** 18, nbins=2 ** 12,
                  gain=49.6, mode='SPECTRUM', loglevel='INFO',
                  source=None, device=0, max_num_samp=None, output_file=None, remove_dc=True, calibrate=True,
-                 output_format='csv'):
+                 output_format='csv', batch=1):
         self.logger = logging.getLogger(__name__)
         self.logger.setLevel(getattr(logging, loglevel))
         self._max_num_samp = int(max_num_samp) if max_num_samp else Correlator._MAX_NUM_SAMP
@@ -212,6 +298,11 @@ class Correlator(object):
         self.device = device
         self.remove_dc = remove_dc
         self.calibrate = calibrate      # the reference always calibrates on the first chunk pair (effex.py:353,399-401)
+        # batch > 1: the RUN state takes that many chunk pairs per device call through the double-buffered host-fed front
+        # end (fxc_pipe_*) -- for replaying recordings and fast streams; 1 = the reference's one call per chunk pair
+        if int(batch) < 1:
+            raise ValueError("batch must be >= 1")
+        self.batch = int(batch)
         self._fx_plan = None
         self._f_plans = {}
         self._rot_key = None
@@ -488,6 +579,74 @@ class Correlator(object):
             self.gpu_iq_0 = _without_mean(self.gpu_iq_0)
             self.gpu_iq_1 = _without_mean(self.gpu_iq_1)
 
+    def _run_batched(self, first_pair, sink, fh):
+        """The RUN state for ``batch`` > 1: chunk pairs go ``batch`` at a time through a three-slot ``FxPipeline`` -- the
+        source fills a pinned slot in place (``IQSource.read_into``), the copy in, the F+X call and the rows' copy out of
+        successive batches overlap, and with the binary sidecar the rows land in a mapped window of the file.  Same rows
+        as the one-call-per-pair loop up to float32 summation order (a batch is split over the workgroups differently);
+        a last, short batch goes through one blocking call.  Returns the number of rows written."""
+        from .plan import FxPipeline
+        plan = self._plan()
+        n, K = int(self.num_samp), self.batch
+        u8 = np.asarray(first_pair[0]).dtype == np.uint8
+        mode = 'CONTINUUM' if 'CONTINUUM' == self.mode else 'SPECTRUM'
+        rows = 0
+
+        def emit(out):          # out: [k, 1, nchan] complex64 or [k, 1] complex128
+            for row in out[:, 0]:
+                self._write_row(fh, row)
+
+        def fill(view, pair):
+            """view[0] from ``pair`` when there is one, the rest from the source; returns the chunk pairs filled."""
+            k = 0
+            if pair is not None:
+                view[0, 0][...] = np.asarray(pair[0]).reshape(view[0, 0].shape)
+                view[0, 1][...] = np.asarray(pair[1]).reshape(view[0, 1].shape)
+                k = 1
+            k += self.source.read_many_into(n, view[k:])
+            if not u8 and self.remove_dc:       # effex.py:394-395, in complex128, rounded once like the per-pair path
+                for c in range(k):
+                    for a in range(2):
+                        view[c, a][...] = _without_mean(view[c, a])
+            return k
+
+        with FxPipeline(plan, K, depth=3, mode=mode, bandwidth=self.bandwidth, u8=u8, remove_dc=self.remove_dc) as pipe:
+            def drain():
+                if sink is not None:
+                    pipe.pop(out=sink.reserve(K))
+                    sink.commit(K)
+                else:
+                    emit(pipe.pop())
+                return K
+
+            # the fill of a slot (file / socket -> pinned memory, no library call) runs beside the main thread, which
+            # meanwhile collects the oldest batch in flight; every fxc_* call stays on the main thread
+            import concurrent.futures
+            with concurrent.futures.ThreadPoolExecutor(max_workers=1) as filler:
+                pending, k = first_pair, 0
+                while True:
+                    view = pipe.acquire()
+                    job = filler.submit(fill, view, pending)
+                    pending = None
+                    if pipe.in_flight == 2:
+                        rows += drain()
+                    k = job.result()
+                    if k < K:
+                        break
+                    pipe.submit()
+            while pipe.in_flight:
+                rows += drain()
+            if k:               # the stream ended inside a batch
+                tail = view[:k]
+                out = (plan.fx_rows_u8(tail, mode, self.bandwidth, remove_dc=self.remove_dc) if u8
+                       else plan.fx_rows(tail, mode, self.bandwidth))
+                if sink is not None:
+                    sink.write_rows(out[:, 0])
+                else:
+                    emit(out)
+                rows += k
+        return rows
+
     def run_state_machine(self):
         """OFF -> STARTUP -> CALIBRATE -> RUN ... -> SHUTDOWN -> OFF over the source's chunk pairs; the first
         pair calibrates the delay (unless ``calibrate=False``), every further pair writes one csv row."""
@@ -508,6 +667,10 @@ class Correlator(object):
                 elif self.state in ('CALIBRATE', 'RUN'):
                     pair = self.source.read(int(self.num_samp))
                     if pair is None:
+                        self.state = 'SHUTDOWN'
+                        continue
+                    if 'RUN' == self.state and self.batch > 1 and self.mode not in ['TEST']:
+                        rows += self._run_batched(pair, sink, fh)      # to the end of the stream
                         self.state = 'SHUTDOWN'
                         continue
                     self._stage(pair)

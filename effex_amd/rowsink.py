@@ -125,9 +125,9 @@ class BinSink(object):
             self._drop_map()
 
     def _drop_map(self):
-        if self._map is not None:
-            self._map.flush()
-            self._map = None
+        # no msync here: rows written through the window are in the page cache, where every reader of the file sees them;
+        # forcing them to the disk after every batch cost more than producing them
+        self._map = None
         self._map_rows = 0
 
     def close(self):

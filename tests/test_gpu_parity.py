@@ -337,6 +337,53 @@ def test_state_machine_on_recorded_files(tmp_path, torch):
     assert abs(rows["c64"][1] - rows["memory"][1]) < 1e-12 and rel_err(rows["c64"][0], rows["memory"][0]) < 1e-3
 
 
+@pytest.mark.parametrize("mode", ["SPECTRUM", "CONTINUUM"])
+def test_batched_run_writes_the_rows_of_the_per_pair_run(tmp_path, torch, mode):
+    """Correlator(batch=4): the RUN state takes four chunk pairs per device call through the host-fed pipeline -- byte
+    recordings, complex64 recordings and an in-memory source, csv and binary sidecar -- and writes the rows the
+    one-call-per-pair loop writes (float32 summation order aside), the short last batch and the dropped partial chunk
+    included; calibration is the per-pair loop's."""
+    from effex_amd import rowsink
+    from effex_amd.correlator import ArraySource, Correlator, FileSource
+    n_chunks, num_samp, nbins = 11, 4096 * 6, 4096          # 1 calibration pair + 10 rows = two batches of four + two
+    rng = np.random.default_rng(23)
+    base = rng.integers(0, 256, size=(n_chunks * num_samp + 300 + 3, 2), dtype=np.uint8)
+    own = rng.integers(0, 256, size=(2, n_chunks * num_samp + 300, 2), dtype=np.uint8)
+    streams = [base[3:] // 2 + own[0] // 2, base[:-3] // 2 + own[1] // 2]
+    for a in range(2):
+        streams[a].tofile(str(tmp_path / ("rx%d.u8" % a)))
+        fx_oracle.u8_to_complex(streams[a][None, None])[0, 0].astype(np.complex64).tofile(str(tmp_path / ("rx%d.c64" % a)))
+    chunks_c = np.stack([fx_oracle.u8_to_complex(s[: n_chunks * num_samp].reshape(n_chunks, num_samp, 2)[None])[0]
+                         for s in streams], axis=1)
+    sources = {"u8": lambda: FileSource(str(tmp_path / "rx0.u8"), str(tmp_path / "rx1.u8"), fmt='u8'),
+               "c64": lambda: FileSource(str(tmp_path / "rx0.c64"), str(tmp_path / "rx1.c64"), fmt='c64'),
+               "memory": lambda: ArraySource(chunks_c)}
+    skip = 2 if mode == "SPECTRUM" else 1
+    for name, make in sources.items():
+        got = {}
+        for batch, fmt in ((1, 'csv'), (4, 'csv'), (4, 'bin'), (16, 'bin')):
+            path = str(tmp_path / ("%s_%d.%s" % (name, batch, fmt)))
+            src = make()
+            cor = Correlator(num_samp=num_samp, nbins=nbins, source=src, output_file=path, mode=mode, output_format=fmt,
+                             batch=batch)
+            assert cor.run_state_machine() == n_chunks - 1, (name, batch, fmt)
+            assert src.closed and cor.state == 'OFF'
+            if fmt == 'csv':
+                rows = np.loadtxt(path, dtype=np.complex128, delimiter=',', skiprows=skip).reshape(n_chunks - 1, -1)
+            else:
+                rf = rowsink.RowFile(path)
+                assert rf.rows.shape[0] == n_chunks - 1
+                rows = np.asarray(rf.rows).astype(np.complex128)
+            got[(batch, fmt)] = (rows, cor.calibrated_delay)
+        ref_rows, ref_delay = got[(1, 'csv')]
+        assert abs(ref_delay * 2.4e6 - 3) < 0.5
+        for key, (rows, delay) in got.items():
+            assert delay == ref_delay, (name, key)
+            assert rows.shape == ref_rows.shape
+            for c in range(n_chunks - 1):
+                assert rel_err(rows[c], ref_rows[c]) < 2e-5, (name, key, c)
+
+
 def test_delay_calibration_against_reference(plan_mod, torch, golden):
     """The reference's delay tests (tests/test_effex.py:92-121): 14 cases, |k - est*rate| < 0.5 sample and
     |k/rate - est| < 1e-6 s, plus agreement with the reference's own estimate (golden)."""

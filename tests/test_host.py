@@ -192,6 +192,44 @@ def test_file_source_reads_chunk_pairs(tmp_path):
         FileSource(str(tmp_path / "rx0.u8"), str(tmp_path / "rx1.u8"), fmt='s16')
 
 
+def test_sources_fill_staging_windows_in_place(tmp_path):
+    """IQSource.read_into (what the batched run feeds its pinned slots with): file and in-memory sources write the chunk
+    pairs read() returns into caller-owned windows, and report the end of the stream the same way."""
+    from effex_amd.correlator import ArraySource, FileSource
+    rng = np.random.default_rng(4)
+    n, n_chunks = 96, 3
+    raw = rng.integers(0, 256, size=(2, n_chunks * n + 10, 2), dtype=np.uint8)
+    for a in range(2):
+        raw[a].tofile(str(tmp_path / ("rx%d.u8" % a)))
+    cplx = (rng.standard_normal((n_chunks, 2, n)) + 1j * rng.standard_normal((n_chunks, 2, n))).astype(np.complex64)
+    for a in range(2):
+        cplx[:, a].reshape(-1).tofile(str(tmp_path / ("rx%d.c64" % a)))
+    cases = [(lambda: FileSource(str(tmp_path / "rx0.u8"), str(tmp_path / "rx1.u8"), fmt='u8'), np.uint8, (n, 2)),
+             (lambda: FileSource(str(tmp_path / "rx0.c64"), str(tmp_path / "rx1.c64"), fmt='c64'), np.complex64, (n,)),
+             (lambda: ArraySource(cplx), np.complex64, (n,))]
+    for make, dtype, shape in cases:
+        by_read, by_fill = make(), make()
+        slot = np.zeros((n_chunks + 1, 2) + shape, dtype=dtype)         # windows of one larger buffer, like a staging slot
+        for c in range(n_chunks):
+            pair = by_read.read(n)
+            assert by_fill.read_into(n, slot[c, 0], slot[c, 1]) is True
+            np.testing.assert_array_equal(slot[c, 0], np.asarray(pair[0]).reshape(shape))
+            np.testing.assert_array_equal(slot[c, 1], np.asarray(pair[1]).reshape(shape))
+        assert by_read.read(n) is None
+        assert by_fill.read_into(n, slot[n_chunks, 0], slot[n_chunks, 1]) is False
+        assert not slot[n_chunks].any()
+        many = make()                                                   # a batch window at a time; a short last batch
+        batch = np.zeros((2, 2) + shape, dtype=dtype)
+        assert many.read_many_into(n, batch) == 2
+        np.testing.assert_array_equal(batch, slot[:2])
+        batch[...] = 0
+        assert many.read_many_into(n, batch) == n_chunks - 2
+        np.testing.assert_array_equal(batch[0], slot[2])
+        assert not batch[1].any() and many.read_many_into(n, batch) == 0
+        for src in (by_read, by_fill, many):
+            src.close()
+
+
 def test_socket_source_reads_chunk_pairs_from_two_streams():
     """SocketSource (a network stream in place of effex.py:630-664's live dongles): two TCP streams of
     rtl_tcp-style bytes -- a 12-byte greeting, then interleaved uint8 I,Q -- read chunk pair by chunk pair whatever the
@@ -240,9 +278,18 @@ def test_socket_source_reads_chunk_pairs_from_two_streams():
     z0, z1 = src.read(64)
     np.testing.assert_array_equal(z0, z)
     np.testing.assert_array_equal(z1, 2 * z)
-    src.close()
+    slot = np.zeros((2, 2, 64), dtype=np.complex64)      # read_into: straight into windows of a staging slot
+    b.sendall((3 * z).tobytes())
+    d.sendall((4 * z).tobytes())
+    assert src.read_into(64, slot[1, 0], slot[1, 1]) is True
+    np.testing.assert_array_equal(slot[1, 0], 3 * z)
+    np.testing.assert_array_equal(slot[1, 1], 4 * z)
+    assert not slot[0].any()
+    b.sendall(z.tobytes()[:100])                         # ends inside a chunk
     b.close()
     d.close()
+    assert src.read_into(64, slot[0, 0], slot[0, 1]) is False
+    src.close()
     with pytest.raises(ValueError):
         SocketSource([("127.0.0.1", 1)], fmt='u8')
 
