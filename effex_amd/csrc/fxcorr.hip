@@ -3,7 +3,7 @@
 // One translation unit.  This file holds the ABI entry points; it includes
 //   fx_math.h, fx_fused4096.h, fx_tiled.h   index maps, butterflies and kernel phases (also compiled by g++ for the
 //                                           host emulation under tests/emul)
-//   k_generic.h k_finish.h k_fused4096.h k_tiled.h k_prepass.h k_stream.h k_conditioning.h k_delay.h k_synth.h
+//   k_generic.h k_finish.h k_fused4096.h k_tiled.h k_small.h k_prepass.h k_stream.h k_conditioning.h k_delay.h k_synth.h
 //                                           the __global__ kernels, one file per path / step
 //   h_plan.h h_launch.h h_run.h h_rccl.h    fxc_plan, the per-path launchers and workspace passes, the device-resident
 //                                           fx_accumulate / fx_rows, the run-time binding of librccl
@@ -18,7 +18,8 @@
 //   delay calibration                             effex/effex.py:583-627 -> delay_* / stockham_stage kernels
 //   per-chunk blocking copies                     effex/effex.py:391-392, 508-509, 693 -> fxc_pipe_* (host side)
 // Paths: fused (nchan 4096, ntaps 4; 2 antennas in one kernel, 4/6/8 via F-only + X-engine), tiled (2 antennas,
-// nchan 512..8192, any ntaps: the fused design generalised, fx_tiled.h), stream (nchan 1), generic (everything else).  Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap, buffer loads.
+// nchan 512..8192, any ntaps: the fused design generalised, fx_tiled.h; nchan 16..256, ntaps <= 4: the same inside one
+// wave, k_small.h), stream (nchan 1), generic (everything else).  Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap, buffer loads.
 // No CPU fallback.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -88,6 +89,7 @@ int64_t ws_target() {
 #include "k_finish.h"
 #include "k_fused4096.h"
 #include "k_tiled.h"
+#include "k_small.h"
 #include "k_prepass.h"
 #include "k_stream.h"
 #include "k_conditioning.h"
@@ -140,7 +142,7 @@ int fxc_plan_destroy(fxc_plan* p) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_stamps,
+    void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_tw_small, p->d_stamps,
                     p->d_acc, p->d_sums, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
                     p->d_ones, p->d_pre, p->d_tw8192};
     for (void* b : bufs)
@@ -184,7 +186,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         return fail(p, FXC_ERR_UNSUPPORTED, "the streaming kernel needs n_ant=2, nchan=1");
     // 2 antennas: X fused into the tiled kernel; 3 .. 8: F-only tiled kernel (an odd stream count leaves the last pair
     // half empty) + X-engine
-    const bool tiled_shape = (p->n_ant >= 2 && p->n_ant <= 8 && tiled_nchan(N) && p->num_samp <= (1ll << 27));
+    // 2 antennas, 16 .. 256 channels, up to four taps: the wave-local variant of the tiled design (k_small.h)
+    const bool small_shape = (p->n_ant == 2 && small_nchan(N) && T <= 4);
+    const bool tiled_shape = small_shape || (p->n_ant >= 2 && p->n_ant <= 8 && tiled_nchan(N) && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_TILED && !tiled_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for n_ant=%d nchan=%d", p->n_ant, N);
     p->path = FXC_PATH_GENERIC;
@@ -274,8 +278,35 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + kDckLdsBytes));
     }
+    p->small = small_shape && p->path == FXC_PATH_TILED;
+    if (p->small) {
+        const int P = N / 16;
+        std::vector<f4> w4((size_t)N);          // window quads [r P + u] = h[t N + u + P r], t = x, y, z, w (zero beyond ntaps)
+        for (int r = 0; r < 16; ++r)
+            for (int u = 0; u < P; ++u) {
+                const int m = u + P * r;
+                f4 w;
+                w.x = wf[m];
+                w.y = T > 1 ? wf[(size_t)1 * N + m] : 0.f;
+                w.z = T > 2 ? wf[(size_t)2 * N + m] : 0.f;
+                w.w = T > 3 ? wf[(size_t)3 * N + m] : 0.f;
+                w4[(size_t)r * P + u] = w;
+            }
+        FXC_HIP(p, hipMalloc(&p->d_win4, w4.size() * sizeof(f4)));
+        FXC_HIP(p, hipMemcpy(p->d_win4, w4.data(), w4.size() * sizeof(f4), hipMemcpyHostToDevice));
+        std::vector<cf> tw((size_t)N);
+        for (int u = 0; u < P; ++u)
+            for (int k1 = 0; k1 < 16; ++k1) {
+                const double ph = kTwoPi * (double)((u * k1) % N) / (double)N;
+                tw[(size_t)u * 16 + k1] = fxc::mk((float)std::cos(ph), (float)std::sin(ph));
+            }
+        FXC_HIP(p, hipMalloc(&p->d_tw_small, tw.size() * sizeof(cf)));
+        FXC_HIP(p, hipMemcpy(p->d_tw_small, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+        const int rc = small_setup(p);
+        if (rc) return rc;
+    }
     p->tiled_f = (tiled_nchan(N) && p->num_samp <= (1ll << 27) && force_path != FXC_PATH_GENERIC);
-    if (p->path == FXC_PATH_TILED || p->tiled_f) {
+    if ((p->path == FXC_PATH_TILED && !p->small) || p->tiled_f) {
         // pre-stage twiddles wN^((u + P g) k) at [g + G k][u]; stage tables as on the fused path
         const int P = N / 16, R0 = N >= 4096 ? N / 4096 : N / 256, G = 16 / R0;
         std::vector<cf> tw0((size_t)16 * P);
@@ -465,6 +496,10 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
         info->grid = p->fused_grid_max;
         info->block = fxc::fused::kThreads;
         info->lds_bytes = fxc::fused::kLdsBytes;
+    } else if (p->path == FXC_PATH_TILED && p->small) {
+        info->grid = p->small_wgs;
+        info->block = 256;
+        info->lds_bytes = p->nchan * (int)sizeof(f4) + 4 * 1088 * (int)sizeof(cf);
     } else if (p->path == FXC_PATH_TILED) {
         info->grid = p->tiled_grid_max;
         info->block = p->nchan / 8;

@@ -325,6 +325,36 @@ void tiled_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, i
 bool use_tiled(const fxc_plan* p, int64_t) { return p->path == FXC_PATH_TILED; }
 
 bool tiled_nchan(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
+bool small_nchan(int n) { return n == 16 || n == 32 || n == 64 || n == 128 || n == 256; }
+
+// ---- tiled path, 16 .. 256 channels (k_small.h) -----------------------------------------------------
+#define FXC_SMALL_DISPATCH(p, CALL)                                                   \
+    switch ((p)->nchan) {                                                             \
+        case 16: { constexpr int P = 1; CALL; } break;                                \
+        case 32: { constexpr int P = 2; CALL; } break;                                \
+        case 64: { constexpr int P = 4; CALL; } break;                                \
+        case 128: { constexpr int P = 8; CALL; } break;                               \
+        case 256: { constexpr int P = 16; CALL; } break;                              \
+        default: return fail(p, FXC_ERR_UNSUPPORTED, "no small-transform kernel for nchan=%d", (p)->nchan); \
+    }
+
+int small_setup(fxc_plan* p) {
+    int per_cu = 0;
+    FXC_SMALL_DISPATCH(p, FXC_HIP(p, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                              &per_cu, reinterpret_cast<const void*>(&fx_small_ring_kernel<P>), 256, 0)));
+    if (per_cu < 1) return fail(p, FXC_ERR_HIP, "small-transform kernel for nchan=%d does not fit a CU", p->nchan);
+    p->small_wgs = per_cu * p->cu_count;
+    p->tiled_grid_max = p->small_wgs * 4 * (32 / (p->nchan / 16));      // work items resident at once (tiled_splits)
+    return FXC_OK;
+}
+
+int small_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw) {
+    const int64_t items_per_wg = 4 * (32 / (p->nchan / 16));
+    const int grid = (int)std::min<int64_t>((nc * n_splits + items_per_wg - 1) / items_per_wg, p->small_wgs);
+    FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P>), dim3(grid), dim3(256), 0, p->stream, x, p->num_samp,
+                                             p->n_pts, nc, n_splits, p->d_win4, p->d_tw_small, raw));
+    return FXC_OK;
+}
 
 // frame ranges per chunk so that a launch has at least ~2 work items per resident workgroup
 int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false) {
@@ -379,6 +409,13 @@ int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_ou
 // raw[split][c][k] (natural bin order) for nc chunks starting at x (nc * 2 <= prefilter_streams_per_pass())
 int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
     KernelTimer kt(p);
+    if (p->small) {
+        const int rc = small_launch(p, x, nc, n_splits, raw);
+        if (rc) return rc;
+        kt.stop();
+        FXC_HIP(p, hipGetLastError());
+        return FXC_OK;
+    }
     if (p->prefilter && !dc_u8) {
         const int rc = tiled_prefilter(p, x, 2 * nc, &x);
         if (rc) return rc;

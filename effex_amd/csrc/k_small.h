@@ -1,0 +1,191 @@
+// Part of libfxcorr's single translation unit: included by fxcorr.hip (not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// fused 2-antenna F+X kernel for the small channel counts nchan = 16 P, P in {1, 2, 4, 8, 16} (16 ... 256), ntaps <= 4
+// (--nfft is a free integer in the reference, effex/effex.py:733-739; its ntaps is 4, effex.py:115).
+//
+// The design of k_tiled.h's ring kernel with the workgroup taken out: a transform this small fits P lanes, so nothing
+// crosses a wave and there is no s_barrier after the set-up.  Lanes 0-31 of a wave carry antenna 0, lanes 32-63 antenna 1;
+// each half holds 32 / P work items -- (chunk, range of frames), as in the tiled kernels -- of P adjacent lanes.  Lane u of
+// an item owns the 16 branches m = u + P r (sample N - 1 - m of a frame), keeps four frames of them in a VGPR ring (every
+// sample is fetched once) and the window as quads in LDS.  Decimation in frequency, bin k = k1 + 16 k2:
+//   radix-16 over r in registers                      Y[u][k1] = sum_r v[r] w16^(r k1)
+//   twiddle wN^(u k1)                                 [registers]
+//   transposition inside the P lanes of the item      lane j takes the 16 / P values k1 = j 16/P + t, all u   [LDS, no barrier]
+//   P-point DFTs over u in registers                  v[t P + k2] = bin (j 16/P + t) + 16 k2
+//   v_permlane32_swap pairs the antennas as in fx_fused4096.h; 8 accumulators per lane.
+// Raw rows in natural bin order: raw[(split * n_chunks + c) * N + k], the layout of fx_tiled_kernel (h_run.h folds them).
+// ------------------------------------------------------------------------------------------
+template <int P_>
+struct SmallGeo {
+    static constexpr int P = P_;
+    static constexpr int N = 16 * P;
+    static constexpr int kSub = 32 / P;                 // work items per antenna half of a wave
+    static constexpr int kWaves = 4;
+    static constexpr int kThreads = 64 * kWaves;
+    static constexpr int kItemsPerWg = kWaves * kSub;
+    static constexpr int kGroup = 17 * P;               // cf per item and antenna in the exchange rows: f -> f + (f >> 4)
+    static constexpr int kXchgPerWave = (64 / P) * kGroup;
+};
+
+// a window quad from LDS, read where it is used: the quads are the same for every frame of a lane, and hoisted out of the
+// frame loop they would take 64 VGPRs the ring needs
+__device__ __forceinline__ f4 small_quad(const f4* p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
+    const v4f q = *(lds_v4f_ptr)(p);
+    f4 r;
+    r.x = q[0];
+    r.y = q[1];
+    r.z = q[2];
+    r.w = q[3];
+    return r;
+}
+
+template <class G, int CNT>
+__device__ __forceinline__ void small_load(cf (&xr)[16], const cf* __restrict__ frame, int r0) {
+#pragma unroll
+    for (int r = r0; r < r0 + CNT; ++r) xr[r] = frame[G::P * (15 - r)];
+}
+
+template <class G>
+struct SmallRing {
+    cf h[4][16];
+    cf acc[8];
+};
+
+// one spectrum of both antennas for every item of the wave; the item's frame i sits in ring slot PH; `next` = the frame to
+// fetch into the slot that becomes free (clamped into the chunk by the caller), `active`: frame i belongs to the item's range
+template <class G, int PH>
+__device__ __forceinline__ void small_ring_step(SmallRing<G>& s, const f4* __restrict__ win, const cf* __restrict__ tw,
+                                                cf* __restrict__ grp, int u, const cf* __restrict__ next, bool active) {
+    constexpr int P = G::P;
+    const cf (&x0)[16] = s.h[PH];
+    const cf (&x1)[16] = s.h[(PH + 3) & 3];
+    const cf (&x2)[16] = s.h[(PH + 2) & 3];
+    const cf (&x3)[16] = s.h[(PH + 1) & 3];
+    cf v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const f4 t = small_quad(win + r * P + u);
+        cf a = fxc::cscale(x0[r], t.x);
+        a = fxc::cfma(t.y, x1[r], a);
+        a = fxc::cfma(t.z, x2[r], a);
+        v[r] = fxc::cfma(t.w, x3[r], a);
+    }
+    // the oldest slot is dead: refill it (unconditionally: no branch guards a definition of ring registers)
+    cf (&nx)[16] = s.h[(PH + 1) & 3];
+    small_load<G, 8>(nx, next, 0);
+    fxc::dft16(v);
+    small_load<G, 8>(nx, next, 8);
+    if (P > 1) {
+        cf t[16];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t[k] = fxc::fused::lds_load(tw + u * 16 + k);       // wN^(u k)
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = fxc::cmul(v[k], t[k]);
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int f = k * P + u;
+            grp[f + (f >> 4)] = v[k];
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = fxc::fused::lds_load(grp + 17 * u + q);
+        if (P == 16) {
+            fxc::dft16(v);
+        } else if (P == 8) {
+            fxc::tiled::dft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            fxc::tiled::dft8(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
+        } else if (P == 4) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fxc::dft4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) fxc::tiled::dft2(v[2 * t], v[2 * t + 1]);
+        }
+    }
+    // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same item and bins (see fused_step)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        cf a = v[q], b = v[q + 8];
+        permlane32_swap(a, b);
+        const cf prod = fxc::cmulc(a, b);
+        if (active) s.acc[q] = fxc::cadd(s.acc[q], prod);
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
+                                                              int64_t n_chunks, int n_splits, const f4* __restrict__ win_g,
+                                                              const cf* __restrict__ tw_g, cf* __restrict__ raw) {
+    using G = SmallGeo<P>;
+    __shared__ f4 win[G::N];
+    __shared__ cf tw[G::N];
+    __shared__ cf xchg[G::kWaves * G::kXchgPerWave];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, ant = lane >> 5, l32 = lane & 31;
+    const int sub = l32 / P;
+    const int u = l32 % P;
+    for (int idx = tid; idx < G::N; idx += G::kThreads) {
+        win[idx] = win_g[idx];
+        tw[idx] = tw_g[idx];
+    }
+    SmallRing<G> s;
+    __syncthreads();
+    cf* grp = xchg + wave * G::kXchgPerWave + (lane / P) * G::kGroup;
+    const int64_t per = (n_pts + n_splits - 1) / n_splits;
+    const int64_t total = n_chunks * n_splits;
+    const int64_t stride = (int64_t)gridDim.x * G::kItemsPerWg;
+    for (int64_t w0 = ((int64_t)blockIdx.x * G::kWaves + wave) * G::kSub; w0 < total; w0 += stride) {
+        // this lane's item; the items of a wave beyond the last one run on the last one's samples and store nothing
+        const int64_t w = w0 + sub;
+        const bool live = w < total;
+        const int64_t wc = live ? w : total - 1;
+        const int64_t c = wc % n_chunks, split = wc / n_chunks;
+        const int64_t i0 = split * per;
+        const int64_t i1 = !live ? i0 : ((i0 + per < n_pts) ? i0 + per : n_pts);
+        const cf* px = x + (c * 2 + ant) * num_samp + (P - 1 - u);        // branch u of frame 0
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
+        // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the chunk)
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+            const int64_t f = i0 - d;
+            const bool have = f >= 0 && i0 < i1;
+            small_load<G, 16>(s.h[4 - d], px + (have ? f : 0) * G::N, 0);
+            if (!have) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s.h[4 - d][r] = fxc::mk(0.f, 0.f);
+            }
+        }
+        small_load<G, 16>(s.h[0], px + (i0 < n_pts ? i0 : n_pts - 1) * G::N, 0);
+        for (int64_t st = 0; st < per; st += 4) {
+#define FXC_SMALL_STEP(PH)                                                                                     \
+    {                                                                                                          \
+        const int64_t i = i0 + st + PH;                                                                        \
+        const int64_t nf = i + 1 < n_pts ? i + 1 : n_pts - 1;                                                  \
+        small_ring_step<G, PH>(s, win, tw, grp, u, px + nf * G::N, i < i1);                                        \
+    }
+            FXC_SMALL_STEP(0)
+            if (st + 1 < per) FXC_SMALL_STEP(1)
+            if (st + 2 < per) FXC_SMALL_STEP(2)
+            if (st + 3 < per) FXC_SMALL_STEP(3)
+#undef FXC_SMALL_STEP
+        }
+        if (live) {
+            cf* row = raw + (split * n_chunks + c) * G::N;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = q + 8 * ant, t = idx / P, k2 = idx % P;
+                row[u * (16 / P) + t + 16 * k2] = s.acc[q];
+            }
+        }
+    }
+}
+
+}  // namespace

@@ -624,6 +624,51 @@ def test_tiled_path_matches_oracle(plan_mod, torch, nchan, ntaps, n_chunks, fram
         assert rel_err(rows, g.fx_rows(xd, "SPECTRUM").cpu().numpy()) < 4e-6
 
 
+@pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [
+    (256, 4, 3, 40, 7), (256, 4, 1, 1024, 0), (128, 4, 5, 33, 100), (64, 4, 2, 500, 3), (32, 4, 9, 70, 1), (16, 4, 4, 300, 0),
+    (256, 3, 2, 9, 0), (128, 1, 7, 5, 2), (64, 2, 300, 3, 0), (16, 4, 1, 16384, 5), (32, 4, 1, 1, 0), (256, 4, 700, 2, 0),
+    (16, 4, 1, 3, 0)])
+def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
+    """--nfft 16 ... 256 (a free integer in the reference, effex.py:733-739) on the wave-local kernel (k_small.h): several
+    work items per wave, items beyond the last one, ranges of one frame and empty ranges, ragged tails, integration in
+    uneven calls, continuum, bytes in -- against the oracle and against the generic kernels."""
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(4321, n_chunks, 2, num_samp)
+    window = design_window(ntaps, nchan)
+    rot = plan_mod.rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, -2e-7)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as p:
+        assert p.path == "tiled"
+        p.set_rot(rot)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        for c in range(min(n_chunks, 4)):
+            ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, -2e-7,
+                                      "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        p.fx_accumulate(xd[: n_chunks // 3 + 1])
+        p.fx_accumulate(xd[n_chunks // 3 + 1:])
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ[0], rows[:, 0].astype(np.complex128).mean(axis=0)) < 2e-6
+        cont_rows = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
+        np.testing.assert_allclose(cont_rows[:, 0], rows[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH,
+                                   rtol=2e-5, atol=1e-7 * np.abs(cont_rows).max())
+        u8 = torch.from_numpy(np.random.default_rng(nchan + frames).integers(
+            0, 256, size=(min(n_chunks, 5), 2, num_samp, 2), dtype=np.uint8)).cuda()
+        rows_u8 = p.fx_rows_u8(u8).cpu().numpy()
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window, path="generic") as g:
+        g.set_rot(rot)
+        assert rel_err(rows, g.fx_rows(xd, "SPECTRUM").cpu().numpy()) < 4e-6
+        assert rel_err(rows_u8, g.fx_rows_u8(u8).cpu().numpy()) < TOL_VIS
+
+
+def test_small_channel_counts_outside_the_kernel_fall_back(plan_mod, torch):
+    """More than four taps or more than two antennas at 16 ... 256 channels: the generic kernels, as before."""
+    with plan_mod.FxPlan(2, 256, 8, 256 * 20) as p, plan_mod.FxPlan(3, 128, 4, 128 * 20) as q:
+        assert p.path == "generic" and q.path == "generic"
+    with pytest.raises(NotImplementedError):
+        plan_mod.FxPlan(2, 256, 8, 256 * 20, path="tiled")
+
+
 @pytest.mark.parametrize("n_chunks", [1, 2, 7])
 def test_headline_shape_small_calls_split_frames(plan_mod, torch, n_chunks):
     """The reference hands over one chunk pair per call (effex.py:497-527): with fewer chunks than CUs the headline
@@ -665,9 +710,9 @@ def test_randomized_shapes_tiled_vs_generic(plan_mod, torch):
     splits, uint8 ingest where it applies) against the generic kernels, which share no code with them."""
     rng = np.random.default_rng(20261002)
     for case in range(150):
-        nchan = int(rng.choice([512, 1024, 2048, 4096, 8192]))
-        ntaps = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8, 13, 32]))
-        frames = int(rng.integers(1, 70 if nchan <= 1024 else 24))
+        nchan = int(rng.choice([16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192]))
+        ntaps = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8, 13, 32])) if nchan >= 512 else int(rng.choice([1, 2, 3, 4, 4]))
+        frames = int(rng.integers(1, 70 if nchan <= 1024 else 24)) if nchan >= 512 else int(rng.integers(1, 2000))
         n_chunks = int(rng.choice([1, 1, 2, 3, 7, 19]))
         num_samp = nchan * frames + int(rng.integers(0, nchan))
         x = torch.from_numpy(synth.synth_iq(1000 + case, n_chunks, 2, num_samp)).cuda()
@@ -682,6 +727,8 @@ def test_randomized_shapes_tiled_vs_generic(plan_mod, torch):
             if case % 3 == 0:
                 u8 = torch.from_numpy(rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)).cuda()
                 assert rel_err(t.fx_rows_u8(u8).cpu().numpy(), g.fx_rows_u8(u8).cpu().numpy()) < TOL_VIS, tag
+            if nchan < 512:
+                continue
             if case % 5 == 0:                                        # 3 .. 8 antennas: F-only tiled kernel + X-engine
                 n_ant = int(rng.integers(3, 9))
                 xm = torch.from_numpy(synth.synth_iq(5000 + case, n_chunks, n_ant, num_samp)).cuda()

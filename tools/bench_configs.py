@@ -77,7 +77,7 @@ def main():
     report("8 antennas, 28 baselines, N=1024 (tiled F-only kernel + X-engine)", 8, 1024, 4, 2 ** 18, 512, "SPECTRUM")
     report("4 antennas, 6 baselines, N=4096", 4, 4096, 4, 2 ** 18, 1024, "SPECTRUM")
     report("N=2048 T=32 (reference test shape), 2 antennas", 2, 2048, 32, 2 ** 18, 256, "SPECTRUM")
-    for nfft in (512, 1024, 2048):   # the reference's --nfft at its fixed ntaps = 4 (effex.py:115,778)
+    for nfft in (16, 64, 256, 512, 1024, 2048):   # the reference's --nfft at its fixed ntaps = 4 (effex.py:115,778)
         report("--nfft %d, integrate" % nfft, 2, nfft, 4, 2 ** 18, 4096, "SPECTRUM")
     report("--nfft 8192, integrate (split into two 4096-channel problems)", 2, 8192, 4, 2 ** 18, 1024, "SPECTRUM")
     report("headline shape, one chunk pair per call (the reference's call pattern)", 2, 4096, 4, 2 ** 18, 1, "SPECTRUM",
