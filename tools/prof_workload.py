@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: one named workload a few times, for rocprofv3 (kernel trace / PMC passes; tools/collect_profiles.sh).
 
-    python3 tools/prof_workload.py 8ant | stream1 | nfft2048 | taps32 [reps]
+    python3 tools/prof_workload.py 8ant | stream1 | nfft2048 | taps32 | nfft256 [reps]
 """
 import os
 import sys
@@ -17,6 +17,7 @@ WORKLOADS = {
     "stream1": (2, 1, 4, 2 ** 20, 2048, "CONTINUUM", True),          # BASELINE configs[2](i)
     "nfft2048": (2, 2048, 4, 2 ** 18, 10000, "SPECTRUM", False),     # --nfft 2048, tiled ring kernel
     "taps32": (2, 2048, 32, 2 ** 18, 1024, "SPECTRUM", False),       # the reference test's taps = 32 shape
+    "nfft256": (2, 256, 4, 2 ** 18, 10000, "SPECTRUM", False),       # --nfft 256, the wave-local kernel (k_small.h)
 }
 
 
