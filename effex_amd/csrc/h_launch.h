@@ -341,18 +341,25 @@ bool small_nchan(int n) { return n == 16 || n == 32 || n == 64 || n == 128 || n 
 int small_setup(fxc_plan* p) {
     int per_cu = 0;
     FXC_SMALL_DISPATCH(p, FXC_HIP(p, hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                              &per_cu, reinterpret_cast<const void*>(&fx_small_ring_kernel<P>), 256, 0)));
+                              &per_cu, reinterpret_cast<const void*>(&fx_small_ring_kernel<P, false>), 256, 0)));
     if (per_cu < 1) return fail(p, FXC_ERR_HIP, "small-transform kernel for nchan=%d does not fit a CU", p->nchan);
     p->small_wgs = per_cu * p->cu_count;
     p->tiled_grid_max = p->small_wgs * 4 * (32 / (p->nchan / 16));      // work items resident at once (tiled_splits)
     return FXC_OK;
 }
 
-int small_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw) {
+// dc_u8 != nullptr: x is the byte stream, dc_u8 the streams' conversion offsets
+int small_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, const cf* dc_u8) {
     const int64_t items_per_wg = 4 * (32 / (p->nchan / 16));
     const int grid = (int)std::min<int64_t>((nc * n_splits + items_per_wg - 1) / items_per_wg, p->small_wgs);
-    FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P>), dim3(grid), dim3(256), 0, p->stream, x, p->num_samp,
-                                             p->n_pts, nc, n_splits, p->d_win4, p->d_tw_small, raw));
+    if (dc_u8) {
+        FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P, true>), dim3(grid), dim3(256), 0, p->stream, x,
+                                                 p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw_small, raw, dc_u8));
+    } else {
+        FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P, false>), dim3(grid), dim3(256), 0, p->stream, x,
+                                                 p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw_small, raw,
+                                                 (const cf*)nullptr));
+    }
     return FXC_OK;
 }
 
@@ -410,7 +417,7 @@ int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_ou
 int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
     KernelTimer kt(p);
     if (p->small) {
-        const int rc = small_launch(p, x, nc, n_splits, raw);
+        const int rc = small_launch(p, x, nc, n_splits, raw, dc_u8);
         if (rc) return rc;
         kt.stop();
         FXC_HIP(p, hipGetLastError());

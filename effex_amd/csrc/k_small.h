@@ -45,10 +45,25 @@ __device__ __forceinline__ f4 small_quad(const f4* p) {
     return r;
 }
 
-template <class G, int CNT>
+// CNT branches of a frame into ring registers; U8: the stream is byte pairs (uint8 I, Q), a pair goes into .x as it is
+// and convert_frame_u8 turns the slot into samples when its frame comes up (k_fused4096.h)
+template <class G, int CNT, bool U8>
 __device__ __forceinline__ void small_load(cf (&xr)[16], const cf* __restrict__ frame, int r0) {
+    if (U8) {
+        const unsigned short* f8 = reinterpret_cast<const unsigned short*>(frame);
 #pragma unroll
-    for (int r = r0; r < r0 + CNT; ++r) xr[r] = frame[G::P * (15 - r)];
+        for (int r = r0; r < r0 + CNT; ++r) xr[r].x = __uint_as_float((unsigned)f8[G::P * (15 - r)]);
+    } else {
+#pragma unroll
+        for (int r = r0; r < r0 + CNT; ++r) xr[r] = frame[G::P * (15 - r)];
+    }
+}
+
+// frame f of the stream whose branch-u sample of frame 0 is at px (a pointer to samples, or to byte pairs for U8)
+template <class G, bool U8>
+__device__ __forceinline__ const cf* small_frame(const cf* px, int64_t f) {
+    if (U8) return reinterpret_cast<const cf*>(reinterpret_cast<const unsigned short*>(px) + f * G::N);
+    return px + f * G::N;
 }
 
 template <class G>
@@ -59,10 +74,11 @@ struct SmallRing {
 
 // one spectrum of both antennas for every item of the wave; the item's frame i sits in ring slot PH; `next` = the frame to
 // fetch into the slot that becomes free (clamped into the chunk by the caller), `active`: frame i belongs to the item's range
-template <class G, int PH>
+template <class G, int PH, bool U8>
 __device__ __forceinline__ void small_ring_step(SmallRing<G>& s, const f4* __restrict__ win, const cf* __restrict__ tw,
-                                                cf* __restrict__ grp, int u, const cf* __restrict__ next, bool active) {
+                                                cf* __restrict__ grp, int u, const cf* __restrict__ next, bool active, cf off) {
     constexpr int P = G::P;
+    if (U8) convert_frame_u8(s.h[PH], off);   // the byte pairs fetched a step ago become the samples of slot PH
     const cf (&x0)[16] = s.h[PH];
     const cf (&x1)[16] = s.h[(PH + 3) & 3];
     const cf (&x2)[16] = s.h[(PH + 2) & 3];
@@ -78,9 +94,9 @@ __device__ __forceinline__ void small_ring_step(SmallRing<G>& s, const f4* __res
     }
     // the oldest slot is dead: refill it (unconditionally: no branch guards a definition of ring registers)
     cf (&nx)[16] = s.h[(PH + 1) & 3];
-    small_load<G, 8>(nx, next, 0);
+    small_load<G, 8, U8>(nx, next, 0);
     fxc::dft16(v);
-    small_load<G, 8>(nx, next, 8);
+    small_load<G, 8, U8>(nx, next, 8);
     if (P > 1) {
         cf t[16];
 #pragma unroll
@@ -119,10 +135,12 @@ __device__ __forceinline__ void small_ring_step(SmallRing<G>& s, const f4* __res
     }
 }
 
-template <int P>
+// U8: x is the receivers' bytes (uint8 I,Q pairs), dc[c * 2 + ant] the conversion offset of a stream (k_conditioning.h)
+template <int P, bool U8 = false>
 __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
                                                               int64_t n_chunks, int n_splits, const f4* __restrict__ win_g,
-                                                              const cf* __restrict__ tw_g, cf* __restrict__ raw) {
+                                                              const cf* __restrict__ tw_g, cf* __restrict__ raw,
+                                                              const cf* __restrict__ dc) {
     using G = SmallGeo<P>;
     __shared__ f4 win[G::N];
     __shared__ cf tw[G::N];
@@ -149,7 +167,10 @@ __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restr
         const int64_t c = wc % n_chunks, split = wc / n_chunks;
         const int64_t i0 = split * per;
         const int64_t i1 = !live ? i0 : ((i0 + per < n_pts) ? i0 + per : n_pts);
-        const cf* px = x + (c * 2 + ant) * num_samp + (P - 1 - u);        // branch u of frame 0
+        // branch u of frame 0 (U8: the same element count in byte pairs)
+        const cf* px = U8 ? reinterpret_cast<const cf*>(reinterpret_cast<const unsigned short*>(x) + (c * 2 + ant) * num_samp + (P - 1 - u))
+                          : x + (c * 2 + ant) * num_samp + (P - 1 - u);
+        const cf off = U8 ? dc[c * 2 + ant] : fxc::mk(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
         // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the chunk)
@@ -157,19 +178,20 @@ __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restr
         for (int d = 1; d < 4; ++d) {
             const int64_t f = i0 - d;
             const bool have = f >= 0 && i0 < i1;
-            small_load<G, 16>(s.h[4 - d], px + (have ? f : 0) * G::N, 0);
+            small_load<G, 16, U8>(s.h[4 - d], small_frame<G, U8>(px, have ? f : 0), 0);
+            if (U8) convert_frame_u8(s.h[4 - d], off);
             if (!have) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s.h[4 - d][r] = fxc::mk(0.f, 0.f);
             }
         }
-        small_load<G, 16>(s.h[0], px + (i0 < n_pts ? i0 : n_pts - 1) * G::N, 0);
+        small_load<G, 16, U8>(s.h[0], small_frame<G, U8>(px, i0 < n_pts ? i0 : n_pts - 1), 0);
         for (int64_t st = 0; st < per; st += 4) {
 #define FXC_SMALL_STEP(PH)                                                                                     \
     {                                                                                                          \
         const int64_t i = i0 + st + PH;                                                                        \
         const int64_t nf = i + 1 < n_pts ? i + 1 : n_pts - 1;                                                  \
-        small_ring_step<G, PH>(s, win, tw, grp, u, px + nf * G::N, i < i1);                                        \
+        small_ring_step<G, PH, U8>(s, win, tw, grp, u, small_frame<G, U8>(px, nf), i < i1, off);              \
     }
             FXC_SMALL_STEP(0)
             if (st + 1 < per) FXC_SMALL_STEP(1)
