@@ -1,7 +1,7 @@
 // fxcorr.hip — MI355X (gfx950) F/X hot path: the C ABI of include/fxcorr.h over the kernels.
 //
 // One translation unit.  This file holds the ABI entry points; it includes
-//   fx_math.h, fx_fused4096.h, fx_tiled.h   index maps, butterflies and kernel phases (also compiled by g++ for the
+//   fx_math.h, fx_fused4096.h, fx_tiled.h, fx_small.h   index maps, butterflies and kernel phases (also compiled by g++ for the
 //                                           host emulation under tests/emul)
 //   k_generic.h k_finish.h k_fused4096.h k_tiled.h k_small.h k_prepass.h k_stream.h k_conditioning.h k_delay.h k_synth.h
 //                                           the __global__ kernels, one file per path / step
@@ -57,6 +57,7 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
 #include "../../include/fxcorr.h"
 #include "fx_fused4096.h"
 #include "fx_tiled.h"
+#include "fx_small.h"
 #include "fx_math.h"
 
 using fxc::cd;

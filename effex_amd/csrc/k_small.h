@@ -18,33 +18,8 @@ namespace {
 //   P-point DFTs over u in registers                  v[t P + k2] = bin (j 16/P + t) + 16 k2
 //   v_permlane32_swap pairs the antennas as in fx_fused4096.h; 8 accumulators per lane.
 // Raw rows in natural bin order: raw[(split * n_chunks + c) * N + k], the layout of fx_tiled_kernel (h_run.h folds them).
+// The per-lane phases are in fx_small.h (tests/emul runs them on the host).
 // ------------------------------------------------------------------------------------------
-template <int P_>
-struct SmallGeo {
-    static constexpr int P = P_;
-    static constexpr int N = 16 * P;
-    static constexpr int kSub = 32 / P;                 // work items per antenna half of a wave
-    static constexpr int kWaves = 4;
-    static constexpr int kThreads = 64 * kWaves;
-    static constexpr int kItemsPerWg = kWaves * kSub;
-    static constexpr int kGroup = 17 * P;               // cf per item and antenna in the exchange rows: f -> f + (f >> 4)
-    static constexpr int kXchgPerWave = (64 / P) * kGroup;
-};
-
-// a window quad from LDS, read where it is used: the quads are the same for every frame of a lane, and hoisted out of the
-// frame loop they would take 64 VGPRs the ring needs
-__device__ __forceinline__ f4 small_quad(const f4* p) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
-    const v4f q = *(lds_v4f_ptr)(p);
-    f4 r;
-    r.x = q[0];
-    r.y = q[1];
-    r.z = q[2];
-    r.w = q[3];
-    return r;
-}
-
 // CNT branches of a frame into ring registers; U8: the stream is byte pairs (uint8 I, Q), a pair goes into .x as it is
 // and convert_frame_u8 turns the slot into samples when its frame comes up (k_fused4096.h)
 template <class G, int CNT, bool U8>
@@ -79,51 +54,20 @@ __device__ __forceinline__ void small_ring_step(SmallRing<G>& s, const f4* __res
                                                 cf* __restrict__ grp, int u, const cf* __restrict__ next, bool active, cf off) {
     constexpr int P = G::P;
     if (U8) convert_frame_u8(s.h[PH], off);   // the byte pairs fetched a step ago become the samples of slot PH
-    const cf (&x0)[16] = s.h[PH];
-    const cf (&x1)[16] = s.h[(PH + 3) & 3];
-    const cf (&x2)[16] = s.h[(PH + 2) & 3];
-    const cf (&x3)[16] = s.h[(PH + 1) & 3];
     cf v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const f4 t = small_quad(win + r * P + u);
-        cf a = fxc::cscale(x0[r], t.x);
-        a = fxc::cfma(t.y, x1[r], a);
-        a = fxc::cfma(t.z, x2[r], a);
-        v[r] = fxc::cfma(t.w, x3[r], a);
-    }
+    G::template fir_ring<PH>(s.h, win, u, v);
     // the oldest slot is dead: refill it (unconditionally: no branch guards a definition of ring registers)
     cf (&nx)[16] = s.h[(PH + 1) & 3];
     small_load<G, 8, U8>(nx, next, 0);
     fxc::dft16(v);
     small_load<G, 8, U8>(nx, next, 8);
     if (P > 1) {
-        cf t[16];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) t[k] = fxc::fused::lds_load(tw + u * 16 + k);       // wN^(u k)
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = fxc::cmul(v[k], t[k]);
+        G::twiddle(v, tw, u);
         wave_sync();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int f = k * P + u;
-            grp[f + (f >> 4)] = v[k];
-        }
+        G::store(v, grp, u);
         wave_sync();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = fxc::fused::lds_load(grp + 17 * u + q);
-        if (P == 16) {
-            fxc::dft16(v);
-        } else if (P == 8) {
-            fxc::tiled::dft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-            fxc::tiled::dft8(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
-        } else if (P == 4) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fxc::dft4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) fxc::tiled::dft2(v[2 * t], v[2 * t + 1]);
-        }
+        G::load(grp, u, v);
+        G::transforms(v);
     }
     // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same item and bins (see fused_step)
 #pragma unroll
@@ -141,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restr
                                                               int64_t n_chunks, int n_splits, const f4* __restrict__ win_g,
                                                               const cf* __restrict__ tw_g, cf* __restrict__ raw,
                                                               const cf* __restrict__ dc) {
-    using G = SmallGeo<P>;
+    using G = fxc::small::Geo<P>;
     __shared__ f4 win[G::N];
     __shared__ cf tw[G::N];
     __shared__ cf xchg[G::kWaves * G::kXchgPerWave];
@@ -203,8 +147,7 @@ __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restr
             cf* row = raw + (split * n_chunks + c) * G::N;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int idx = q + 8 * ant, t = idx / P, k2 = idx % P;
-                row[u * (16 / P) + t + 16 * k2] = s.acc[q];
+                row[G::bin_of(u, q + 8 * ant)] = s.acc[q];
             }
         }
     }

@@ -83,6 +83,34 @@ def test_tiled_phases_match_oracle(emul_tiled, nchan, ntaps, frames, ring):
 
 
 @pytest.fixture(scope="module")
+def emul_small():
+    src = os.path.join(HERE, "emul", "emul_small.cpp")
+    lib = os.path.join(HERE, "emul", "libemul_small.so")
+    deps = [src] + [os.path.join(HERE, "..", "effex_amd", "csrc", h) for h in ("fx_small.h", "fx_tiled.h", "fx_fused4096.h", "fx_math.h")]
+    if not os.path.isfile(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", lib, src], check=True)
+    return ctypes.CDLL(lib)
+
+
+@pytest.mark.parametrize("nchan,ntaps,frames", [(16, 4, 40), (32, 4, 33), (64, 4, 21), (128, 4, 12), (256, 4, 9), (256, 3, 5),
+                                                (64, 1, 7), (32, 2, 6)])
+def test_small_phases_match_oracle(emul_small, nchan, ntaps, frames):
+    """fx_small.h (--nfft 16 ... 256 inside one wave): radix-16, twiddle, transposition rows inside the item's lanes,
+    the transforms of P points and the bin mapping, on the host."""
+    num_samp = nchan * frames + 5
+    x = synth.synth_iq(77, 1, 2, num_samp)[0]
+    w = design_window(ntaps, nchan)
+    out = np.zeros(nchan, np.complex128)
+    rc = emul_small.emul_small(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(num_samp), nchan, ntaps,
+                               w.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    f0 = fx_oracle.spectrometer_poly(x[0], ntaps, nchan, w)
+    f1 = fx_oracle.spectrometer_poly(x[1], ntaps, nchan, w)
+    ref = (f0 * np.conj(f1)).sum(axis=0)
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-6
+
+
+@pytest.fixture(scope="module")
 def emul_sched():
     src = os.path.join(HERE, "emul", "emul_sched.cpp")
     lib = os.path.join(HERE, "emul", "libemul_sched.so")
