@@ -187,8 +187,10 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         return fail(p, FXC_ERR_UNSUPPORTED, "the streaming kernel needs n_ant=2, nchan=1");
     // 2 antennas: X fused into the tiled kernel; 3 .. 8: F-only tiled kernel (an odd stream count leaves the last pair
     // half empty) + X-engine
-    // 2 antennas, 16 .. 256 channels, up to four taps: the wave-local variant of the tiled design (k_small.h)
-    const bool small_shape = (p->n_ant == 2 && small_nchan(N) && T <= 4);
+    // 16 .. 256 channels, up to four taps: the wave-local variant of the tiled design (k_small.h) -- 2 antennas in one
+    // F+X kernel, 3 .. 8 through its F-only variant + X-engine (whose one-wave workgroups cover 64 bins: nchan >= 64)
+    const bool small_n = small_nchan(N) && T <= 4;
+    const bool small_shape = small_n && (p->n_ant == 2 || (p->n_ant >= 3 && p->n_ant <= 8 && N >= 64));
     const bool tiled_shape = small_shape || (p->n_ant >= 2 && p->n_ant <= 8 && tiled_nchan(N) && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_TILED && !tiled_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for n_ant=%d nchan=%d", p->n_ant, N);
@@ -279,8 +281,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + kDckLdsBytes));
     }
-    p->small = small_shape && p->path == FXC_PATH_TILED;
-    if (p->small) {
+    p->small = small_shape && p->n_ant == 2 && p->path == FXC_PATH_TILED;
+    p->small_f = small_n && force_path != FXC_PATH_GENERIC;
+    if (p->small || p->small_f) {
         const int P = N / 16;
         std::vector<f4> w4((size_t)N);          // window quads [r P + u] = h[t N + u + P r], t = x, y, z, w (zero beyond ntaps)
         for (int r = 0; r < 16; ++r)
@@ -306,8 +309,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         const int rc = small_setup(p);
         if (rc) return rc;
     }
-    p->tiled_f = (tiled_nchan(N) && p->num_samp <= (1ll << 27) && force_path != FXC_PATH_GENERIC);
-    if ((p->path == FXC_PATH_TILED && !p->small) || p->tiled_f) {
+    p->tiled_f = p->small_f || (tiled_nchan(N) && p->num_samp <= (1ll << 27) && force_path != FXC_PATH_GENERIC);
+    if (!small_nchan(N) && (p->path == FXC_PATH_TILED || p->tiled_f)) {
         // pre-stage twiddles wN^((u + P g) k) at [g + G k][u]; stage tables as on the fused path
         const int P = N / 16, R0 = N >= 4096 ? N / 4096 : N / 256, G = 16 / R0;
         std::vector<cf> tw0((size_t)16 * P);
@@ -497,7 +500,7 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
         info->grid = p->fused_grid_max;
         info->block = fxc::fused::kThreads;
         info->lds_bytes = fxc::fused::kLdsBytes;
-    } else if (p->path == FXC_PATH_TILED && p->small) {
+    } else if (p->path == FXC_PATH_TILED && small_nchan(p->nchan)) {
         info->grid = p->small_wgs;
         info->block = 256;
         info->lds_bytes = p->nchan * (int)sizeof(f4) + 4 * 1088 * (int)sizeof(cf);

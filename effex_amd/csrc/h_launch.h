@@ -341,30 +341,52 @@ bool small_nchan(int n) { return n == 16 || n == 32 || n == 64 || n == 128 || n 
 int small_setup(fxc_plan* p) {
     int per_cu = 0;
     FXC_SMALL_DISPATCH(p, FXC_HIP(p, hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                              &per_cu, reinterpret_cast<const void*>(&fx_small_ring_kernel<P, false>), 256, 0)));
+                              &per_cu, reinterpret_cast<const void*>(&fx_small_ring_kernel<P, false, false>), 256, 0)));
     if (per_cu < 1) return fail(p, FXC_ERR_HIP, "small-transform kernel for nchan=%d does not fit a CU", p->nchan);
     p->small_wgs = per_cu * p->cu_count;
-    p->tiled_grid_max = p->small_wgs * 4 * (32 / (p->nchan / 16));      // work items resident at once (tiled_splits)
+    // work items resident at once (tiled_splits); the F-only variant has the same launch geometry
+    p->tiled_grid_max = p->tiled_grid_max_f = p->small_wgs * 4 * (32 / (p->nchan / 16));
     return FXC_OK;
+}
+
+int small_grid(const fxc_plan* p, int64_t items) {
+    const int64_t items_per_wg = 4 * (32 / (p->nchan / 16));
+    return (int)std::min<int64_t>((items + items_per_wg - 1) / items_per_wg, p->small_wgs);
 }
 
 // dc_u8 != nullptr: x is the byte stream, dc_u8 the streams' conversion offsets
 int small_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, const cf* dc_u8) {
-    const int64_t items_per_wg = 4 * (32 / (p->nchan / 16));
-    const int grid = (int)std::min<int64_t>((nc * n_splits + items_per_wg - 1) / items_per_wg, p->small_wgs);
+    const int grid = small_grid(p, nc * n_splits);
     if (dc_u8) {
-        FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P, true>), dim3(grid), dim3(256), 0, p->stream, x,
-                                                 p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw_small, raw, dc_u8));
+        FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P, true, false>), dim3(grid), dim3(256), 0, p->stream, x,
+                                                 p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw_small, raw, dc_u8,
+                                                 2 * nc, 0, (int64_t)0));
     } else {
-        FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P, false>), dim3(grid), dim3(256), 0, p->stream, x,
+        FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P, false, false>), dim3(grid), dim3(256), 0, p->stream, x,
                                                  p->num_samp, p->n_pts, nc, n_splits, p->d_win4, p->d_tw_small, raw,
-                                                 (const cf*)nullptr));
+                                                 (const cf*)nullptr, 2 * nc, 0, (int64_t)0));
     }
     return FXC_OK;
 }
 
+int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false);
+
+// F-stage only (see tiled_channelize): n_streams consecutive streams -> natural-order spectra, pairs of streams per item
+int small_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a) {
+    KernelTimer kt(p);
+    const int64_t pairs = (n_streams + 1) / 2;
+    const int n_splits = tiled_splits(p, pairs, true);
+    const int grid = small_grid(p, pairs * n_splits);
+    FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P, false, true>), dim3(grid), dim3(256), 0, p->stream, x,
+                                             p->num_samp, p->n_pts, pairs, n_splits, p->d_win4, p->d_tw_small, spec,
+                                             (const cf*)nullptr, n_streams, spec_a, (int64_t)0));
+    kt.stop();
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
 // frame ranges per chunk so that a launch has at least ~2 work items per resident workgroup
-int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false) {
+int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only) {
     const int64_t cap = f_only ? p->tiled_grid_max_f : p->tiled_grid_max;
     const int64_t want = (2 * cap + n_chunks - 1) / n_chunks;
     const int64_t most = std::max<int64_t>(1, p->n_pts / 8);
@@ -435,6 +457,7 @@ int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, 
 
 // F-stage only: n_streams consecutive streams -> spec[stream][i][k], pairs of streams per work item
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a) {
+    if (p->small_f) return small_channelize(p, x, spec, n_streams, spec_a);
     KernelTimer kt(p);
     const int64_t per_pass = prefilter_streams_per_pass(p);
     for (int64_t s0 = 0; s0 < n_streams; s0 += per_pass) {

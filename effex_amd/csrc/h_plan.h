@@ -46,8 +46,9 @@ struct fxc_plan {
     cf* d_tw0 = nullptr;           // tiled: pre-stage twiddles [16][nchan/16]
     int tiled_grid_max = 0, tiled_grid_max_f = 0;   // resident workgroups of the F+X / F-only tiled kernels
     bool tiled_f = false;          // the F-only tiled kernel serves fxc_channelize
-    bool small = false;            // tiled path, nchan 16 .. 256: fx_small_ring_kernel (k_small.h); tiled_grid_max counts
-                                   // the work items resident at once, small_wgs the workgroups
+    bool small = false;            // tiled path, 2 antennas, nchan 16 .. 256: fx_small_ring_kernel (k_small.h);
+                                   // tiled_grid_max counts the work items resident at once, small_wgs the workgroups
+    bool small_f = false;          // its F-only variant serves fxc_channelize and the 3 .. 8 antenna route (with tiled_f)
     int small_wgs = 0;
     cf* d_tw_small = nullptr;      // [nchan/16][16] wN^(u k1)
     bool tiled_ring = false;       // ntaps <= 4 and nchan <= 4096: VGPR frame ring + window in LDS

@@ -4,7 +4,8 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// fused 2-antenna F+X kernel for the small channel counts nchan = 16 P, P in {1, 2, 4, 8, 16} (16 ... 256), ntaps <= 4
+// fused 2-antenna F+X kernel (and its F-only variant) for the small channel counts nchan = 16 P, P in {1, 2, 4, 8, 16}
+// (16 ... 256), ntaps <= 4
 // (--nfft is a free integer in the reference, effex/effex.py:733-739; its ntaps is 4, effex.py:115).
 //
 // The design of k_tiled.h's ring kernel with the workgroup taken out: a transform this small fits P lanes, so nothing
@@ -49,9 +50,11 @@ struct SmallRing {
 
 // one spectrum of both antennas for every item of the wave; the item's frame i sits in ring slot PH; `next` = the frame to
 // fetch into the slot that becomes free (clamped into the chunk by the caller), `active`: frame i belongs to the item's range
-template <class G, int PH, bool U8>
+// SPEC (F-only): the spectrum of frame i goes to out_row in natural bin order instead of into the X-stage
+template <class G, int PH, bool U8, bool SPEC>
 __device__ __forceinline__ void small_ring_step(SmallRing<G>& s, const f4* __restrict__ win, const cf* __restrict__ tw,
-                                                cf* __restrict__ grp, int u, const cf* __restrict__ next, bool active, cf off) {
+                                                cf* __restrict__ grp, int u, const cf* __restrict__ next, bool active, cf off,
+                                                cf* __restrict__ out_row) {
     constexpr int P = G::P;
     if (U8) convert_frame_u8(s.h[PH], off);   // the byte pairs fetched a step ago become the samples of slot PH
     cf v[16];
@@ -69,6 +72,13 @@ __device__ __forceinline__ void small_ring_step(SmallRing<G>& s, const f4* __res
         G::load(grp, u, v);
         G::transforms(v);
     }
+    if (SPEC) {
+        if (active) {
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) out_row[G::bin_of(u, idx)] = v[idx];
+        }
+        return;
+    }
     // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same item and bins (see fused_step)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -79,12 +89,16 @@ __device__ __forceinline__ void small_ring_step(SmallRing<G>& s, const f4* __res
     }
 }
 
-// U8: x is the receivers' bytes (uint8 I,Q pairs), dc[c * 2 + ant] the conversion offset of a stream (k_conditioning.h)
-template <int P, bool U8 = false>
+// U8: x is the receivers' bytes (uint8 I,Q pairs), dc[c * 2 + ant] the conversion offset of a stream (k_conditioning.h).
+// SPEC: F-only -- a "chunk" is a pair of consecutive streams (n_streams of them in all: an odd count leaves the last pair
+// half empty), raw is the spectra buffer with rows placed by spec_row (k_tiled.h), n_chunks the number of pairs.
+template <int P, bool U8 = false, bool SPEC = false>
 __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
                                                               int64_t n_chunks, int n_splits, const f4* __restrict__ win_g,
                                                               const cf* __restrict__ tw_g, cf* __restrict__ raw,
-                                                              const cf* __restrict__ dc) {
+                                                              const cf* __restrict__ dc, int64_t n_streams, int spec_a,
+                                                              int64_t s_base) {
+    static_assert(!(SPEC && U8), "uint8 ingest: F+X only");
     using G = fxc::small::Geo<P>;
     __shared__ f4 win[G::N];
     __shared__ cf tw[G::N];
@@ -111,9 +125,14 @@ __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restr
         const int64_t c = wc % n_chunks, split = wc / n_chunks;
         const int64_t i0 = split * per;
         const int64_t i1 = !live ? i0 : ((i0 + per < n_pts) ? i0 + per : n_pts);
+        // SPEC with an odd stream count: the missing second stream of the last pair re-reads the first and stores nothing
+        const bool valid = !SPEC || (2 * c + ant) < n_streams;
+        const int ant_ld = valid ? ant : 0;
         // branch u of frame 0 (U8: the same element count in byte pairs)
-        const cf* px = U8 ? reinterpret_cast<const cf*>(reinterpret_cast<const unsigned short*>(x) + (c * 2 + ant) * num_samp + (P - 1 - u))
-                          : x + (c * 2 + ant) * num_samp + (P - 1 - u);
+        const cf* px = U8 ? reinterpret_cast<const cf*>(reinterpret_cast<const unsigned short*>(x) + (c * 2 + ant_ld) * num_samp + (P - 1 - u))
+                          : x + (c * 2 + ant_ld) * num_samp + (P - 1 - u);
+        cf* out_base = SPEC ? raw + spec_row(s_base + 2 * c + ant, 0, n_pts, spec_a) * G::N : nullptr;
+        const int64_t out_step = (int64_t)(spec_a > 0 ? spec_a : 1) * G::N;
         const cf off = U8 ? dc[c * 2 + ant] : fxc::mk(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
@@ -135,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restr
     {                                                                                                          \
         const int64_t i = i0 + st + PH;                                                                        \
         const int64_t nf = i + 1 < n_pts ? i + 1 : n_pts - 1;                                                  \
-        small_ring_step<G, PH, U8>(s, win, tw, grp, u, small_frame<G, U8>(px, nf), i < i1, off);              \
+        small_ring_step<G, PH, U8, SPEC>(s, win, tw, grp, u, small_frame<G, U8>(px, nf), valid && i < i1, off, \
+                                         SPEC ? out_base + i * out_step : nullptr);                            \
     }
             FXC_SMALL_STEP(0)
             if (st + 1 < per) FXC_SMALL_STEP(1)
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restr
             if (st + 3 < per) FXC_SMALL_STEP(3)
 #undef FXC_SMALL_STEP
         }
-        if (live) {
+        if (!SPEC && live) {
             cf* row = raw + (split * n_chunks + c) * G::N;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {

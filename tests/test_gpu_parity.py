@@ -662,11 +662,54 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
 
 
 def test_small_channel_counts_outside_the_kernel_fall_back(plan_mod, torch):
-    """More than four taps or more than two antennas at 16 ... 256 channels: the generic kernels, as before."""
-    with plan_mod.FxPlan(2, 256, 8, 256 * 20) as p, plan_mod.FxPlan(3, 128, 4, 128 * 20) as q:
-        assert p.path == "generic" and q.path == "generic"
+    """More than four taps, more than eight antennas, or three and more antennas below 64 channels (an X-engine workgroup
+    covers 64 bins): the generic kernels, as before."""
+    with plan_mod.FxPlan(2, 256, 8, 256 * 20) as p, plan_mod.FxPlan(3, 32, 4, 32 * 20) as q, \
+            plan_mod.FxPlan(9, 128, 4, 128 * 20) as r:
+        assert p.path == "generic" and q.path == "generic" and r.path == "generic"
     with pytest.raises(NotImplementedError):
         plan_mod.FxPlan(2, 256, 8, 256 * 20, path="tiled")
+
+
+@pytest.mark.parametrize("n_ant,nchan,ntaps,n_chunks,frames,extra", [
+    (3, 256, 4, 3, 40, 7), (8, 64, 4, 5, 200, 3), (4, 128, 4, 1, 700, 0), (5, 256, 2, 2, 9, 100), (8, 256, 4, 40, 16, 0),
+    (7, 64, 4, 2, 1, 0)])
+def test_small_channel_counts_multi_antenna(plan_mod, torch, n_ant, nchan, ntaps, n_chunks, frames, extra):
+    """3 ... 8 antennas at 64 ... 256 channels: the F-only variant of the wave-local kernel (odd stream counts leave the last
+    pair half empty) + the X-engine, against the oracle and the generic kernels."""
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(99 + n_ant, n_chunks, n_ant, num_samp)
+    window = design_window(ntaps, nchan)
+    xd = torch.from_numpy(x).cuda()
+    pairs = [(a, b) for a in range(n_ant) for b in range(a + 1, n_ant)]
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as p, \
+            plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window, path="generic") as g:
+        assert p.path == "tiled" and g.path == "generic"
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 0.0)
+        g.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 0.0)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        assert rel_err(rows, g.fx_rows(xd, "SPECTRUM").cpu().numpy()) < 4e-6
+        for idx in (0, len(pairs) // 2, len(pairs) - 1):
+            a, b = pairs[idx]
+            ref = fx_oracle.pfb_xcorr(x[0, a], x[0, b], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+            assert rel_err(rows[0, idx], ref) < TOL_VIS, (a, b)
+        p.fx_accumulate(xd)
+        assert rel_err(p.finalize("SPECTRUM"), rows.astype(np.complex128).mean(axis=0)) < 2e-6
+
+
+@pytest.mark.parametrize("nchan,ntaps,n_streams,frames,extra", [(256, 4, 5, 33, 9), (128, 4, 2, 900, 0), (64, 3, 1, 50, 3),
+                                                                (16, 4, 7, 300, 1), (32, 1, 4, 4, 0)])
+def test_small_channel_counts_channelize(plan_mod, torch, nchan, ntaps, n_streams, frames, extra):
+    """fxc_channelize (the _spectrometer_poly drop-in, effex.py:530-555) at 16 ... 256 branches: natural-order spectra
+    from the F-only variant of the wave-local kernel, against the oracle."""
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(7, n_streams, 1, num_samp)[:, 0]
+    window = design_window(ntaps, nchan)
+    with plan_mod.FxPlan(1, nchan, ntaps, num_samp, window=window) as f:
+        spec = f.channelize(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert spec.shape == (n_streams, num_samp // nchan, nchan)
+    for s_ in range(n_streams):
+        assert rel_err(spec[s_], fx_oracle.spectrometer_poly(x[s_], ntaps, nchan, window)) < TOL_SPEC, s_
 
 
 @pytest.mark.parametrize("n_chunks", [1, 2, 7])
@@ -727,9 +770,7 @@ def test_randomized_shapes_tiled_vs_generic(plan_mod, torch):
             if case % 3 == 0:
                 u8 = torch.from_numpy(rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)).cuda()
                 assert rel_err(t.fx_rows_u8(u8).cpu().numpy(), g.fx_rows_u8(u8).cpu().numpy()) < TOL_VIS, tag
-            if nchan < 512:
-                continue
-            if case % 5 == 0:                                        # 3 .. 8 antennas: F-only tiled kernel + X-engine
+            if case % 5 == 0 and nchan >= 64:                        # 3 .. 8 antennas: F-only tiled kernel + X-engine
                 n_ant = int(rng.integers(3, 9))
                 xm = torch.from_numpy(synth.synth_iq(5000 + case, n_chunks, n_ant, num_samp)).cuda()
                 with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp) as m, \
