@@ -68,6 +68,7 @@ namespace {
 
 constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 channeliser kernels only
+constexpr int kMaxXAnt = 64;         // antennas the F-only + X-engine route takes (fxc_plan_create's own limit)
 constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
 size_t res_direct_bytes() {      // finalize results up to this size are written to host memory by the kernel (FXC_RES_DIRECT: developer knob, bytes)
     static const size_t v = [] { const char* e = std::getenv("FXC_RES_DIRECT"); return e ? (size_t)std::atoll(e) : (size_t)(256 << 10); }();
@@ -190,8 +191,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     // 16 .. 256 channels, up to four taps: the wave-local variant of the tiled design (k_small.h) -- 2 antennas in one
     // F+X kernel, 3 .. 8 through its F-only variant + X-engine (whose one-wave workgroups cover 64 bins: nchan >= 64)
     const bool small_n = small_nchan(N) && T <= 4;
-    const bool small_shape = small_n && (p->n_ant == 2 || (p->n_ant >= 3 && p->n_ant <= 8 && N >= 64));
-    const bool tiled_shape = small_shape || (p->n_ant >= 2 && p->n_ant <= 8 && tiled_nchan(N) && p->num_samp <= (1ll << 27));
+    const bool small_shape = small_n && (p->n_ant == 2 || (p->n_ant >= 3 && p->n_ant <= kMaxXAnt && N >= 64));
+    const bool tiled_shape = small_shape || (p->n_ant >= 2 && p->n_ant <= kMaxXAnt && tiled_nchan(N) && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_TILED && !tiled_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for n_ant=%d nchan=%d", p->n_ant, N);
     p->path = FXC_PATH_GENERIC;
@@ -407,7 +408,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_TILED_DISPATCH(p, rc = tiled_setup<G>(p));
         if (rc) return rc;
     }
-    if (p->n_ant >= 3 && p->n_ant <= 8) {
+    if (p->n_ant >= 3 && p->n_ant <= kMaxXAnt) {
         const void* xfn = nullptr;
         switch (p->n_ant) {
             case 3: xfn = reinterpret_cast<const void*>(&xengine_kernel<3>); break;
@@ -415,7 +416,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             case 5: xfn = reinterpret_cast<const void*>(&xengine_kernel<5>); break;
             case 6: xfn = reinterpret_cast<const void*>(&xengine_kernel<6>); break;
             case 7: xfn = reinterpret_cast<const void*>(&xengine_kernel<7>); break;
-            default: xfn = reinterpret_cast<const void*>(&xengine_kernel<8>); break;
+            case 8: xfn = reinterpret_cast<const void*>(&xengine_kernel<8>); break;
+            default: xfn = reinterpret_cast<const void*>(&xengine_block_kernel); break;
         }
         // one-wave workgroups resident per CU: the occupancy API, bounded by the register file (512 VGPRs per SIMD lane in
         // granules of 8, at most 8 waves per SIMD) -- the API has been seen one block per CU high (MI355X_MICROARCH.md),

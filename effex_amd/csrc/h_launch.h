@@ -199,7 +199,9 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
 // all do the same work, so the launch is cut into exactly as many as are resident at once (p->x_resident, from the
 // occupancy API: one round, no tail) unless a float32 row (fused_unit) allows fewer chunks than that: then many rounds
 int64_t xengine_group(const fxc_plan* p, int64_t nc, int64_t unit) {
-    const int64_t cols = std::max<int64_t>(1, p->nchan / kXThreads);
+    // more than 8 antennas: a column is shared by the G (G + 1) / 2 pairs of antenna blocks (xengine_block_kernel)
+    const int64_t gb = (p->n_ant + kXB - 1) / kXB;
+    const int64_t cols = std::max<int64_t>(1, p->nchan / kXThreads) * (p->n_ant > kXB ? gb * (gb + 1) / 2 : 1);
     const int64_t groups = std::max<int64_t>(1, p->x_resident / cols);
     return std::max<int64_t>(1, std::min<int64_t>(unit, (nc + groups - 1) / groups));
 }
@@ -227,8 +229,9 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
                    bool rows_are_chunks = true, bool dck = false) {
     using namespace fxc::fused;
     if (p->n_ant == 2) return launch_fused(p, x, nc, raw, false, dc_u8, unit, rows_are_chunks, 0, dck);
-    // 3 .. 8 antennas: spectra to HBM as [chunk][frame][antenna] rows (the F-only fused kernel in its own position order
-    // at nchan 4096 / ntaps 4, the F-only tiled kernel in natural order otherwise), then the register-resident X-engine.
+    // 3 .. 64 antennas: spectra to HBM as [chunk][frame][antenna] rows (the F-only fused kernel in its own position order
+    // at nchan 4096 / ntaps 4, the F-only tiled kernel in natural order otherwise), then the register-resident X-engine
+    // (over blocks of 8 antennas beyond 8).
     // unit = chunks per raw row here too: ceil(nc / unit) rows come out
     int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
                                        : tiled_channelize(p, x, spec, nc * p->n_ant, p->n_ant);
@@ -244,7 +247,11 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
         case 6: FXC_X_LAUNCH(6); break;
         case 7: FXC_X_LAUNCH(7); break;
         case 8: FXC_X_LAUNCH(8); break;
-        default: return fail(p, FXC_ERR_UNSUPPORTED, "no X-engine instantiation for n_ant=%d", p->n_ant);
+        default: {
+            const unsigned gb = (unsigned)((p->n_ant + kXB - 1) / kXB);
+            hipLaunchKernelGGL(xengine_block_kernel, dim3(grid.x, grid.y, gb * (gb + 1) / 2), dim3(kXThreads), 0, p->stream, spec,
+                               raw, p->n_pts, p->nchan, nc, cg, p->n_ant);
+        } break;
     }
 #undef FXC_X_LAUNCH
     FXC_HIP(p, hipGetLastError());

@@ -334,6 +334,71 @@ __global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict
     for (int p = 0; p < NB; ++p) raw[(grp * NB + p) * nchan + pos] = fxc::mk(ar[p], ai[p]);
 }
 
+// More than 8 antennas: the same X-engine over blocks of kXB antennas.  A workgroup (one wave, as above) takes a column of
+// 64 positions, a group of chunks and one pair of antenna blocks (I <= J, blockIdx.z): the 64 products of block I with
+// block J, or the 28 of a block with itself, accumulate in registers; every spectrum row is read (A / kXB + 1) / 2 times
+// on average.  Antennas past the last one of a partial block are read as the last one and their products dropped.
+// raw[group][p][pos] with the baselines in the order of xengine_kernel: p(a, b) = a A - a (a + 1) / 2 + b - a - 1.
+constexpr int kXB = 8;
+__global__ __launch_bounds__(kXThreads) void xengine_block_kernel(const cf* __restrict__ spec, cf* __restrict__ raw,
+                                                                 int64_t n_pts, int nchan, int64_t n_chunks, int cg, int A) {
+    const int G = (A + kXB - 1) / kXB;
+    int bi = 0, rem = (int)blockIdx.z;
+    while (rem >= G - bi) {
+        rem -= G - bi;
+        ++bi;
+    }
+    const int bj = bi + rem;
+    const bool diag = bi == bj;
+    const int a0 = bi * kXB, b0 = bj * kXB;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t grp = blockIdx.y;
+    int ra[kXB], rb[kXB];          // row offsets of the blocks' antennas inside a frame's A rows
+#pragma unroll
+    for (int k = 0; k < kXB; ++k) {
+        ra[k] = (a0 + k < A ? a0 + k : A - 1) * nchan;
+        rb[k] = (b0 + k < A ? b0 + k : A - 1) * nchan;
+    }
+    float ar[kXB * kXB], ai[kXB * kXB];
+#pragma unroll
+    for (int p = 0; p < kXB * kXB; ++p) ar[p] = ai[p] = 0.f;
+    const int64_t c_end = (grp + 1) * cg < n_chunks ? (grp + 1) * cg : n_chunks;
+    for (int64_t c = grp * cg; c < c_end; ++c) {
+        const cf* base = spec + (c * A * n_pts) * nchan + pos;
+        for (int64_t i = 0; i < n_pts; ++i) {
+            const cf* frame = base + i * A * nchan;
+            cf za[kXB], zb[kXB];
+#pragma unroll
+            for (int k = 0; k < kXB; ++k) za[k] = frame[ra[k]];
+            if (diag) {
+#pragma unroll
+                for (int k = 0; k < kXB; ++k) zb[k] = za[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < kXB; ++k) zb[k] = frame[rb[k]];
+            }
+#pragma unroll
+            for (int ka = 0; ka < kXB; ++ka)
+#pragma unroll
+                for (int kb = 0; kb < kXB; ++kb) {
+                    ar[ka * kXB + kb] += za[ka].x * zb[kb].x + za[ka].y * zb[kb].y;
+                    ai[ka * kXB + kb] += za[ka].y * zb[kb].x - za[ka].x * zb[kb].y;
+                }
+        }
+    }
+    const int64_t n_base = (int64_t)A * (A - 1) / 2;
+#pragma unroll
+    for (int ka = 0; ka < kXB; ++ka)
+#pragma unroll
+        for (int kb = 0; kb < kXB; ++kb) {
+            const int a = a0 + ka, b = b0 + kb;
+            if (a < b && b < A) {
+                const int64_t p = (int64_t)a * A - (int64_t)a * (a + 1) / 2 + (b - a - 1);
+                raw[(grp * n_base + p) * nchan + pos] = fxc::mk(ar[ka * kXB + kb], ai[ka * kXB + kb]);
+            }
+        }
+}
+
 // out[p][(k + N/2) % N] = sums[p][k] * conj(rot[k]) / count      (effex.py:520-521, integrated)
 __global__ void finalize_spectrum_kernel(const cd* __restrict__ sums, cd* __restrict__ out, const cd* __restrict__ rot,
                                          int nchan, int n_base) {

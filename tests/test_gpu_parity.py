@@ -662,10 +662,10 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
 
 
 def test_small_channel_counts_outside_the_kernel_fall_back(plan_mod, torch):
-    """More than four taps, more than eight antennas, or three and more antennas below 64 channels (an X-engine workgroup
-    covers 64 bins): the generic kernels, as before."""
+    """More than four taps, or three and more antennas below 64 channels (an X-engine workgroup covers 64 bins): the
+    generic kernels, as before."""
     with plan_mod.FxPlan(2, 256, 8, 256 * 20) as p, plan_mod.FxPlan(3, 32, 4, 32 * 20) as q, \
-            plan_mod.FxPlan(9, 128, 4, 128 * 20) as r:
+            plan_mod.FxPlan(9, 16, 4, 16 * 20) as r:
         assert p.path == "generic" and q.path == "generic" and r.path == "generic"
     with pytest.raises(NotImplementedError):
         plan_mod.FxPlan(2, 256, 8, 256 * 20, path="tiled")
@@ -836,6 +836,34 @@ def test_multi_antenna_fused_path(plan_mod, torch, n_ant, nchan, ntaps):
     assert rel_err(rows, rows_g) < 2e-6
     np.testing.assert_allclose(cont, rows.astype(np.complex128).mean(axis=2) / gi.BANDWIDTH, rtol=2e-5,
                                atol=1e-7 * np.abs(cont).max())
+
+
+@pytest.mark.parametrize("n_ant,nchan,ntaps,frames,n_chunks", [(9, 512, 4, 6, 3), (12, 1024, 4, 5, 2), (16, 4096, 4, 4, 3),
+                                                             (17, 256, 4, 30, 2), (24, 2048, 8, 3, 1), (33, 64, 4, 50, 2),
+                                                             (64, 512, 4, 3, 1), (10, 8192, 4, 2, 2)])
+def test_more_than_eight_antennas(plan_mod, torch, n_ant, nchan, ntaps, frames, n_chunks):
+    """9 ... 64 antennas: an F-only kernel + the X-engine over blocks of 8 antennas (partial last blocks, every pair of
+    blocks), baselines in the order (0,1),(0,2)...: against the oracle's integration and the generic kernels' rows."""
+    num_samp = nchan * frames + 5
+    x = synth.synth_iq(31, n_chunks, n_ant, num_samp, delays=np.arange(n_ant) % 9)
+    window = design_window(ntaps, nchan)
+    rot = plan_mod.rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, 1e-7)
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp) as p, \
+            plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, path="generic") as g:
+        assert p.path == "tiled" and g.path == "generic"
+        assert p.n_baselines == n_ant * (n_ant - 1) // 2
+        p.set_rot(rot)
+        g.set_rot(rot)
+        xd = torch.from_numpy(x).cuda()
+        p.fx_accumulate(xd[:1])
+        p.fx_accumulate(xd[1:])
+        integ = p.finalize("SPECTRUM")
+        rows = p.fx_rows(xd).cpu().numpy()
+        rows_g = g.fx_rows(xd).cpu().numpy()
+    assert rel_err(rows, rows_g) < 2e-6
+    assert rel_err(integ, rows.astype(np.complex128).mean(axis=0)) < 2e-6
+    ref = fx_oracle.fx_integrate(x, nchan, window, rot=rot)
+    assert rel_err(integ, ref) < TOL_VIS
 
 
 @pytest.mark.parametrize("ntaps,num_samp", [(4, 2 ** 16 + 3), (4, 2 ** 16), (3, 4098), (32, 5000), (1, 2048), (4, 100),

@@ -40,7 +40,7 @@ def main():
 
     def report(name, n_ant, nchan, ntaps, num_samp, n_chunks, mode, window=None, rows=False):
         x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")
-        synth_fill(x, 1234)
+        synth_fill(x, 1234, delays=None if n_ant <= 8 else [a % 7 for a in range(n_ant)])
         plan = FxPlan(n_ant, nchan, ntaps, num_samp, window=window)
         if rows:
             def fn(k):
@@ -76,6 +76,7 @@ def main():
     report("8 antennas, 28 baselines, N=2048 (tiled F-only kernel + X-engine)", 8, 2048, 4, 2 ** 18, 512, "SPECTRUM")
     report("8 antennas, 28 baselines, N=1024 (tiled F-only kernel + X-engine)", 8, 1024, 4, 2 ** 18, 512, "SPECTRUM")
     report("4 antennas, 6 baselines, N=4096", 4, 4096, 4, 2 ** 18, 1024, "SPECTRUM")
+    report("16 antennas, 120 baselines, N=4096 (tiled F-only kernel + X-engine over blocks of 8)", 16, 4096, 4, 2 ** 18, 128, "SPECTRUM")
     report("N=2048 T=32 (reference test shape), 2 antennas", 2, 2048, 32, 2 ** 18, 256, "SPECTRUM")
     for nfft in (16, 64, 256, 512, 1024, 2048):   # the reference's --nfft at its fixed ntaps = 4 (effex.py:115,778)
         report("--nfft %d, integrate" % nfft, 2, nfft, 4, 2 ** 18, 4096, "SPECTRUM")
