@@ -34,7 +34,7 @@ def main():
     while time.time() < t_end:
         nchan = int(rng.choice([1, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 4096, 4096, 8192]))
         ntaps = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8, 9, 16, 17, 32]))
-        n_ant = int(rng.choice([2, 2, 2, 2, 3, 4, 8]))
+        n_ant = int(rng.choice([2, 2, 2, 2, 3, 4, 8, 11, 16]))
         if nchan == 1:
             n_ant, ntaps = 2, int(rng.choice([1, 3, 4, 7]))
         frames = int(rng.integers(1, 3000 if 1 < nchan <= 256 else (80 if nchan <= 1024 else 30)))
@@ -44,7 +44,8 @@ def main():
         if nchan == 1:
             num_samp = int(rng.integers(ntaps + 1, 70000))
         n_chunks = max(1, min(n_chunks, int(budget // (n_ant * num_samp))))
-        x = torch.from_numpy(synth.synth_iq(int(rng.integers(1, 1 << 30)), n_chunks, n_ant, num_samp)).cuda()
+        x = torch.from_numpy(synth.synth_iq(int(rng.integers(1, 1 << 30)), n_chunks, n_ant, num_samp,
+                                             delays=np.arange(n_ant) % 8)).cuda()
         window = np.linspace(0.4, 0.1, ntaps) if nchan == 1 else None
         tag = dict(nchan=nchan, ntaps=ntaps, n_ant=n_ant, frames=frames, n_chunks=n_chunks, num_samp=num_samp)
         try:
