@@ -230,6 +230,113 @@ def test_sources_fill_staging_windows_in_place(tmp_path):
             src.close()
 
 
+class _FakePipe(object):
+    """The host-visible behaviour of FxPipeline (fxc_pipe_*): ``depth`` pinned slots, acquire refuses when all are in flight,
+    rows come back in submission order.  A 'row' is the per-stream byte / sample sum, so order and content are checkable."""
+    made = []
+
+    def __init__(self, plan, chunks_per_batch, depth=2, mode="SPECTRUM", bandwidth=1.0, u8=False, remove_dc=True):
+        self.chunks, self.depth, self.mode, self.u8 = int(chunks_per_batch), int(depth), mode, u8
+        shape = (self.chunks, 2, plan.num_samp) + ((2,) if u8 else ())
+        self.slots = [np.zeros(shape, dtype=np.uint8 if u8 else np.complex64) for _ in range(self.depth)]
+        self.queue, self.pushed, self.popped, self.plan = [], 0, 0, plan
+        self.max_in_flight = 0
+        _FakePipe.made.append(self)
+
+    @property
+    def in_flight(self):
+        return self.pushed - self.popped
+
+    def acquire(self):
+        assert self.in_flight < self.depth, "acquire with every slot in flight"
+        return self.slots[self.pushed % self.depth]
+
+    def submit(self):
+        assert self.in_flight < self.depth
+        self.queue.append(self.plan.rows_of(self.slots[self.pushed % self.depth], self.mode))
+        self.pushed += 1
+        self.max_in_flight = max(self.max_in_flight, self.in_flight)
+
+    def pop(self, out=None):
+        assert self.in_flight > 0
+        rows = self.queue.pop(0)
+        self.popped += 1
+        if out is None:
+            return rows
+        out.reshape(rows.shape)[...] = rows
+        return out
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class _FakePlan(object):
+    def __init__(self, num_samp, nchan):
+        self.num_samp, self.nchan, self.tail_calls = num_samp, nchan, 0
+
+    def rows_of(self, batch, mode):
+        sums = batch.reshape(batch.shape[0], -1).astype(np.complex128).sum(axis=1)
+        if mode == "SPECTRUM":
+            return (sums[:, None, None] * np.ones((1, 1, self.nchan))).astype(np.complex64)
+        return sums[:, None].astype(np.complex128)
+
+    def fx_rows_u8(self, x, mode, bandwidth, remove_dc=True):
+        self.tail_calls += 1
+        return self.rows_of(np.asarray(x), mode)
+
+    def fx_rows(self, x, mode, bandwidth):
+        self.tail_calls += 1
+        return self.rows_of(np.asarray(x), mode)
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("mode,fmt,n_chunks,batch", [("SPECTRUM", "bin", 11, 4), ("CONTINUUM", "bin", 9, 4), ("SPECTRUM", "csv", 7, 3),
+                                                    ("CONTINUUM", "csv", 5, 8), ("SPECTRUM", "bin", 8, 4), ("SPECTRUM", "bin", 1, 4)])
+def test_batched_run_control_flow(tmp_path, monkeypatch, mode, fmt, n_chunks, batch):
+    """Correlator(batch=K) without a device (a stand-in pipeline and plan): every chunk pair of the recordings becomes one
+    row, in order, whole batches through the pipeline (never more in flight than it has slots), the short last batch
+    through one blocking call, the trailing partial chunk dropped, rows in the sidecar or the csv."""
+    import effex_amd.plan as plan_module
+    from effex_amd import rowsink
+    from effex_amd.correlator import FileSource
+    num_samp, nbins = 256, 16
+    rng = np.random.default_rng(n_chunks * 10 + batch)
+    raw = rng.integers(0, 256, size=(2, n_chunks * num_samp + 9, 2), dtype=np.uint8)
+    for a in range(2):
+        raw[a].tofile(str(tmp_path / ("rx%d.u8" % a)))
+    fake = _FakePlan(num_samp, nbins)
+    _FakePipe.made = []
+    monkeypatch.setattr(plan_module, "FxPipeline", _FakePipe)
+    monkeypatch.setattr(Correlator, "_plan", lambda self: fake)
+    path = str(tmp_path / ("rows." + fmt))
+    src = FileSource(str(tmp_path / "rx0.u8"), str(tmp_path / "rx1.u8"), fmt='u8')
+    cor = Correlator(num_samp=num_samp, nbins=nbins, source=src, output_file=path, mode=mode, output_format=fmt, batch=batch,
+                     calibrate=False)
+    assert cor.num_samp == num_samp
+    assert cor.run_state_machine() == n_chunks
+    assert src.closed and cor.state == 'OFF'
+    want = np.array([raw[:, c * num_samp:(c + 1) * num_samp].astype(np.float64).sum() for c in range(n_chunks)])
+    if fmt == "bin":
+        rf = rowsink.RowFile(path)
+        got = np.asarray(rf.rows)[:, 0].real
+    else:
+        skip = 2 if mode == "SPECTRUM" else 1
+        got = np.loadtxt(path, dtype=np.complex128, delimiter=',', skiprows=skip).reshape(n_chunks, -1)[:, 0].real
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+    pipe, = _FakePipe.made
+    assert pipe.chunks == batch and pipe.u8 and pipe.pushed == pipe.popped == n_chunks // batch
+    assert pipe.max_in_flight <= pipe.depth
+    assert fake.tail_calls == (1 if n_chunks % batch else 0)
+
+
 def test_socket_source_reads_chunk_pairs_from_two_streams():
     """SocketSource (a network stream in place of effex.py:630-664's live dongles): two TCP streams of
     rtl_tcp-style bytes -- a 12-byte greeting, then interleaved uint8 I,Q -- read chunk pair by chunk pair whatever the
