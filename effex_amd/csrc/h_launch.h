@@ -397,7 +397,12 @@ int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only) {
     const int64_t cap = f_only ? p->tiled_grid_max_f : p->tiled_grid_max;
     const int64_t want = (2 * cap + n_chunks - 1) / n_chunks;
     const int64_t most = std::max<int64_t>(1, p->n_pts / 8);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 256));
+    const int64_t fill = std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 256));
+    if (f_only) return (int)fill;
+    // F+X: a work item sums its frames in float32, like the headline kernel's rows at most kRowSpectra of them (small
+    // channel counts and long chunks have thousands of frames per chunk)
+    const int64_t exact = std::min<int64_t>((p->n_pts + kRowSpectra - 1) / kRowSpectra, 65536);
+    return (int)std::max(fill, exact);
 }
 
 // streams the pre-filter handles per pass (its output stays within the workspace target)
