@@ -206,17 +206,25 @@ int64_t xengine_group(const fxc_plan* p, int64_t nc, int64_t unit) {
     return std::max<int64_t>(1, std::min<int64_t>(unit, (nc + groups - 1) / groups));
 }
 
+// frame ranges per chunk group of the X-engines (k_finish.h::x_range): groups of one chunk with more than kRowSpectra frames
+int x_ranges(const fxc_plan* p, int64_t unit) {
+    if (p->n_ant <= 2 || unit > 1) return 1;
+    return (int)std::min<int64_t>((p->n_pts + kRowSpectra - 1) / kRowSpectra, 4096);
+}
+
 // layout of the raw per-chunk sums the fused paths produce (see raw_index)
 int fused_layout(const fxc_plan* p) { return p->n_ant == 2 ? 1 : (p->path == FXC_PATH_FUSED ? 2 : 0); }
 
 // chunks per pass on the fused paths: 2 antennas only need the raw rows; more antennas also the spectra
 int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec_bytes, int64_t* raw_bytes) {
-    const int64_t raw_per_chunk = (int64_t)p->n_base * p->nchan * (int64_t)sizeof(cf);
+    // (3 and more antennas: one raw row per chunk and frame range at most, x_ranges)
+    const int64_t xr = x_ranges(p, 1);
+    const int64_t raw_per_chunk = (int64_t)p->n_base * p->nchan * (int64_t)sizeof(cf) * xr;
     const int64_t spec_per_chunk = p->n_ant == 2 ? 0 : (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
     int64_t cb = ws_target() / (raw_per_chunk + spec_per_chunk);
     if (cb < 1) cb = 1;
     if (cb > n_chunks) cb = n_chunks;
-    if (p->n_ant > 2 && cb > 65535) cb = 65535;   // xengine_kernel carries the chunk in grid.y
+    if (p->n_ant > 2 && cb > 65535 / xr) cb = std::max<int64_t>(1, 65535 / xr);   // the X-engines carry group and range in grid.y
     *spec_bytes = (cb * spec_per_chunk + 255) / 256 * 256;
     // 2 antennas: one leading-part row per workgroup after the chunk rows (fx_fused4096_kernel)
     *raw_bytes = ((cb + (p->n_ant == 2 ? p->fused_grid_max : 0)) * raw_per_chunk + 255) / 256 * 256;
@@ -237,9 +245,10 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
                                        : tiled_channelize(p, x, spec, nc * p->n_ant, p->n_ant);
     if (rc) return rc;
     const int cg = (int)unit;
-    const dim3 grid(p->nchan / kXThreads, (unsigned)((nc + cg - 1) / cg));
+    const int xr = x_ranges(p, unit);
+    const dim3 grid(p->nchan / kXThreads, (unsigned)(((nc + cg - 1) / cg) * xr));
 #define FXC_X_LAUNCH(A) \
-    hipLaunchKernelGGL(xengine_kernel<A>, grid, dim3(kXThreads), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg)
+    hipLaunchKernelGGL(xengine_kernel<A>, grid, dim3(kXThreads), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg, xr)
     switch (p->n_ant) {
         case 3: FXC_X_LAUNCH(3); break;
         case 4: FXC_X_LAUNCH(4); break;
@@ -250,7 +259,7 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
         default: {
             const unsigned gb = (unsigned)((p->n_ant + kXB - 1) / kXB);
             hipLaunchKernelGGL(xengine_block_kernel, dim3(grid.x, grid.y, gb * (gb + 1) / 2), dim3(kXThreads), 0, p->stream, spec,
-                               raw, p->n_pts, p->nchan, nc, cg, p->n_ant);
+                               raw, p->n_pts, p->nchan, nc, cg, p->n_ant, xr);
         } break;
     }
 #undef FXC_X_LAUNCH

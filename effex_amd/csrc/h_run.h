@@ -40,7 +40,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
                                 dc_u8 ? dc_u8 + c0 * 2 : nullptr, unit, false, dc_u8 && p->u8_dck);
             if (rc) return rc;
             // 2 antennas: all the raw rows, leading parts included; more: one row [n_base][nchan] per chunk group
-            const int64_t n_rows = p->n_ant == 2 ? fused_rows(p, nc, unit, false) : (nc + unit - 1) / unit;
+            const int64_t n_rows = p->n_ant == 2 ? fused_rows(p, nc, unit, false) : (nc + unit - 1) / unit * x_ranges(p, unit);
             rc = fold_or_defer(p, raw, part, n_rows, fused_layout(p), c0 + nc >= n_chunks);
             if (rc) return rc;
         }
@@ -158,14 +158,17 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
             if (rc) return rc;
             const int64_t rows = nc * p->n_base;
             const LeadRows lead = p->n_ant == 2 ? fused_lead(p, nc) : kNoLead;
+            // 3 and more antennas: the frame ranges of a chunk are the rows kernels' splits (range-major raw rows)
+            const int xr = x_ranges(p, 1);
+            const int64_t xr_stride = rows * p->nchan;
             if (mode == FXC_MODE_SPECTRUM)
                 hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(rows * p->nchan, 256, p->cu_count)), dim3(256), 0,
                                    p->stream, raw, static_cast<cf*>(out) + c0 * p->n_base * p->nchan, p->d_rot, p->nchan,
-                                   rows, 1, (int64_t)0, inv_pts, fused_layout(p), lead);
+                                   rows, xr, xr_stride, inv_pts, fused_layout(p), lead);
             else
                 hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
                                    dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot,
-                                   p->nchan, rows, 1, (int64_t)0, cscale, fused_layout(p), lead);
+                                   p->nchan, rows, xr, xr_stride, cscale, fused_layout(p), lead);
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;

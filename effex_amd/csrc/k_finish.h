@@ -283,22 +283,41 @@ __global__ void acc_finish_kernel(cd* __restrict__ acc, int nchan, int n_base, F
 // (0,1),(0,2)..(A-2,A-1) -- effex.py:520 for A > 2.
 // Measured and dropped (profiles/r03/experiments.md): two positions per thread with 16-byte loads (+10 %), 1 or 4
 // spectra per trip instead of 2 (+-0.5 %).
+// A group of chunks whose frames are too many for one float32 sum (more than kRowSpectra of them: one chunk per group, cg = 1)
+// is cut into n_ranges frame ranges, each a raw row of its own: blockIdx.y = group * n_ranges + range, raw row =
+// range * n_groups + group -- range-major, so that the rows kernels read the ranges as their splits (k_finish.h top).
+struct XRange {
+    int64_t grp, row, i0, i1;
+};
+__device__ __forceinline__ XRange x_range(int64_t n_pts, int64_t n_chunks, int cg, int n_ranges) {
+    XRange r;
+    const int64_t n_groups = (n_chunks + cg - 1) / cg;
+    r.grp = blockIdx.y / n_ranges;
+    const int64_t rg = blockIdx.y - r.grp * n_ranges;
+    const int64_t per = (n_pts + n_ranges - 1) / n_ranges;
+    r.i0 = rg * per < n_pts ? rg * per : n_pts;
+    r.i1 = r.i0 + per < n_pts ? r.i0 + per : n_pts;
+    r.row = rg * n_groups + r.grp;
+    return r;
+}
+
 constexpr int kXU = 2;           // spectra per trip: kXU * A independent 8-byte loads in flight before the multiply-accumulates
 constexpr int kXThreads = 64;
 template <int A>
 __global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int64_t n_pts,
-                                                           int nchan, int64_t n_chunks, int cg) {
+                                                           int nchan, int64_t n_chunks, int cg, int n_ranges) {
     constexpr int NB = A * (A - 1) / 2;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t grp = blockIdx.y;
+    const XRange xr = x_range(n_pts, n_chunks, cg, n_ranges);
+    const int64_t grp = xr.grp;
     float ar[NB], ai[NB];
 #pragma unroll
     for (int p = 0; p < NB; ++p) ar[p] = ai[p] = 0.f;
     const int64_t c_end = (grp + 1) * cg < n_chunks ? (grp + 1) * cg : n_chunks;
     for (int64_t c = grp * cg; c < c_end; ++c) {
         const cf* base = spec + (c * A * n_pts) * nchan + pos;
-        int64_t i = 0;
-        for (; i + kXU <= n_pts; i += kXU) {
+        int64_t i = xr.i0;
+        for (; i + kXU <= xr.i1; i += kXU) {
             cf z[kXU][A];
 #pragma unroll
             for (int u = 0; u < kXU; ++u)
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict
                     }
             }
         }
-        for (; i < n_pts; ++i) {
+        for (; i < xr.i1; ++i) {
             cf z[A];
 #pragma unroll
             for (int a = 0; a < A; ++a) z[a] = base[(i * A + a) * nchan];
@@ -331,7 +350,7 @@ __global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict
         }
     }
 #pragma unroll
-    for (int p = 0; p < NB; ++p) raw[(grp * NB + p) * nchan + pos] = fxc::mk(ar[p], ai[p]);
+    for (int p = 0; p < NB; ++p) raw[(xr.row * NB + p) * nchan + pos] = fxc::mk(ar[p], ai[p]);
 }
 
 // More than 8 antennas: the same X-engine over blocks of kXB antennas.  A workgroup (one wave, as above) takes a column of
@@ -341,7 +360,8 @@ __global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict
 // raw[group][p][pos] with the baselines in the order of xengine_kernel: p(a, b) = a A - a (a + 1) / 2 + b - a - 1.
 constexpr int kXB = 8;
 __global__ __launch_bounds__(kXThreads) void xengine_block_kernel(const cf* __restrict__ spec, cf* __restrict__ raw,
-                                                                 int64_t n_pts, int nchan, int64_t n_chunks, int cg, int A) {
+                                                                 int64_t n_pts, int nchan, int64_t n_chunks, int cg, int A,
+                                                                 int n_ranges) {
     const int G = (A + kXB - 1) / kXB;
     int bi = 0, rem = (int)blockIdx.z;
     while (rem >= G - bi) {
@@ -352,7 +372,8 @@ __global__ __launch_bounds__(kXThreads) void xengine_block_kernel(const cf* __re
     const bool diag = bi == bj;
     const int a0 = bi * kXB, b0 = bj * kXB;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t grp = blockIdx.y;
+    const XRange xr = x_range(n_pts, n_chunks, cg, n_ranges);
+    const int64_t grp = xr.grp;
     int ra[kXB], rb[kXB];          // row offsets of the blocks' antennas inside a frame's A rows
 #pragma unroll
     for (int k = 0; k < kXB; ++k) {
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(kXThreads) void xengine_block_kernel(const cf* __re
     const int64_t c_end = (grp + 1) * cg < n_chunks ? (grp + 1) * cg : n_chunks;
     for (int64_t c = grp * cg; c < c_end; ++c) {
         const cf* base = spec + (c * A * n_pts) * nchan + pos;
-        for (int64_t i = 0; i < n_pts; ++i) {
+        for (int64_t i = xr.i0; i < xr.i1; ++i) {
             const cf* frame = base + i * A * nchan;
             cf za[kXB], zb[kXB];
 #pragma unroll
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(kXThreads) void xengine_block_kernel(const cf* __re
             const int a = a0 + ka, b = b0 + kb;
             if (a < b && b < A) {
                 const int64_t p = (int64_t)a * A - (int64_t)a * (a + 1) / 2 + (b - a - 1);
-                raw[(grp * n_base + p) * nchan + pos] = fxc::mk(ar[ka * kXB + kb], ai[ka * kXB + kb]);
+                raw[(xr.row * n_base + p) * nchan + pos] = fxc::mk(ar[ka * kXB + kb], ai[ka * kXB + kb]);
             }
         }
 }

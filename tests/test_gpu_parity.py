@@ -673,7 +673,7 @@ def test_small_channel_counts_outside_the_kernel_fall_back(plan_mod, torch):
 
 @pytest.mark.parametrize("n_ant,nchan,ntaps,n_chunks,frames,extra", [
     (3, 256, 4, 3, 40, 7), (8, 64, 4, 5, 200, 3), (4, 128, 4, 1, 700, 0), (5, 256, 2, 2, 9, 100), (8, 256, 4, 40, 16, 0),
-    (7, 64, 4, 2, 1, 0)])
+    (7, 64, 4, 2, 1, 0), (3, 64, 4, 2, 2500, 7), (6, 128, 4, 3, 1025, 0)])    # the last two: more than 1024 frames per chunk
 def test_small_channel_counts_multi_antenna(plan_mod, torch, n_ant, nchan, ntaps, n_chunks, frames, extra):
     """3 ... 8 antennas at 64 ... 256 channels: the F-only variant of the wave-local kernel (odd stream counts leave the last
     pair half empty) + the X-engine, against the oracle and the generic kernels."""
@@ -840,7 +840,7 @@ def test_multi_antenna_fused_path(plan_mod, torch, n_ant, nchan, ntaps):
 
 @pytest.mark.parametrize("n_ant,nchan,ntaps,frames,n_chunks", [(9, 512, 4, 6, 3), (12, 1024, 4, 5, 2), (16, 4096, 4, 4, 3),
                                                              (17, 256, 4, 30, 2), (24, 2048, 8, 3, 1), (33, 64, 4, 50, 2),
-                                                             (64, 512, 4, 3, 1), (10, 8192, 4, 2, 2)])
+                                                             (64, 512, 4, 3, 1), (10, 8192, 4, 2, 2), (12, 64, 4, 3000, 2)])
 def test_more_than_eight_antennas(plan_mod, torch, n_ant, nchan, ntaps, frames, n_chunks):
     """9 ... 64 antennas: an F-only kernel + the X-engine over blocks of 8 antennas (partial last blocks, every pair of
     blocks), baselines in the order (0,1),(0,2)...: against the oracle's integration and the generic kernels' rows."""
