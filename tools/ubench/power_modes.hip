@@ -1,5 +1,5 @@
 // Developer micro-benchmark: run ONE kind of work for ~8 s so rocm-smi can sample package power and sclk.
-//   power_modes <mode>   mode: fma | add | read | read8 | read_fx | read_lin8 | lds | fma_read
+//   power_modes <mode> [seconds] [K]   mode: fma | add | read | read8 | read_fx | read_lin8 | lds | fma_read (K FMAs per 16-byte load, default 6)
 // hipcc --offload-arch=gfx950 -O3 -o power_modes power_modes.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -165,7 +165,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(mode, "read8")) hipLaunchKernelGGL(read8_k, dim3(2048), dim3(512), 0, 0, (const float2*)in, out, n_vec * 2);
         else if (!strcmp(mode, "read_fx")) hipLaunchKernelGGL(read_fx_k, dim3(256), dim3(512), kPin, 0, (const float2*)in, out, 2048);
         else if (!strcmp(mode, "read_lin8")) hipLaunchKernelGGL(read_lin8_k, dim3(256), dim3(512), kPin, 0, (const float2*)in, out, n_vec * 2);
-        else if (!strcmp(mode, "fma_read")) hipLaunchKernelGGL(read_k, dim3(2048), dim3(512), 0, 0, in, out, n_vec, 6);
+        else if (!strcmp(mode, "fma_read")) hipLaunchKernelGGL(read_k, dim3(2048), dim3(512), 0, 0, in, out, n_vec, argc > 3 ? atoi(argv[3]) : 6);
         else if (!strcmp(mode, "lds")) hipLaunchKernelGGL(lds_k, dim3(256), dim3(512), 0, 0, out, 100000);
         else if (!strcmp(mode, "sleep")) hipLaunchKernelGGL(sleep_k, dim3(256), dim3(512), 0, 0, out, 100000, 0);
         else if (!strcmp(mode, "nop")) hipLaunchKernelGGL(sleep_k, dim3(256), dim3(512), 0, 0, out, 1000000, 1);
