@@ -189,9 +189,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     // 2 antennas: X fused into the tiled kernel; 3 .. 8: F-only tiled kernel (an odd stream count leaves the last pair
     // half empty) + X-engine
     // 16 .. 256 channels, up to four taps: the wave-local variant of the tiled design (k_small.h) -- 2 antennas in one
-    // F+X kernel, 3 .. 8 through its F-only variant + X-engine (whose one-wave workgroups cover 64 bins: nchan >= 64)
+    // F+X kernel, 3 .. 64 through its F-only variant + X-engine
     const bool small_n = small_nchan(N) && T <= 4;
-    const bool small_shape = small_n && (p->n_ant == 2 || (p->n_ant >= 3 && p->n_ant <= kMaxXAnt && N >= 64));
+    const bool small_shape = small_n && p->n_ant >= 2 && p->n_ant <= kMaxXAnt;
     const bool tiled_shape = small_shape || (p->n_ant >= 2 && p->n_ant <= kMaxXAnt && tiled_nchan(N) && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_TILED && !tiled_shape)
         return fail(p, FXC_ERR_UNSUPPORTED, "no tiled kernel for n_ant=%d nchan=%d", p->n_ant, N);

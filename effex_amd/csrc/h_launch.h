@@ -246,7 +246,7 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
     if (rc) return rc;
     const int cg = (int)unit;
     const int xr = x_ranges(p, unit);
-    const dim3 grid(p->nchan / kXThreads, (unsigned)(((nc + cg - 1) / cg) * xr));
+    const dim3 grid((p->nchan + kXThreads - 1) / kXThreads, (unsigned)(((nc + cg - 1) / cg) * xr));
 #define FXC_X_LAUNCH(A) \
     hipLaunchKernelGGL(xengine_kernel<A>, grid, dim3(kXThreads), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg, xr)
     switch (p->n_ant) {

@@ -308,6 +308,7 @@ __global__ __launch_bounds__(kXThreads) void xengine_kernel(const cf* __restrict
                                                            int nchan, int64_t n_chunks, int cg, int n_ranges) {
     constexpr int NB = A * (A - 1) / 2;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= nchan) return;          // 16 and 32 channels: part of a wave
     const XRange xr = x_range(n_pts, n_chunks, cg, n_ranges);
     const int64_t grp = xr.grp;
     float ar[NB], ai[NB];
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(kXThreads) void xengine_block_kernel(const cf* __re
     const bool diag = bi == bj;
     const int a0 = bi * kXB, b0 = bj * kXB;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= nchan) return;
     const XRange xr = x_range(n_pts, n_chunks, cg, n_ranges);
     const int64_t grp = xr.grp;
     int ra[kXB], rb[kXB];          // row offsets of the blocks' antennas inside a frame's A rows

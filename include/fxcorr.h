@@ -52,7 +52,7 @@ enum fxc_path {
     FXC_PATH_STREAM = 2,  /* nchan 1, 2 antennas: the continuum streaming limit                             */
     FXC_PATH_TILED = 3    /* nchan 512/1024/2048/4096/8192, any ntaps: 2 antennas in one fused F+X kernel, 3..64
                              via its F-only variant + X-engine; nchan 16/32/64/128/256, ntaps <= 4: the same
-                             design inside one wave (2 antennas; 3..64 from 64 channels on)                  */
+                             design inside one wave (2 antennas, or 3..64 via its F-only variant)           */
 };
 
 typedef struct fxc_info {

@@ -39,7 +39,7 @@ def rel_err(a, b):
 SHAPES = [  # n_ant, nchan, ntaps, num_samp, n_chunks, path
     (2, 4096, 4, 4096 * 6, 7, "fused"), (2, 4096, 4, 4096 * 3, 300, "fused"), (2, 2048, 4, 2048 * 9 + 5, 11, "tiled"),
     (2, 2048, 32, 2048 * 40, 3, "tiled"), (2, 8192, 4, 8192 * 5, 4, "tiled"), (8, 4096, 4, 4096 * 4, 3, "fused"),
-    (2, 1, 4, 5000, 6, "stream"), (3, 32, 4, 32 * 20, 5, "generic"), (3, 64, 4, 64 * 20, 5, "tiled"), (2, 256, 4, 256 * 20, 5, "tiled")]
+    (2, 1, 4, 5000, 6, "stream"), (3, 8, 4, 8 * 20, 5, "generic"), (3, 64, 4, 64 * 20, 5, "tiled"), (2, 256, 4, 256 * 20, 5, "tiled")]
 
 
 @pytest.mark.parametrize("n_ant,nchan,ntaps,num_samp,n_chunks,path", SHAPES)
@@ -233,7 +233,7 @@ sys.path.insert(0, %r)
 from effex_amd import synth
 from effex_amd.plan import FxPlan
 for n_ant, nchan, num_samp, n_chunks, path in ((2, 4096, 4096 * 8, 700, "fused"), (8, 4096, 4096 * 4, 40, "fused"),
-                                               (2, 1024, 1024 * 16, 300, "tiled"), (3, 32, 32 * 40, 200, "generic"),
+                                               (2, 1024, 1024 * 16, 300, "tiled"), (3, 8, 8 * 40, 200, "generic"),
                                                (3, 64, 64 * 40, 200, "tiled"), (2, 128, 128 * 40, 200, "tiled")):
     x = torch.from_numpy(synth.synth_iq(7, n_chunks, n_ant, num_samp)).cuda()
     with FxPlan(n_ant, nchan, 4, num_samp) as p:

@@ -662,10 +662,9 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
 
 
 def test_small_channel_counts_outside_the_kernel_fall_back(plan_mod, torch):
-    """More than four taps, or three and more antennas below 64 channels (an X-engine workgroup covers 64 bins): the
-    generic kernels, as before."""
-    with plan_mod.FxPlan(2, 256, 8, 256 * 20) as p, plan_mod.FxPlan(3, 32, 4, 32 * 20) as q, \
-            plan_mod.FxPlan(9, 16, 4, 16 * 20) as r:
+    """More than four taps, or fewer than 16 channels: the generic kernels, as before."""
+    with plan_mod.FxPlan(2, 256, 8, 256 * 20) as p, plan_mod.FxPlan(3, 32, 5, 32 * 20) as q, \
+            plan_mod.FxPlan(9, 8, 4, 8 * 20) as r:
         assert p.path == "generic" and q.path == "generic" and r.path == "generic"
     with pytest.raises(NotImplementedError):
         plan_mod.FxPlan(2, 256, 8, 256 * 20, path="tiled")
@@ -673,12 +672,13 @@ def test_small_channel_counts_outside_the_kernel_fall_back(plan_mod, torch):
 
 @pytest.mark.parametrize("n_ant,nchan,ntaps,n_chunks,frames,extra", [
     (3, 256, 4, 3, 40, 7), (8, 64, 4, 5, 200, 3), (4, 128, 4, 1, 700, 0), (5, 256, 2, 2, 9, 100), (8, 256, 4, 40, 16, 0),
-    (7, 64, 4, 2, 1, 0), (3, 64, 4, 2, 2500, 7), (6, 128, 4, 3, 1025, 0)])    # the last two: more than 1024 frames per chunk
+    (7, 64, 4, 2, 1, 0), (3, 64, 4, 2, 2500, 7), (6, 128, 4, 3, 1025, 0),    # the last two: more than 1024 frames per chunk
+    (3, 32, 4, 2, 300, 5), (8, 16, 4, 3, 90, 0), (11, 32, 4, 2, 40, 1)])     # part of a wave in the X-engine; blocks of 8
 def test_small_channel_counts_multi_antenna(plan_mod, torch, n_ant, nchan, ntaps, n_chunks, frames, extra):
-    """3 ... 8 antennas at 64 ... 256 channels: the F-only variant of the wave-local kernel (odd stream counts leave the last
-    pair half empty) + the X-engine, against the oracle and the generic kernels."""
+    """3 and more antennas at 16 ... 256 channels: the F-only variant of the wave-local kernel (odd stream counts leave the
+    last pair half empty) + the X-engine, against the oracle and the generic kernels."""
     num_samp = nchan * frames + extra
-    x = synth.synth_iq(99 + n_ant, n_chunks, n_ant, num_samp)
+    x = synth.synth_iq(99 + n_ant, n_chunks, n_ant, num_samp, delays=np.arange(n_ant) % 7)
     window = design_window(ntaps, nchan)
     xd = torch.from_numpy(x).cuda()
     pairs = [(a, b) for a in range(n_ant) for b in range(a + 1, n_ant)]
@@ -770,7 +770,7 @@ def test_randomized_shapes_tiled_vs_generic(plan_mod, torch):
             if case % 3 == 0:
                 u8 = torch.from_numpy(rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)).cuda()
                 assert rel_err(t.fx_rows_u8(u8).cpu().numpy(), g.fx_rows_u8(u8).cpu().numpy()) < TOL_VIS, tag
-            if case % 5 == 0 and nchan >= 64:                        # 3 .. 8 antennas: F-only tiled kernel + X-engine
+            if case % 5 == 0:                                        # 3 .. 8 antennas: F-only tiled kernel + X-engine
                 n_ant = int(rng.integers(3, 9))
                 xm = torch.from_numpy(synth.synth_iq(5000 + case, n_chunks, n_ant, num_samp)).cuda()
                 with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp) as m, \
