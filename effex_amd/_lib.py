@@ -32,6 +32,9 @@ FXC_MEM_HOST = 0
 FXC_MEM_DEVICE = 1
 FXC_MODE_SPECTRUM = 0
 FXC_MODE_CONTINUUM = 1
+FXC_IQ_C64 = 0
+FXC_IQ_U8 = 1
+FXC_IQ_C128 = 2
 FXC_PATH_GENERIC = 0
 FXC_PATH_FUSED = 1
 FXC_PATH_STREAM = 2
@@ -80,9 +83,15 @@ SIGNATURES = {
     "fxc_convert_u8": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int]),
     "fxc_fx_rows_u8": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double, _c.c_int]),
     "fxc_fx_accumulate_u8": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int]),
+    "fxc_fx_rows_iq": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int]),
+    "fxc_fx_accumulate_iq": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
+    "fxc_host_alloc": (_c.c_int, [_c.POINTER(_vp), _c.c_int64]),
+    "fxc_host_free": (_c.c_int, [_vp]),
     "fxc_estimate_delay": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_double, _c.POINTER(_c.c_double)]),
     "fxc_pipe_create": (_c.c_int, [_c.POINTER(_vp), _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double]),
     "fxc_pipe_create_u8": (_c.c_int, [_c.POINTER(_vp), _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double, _c.c_int]),
+    "fxc_pipe_create_iq": (_c.c_int, [_c.POINTER(_vp), _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_double, _c.c_int,
+                                      _c.c_int]),
     "fxc_pipe_acquire": (_c.c_int, [_vp, _c.POINTER(_vp)]),
     "fxc_pipe_submit": (_c.c_int, [_vp]),
     "fxc_pipe_push": (_c.c_int, [_vp, _vp]),

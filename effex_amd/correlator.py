@@ -16,7 +16,8 @@ import time
 import numpy as np
 
 from . import rowsink, synth
-from .plan import FxPlan, rot_table
+from . import _lib
+from .plan import FxPlan, pinned_empty, rot_table
 from .window import design_window
 
 
@@ -259,9 +260,22 @@ class SocketSource(IQSource):
 
 
 def _without_mean(x):
-    """x minus its complex mean (= the mean of the real parts and of the imaginary parts), in complex128."""
+    """x minus its complex mean (= the mean of the real parts and of the imaginary parts), in complex128 -- effex.py:394-395
+    on the host.  Only the CALIBRATE state's one chunk pair per run still takes this route (the delay estimate reads the
+    host arrays); RUN-state chunks are de-meaned on the device."""
     z = np.asarray(x).astype(np.complex128)
     return z - complex(z.real.mean(), z.imag.mean())
+
+
+def _staging_empty(shape, dtype):
+    """Pinned memory when a device is there to pin it for (``fxc_host_alloc``); on a box without one -- where no F/X call
+    can succeed anyway -- an ordinary array, so that the class can still be constructed and configured."""
+    try:
+        return pinned_empty(shape, dtype), True
+    except _lib.FxcError as exc:
+        if exc.status != _lib.FXC_ERR_NODEVICE:
+            raise
+        return np.empty(shape, dtype=dtype), False
 
 
 class Correlator(object):
@@ -317,10 +331,11 @@ class Correlator(object):
         self.mode = mode
         self.start_time = -1
 
-        # staging buffers the hot path reads — effex.py:109-110 (complex128 there; the HIP path
-        # computes in complex64)
-        self.gpu_iq_0 = np.zeros(int(self.num_samp), dtype=np.complex64)
-        self.gpu_iq_1 = np.zeros(int(self.num_samp), dtype=np.complex64)
+        # staging buffers the hot path reads — effex.py:109-110: mapped pinned memory there (cusignal.get_shared_mem) and
+        # here (fxc_host_alloc; complex128 there, complex64 here: the HIP path computes in complex64).
+        # gpu_iq_0 / gpu_iq_1 are the two halves of one pinned chunk pair: _pfb_xcorr hands that buffer to the library as
+        # it is.  Rebinding them to other arrays (as effex.py:394-395 does) is allowed: those are copied in per call.
+        self._alloc_staging(int(self.num_samp))
 
         self.ntaps = 4                                           # effex.py:115
         n_int = len(self.gpu_iq_0) // self.ntaps // self.nbins   # effex.py:118-124
@@ -342,6 +357,54 @@ class Correlator(object):
         self.test_delay_sweep_step = crit_delay / 2
         self.test_delay_offset = self.test_delay_sweep_step * 1600
 
+
+    # -- staging buffers (effex.py:109-110) -------------------------------------------------
+    def _alloc_staging(self, n):
+        self._pair_buf, self._pinned = _staging_empty((1, 2, n), np.complex64)
+        self._pair_buf[...] = 0
+        self._gpu_iq = [self._pair_buf[0, 0], self._pair_buf[0, 1]]
+        self._row_bufs = {}
+        self._staged_dc = False     # the staged pair still carries its mean: the device removes it (set by _stage)
+
+    def _row_buf(self, shape, dtype):
+        key = (shape, np.dtype(dtype).str)
+        buf = self._row_bufs.get(key)
+        if buf is None:
+            buf = self._row_bufs[key] = _staging_empty(shape, dtype)[0]
+        return buf
+
+    @property
+    def gpu_iq_0(self):
+        return self._gpu_iq[0]
+
+    @gpu_iq_0.setter
+    def gpu_iq_0(self, value):
+        self._gpu_iq[0] = value
+        self._staged_dc = False
+
+    @property
+    def gpu_iq_1(self):
+        return self._gpu_iq[1]
+
+    @gpu_iq_1.setter
+    def gpu_iq_1(self, value):
+        self._gpu_iq[1] = value
+        self._staged_dc = False
+
+    def _staged_pair(self):
+        """The pinned chunk pair [1, 2, n] complex64 holding gpu_iq_0 / gpu_iq_1: as it is when they still are its two
+        halves, else filled from whatever they were rebound to (one narrowing pass per stream)."""
+        n = len(self._gpu_iq[0])
+        if self._pair_buf.shape[2] != n:
+            held = list(self._gpu_iq)
+            dc = self._staged_dc
+            self._alloc_staging(n)
+            self._gpu_iq, self._staged_dc = held, dc
+        for a in range(2):
+            view = self._pair_buf[0, a]
+            if self._gpu_iq[a] is not view:
+                np.copyto(view, np.asarray(self._gpu_iq[a]).reshape(n), casting='same_kind')
+        return self._pair_buf
 
     # -- lifecycle --------------------------------------------------------------------------
     def close(self):
@@ -492,18 +555,18 @@ class Correlator(object):
         u8 = getattr(self, "_u8_pair", None)
         if u8 is not None:          # byte source: convert + de-mean + F+X in one device call
             if self.mode in ('CONTINUUM', 'TEST'):
-                return plan.fx_rows_u8(u8, 'CONTINUUM', self.bandwidth, remove_dc=self.remove_dc)[0, 0]
-            return plan.fx_rows_u8(u8, 'SPECTRUM', remove_dc=self.remove_dc)[0, 0].astype(np.complex128)
-        # one pass per stream into a reused complex64 staging array (np.stack + astype costs 8 ms per chunk pair)
-        n = len(self.gpu_iq_0)
-        pair = getattr(self, "_pair_buf", None)
-        if pair is None or pair.shape[2] != n:
-            pair = self._pair_buf = np.empty((1, 2, n), dtype=np.complex64)
-        pair[0, 0] = self.gpu_iq_0
-        pair[0, 1] = self.gpu_iq_1
+                out = self._row_buf((1, 1), np.complex128)
+                return plan.fx_rows_u8(u8, 'CONTINUUM', self.bandwidth, remove_dc=self.remove_dc, out=out)[0, 0]
+            out = self._row_buf((1, 1, int(self.nbins)), np.complex64)
+            return plan.fx_rows_u8(u8, 'SPECTRUM', remove_dc=self.remove_dc, out=out)[0, 0].astype(np.complex128)
+        # the pinned pair goes over PCIe by DMA, the row comes back written by the device into a pinned row buffer; a pair
+        # staged by _stage is de-meaned on the device on the way (effex.py:394-395)
+        pair = self._staged_pair()
         if self.mode in ('CONTINUUM', 'TEST'):
-            return plan.fx_rows(pair, 'CONTINUUM', self.bandwidth)[0, 0]
-        return plan.fx_rows(pair, 'SPECTRUM')[0, 0].astype(np.complex128)
+            out = self._row_buf((1, 1), np.complex128)
+            return plan.fx_rows(pair, 'CONTINUUM', self.bandwidth, remove_dc=self._staged_dc, out=out)[0, 0]
+        out = self._row_buf((1, 1, int(self.nbins)), np.complex64)
+        return plan.fx_rows(pair, 'SPECTRUM', remove_dc=self._staged_dc, out=out)[0, 0].astype(np.complex128)
 
     def _run_task(self):
         """effex.py:490-494."""
@@ -569,15 +632,29 @@ class Correlator(object):
             b0 = np.ascontiguousarray(iq_0, dtype=np.uint8).reshape(-1, 2)
             b1 = np.ascontiguousarray(iq_1, dtype=np.uint8).reshape(-1, 2)
             if 'CALIBRATE' != self.state:
-                self._u8_pair = np.stack([b0, b1])[None]
+                n = len(b0)
+                buf = getattr(self, "_u8_buf", None)
+                if buf is None or buf.shape[2] != n:
+                    buf = self._u8_buf = _staging_empty((1, 2, n, 2), np.uint8)[0]
+                buf[0, 0], buf[0, 1] = b0, b1
+                self._u8_pair = buf
                 return
             iq_0 = ((b0[:, 0].astype(np.float64) - 127.5) + 1j * (b0[:, 1].astype(np.float64) - 127.5)) / 127.5
             iq_1 = ((b1[:, 0].astype(np.float64) - 127.5) + 1j * (b1[:, 1].astype(np.float64) - 127.5)) / 127.5
-        self.gpu_iq_0 = np.asarray(iq_0)
-        self.gpu_iq_1 = np.asarray(iq_1)
-        if self.remove_dc:   # per-chunk mean of I and of Q removed on the host, as effex.py:394-395 does
-            self.gpu_iq_0 = _without_mean(self.gpu_iq_0)
-            self.gpu_iq_1 = _without_mean(self.gpu_iq_1)
+        if 'CALIBRATE' == self.state:
+            # one chunk pair per run, read by the delay estimate on the host side of the ABI: de-meaned as effex.py:394-395
+            self.gpu_iq_0 = _without_mean(iq_0) if self.remove_dc else np.asarray(iq_0)
+            self.gpu_iq_1 = _without_mean(iq_1) if self.remove_dc else np.asarray(iq_1)
+            return
+        # RUN: one narrowing pass per stream into the pinned pair; the mean (effex.py:394-395) comes off on the device,
+        # in front of the F+X kernels, when _pfb_xcorr hands the pair over
+        n = len(iq_0)
+        if self._pair_buf.shape[2] != n:
+            self._alloc_staging(n)
+        for a, iq in enumerate((iq_0, iq_1)):
+            np.copyto(self._pair_buf[0, a], np.asarray(iq).reshape(n), casting='same_kind')
+        self._gpu_iq = [self._pair_buf[0, 0], self._pair_buf[0, 1]]
+        self._staged_dc = bool(self.remove_dc)
 
     def _run_batched(self, first_pair, sink, fh):
         """The RUN state for ``batch`` > 1: chunk pairs go ``batch`` at a time through a three-slot ``FxPipeline`` -- the
@@ -604,12 +681,10 @@ class Correlator(object):
                 view[0, 1][...] = np.asarray(pair[1]).reshape(view[0, 1].shape)
                 k = 1
             k += self.source.read_many_into(n, view[k:])
-            if not u8 and self.remove_dc:       # effex.py:394-395, in complex128, rounded once like the per-pair path
-                for c in range(k):
-                    for a in range(2):
-                        view[c, a][...] = _without_mean(view[c, a])
             return k
 
+        # complex sources: samples are rounded to complex64 in the pinned slot and de-meaned on the device
+        # (effex.py:394-395 through fxc_pipe_create_iq) -- no host pass over the samples
         with FxPipeline(plan, K, depth=3, mode=mode, bandwidth=self.bandwidth, u8=u8, remove_dc=self.remove_dc) as pipe:
             def drain():
                 if sink is not None:
@@ -622,7 +697,8 @@ class Correlator(object):
             # the fill of a slot (file / socket -> pinned memory, no library call) runs beside the main thread, which
             # meanwhile collects the oldest batch in flight; every fxc_* call stays on the main thread
             import concurrent.futures
-            with concurrent.futures.ThreadPoolExecutor(max_workers=1) as filler:
+            filler = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            try:
                 pending, k = first_pair, 0
                 while True:
                     view = pipe.acquire()
@@ -634,12 +710,19 @@ class Correlator(object):
                     if k < K:
                         break
                     pipe.submit()
+            except BaseException:
+                # the filler may sit in a blocking read (a socket source): closing the source ends that read, and the
+                # exit below does not wait for it
+                self.source.close()
+                filler.shutdown(wait=False, cancel_futures=True)
+                raise
+            filler.shutdown(wait=True)
             while pipe.in_flight:
                 rows += drain()
             if k:               # the stream ended inside a batch
                 tail = view[:k]
                 out = (plan.fx_rows_u8(tail, mode, self.bandwidth, remove_dc=self.remove_dc) if u8
-                       else plan.fx_rows(tail, mode, self.bandwidth))
+                       else plan.fx_rows(tail, mode, self.bandwidth, remove_dc=self.remove_dc))
                 if sink is not None:
                     sink.write_rows(out[:, 0])
                 else:

@@ -51,6 +51,7 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -190,7 +191,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     // half empty) + X-engine
     // 16 .. 256 channels, up to four taps: the wave-local variant of the tiled design (k_small.h) -- 2 antennas in one
     // F+X kernel, 3 .. 64 through its F-only variant + X-engine
-    const bool small_n = small_nchan(N) && T <= 4;
+    const bool small_n = small_nchan(N) && T <= 4 && p->num_samp / N < (1ll << 31);   // (32-bit frame counters in the kernel)
     const bool small_shape = small_n && p->n_ant >= 2 && p->n_ant <= kMaxXAnt;
     const bool tiled_shape = small_shape || (p->n_ant >= 2 && p->n_ant <= kMaxXAnt && tiled_nchan(N) && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_TILED && !tiled_shape)
@@ -811,6 +812,12 @@ int fxc_finalize(fxc_plan* p, void* out_host, int mode, double bandwidth, int re
     return fxc_finalize_wait(p, out_host);
 }
 
+// workgroups per stream of the subtract / narrow pass: enough to fill the chip when a call has few streams (one chunk
+// pair: the reference's own call), a handful when it has thousands
+static int cond_slices(const fxc_plan* p, int64_t n_streams) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)p->cu_count * 8 + n_streams - 1) / n_streams));
+}
+
 static int conditioning_common(fxc_plan* p, int64_t n_streams, const void* x, void* out) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     if (n_streams < 0) return fail(p, FXC_ERR_ARG, "n_streams < 0");
@@ -827,11 +834,11 @@ int fxc_remove_dc(fxc_plan* p, const void* x_dev, void* out_dev, int64_t n_strea
     rc = ensure_ws(p, n_streams * n_slices * 2 * (int64_t)sizeof(double));
     if (rc) return rc;
     double* part = static_cast<double*>(p->d_ws);
-    const int64_t total = n_streams * p->num_samp;
     hipLaunchKernelGGL(dc_sum_c64_kernel, dim3(n_slices, (unsigned)n_streams), dim3(256), 0, p->stream,
                        static_cast<const cf*>(x_dev), part, p->num_samp, n_slices);
-    hipLaunchKernelGGL(dc_apply_c64_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream,
-                       static_cast<const cf*>(x_dev), static_cast<cf*>(out_dev), part, p->num_samp, n_slices, total);
+    hipLaunchKernelGGL(dc_apply_c64_kernel, dim3(cond_slices(p, n_streams), (unsigned)n_streams), dim3(256), 0, p->stream,
+                       static_cast<const cf*>(x_dev), static_cast<cf*>(out_dev), part, p->num_samp, cond_slices(p, n_streams),
+                       n_slices, 1);
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
 }
@@ -956,6 +963,129 @@ int fx_u8_entry(fxc_plan* p, const void* iq_u8, void* out, int64_t n_chunks, int
 
 }  // namespace
 
+namespace {
+
+// complex64 with DC removal, or complex128 (narrowed on the device, after the DC removal when asked for): sums, then
+// subtract / narrow into a complex64 staging buffer -- or in place when x is the library's own complex64 staging copy of a
+// host buffer (x_is_scratch) -- then the plan's usual kernels.  The caller's device buffers are never written.
+int fx_cond_dev(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mode, double bandwidth, int fmt, int remove_dc,
+                bool rows, bool x_is_scratch) {
+    constexpr int kSlices = 32;
+    const size_t in_elem = fmt == FXC_IQ_C128 ? sizeof(cd) : sizeof(cf);
+    const size_t row_bytes = mode == FXC_MODE_SPECTRUM ? (size_t)p->n_base * p->nchan * sizeof(cf) : (size_t)p->n_base * sizeof(cd);
+    const bool in_place = x_is_scratch && fmt == FXC_IQ_C64;
+    // streams per pass: the stream index rides in grid.y, and the staging buffer stays within the workspace target
+    int64_t per_pass = 65535 / p->n_ant;
+    if (!in_place) per_pass = std::min<int64_t>(per_pass, ws_target() / ((int64_t)p->n_ant * p->num_samp * (int64_t)sizeof(cf)));
+    per_pass = std::max<int64_t>(1, std::min<int64_t>(per_pass, n_chunks));
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += per_pass) {
+        const int64_t nc = std::min<int64_t>(per_pass, n_chunks - c0);
+        const int64_t n_streams = nc * p->n_ant;
+        const char* xb = static_cast<const char*>(x) + (size_t)c0 * p->n_ant * p->num_samp * in_elem;
+        void* ob = rows ? static_cast<char*>(out) + (size_t)c0 * row_bytes : nullptr;
+        int rc = grow(p, &p->d_dc, &p->dc_bytes, (size_t)n_streams * kSlices * 2 * sizeof(double));
+        if (rc) return rc;
+        double* part = static_cast<double*>(p->d_dc);
+        cf* xc = in_place ? reinterpret_cast<cf*>(const_cast<char*>(xb)) : nullptr;
+        if (!in_place) {
+            rc = grow(p, &p->d_stage[2], &p->stage_bytes[2], (size_t)n_streams * p->num_samp * sizeof(cf));
+            if (rc) return rc;
+            xc = static_cast<cf*>(p->d_stage[2]);
+        }
+        const dim3 sum_grid(kSlices, (unsigned)n_streams), app_grid(cond_slices(p, n_streams), (unsigned)n_streams);
+        if (fmt == FXC_IQ_C128) {
+            if (remove_dc)
+                hipLaunchKernelGGL(dc_sum_c128_kernel, sum_grid, dim3(256), 0, p->stream, reinterpret_cast<const cd*>(xb), part,
+                                   p->num_samp, kSlices);
+            hipLaunchKernelGGL(narrow_c128_kernel, app_grid, dim3(256), 0, p->stream, reinterpret_cast<const cd*>(xb), xc, part,
+                               p->num_samp, (int)app_grid.x, kSlices, remove_dc ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL(dc_sum_c64_kernel, sum_grid, dim3(256), 0, p->stream, reinterpret_cast<const cf*>(xb), part,
+                               p->num_samp, kSlices);
+            hipLaunchKernelGGL(dc_apply_c64_kernel, app_grid, dim3(256), 0, p->stream, reinterpret_cast<const cf*>(xb), xc, part,
+                               p->num_samp, (int)app_grid.x, kSlices, 1);
+        }
+        FXC_HIP(p, hipGetLastError());
+        rc = rows ? fx_rows_dev(p, xc, ob, nc, mode, bandwidth) : fx_accumulate_dev(p, xc, nc);
+        if (rc) return rc;
+    }
+    return FXC_OK;
+}
+
+int fx_iq_entry(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mem_kind, int mode, double bandwidth, int fmt,
+                int remove_dc, bool rows) {
+    if (fmt == FXC_IQ_U8) return fx_u8_entry(p, x, out, n_chunks, mem_kind, mode, bandwidth, remove_dc, rows);
+    if (fmt != FXC_IQ_C64 && fmt != FXC_IQ_C128) return fail(p, FXC_ERR_ARG, "bad iq_format %d", fmt);
+    if (fmt == FXC_IQ_C64 && !remove_dc)
+        return rows ? fxc_fx_rows(p, x, out, n_chunks, mem_kind, mode, bandwidth) : fxc_fx_accumulate(p, x, n_chunks, mem_kind);
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
+    if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
+    if (n_chunks < 0) return fail(p, FXC_ERR_ARG, "n_chunks < 0");
+    if (rows && mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
+    if (rows && mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
+    if (n_chunks == 0) return FXC_OK;
+    if (!x || (rows && !out)) return fail(p, FXC_ERR_ARG, "NULL buffer");
+    FXC_DEVICE(p, p->device);
+    if (mem_kind == FXC_MEM_DEVICE) return fx_cond_dev(p, x, out, n_chunks, mode, bandwidth, fmt, remove_dc, rows, false);
+    if (mem_kind != FXC_MEM_HOST) return fail(p, FXC_ERR_ARG, "bad mem_kind %d", mem_kind);
+    const size_t xb = (size_t)n_chunks * p->n_ant * p->num_samp * (fmt == FXC_IQ_C128 ? sizeof(cd) : sizeof(cf));
+    const size_t ob = !rows ? 0
+                            : (mode == FXC_MODE_SPECTRUM ? (size_t)n_chunks * p->n_base * p->nchan * sizeof(cf)
+                                                         : (size_t)n_chunks * p->n_base * sizeof(cd));
+    return with_host_staging(p, x, xb, out, ob, [&](const cf* dx, void* dout) {
+        return fx_cond_dev(p, dx, dout, n_chunks, mode, bandwidth, fmt, remove_dc, rows, true);
+    });
+}
+
+}  // namespace
+
+int fxc_fx_rows_iq(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mem_kind, int mode, double bandwidth,
+                   int iq_format, int remove_dc) {
+    return fx_iq_entry(p, x, out, n_chunks, mem_kind, mode, bandwidth, iq_format, remove_dc, true);
+}
+
+int fxc_fx_accumulate_iq(fxc_plan* p, const void* x, int64_t n_chunks, int mem_kind, int iq_format, int remove_dc) {
+    return fx_iq_entry(p, x, nullptr, n_chunks, mem_kind, FXC_MODE_SPECTRUM, 1.0, iq_format, remove_dc, false);
+}
+
+int fxc_host_alloc(void** out, int64_t bytes) {
+    if (!out) return fail(nullptr, FXC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (bytes <= 0) return fail(nullptr, FXC_ERR_ARG, "bytes must be > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device available (pinned memory needs the HIP runtime)");
+    void* h = nullptr;
+    const hipError_t e = hipHostMalloc(&h, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) return fail(nullptr, FXC_ERR_NOMEM, "hipHostMalloc of %lld bytes failed: %s", (long long)bytes, hipGetErrorString(e));
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) {
+        (void)hipHostFree(h);
+        return fail(nullptr, FXC_ERR_HIP, "hipHostGetDevicePointer failed for a fresh pinned block");
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        g_pinned.push_back({static_cast<char*>(h), static_cast<char*>(d), (size_t)bytes});
+    }
+    *out = h;
+    return FXC_OK;
+}
+
+int fxc_host_free(void* ptr) {
+    if (!ptr) return FXC_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        size_t k = 0;
+        while (k < g_pinned.size() && g_pinned[k].host != ptr) ++k;
+        if (k == g_pinned.size()) return fail(nullptr, FXC_ERR_ARG, "not a pointer fxc_host_alloc returned");
+        g_pinned.erase(g_pinned.begin() + (long)k);
+    }
+    // hipHostFree waits for the device: nothing queued can still touch the block when it goes
+    const hipError_t e = hipHostFree(ptr);
+    if (e != hipSuccess) return fail(nullptr, FXC_ERR_HIP, "hipHostFree failed: %s", hipGetErrorString(e));
+    return FXC_OK;
+}
+
 int fxc_fx_rows_u8(fxc_plan* p, const void* iq_u8, void* out, int64_t n_chunks, int mem_kind, int mode, double bandwidth,
                    int remove_dc) {
     return fx_u8_entry(p, iq_u8, out, n_chunks, mem_kind, mode, bandwidth, remove_dc, true);
@@ -1061,19 +1191,16 @@ int fxc_pipe_destroy(fxc_pipe* q) {
     return FXC_OK;
 }
 
-static int pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth, bool u8,
-                       int remove_dc);
-
 int fxc_pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth) {
-    return pipe_create(out, p, chunks_per_batch, depth, mode, bandwidth, false, 0);
+    return fxc_pipe_create_iq(out, p, chunks_per_batch, depth, mode, bandwidth, FXC_IQ_C64, 0);
 }
 
 int fxc_pipe_create_u8(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth,
                        int remove_dc) {
-    return pipe_create(out, p, chunks_per_batch, depth, mode, bandwidth, true, remove_dc);
+    return fxc_pipe_create_iq(out, p, chunks_per_batch, depth, mode, bandwidth, FXC_IQ_U8, remove_dc);
 }
 
-static int pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth, bool u8,
+int fxc_pipe_create_iq(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, int depth, int mode, double bandwidth, int fmt,
                        int remove_dc) {
     if (!out || !p) return fail(p, FXC_ERR_ARG, "NULL argument");
     *out = nullptr;
@@ -1081,6 +1208,7 @@ static int pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, in
     if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
     if (mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
     if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
+    if (fmt != FXC_IQ_C64 && fmt != FXC_IQ_U8 && fmt != FXC_IQ_C128) return fail(p, FXC_ERR_ARG, "bad iq_format %d", fmt);
     FXC_DEVICE(p, p->device);
     fxc_pipe* q = new (std::nothrow) fxc_pipe();
     if (!q) return fail(p, FXC_ERR_NOMEM, "host allocation failed");
@@ -1089,9 +1217,9 @@ static int pipe_create(fxc_pipe** out, fxc_plan* p, int64_t chunks_per_batch, in
     q->depth = depth;
     q->mode = mode;
     q->bandwidth = bandwidth;
-    q->u8 = u8;
+    q->fmt = fmt;
     q->remove_dc = remove_dc;
-    q->in_bytes = (size_t)chunks_per_batch * p->n_ant * p->num_samp * (u8 ? 2 : sizeof(cf));
+    q->in_bytes = (size_t)chunks_per_batch * p->n_ant * p->num_samp * (fmt == FXC_IQ_U8 ? 2 : (fmt == FXC_IQ_C128 ? sizeof(cd) : sizeof(cf)));
     q->out_bytes = mode == FXC_MODE_SPECTRUM ? (size_t)chunks_per_batch * p->n_base * p->nchan * sizeof(cf)
                                              : (size_t)chunks_per_batch * p->n_base * sizeof(cd);
     q->slots.resize((size_t)depth);
@@ -1136,9 +1264,12 @@ int fxc_pipe_submit(fxc_pipe* q) {
     FXC_HIP(p, hipMemcpyAsync(sl.d_in, sl.h_in, q->in_bytes, hipMemcpyHostToDevice, q->s_in));
     FXC_HIP(p, hipEventRecord(sl.ev_in, q->s_in));
     FXC_HIP(p, hipStreamWaitEvent(p->stream, sl.ev_in, 0));
-    int rc = q->u8 ? fx_u8_dev(p, static_cast<const unsigned char*>(sl.d_in), sl.d_out, q->chunks, q->mode, q->bandwidth,
-                               q->remove_dc, true)
-                   : fx_rows_dev(p, static_cast<const cf*>(sl.d_in), sl.d_out, q->chunks, q->mode, q->bandwidth);
+    // the slot's device copy is the pipe's own: complex64 batches are de-meaned in place
+    int rc = q->fmt == FXC_IQ_U8 ? fx_u8_dev(p, static_cast<const unsigned char*>(sl.d_in), sl.d_out, q->chunks, q->mode,
+                                             q->bandwidth, q->remove_dc, true)
+             : (q->fmt == FXC_IQ_C128 || q->remove_dc)
+                 ? fx_cond_dev(p, sl.d_in, sl.d_out, q->chunks, q->mode, q->bandwidth, q->fmt, q->remove_dc, true, true)
+                 : fx_rows_dev(p, static_cast<const cf*>(sl.d_in), sl.d_out, q->chunks, q->mode, q->bandwidth);
     if (rc) return rc;
     FXC_HIP(p, hipEventRecord(sl.ev_compute, p->stream));
     FXC_HIP(p, hipStreamWaitEvent(q->s_out, sl.ev_compute, 0));

@@ -8,6 +8,25 @@ namespace {
 
 thread_local std::string g_lib_error;
 
+// Pinned host allocations handed out by fxc_host_alloc (process-wide).  with_host_staging looks a caller's pointer up
+// here: an output buffer inside one of them is written by the finishing kernel through `dev` (no copy back).
+struct PinnedBlock {
+    char* host;
+    char* dev;       // the same memory as the devices see it
+    size_t bytes;
+};
+std::mutex g_pinned_mutex;
+std::vector<PinnedBlock> g_pinned;
+
+// device address of [ptr, ptr + bytes) if it lies inside one fxc_host_alloc block, else nullptr
+void* pinned_device_ptr(const void* ptr, size_t bytes) {
+    const char* q = static_cast<const char*>(ptr);
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (const PinnedBlock& b : g_pinned)
+        if (q >= b.host && q + bytes <= b.host + b.bytes) return b.dev + (q - b.host);
+    return nullptr;
+}
+
 }  // namespace
 
 
@@ -117,7 +136,7 @@ struct fxc_pipe {
     double bandwidth = 1.0;
     size_t in_bytes = 0, out_bytes = 0;
     bool counted = false;      // registered in plan->live_pipes
-    bool u8 = false;           // batches are RTL-SDR byte pairs (fxc_pipe_create_u8)
+    int fmt = FXC_IQ_C64;      // sample format of the batches (fxc_iq_format)
     int remove_dc = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<fxc_pipe_slot> slots;

@@ -253,22 +253,47 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
     return FXC_OK;
 }
 
+bool h2d_by_kernel() {
+    static const bool v = [] { const char* e = std::getenv("FXC_H2D"); return e && std::string(e) == "kernel"; }();
+    return v;
+}
+
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void host_fetch_kernel(const v4f_t* __restrict__ src, v4f_t* __restrict__ dst, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += stride) dst[k] = __builtin_nontemporal_load(src + k);
+}
+
 // host-buffer helper: stage in, run, stage out (synchronous)
+// Pageable buffers go through the runtime's bounce buffers inside hipMemcpyAsync; buffers from fxc_host_alloc are pinned, so
+// the same call is one DMA -- and an `out` inside such a block is handed to fn as the device's mapping of it: the finishing
+// kernel writes the rows over PCIe itself (32 KiB per chunk pair) and no copy back is queued.
 template <class Fn>
 int with_host_staging(fxc_plan* p, const void* x, size_t x_bytes, void* out, size_t out_bytes, Fn fn) {
     // staging buffers live in the plan and only grow: the reference calls once per chunk pair (effex.py:490-494),
     // and a hipMalloc / hipFree pair per call costs more than the copy of one chunk
-    const size_t want[2] = {x_bytes ? x_bytes : 1, out_bytes};
+    void* out_mapped = out_bytes ? pinned_device_ptr(out, out_bytes) : nullptr;
+    const size_t want[2] = {x_bytes ? x_bytes : 1, out_mapped ? 0 : out_bytes};
     for (int k = 0; k < 2; ++k) {
         const int rg = grow(p, &p->d_stage[k], &p->stage_bytes[k], want[k]);
         if (rg) return rg;
     }
     void* dx = p->d_stage[0];
-    void* dout = out_bytes ? p->d_stage[1] : nullptr;
+    void* dout = out_bytes ? (out_mapped ? out_mapped : p->d_stage[1]) : nullptr;
     int rc = FXC_OK;
-    hipError_t e = hipMemcpyAsync(dx, x, x_bytes, hipMemcpyHostToDevice, p->stream);
+    hipError_t e = hipSuccess;
+    const void* x_mapped = h2d_by_kernel() ? pinned_device_ptr(x, x_bytes) : nullptr;
+    if (x_mapped && x_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(x_mapped) % 16 == 0) {
+        // developer knob FXC_H2D=kernel: the CUs fetch the pinned block over PCIe themselves instead of the copy engine
+        const int64_t n16 = (int64_t)(x_bytes / 16);
+        hipLaunchKernelGGL(host_fetch_kernel, dim3((unsigned)std::min<int64_t>((n16 + 255) / 256, (int64_t)p->cu_count * 8)), dim3(256),
+                           0, p->stream, static_cast<const v4f_t*>(x_mapped), static_cast<v4f_t*>(dx), n16);
+        e = hipGetLastError();
+    } else {
+        e = hipMemcpyAsync(dx, x, x_bytes, hipMemcpyHostToDevice, p->stream);
+    }
     if (e == hipSuccess) rc = fn(static_cast<const cf*>(dx), dout);
-    if (e == hipSuccess && rc == FXC_OK && out_bytes)
+    if (e == hipSuccess && rc == FXC_OK && out_bytes && !out_mapped)
         e = hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, p->stream);
     hipError_t e2 = hipStreamSynchronize(p->stream);
     if (rc != FXC_OK) return rc;

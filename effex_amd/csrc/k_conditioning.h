@@ -102,19 +102,69 @@ __global__ __launch_bounds__(256) void dc_sum_u8_stream_kernel(const unsigned ch
     }
 }
 
-// out = x - mean (complex64 in place or out of place)
-__global__ void dc_apply_c64_kernel(const cf* __restrict__ x, cf* __restrict__ out, const double* __restrict__ part,
-                                    int64_t num_samp, int n_slices, int64_t total) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const int64_t s = idx / num_samp;
-        double mr = 0.0, mi = 0.0;
-        for (int k = 0; k < n_slices; ++k) {
-            mr += part[(s * n_slices + k) * 2];
-            mi += part[(s * n_slices + k) * 2 + 1];
-        }
-        const cf v = x[idx];
-        out[idx] = fxc::mk((float)((double)v.x - mr / (double)num_samp), (float)((double)v.y - mi / (double)num_samp));
+// the same sums of a complex128 stream (the reference's own sample type, effex.py:109-110, 394-395)
+__global__ __launch_bounds__(256) void dc_sum_c128_kernel(const cd* __restrict__ x, double* __restrict__ part,
+                                                         int64_t num_samp, int n_slices) {
+    __shared__ double red[256];
+    const int64_t s = blockIdx.y;
+    const int slice = blockIdx.x;
+    const int64_t per = (num_samp + n_slices - 1) / n_slices;
+    const int64_t lo = slice * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
+    double ar = 0.0, ai = 0.0;
+    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+        const cd v = x[s * num_samp + n];
+        ar += v.x;
+        ai += v.y;
+    }
+    ar = block_sum(ar, red);
+    ai = block_sum(ai, red);
+    if (threadIdx.x == 0) {
+        part[(s * n_slices + slice) * 2] = ar;
+        part[(s * n_slices + slice) * 2 + 1] = ai;
+    }
+}
+
+// mean of stream s from its slice sums, the same fixed order in every thread
+__device__ __forceinline__ void dc_mean(const double* __restrict__ part, int64_t s, int n_slices, int64_t num_samp,
+                                        double* mr, double* mi) {
+    double ar = 0.0, ai = 0.0;
+    for (int k = 0; k < n_slices; ++k) {
+        ar += part[(s * n_slices + k) * 2];
+        ai += part[(s * n_slices + k) * 2 + 1];
+    }
+    *mr = ar / (double)num_samp;
+    *mi = ai / (double)num_samp;
+}
+
+// out = x - mean (complex64, in place or out of place): workgroup (slice, stream) of the same grid as the sum kernels,
+// so the mean is formed once per workgroup and no thread divides an index by num_samp.  remove_dc == 0: a copy.
+__global__ __launch_bounds__(256) void dc_apply_c64_kernel(const cf* __restrict__ x, cf* __restrict__ out,
+                                                          const double* __restrict__ part, int64_t num_samp, int n_slices,
+                                                          int part_slices, int remove_dc) {
+    const int64_t s = blockIdx.y;
+    double mr = 0.0, mi = 0.0;
+    if (remove_dc) dc_mean(part, s, part_slices, num_samp, &mr, &mi);
+    const int64_t per = (num_samp + n_slices - 1) / n_slices;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
+    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+        const cf v = x[s * num_samp + n];
+        out[s * num_samp + n] = fxc::mk((float)((double)v.x - mr), (float)((double)v.y - mi));
+    }
+}
+
+// complex128 -> complex64 with the mean removed in float64 first: (float)(x - mean), rounded once -- what the reference's
+// host line effex.py:394-395 followed by a narrowing copy gives.  remove_dc == 0: the narrowing alone.
+__global__ __launch_bounds__(256) void narrow_c128_kernel(const cd* __restrict__ x, cf* __restrict__ out,
+                                                         const double* __restrict__ part, int64_t num_samp, int n_slices,
+                                                         int part_slices, int remove_dc) {
+    const int64_t s = blockIdx.y;
+    double mr = 0.0, mi = 0.0;
+    if (remove_dc) dc_mean(part, s, part_slices, num_samp, &mr, &mi);
+    const int64_t per = (num_samp + n_slices - 1) / n_slices;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
+    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+        const cd v = x[s * num_samp + n];
+        out[s * num_samp + n] = fxc::mk((float)(v.x - mr), (float)(v.y - mi));
     }
 }
 

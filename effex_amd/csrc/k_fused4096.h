@@ -171,6 +171,7 @@ __device__ __forceinline__ void dck_wait_own() { asm volatile("s_waitcnt vmcnt(4
 // this thread's two landing slots cleared: the next unconditional dck_add then adds nothing
 __device__ __forceinline__ void dck_clear(v4u32_t* stage, int tid) {
     unsigned z0;
+    asm volatile("" : "+v"(tid));
     asm volatile("v_mov_b32 %0, 0" : "=v"(z0));      // made here: the compiler otherwise keeps a zero quad in scratch for this
     const v4u32_t z = {z0, z0, z0, z0};
     stage[(tid >> 6) * 128 + (tid & 63)] = z;
@@ -178,6 +179,7 @@ __device__ __forceinline__ void dck_clear(v4u32_t* stage, int tid) {
 }
 
 __device__ __forceinline__ void dck_add(const v4u32_t* stage, unsigned* acc, int tid) {
+    asm volatile("" : "+v"(tid));         // the two LDS addresses are formed here, every step: as loop invariants they are spilled
     unsigned si = 0u, sq = 0u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -194,8 +196,13 @@ __device__ __forceinline__ void dck_add(const v4u32_t* stage, unsigned* acc, int
 
 // chunk start: the 256 threads' counters of this thread's antenna -> its conversion offset; counters cleared
 __device__ __forceinline__ cf dck_offset(unsigned* acc, unsigned* red, int tid, int64_t num_samp) {
+    // (lane addresses and the zero formed here, in the chunk-start branch: hoisted out of the frame loop they live in scratch)
+    asm volatile("" : "+v"(tid));
+    unsigned zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
     unsigned v[2] = {acc[2 * tid], acc[2 * tid + 1]};
-    acc[2 * tid] = acc[2 * tid + 1] = 0u;
+    acc[2 * tid] = zero;
+    acc[2 * tid + 1] = zero;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
 #pragma unroll
@@ -214,6 +221,7 @@ __device__ __forceinline__ cf dck_offset(unsigned* acc, unsigned* red, int tid, 
         ti += red[(4 * ant + wv) * 2];
         tq += red[(4 * ant + wv) * 2 + 1];
     }
+    asm volatile("" : "+s"(num_samp));     // converted here, in the chunk-start branch: hoisted, the double lives in scratch
     const double mr = (double)ti / (double)num_samp, mi = (double)tq / (double)num_samp;
     return fxc::mk((float)(-mr / 127.5), (float)(-mi / 127.5));
 }
@@ -232,7 +240,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
         state_reset_history<PH>(s);
         if (U8) {
             if (DCK && u8.have_next) u8.off = dck_offset(dck_acc, dck_red, tid, num_samp);
-            else u8.off = dc[c * 2 + ((tid >> 8) & 1)];
+            else u8.off = dc[c * 2 + __builtin_amdgcn_readfirstlane((tid >> 8) & 1)];   // the antenna is a wave's: a scalar load
         }
     }
     // DCK: the chunk whose bytes this step helps to sum: this workgroup's next one, or (none left in this part: the sums
@@ -337,11 +345,25 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
     // range: store this lane's 8 bins (fire and forget)
     const bool row_ends = !SPEC_OUT && range_walk_row_ends(pos);
     if (row_ends) {
-        cf* row = rows_raw + (int64_t)pos.row * kN + tid;
+        if (DCK) {
+            // the same stores through a buffer descriptor of the row: a 64-bit lane pointer kept for this rare branch is
+            // a loop invariant the DCK variant has no register for (it was spilled and reloaded here)
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rows_raw + (int64_t)pos.row * kN, 0, (int)(kN * (int64_t)sizeof(cf)), 0x00020000);
+            unsigned t = (unsigned)tid;
+            asm volatile("" : "+v"(t));
 #pragma unroll
-        for (int q = 0; q < kAccPerThread; ++q) {
-            row[q * kThreads] = s.acc[q];
-            s.acc[q] = fxc::mk(0.f, 0.f);
+            for (int q = 0; q < kAccPerThread; ++q) {
+                const v2u32 d = {__float_as_uint(s.acc[q].x), __float_as_uint(s.acc[q].y)};
+                __builtin_amdgcn_raw_buffer_store_b64(d, rs, t * (unsigned)sizeof(cf), (unsigned)(q * kThreads * sizeof(cf)), 0);
+                s.acc[q] = fxc::mk(0.f, 0.f);
+            }
+        } else {
+            cf* row = rows_raw + (int64_t)pos.row * kN + tid;
+#pragma unroll
+            for (int q = 0; q < kAccPerThread; ++q) {
+                row[q * kThreads] = s.acc[q];
+                s.acc[q] = fxc::mk(0.f, 0.f);
+            }
         }
     }
     range_walk_advance(pos, row_ends);
@@ -406,17 +428,22 @@ __global__ __launch_bounds__(fxc::fused::kThreads, 2) void fx_fused4096_kernel(
 #pragma unroll 1
     for (int part = 0; part < 2; ++part) {   // 0: whole chunks, round-robin; 1: this workgroup's range of the tail
         const int walk_unit = SPEC_OUT ? 1 : unit;      // (SPEC_OUT: `unit` carries the stream pairs per chunk)
-        RangeWalk pos = part == 0 ? range_walk_rounds(blockIdx.x, gridDim.x, (int)n_chunks, (int)n_pts, seg, walk_unit, rows_are_chunks != 0)
-                                  : range_walk_tail(blockIdx.x, gridDim.x, (int)n_chunks, (int)n_pts, seg, walk_unit, rows_are_chunks != 0);
+        int np_walk = (int)n_pts, seg_walk = seg, unit_walk = walk_unit;
+        // DCK: the divisions of the split are done per part -- their reciprocals, hoisted over both parts, lived in scratch
+        if (DCK) asm volatile("" : "+s"(np_walk), "+s"(seg_walk), "+s"(unit_walk));
+        RangeWalk pos = part == 0 ? range_walk_rounds(blockIdx.x, gridDim.x, (int)n_chunks, np_walk, seg_walk, unit_walk, rows_are_chunks != 0)
+                                  : range_walk_tail(blockIdx.x, gridDim.x, (int)n_chunks, np_walk, seg_walk, unit_walk, rows_are_chunks != 0);
         const int total = pos.left;
         if (!SPEC_OUT && part == 1 && (!pos.lead || total == 0)) {   // no leading part: its row reads as zeros
             const RangeSplit sp = range_split(gridDim.x, (int)n_chunks, seg, walk_unit, rows_are_chunks != 0);
-            cf* lead_row = rows_raw + (int64_t)(sp.rows_rounds + sp.n_tail + blockIdx.x) * kN + tid;
+            int t_lead = tid;
+            if (DCK) asm volatile("" : "+v"(t_lead));     // (formed here: as an invariant of the part loop the pointer is spilled)
+            cf* lead_row = rows_raw + (int64_t)(sp.rows_rounds + sp.n_tail + blockIdx.x) * kN + t_lead;
 #pragma unroll
             for (int q = 0; q < kAccPerThread; ++q) lead_row[q * kThreads] = fxc::mk(0.f, 0.f);
         }
         if (total == 0) continue;
-        if (U8) u8.off = dc[(int64_t)pos.c * 2 + ant];
+        if (U8) u8.off = dc[(int64_t)pos.c * 2 + __builtin_amdgcn_readfirstlane(ant)];
         u8.have_next = false;      // a part's first chunk and every tail chunk: offsets from dc[]
         u8.rounds = part == 0;
         // ring prologue: frame i -> slot 0, its history i-1, i-2, i-3 -> slots 3, 2, 1 (zeros before the chunk start)

@@ -114,32 +114,37 @@ __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restr
     SmallRing<G> s;
     __syncthreads();
     cf* grp = xchg + wave * G::kXchgPerWave + (lane / P) * G::kGroup;
-    const int64_t per = (n_pts + n_splits - 1) / n_splits;
+    const int per = (int)((n_pts + n_splits - 1) / n_splits);      // frame counters are 32-bit: n_pts < 2^31 (small_setup)
+    const int n_pts_i = (int)n_pts;
     const int64_t total = n_chunks * n_splits;
     const int64_t stride = (int64_t)gridDim.x * G::kItemsPerWg;
     for (int64_t w0 = ((int64_t)blockIdx.x * G::kWaves + wave) * G::kSub; w0 < total; w0 += stride) {
         // this lane's item; the items of a wave beyond the last one run on the last one's samples and store nothing
-        const int64_t w = w0 + sub;
+        int sub_l = sub, ant_l = ant;
+        // (F-only variant at 16 channels, one item per lane: widened to 64 bits and added to the kernel's pointers here, per
+        // item -- as invariants of the item loop those lane values were kept in scratch)
+        if (SPEC && P == 1) asm volatile("" : "+v"(sub_l), "+v"(ant_l));
+        const int64_t w = w0 + sub_l;
         const bool live = w < total;
         const int64_t wc = live ? w : total - 1;
         const int64_t c = wc % n_chunks, split = wc / n_chunks;
-        const int64_t i0 = split * per;
-        const int64_t i1 = !live ? i0 : ((i0 + per < n_pts) ? i0 + per : n_pts);
+        const int i0 = (int)split * per;
+        const int i1 = !live ? i0 : ((i0 + per < n_pts_i) ? i0 + per : n_pts_i);
         // SPEC with an odd stream count: the missing second stream of the last pair re-reads the first and stores nothing
-        const bool valid = !SPEC || (2 * c + ant) < n_streams;
-        const int ant_ld = valid ? ant : 0;
+        const bool valid = !SPEC || (2 * c + ant_l) < n_streams;
+        const int ant_ld = valid ? ant_l : 0;
         // branch u of frame 0 (U8: the same element count in byte pairs)
         const cf* px = U8 ? reinterpret_cast<const cf*>(reinterpret_cast<const unsigned short*>(x) + (c * 2 + ant_ld) * num_samp + (P - 1 - u))
                           : x + (c * 2 + ant_ld) * num_samp + (P - 1 - u);
-        cf* out_base = SPEC ? raw + spec_row(s_base + 2 * c + ant, 0, n_pts, spec_a) * G::N : nullptr;
+        cf* out_base = SPEC ? raw + spec_row(s_base + 2 * c + ant_l, 0, n_pts, spec_a) * G::N : nullptr;
         const int64_t out_step = (int64_t)(spec_a > 0 ? spec_a : 1) * G::N;
-        const cf off = U8 ? dc[c * 2 + ant] : fxc::mk(0.f, 0.f);
+        const cf off = U8 ? dc[c * 2 + ant_l] : fxc::mk(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s.acc[q] = fxc::mk(0.f, 0.f);
         // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the chunk)
 #pragma unroll
         for (int d = 1; d < 4; ++d) {
-            const int64_t f = i0 - d;
+            const int f = i0 - d;
             const bool have = f >= 0 && i0 < i1;
             small_load<G, 16, U8>(s.h[4 - d], small_frame<G, U8>(px, have ? f : 0), 0);
             if (U8) convert_frame_u8(s.h[4 - d], off);
@@ -148,12 +153,12 @@ __global__ __launch_bounds__(256, 2) void fx_small_ring_kernel(const cf* __restr
                 for (int r = 0; r < 16; ++r) s.h[4 - d][r] = fxc::mk(0.f, 0.f);
             }
         }
-        small_load<G, 16, U8>(s.h[0], small_frame<G, U8>(px, i0 < n_pts ? i0 : n_pts - 1), 0);
-        for (int64_t st = 0; st < per; st += 4) {
+        small_load<G, 16, U8>(s.h[0], small_frame<G, U8>(px, i0 < n_pts_i ? i0 : n_pts_i - 1), 0);
+        for (int st = 0; st < per; st += 4) {
 #define FXC_SMALL_STEP(PH)                                                                                     \
     {                                                                                                          \
-        const int64_t i = i0 + st + PH;                                                                        \
-        const int64_t nf = i + 1 < n_pts ? i + 1 : n_pts - 1;                                                  \
+        const int i = i0 + st + PH;                                                                            \
+        const int nf = i + 1 < n_pts_i ? i + 1 : n_pts_i - 1;                                                  \
         small_ring_step<G, PH, U8, SPEC>(s, win, tw, grp, u, small_frame<G, U8>(px, nf), valid && i < i1, off, \
                                          SPEC ? out_base + i * out_step : nullptr);                            \
     }

@@ -134,9 +134,14 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
     const int tid = threadIdx.x;
     const int u = G::u_of(tid), ant = G::ant_of(tid);
     for (int idx = tid; idx < 256; idx += G::kThreads) tw16[idx] = tw16_g[idx];
+    // The 1024-thread geometry (nchan 8192) has 128 VGPRs per thread: the 8 + 15 twiddles of the pre-stage and of stage A
+    // do not fit next to the FIR's 16 samples and 16 coefficients in flight (held, they cost 168 bytes of scratch per lane
+    // and their reloads every frame).  There they are fetched again from their tables (96 KiB, L2) where they are used, once
+    // the FIR's registers are free: 23 more 8-byte loads per frame next to the FIR's 32 per tap.
+    constexpr bool kReloadTw = G::kThreads > 512;
     cf tw0[16], twA[16];
-    if (G::R0 > 1) G::load_tw0(tw0, tw0_g, u);
-    if (G::A3) G::load_twA(twA, twA_g, u);
+    if (G::R0 > 1 && !kReloadTw) G::load_tw0(tw0, tw0_g, u);
+    if (G::A3 && !kReloadTw) G::load_twA(twA, twA_g, u);
     __syncthreads();
     cf* reg = region + ant * G::kRegion;
     const unsigned win_bytes = (unsigned)(ntaps * G::N * (int)sizeof(float));
@@ -156,13 +161,25 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
         for (int q = 0; q < G::kAccPerThread; ++q) acc[q] = fxc::mk(0.f, 0.f);
         // everything after the FIR for one frame
         auto finish = [&](cf (&v)[16], int64_t i) {
-            if (G::R0 > 1) G::prestage(v, tw0);
+            if (G::R0 > 1) {
+                if (kReloadTw) {
+                    const cf* t0 = tw0_g;
+                    asm volatile("" : "+s"(t0));      // a fresh pointer per frame: the loads stay here
+                    G::load_tw0(tw0, t0, u);
+                }
+                G::prestage(v, tw0);
+            }
             if (G::A3) {
                 if (G::R0 > 1) {
                     __syncthreads();   // every wave has finished reading the previous spectrum's exchange rows
                     G::store0(v, reg, u);
                     __syncthreads();
                     G::loadA(reg, u, v);
+                }
+                if (kReloadTw) {
+                    const cf* tA = twA_g;
+                    asm volatile("" : "+s"(tA));
+                    G::load_twA(twA, tA, u);
                 }
                 fxc::dft16(v);
                 __syncthreads();

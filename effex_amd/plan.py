@@ -33,6 +33,27 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+IQ_FORMATS = {"c64": _lib.FXC_IQ_C64, "u8": _lib.FXC_IQ_U8, "c128": _lib.FXC_IQ_C128}
+_IQ_DTYPES = {"c64": np.complex64, "u8": np.uint8, "c128": np.complex128}
+
+
+def pinned_empty(shape, dtype):
+    """A numpy array in pinned host memory from ``fxc_host_alloc`` -- the counterpart of the reference's
+    ``cusignal.get_shared_mem`` staging buffers (effex.py:109-110): host-buffer calls copy from it by direct DMA, and
+    visibility rows asked for into such an array are written by the device itself.  Freed when the last view dies."""
+    import weakref
+    lib = _lib.load()
+    shape = tuple(int(v) for v in (shape if np.ndim(shape) else (shape,)))
+    dtype = np.dtype(dtype)
+    n_bytes = max(1, int(np.prod(shape)) * dtype.itemsize)
+    ptr = ctypes.c_void_p()
+    _lib.check(lib.fxc_host_alloc(ctypes.byref(ptr), n_bytes), None)
+    buf = (ctypes.c_char * n_bytes).from_address(ptr.value)
+    fin = weakref.finalize(buf, lib.fxc_host_free, ctypes.c_void_p(ptr.value))
+    fin.atexit = False          # at interpreter exit the HIP runtime may already be gone; the OS takes the pages back
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 def rot_table(nbins, bandwidth, frequency, calibrated_delay):
     """rot[k] = exp(+2 pi i f_k tau), natural bin order, complex128 — effex/effex.py:516,519.
 
@@ -125,19 +146,29 @@ class FxPlan(object):
         self._check(self._lib.fxc_plan_get_info(self._h, ctypes.byref(info)))
         return {name: getattr(info, name) for name, _ in _lib.FxcInfo._fields_}
 
-    def _in(self, x, shape_tail):
-        """-> (pointer, mem_kind, leading count, keepalive)."""
+    def _in(self, x, shape_tail, c128=False):
+        """-> (pointer, mem_kind, leading count, keepalive).  ``c128``: complex128 input is handed over as it is
+        (``self._fmt`` = FXC_IQ_C128) instead of being narrowed on the host."""
         self._sync_stream()
+        self._fmt = _lib.FXC_IQ_C64
         if _is_torch(x):
             import torch
-            if x.dtype != torch.complex64 or not x.is_cuda or not x.is_contiguous():
+            if c128 and x.dtype == torch.complex128:
+                self._fmt = _lib.FXC_IQ_C128
+            elif x.dtype != torch.complex64:
+                raise ValueError("device input must be a contiguous complex64 CUDA tensor")
+            if not x.is_cuda or not x.is_contiguous():
                 raise ValueError("device input must be a contiguous complex64 CUDA tensor")
             if x.device.index != self.device:
                 raise ValueError("tensor is on device {} but the plan is on {}".format(x.device.index, self.device))
             shape = tuple(x.shape)
             ptr, kind, keep = x.data_ptr(), _lib.FXC_MEM_DEVICE, x
         else:
-            keep = np.ascontiguousarray(x, dtype=np.complex64)
+            if c128 and getattr(x, "dtype", None) == np.complex128:
+                self._fmt = _lib.FXC_IQ_C128
+                keep = np.ascontiguousarray(x)
+            else:
+                keep = np.ascontiguousarray(x, dtype=np.complex64)
             shape = keep.shape
             ptr, kind = keep.ctypes.data, _lib.FXC_MEM_HOST
         if len(shape) == len(shape_tail):
@@ -146,7 +177,19 @@ class FxPlan(object):
             raise ValueError("expected shape [n, {}], got {}".format(", ".join(map(str, shape_tail)), shape))
         return ptr, kind, shape[0], keep
 
-    def _out(self, like, shape, dtype):
+    def _out(self, like, shape, dtype, out=None):
+        if out is not None:
+            if _is_torch(like) != _is_torch(out):
+                raise ValueError("out must be of the same kind (host array / CUDA tensor) as the input")
+            if _is_torch(out):
+                import torch
+                tdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+                if out.dtype != tdt or tuple(out.shape) != tuple(shape) or not out.is_contiguous() or not out.is_cuda:
+                    raise ValueError("out must be a contiguous CUDA tensor of shape {}".format(tuple(shape)))
+                return out, out.data_ptr()
+            if out.dtype != dtype or out.shape != tuple(shape) or not out.flags.c_contiguous or not out.flags.writeable:
+                raise ValueError("out must be a writable C-contiguous {} array of shape {}".format(np.dtype(dtype).name, tuple(shape)))
+            return out, out.ctypes.data
         if _is_torch(like):
             import torch
             tdt = torch.complex64 if dtype == np.complex64 else torch.complex128
@@ -174,25 +217,36 @@ class FxPlan(object):
         return out
 
     # -- F + X ------------------------------------------------------------------------------
-    def fx_accumulate(self, x):
-        """x: [n_chunks, n_ant, num_samp] complex64; adds into the plan's accumulator (async)."""
-        ptr, kind, n, keep = self._in(x, (self.n_ant, self.num_samp))
-        self._check(self._lib.fxc_fx_accumulate(self._h, ptr, n, kind))
+    def fx_accumulate(self, x, remove_dc=False, c128=False):
+        """x: [n_chunks, n_ant, num_samp] complex64; adds into the plan's accumulator (async).  ``remove_dc`` / ``c128``
+        as for ``fx_rows``."""
+        ptr, kind, n, keep = self._in(x, (self.n_ant, self.num_samp), c128)
+        if remove_dc or self._fmt != _lib.FXC_IQ_C64:
+            self._check(self._lib.fxc_fx_accumulate_iq(self._h, ptr, n, kind, self._fmt, int(bool(remove_dc))))
+        else:
+            self._check(self._lib.fxc_fx_accumulate(self._h, ptr, n, kind))
         return n
 
-    def fx_rows(self, x, mode="SPECTRUM", bandwidth=1.0):
+    def fx_rows(self, x, mode="SPECTRUM", bandwidth=1.0, remove_dc=False, out=None, c128=False):
         """One visibility row per chunk (the reference's ``_run_task`` result, effex.py:490-527).
 
         SPECTRUM -> [n_chunks, n_baselines, nchan] complex64; CONTINUUM/TEST -> [n_chunks, n_baselines]
-        complex128.
+        complex128.  ``remove_dc``: the per-chunk, per-antenna mean is removed on the device first (effex.py:394-395;
+        ``fxc_fx_rows_iq``).  ``c128``: complex128 input crosses to the device as it is and is narrowed there (after the
+        DC removal) instead of on the host.  ``out``: an array / tensor of the result's shape to receive the rows -- a
+        ``pinned_empty`` array is written by the device itself.
         """
         m = MODES[mode.upper()]
-        ptr, kind, n, keep = self._in(x, (self.n_ant, self.num_samp))
+        ptr, kind, n, keep = self._in(x, (self.n_ant, self.num_samp), c128)
         if m == _lib.FXC_MODE_SPECTRUM:
-            out, optr = self._out(x, (n, self.n_baselines, self.nchan), np.complex64)
+            out, optr = self._out(x, (n, self.n_baselines, self.nchan), np.complex64, out)
         else:
-            out, optr = self._out(x, (n, self.n_baselines), np.complex128)
-        self._check(self._lib.fxc_fx_rows(self._h, ptr, optr, n, kind, m, float(bandwidth)))
+            out, optr = self._out(x, (n, self.n_baselines), np.complex128, out)
+        if remove_dc or self._fmt != _lib.FXC_IQ_C64:
+            self._check(self._lib.fxc_fx_rows_iq(self._h, ptr, optr, n, kind, m, float(bandwidth), self._fmt,
+                                                 int(bool(remove_dc))))
+        else:
+            self._check(self._lib.fxc_fx_rows(self._h, ptr, optr, n, kind, m, float(bandwidth)))
         return out
 
     def acc_reset(self):
@@ -320,16 +374,16 @@ class FxPlan(object):
             raise ValueError("expected shape [n, {}, {}, 2], got {}".format(self.n_ant, self.num_samp, shape))
         return ptr, kind, shape[0], keep
 
-    def fx_rows_u8(self, iq_u8, mode="SPECTRUM", bandwidth=1.0, remove_dc=True):
+    def fx_rows_u8(self, iq_u8, mode="SPECTRUM", bandwidth=1.0, remove_dc=True, out=None):
         """``fx_rows`` straight from RTL-SDR bytes: uint8 I,Q [n_chunks, n_ant, num_samp, 2], converted as pyrtlsdr does
         (effex.py:652) with the per-stream mean removed (effex.py:394-395) unless ``remove_dc`` is false.  On fused
         plans the F+X kernel reads the bytes itself."""
         m = MODES[mode.upper()]
         ptr, kind, n, keep = self._in_u8(iq_u8)
         if m == _lib.FXC_MODE_SPECTRUM:
-            out, optr = self._out(iq_u8, (n, self.n_baselines, self.nchan), np.complex64)
+            out, optr = self._out(iq_u8, (n, self.n_baselines, self.nchan), np.complex64, out)
         else:
-            out, optr = self._out(iq_u8, (n, self.n_baselines), np.complex128)
+            out, optr = self._out(iq_u8, (n, self.n_baselines), np.complex128, out)
         self._check(self._lib.fxc_fx_rows_u8(self._h, ptr, optr, n, kind, m, float(bandwidth), int(bool(remove_dc))))
         return out
 
@@ -384,21 +438,25 @@ class FxPipeline(object):
     """Host-fed, double-buffered front end on a plan (include/fxcorr.h ``fxc_pipe_*``): push batches of host
     chunks, pop their visibility rows; H2D, compute and D2H of successive batches overlap."""
 
-    def __init__(self, plan, chunks_per_batch, depth=2, mode="SPECTRUM", bandwidth=1.0, u8=False, remove_dc=True):
-        """``u8``: batches are the receivers' bytes, uint8 [chunks, n_ant, num_samp, 2] (``fxc_pipe_create_u8``)."""
+    def __init__(self, plan, chunks_per_batch, depth=2, mode="SPECTRUM", bandwidth=1.0, u8=False, remove_dc=None, fmt=None):
+        """``fmt``: sample format of the batches -- 'c64' (default), 'u8' (the receivers' bytes, uint8
+        [chunks, n_ant, num_samp, 2]; ``u8=True`` is the same) or 'c128'.  ``remove_dc``: the per-chunk mean is removed
+        on the device (effex.py:394-395); default: on for bytes, off otherwise (``fxc_pipe_create_iq``)."""
         self.plan = plan
         self.chunks = int(chunks_per_batch)
         self.mode = MODES[mode.upper()]
-        self.u8 = bool(u8)
+        fmt = fmt or ("u8" if u8 else "c64")
+        if fmt not in IQ_FORMATS:
+            raise ValueError("fmt must be one of {}".format(sorted(IQ_FORMATS)))
+        self.fmt = fmt
+        self.u8 = fmt == "u8"
+        if remove_dc is None:
+            remove_dc = self.u8
         self._shape = (self.chunks, plan.n_ant, plan.num_samp) + ((2,) if self.u8 else ())
-        self._dtype = np.uint8 if self.u8 else np.complex64
+        self._dtype = _IQ_DTYPES[fmt]
         self._h = ctypes.c_void_p()
-        if self.u8:
-            plan._check(plan._lib.fxc_pipe_create_u8(ctypes.byref(self._h), plan._h, self.chunks, int(depth), self.mode,
-                                                     float(bandwidth), int(bool(remove_dc))))
-        else:
-            plan._check(plan._lib.fxc_pipe_create(ctypes.byref(self._h), plan._h, self.chunks, int(depth), self.mode,
-                                                  float(bandwidth)))
+        plan._check(plan._lib.fxc_pipe_create_iq(ctypes.byref(self._h), plan._h, self.chunks, int(depth), self.mode,
+                                                 float(bandwidth), IQ_FORMATS[fmt], int(bool(remove_dc))))
         import weakref
         plan._pipes.append(weakref.ref(self))      # FxPlan.close() closes its pipes first
 
@@ -412,11 +470,8 @@ class FxPipeline(object):
         """Pinned input buffer of the next free slot as a numpy view (the batch shape) to fill in place."""
         ptr = ctypes.c_void_p()
         self.plan._check(self.plan._lib.fxc_pipe_acquire(self._h, ctypes.byref(ptr)))
-        n = int(np.prod(self._shape))
-        if self.u8:
-            buf = (ctypes.c_uint8 * n).from_address(ptr.value)
-        else:
-            buf = (ctypes.c_float * (2 * n)).from_address(ptr.value)
+        n_bytes = int(np.prod(self._shape)) * np.dtype(self._dtype).itemsize
+        buf = (ctypes.c_uint8 * n_bytes).from_address(ptr.value)
         return np.frombuffer(buf, dtype=self._dtype).reshape(self._shape)
 
     def submit(self):

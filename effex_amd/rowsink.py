@@ -6,11 +6,20 @@ as ``%.18e`` pairs, ≈ 200 KiB and ≈ 10 ms of formatting per row (``/root/ref
 than that, so next to the byte-exact csv (``CsvSink``) there is ``BinSink``:
 
     line 1      the csv's own header line, text, '\\n'-terminated  (effex.py:672-678)
-    preamble    b"FXB1", uint32 bytes per element (8 = complex64, 16 = complex128), uint64 elements per row,
-                uint64 data_offset (absolute, 64-byte aligned), uint64 n_freqs
+    preamble    b"FXB2", uint32 bytes per element (8 = complex64, 16 = complex128), uint64 elements per row,
+                uint64 data_offset (absolute, 64-byte aligned), uint64 n_freqs, uint64 rows committed
     freqs       float64[n_freqs]   — the csv's second line in SPECTRUM mode (effex.py:679-682), else n_freqs = 0
     (padding to data_offset)
     rows        row after row, native little-endian, no separators
+
+A reader trusts the committed-row count, not the file size: the file is extended *before* rows are written through a
+mapped window (``reserve``) or by several ranks at once (``create_shared``), and a live reader or a file left behind by a
+killed writer must not show the zero-filled tail as visibilities.  (``FXB1`` files, without the count, are still read by
+size.)
+
+Several ranks, one file (the reference-faithful time-series mode: "ranks own disjoint rows"):
+``create_shared`` (one rank) sizes the file for all rows, every rank maps its own ``RowWindow`` of it and fills it in
+place, ``commit_shared`` (one rank, after a barrier) publishes the count -- no collective on the data path.
 
 Rows can be written one at a time, a batch at a time, or by filling a memory-mapped window of the file in place
 (``reserve`` / ``commit``: ``FxPipeline.pop(out=...)`` copies straight from the pinned result slot into the page cache).
@@ -22,8 +31,11 @@ import struct
 
 import numpy as np
 
-MAGIC = b"FXB1"
-_PRE = struct.Struct("<4sIQQQ")
+MAGIC = b"FXB2"
+MAGIC_V1 = b"FXB1"                       # round-3 files: no committed-row count, rows = what the file size holds
+_PRE = struct.Struct("<4sIQQQQ")
+_PRE_V1 = struct.Struct("<4sIQQQ")
+_COUNT_OFFSET_IN_PRE = _PRE.size - 8     # the committed-row count is the preamble's last field
 
 
 def header_line(run_time, bandwidth, frequency, num_samp, resolution, gain, mode):
@@ -83,9 +95,10 @@ class BinSink(object):
         head = (header + '\n').encode()
         unaligned = len(head) + _PRE.size + freqs.nbytes
         self.data_offset = (unaligned + 63) // 64 * 64
+        self._count_at = len(head) + _COUNT_OFFSET_IN_PRE
         self._fh = open(path, 'w+b')
         self._fh.write(head)
-        self._fh.write(_PRE.pack(MAGIC, self.row_dtype.itemsize, self.row_len, self.data_offset, freqs.size))
+        self._fh.write(_PRE.pack(MAGIC, self.row_dtype.itemsize, self.row_len, self.data_offset, freqs.size, 0))
         self._fh.write(freqs.tobytes())
         self._fh.write(b'\0' * (self.data_offset - unaligned))
         self._fh.flush()
@@ -103,6 +116,12 @@ class BinSink(object):
         self._fh.seek(self.data_offset + self.rows * self.row_bytes)
         self._fh.write(rows.view(np.uint8).data)
         self.rows += len(rows)
+        self._publish()
+
+    def _publish(self):
+        """The committed-row count goes into the preamble behind the rows it counts (same file object: ordered)."""
+        self._fh.flush()
+        os.pwrite(self._fh.fileno(), struct.pack("<Q", self.rows), self._count_at)
 
     def reserve(self, n_rows):
         """A writable [n_rows, row_len] view of the file just behind the committed rows (the file grows to hold it);
@@ -123,10 +142,12 @@ class BinSink(object):
         self._map_rows -= int(n_rows)
         if self._map_rows == 0:
             self._drop_map()
+        self._publish()
 
     def _drop_map(self):
-        # no msync here: rows written through the window are in the page cache, where every reader of the file sees them;
-        # forcing them to the disk after every batch cost more than producing them
+        # no msync here: rows written through the window are in the page cache, where every reader of the file sees them
+        # (and only counts them once ``commit`` has published them); forcing them to the disk after every batch cost more
+        # than producing them
         self._map = None
         self._map_rows = 0
 
@@ -135,6 +156,7 @@ class BinSink(object):
             self._drop_map()
             self._fh.flush()
             os.ftruncate(self._fh.fileno(), self.data_offset + self.rows * self.row_bytes)     # drop rows reserved, never committed
+            self._publish()
             self._fh.close()
             self._fh = None
 
@@ -145,26 +167,95 @@ class BinSink(object):
         self.close()
 
 
+def _read_preamble(fh):
+    """-> (header line bytes, itemsize, row_len, data_offset, n_freqs, committed rows or None (FXB1), offset of the count)."""
+    line = fh.readline()
+    pre = fh.read(_PRE_V1.size)
+    if len(pre) != _PRE_V1.size:
+        raise ValueError("not a visibility sidecar (truncated)")
+    magic, itemsize, row_len, data_offset, n_freqs = _PRE_V1.unpack(pre)
+    committed = None
+    if magic == MAGIC:
+        tail = fh.read(8)
+        if len(tail) != 8:
+            raise ValueError("not a visibility sidecar (truncated)")
+        committed = struct.unpack("<Q", tail)[0]
+    elif magic != MAGIC_V1:
+        raise ValueError("not a visibility sidecar")
+    if itemsize not in (8, 16) or row_len < 1:
+        raise ValueError("not a visibility sidecar")
+    return line, itemsize, row_len, data_offset, n_freqs, committed, len(line) + _COUNT_OFFSET_IN_PRE
+
+
 class RowFile(object):
-    """A sidecar opened for reading: ``header`` (line 1), ``fields`` (its key:value pairs), ``freqs``, ``rows`` (memory map)."""
+    """A sidecar opened for reading: ``header`` (line 1), ``fields`` (its key:value pairs), ``freqs``, ``rows`` (memory map
+    of the *committed* rows: what a writer has reserved or mapped but not yet committed is not shown)."""
 
     def __init__(self, path):
         with open(path, 'rb') as fh:
-            line = fh.readline()
-            pre = fh.read(_PRE.size)
-            if len(pre) != _PRE.size:
-                raise ValueError("{}: not a visibility sidecar (truncated)".format(path))
-            magic, itemsize, row_len, data_offset, n_freqs = _PRE.unpack(pre)
-            if magic != MAGIC or itemsize not in (8, 16) or row_len < 1:
-                raise ValueError("{}: not a visibility sidecar".format(path))
+            try:
+                line, itemsize, row_len, data_offset, n_freqs, committed, _ = _read_preamble(fh)
+            except ValueError as exc:
+                raise ValueError("{}: {}".format(path, exc))
             self.freqs = np.frombuffer(fh.read(8 * n_freqs), dtype=np.float64) if n_freqs else None
         self.header = line.decode().rstrip('\n')
         self.fields = dict(item.split(':', 1) for item in self.header.split(','))
         self.row_dtype = np.dtype(np.complex64 if itemsize == 8 else np.complex128)
         self.row_len = int(row_len)
-        n_rows = (os.path.getsize(path) - data_offset) // (self.row_len * itemsize)
+        held = max(0, (os.path.getsize(path) - data_offset) // (self.row_len * itemsize))
+        n_rows = held if committed is None else min(int(committed), held)
         self.rows = (np.memmap(path, dtype=self.row_dtype, mode='r', offset=data_offset, shape=(n_rows, self.row_len))
                      if n_rows > 0 else np.zeros((0, self.row_len), dtype=self.row_dtype))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# several writers, one file: disjoint row ranges, no collective on the data path (SURVEY.md §8e, time-series mode)
+# ------------------------------------------------------------------------------------------------------------------
+def create_shared(path, header, freqs, row_len, row_dtype, n_rows):
+    """One rank: the sidecar's head and room for ``n_rows`` rows, none of them committed yet."""
+    sink = BinSink(path, header, freqs, row_len, row_dtype)
+    os.ftruncate(sink._fh.fileno(), sink.data_offset + int(n_rows) * sink.row_bytes)
+    sink._fh.close()
+    sink._fh = None
+
+
+class RowWindow(object):
+    """Rows [lo, hi) of a sidecar made by ``create_shared``, mapped for writing: ``rows`` is [hi - lo, row_len]."""
+
+    def __init__(self, path, lo, hi):
+        lo, hi = int(lo), int(hi)
+        self._fh = open(path, 'r+b')
+        _, itemsize, row_len, data_offset, _, _, _ = _read_preamble(self._fh)
+        self.row_dtype = np.dtype(np.complex64 if itemsize == 8 else np.complex128)
+        self.row_len = int(row_len)
+        need = data_offset + hi * self.row_len * itemsize
+        if hi < lo or lo < 0 or os.fstat(self._fh.fileno()).st_size < need:
+            self._fh.close()
+            raise ValueError("{}: rows [{}, {}) are outside the file".format(path, lo, hi))
+        self.lo, self.hi = lo, hi
+        self.rows = (np.memmap(self._fh, dtype=self.row_dtype, mode='r+', offset=data_offset + lo * self.row_len * itemsize,
+                               shape=(hi - lo, self.row_len)) if hi > lo else np.zeros((0, self.row_len), self.row_dtype))
+
+    def close(self):
+        if self._fh is not None:
+            if isinstance(self.rows, np.memmap):
+                self.rows.flush()      # this rank's rows are in the file before it tells the others so (the barrier)
+            self.rows = None
+            self._fh.close()
+            self._fh = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def commit_shared(path, n_rows):
+    """One rank, after every writer has closed its window: publish the count."""
+    with open(path, 'r+b') as fh:
+        count_at = _read_preamble(fh)[6]
+        os.pwrite(fh.fileno(), struct.pack("<Q", int(n_rows)), count_at)
 
 
 def to_csv(path_in, path_out):

@@ -16,8 +16,11 @@ then ``fxc_finalize_sums`` on the root.  Two transports:
   collective is stream-ordered behind the export and the finalize behind the collective.  A plan on a stream
   of its own is fenced with ``plan.sync()`` first.
 
+``ShardedRows`` is the other multi-GPU mode, the reference-faithful one: one visibility row per chunk pair, ranks own
+disjoint rows of one shared row file, no collective at all.
+
 No scaling curve has been measured yet (the builder has one GPU); the control flow is exercised by
-tests/test_dist_gloo.py (world 2 and 3, gloo) and by ``bench.py --dry-run-dist``.
+tests/test_dist_gloo.py (world 2, 3 and 8, gloo) and by ``bench.py --dry-run-dist``.
 """
 
 
@@ -108,7 +111,12 @@ class ShardedIntegrator(object):
         return self.sums
 
     def finalize(self, mode="SPECTRUM", bandwidth=1.0, root=0, to_all=False):
-        """Returns the integrated visibilities on the root (every rank if ``to_all``), else None."""
+        """Returns the integrated visibilities on the root (every rank if ``to_all``), else None.  Like the C call it
+        refuses while asynchronous results are outstanding: ``finalize_wait`` hands out the oldest one, which would not
+        be this integration's."""
+        if self._waits:
+            raise _state_error("{} asynchronous finalize result(s) outstanding: collect them with finalize_wait() first"
+                               .format(len(self._waits)))
         self.finalize_async(mode, bandwidth, root=root, to_all=to_all)
         return self.finalize_wait()
 
@@ -134,7 +142,85 @@ class ShardedIntegrator(object):
 
     def finalize_wait(self):
         """The oldest queued integration: the visibilities on the root (every rank if ``to_all``), else None."""
+        if not self._waits:
+            raise _state_error("no finalize result outstanding")
         item = self._waits.pop(0)
         if item is True:
             return self.plan.finalize_wait()
         return item
+
+
+def _state_error(message):
+    from . import _lib
+    return _lib.FxcError(_lib.FXC_ERR_STATE, message)
+
+
+def batch_range(rank, world_size, n_chunks, batch):
+    """Contiguous [lo, hi) of the global chunk index owned by ``rank`` when chunks are dealt in whole batches of ``batch``
+    (the last one may be short): every rank's device calls then cover exactly the chunk sets a single rank's would, so the
+    rows are the single rank's bit for bit."""
+    n_batches = (int(n_chunks) + int(batch) - 1) // int(batch)
+    b_lo, b_hi = chunk_range(rank, world_size, n_batches)
+    return min(b_lo * batch, n_chunks), min(b_hi * batch, n_chunks)
+
+
+class ShardedRows(object):
+    """The reference-faithful time-series mode over several GPUs (second paragraph): the reference's
+    product is one visibility row per chunk pair (``_run_task`` -> the writer, effex/effex.py:402-410, 687-696; read back by
+    ``post_process.py:201-219``), chunks are independent, so rank r computes the rows of its own contiguous range of the
+    global chunk index and writes them into its own window of ONE shared binary sidecar (``effex_amd.rowsink``):
+
+        rank 0      header line, frequency row, file sized for all rows (``rowsink.create_shared``)      -- barrier --
+        every rank  ``fx_rows`` over its range, ``batch`` chunks per device call, rows land in the mapped window
+                    (host buffers: the library writes them there; device buffers: one copy)              -- barrier --
+        rank 0      publishes the row count (``rowsink.commit_shared``)
+
+    No collective touches the data path; the two barriers go through ``torch.distributed`` (RCCL or gloo).  Ranges are
+    whole batches of the global index (``batch_range``), so the file is byte-identical to a single rank's.
+    ``tools/rows_to_csv.py`` turns it into the reference's csv."""
+
+    def __init__(self, plan, rank=0, world_size=1, group=None, batch=64):
+        if int(batch) < 1:
+            raise ValueError("batch must be >= 1")
+        self.plan, self.rank, self.world_size, self.group, self.batch = plan, int(rank), int(world_size), group, int(batch)
+
+    def my_range(self, n_chunks):
+        return batch_range(self.rank, self.world_size, n_chunks, self.batch)
+
+    def _barrier(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.group)
+
+    def run(self, path, header, freqs, read_chunks, n_chunks, mode="SPECTRUM", bandwidth=1.0, remove_dc=False):
+        """``read_chunks(lo, hi)`` -> the samples of global chunks [lo, hi): a host array or CUDA tensor
+        [hi - lo, n_ant, num_samp] complex64 (or uint8 [..., 2]: the receivers' bytes).  Returns (lo, hi) of this rank."""
+        import numpy as np
+        from . import rowsink
+        spectrum = mode.upper() == "SPECTRUM"
+        row_len = self.plan.n_baselines * (self.plan.nchan if spectrum else 1)
+        dtype = np.complex64 if spectrum else np.complex128
+        lo, hi = self.my_range(n_chunks)
+        if self.rank == 0:
+            rowsink.create_shared(path, header, freqs if spectrum else None, row_len, dtype, n_chunks)
+        self._barrier()
+        shape_tail = (self.plan.n_baselines, self.plan.nchan) if spectrum else (self.plan.n_baselines,)
+        with rowsink.RowWindow(path, lo, hi) as win:
+            for b_lo in range(lo, hi, self.batch):
+                b_hi = min(hi, b_lo + self.batch)
+                x = read_chunks(b_lo, b_hi)
+                dst = win.rows[b_lo - lo:b_hi - lo].reshape((b_hi - b_lo,) + shape_tail)
+                u8 = str(getattr(x, "dtype", "")).endswith("uint8")
+                on_device = type(x).__module__.startswith("torch")
+                kwargs = dict(out=None if on_device else dst)
+                if u8:
+                    out = self.plan.fx_rows_u8(x, mode, bandwidth, remove_dc=remove_dc, **kwargs)
+                else:
+                    out = self.plan.fx_rows(x, mode, bandwidth, remove_dc=remove_dc, **kwargs)
+                if on_device:
+                    dst[...] = out.cpu().numpy()
+        self._barrier()
+        if self.rank == 0:
+            rowsink.commit_shared(path, n_chunks)
+        self._barrier()                      # nobody returns (and reads the file) before the count is there
+        return lo, hi

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FXC_VERSION 103 /* 0.1.0 */
+#define FXC_VERSION 104 /* 0.1.0 */
 
 typedef struct fxc_plan fxc_plan; /* opaque; one per (device, configuration) */
 typedef struct fxc_pipe fxc_pipe; /* opaque; host-fed double-buffered front end on a plan */
@@ -46,6 +46,10 @@ enum fxc_status {
 
 enum fxc_mem_kind { FXC_MEM_HOST = 0, FXC_MEM_DEVICE = 1 };
 enum fxc_mode { FXC_MODE_SPECTRUM = 0, FXC_MODE_CONTINUUM = 1 }; /* TEST == CONTINUUM arithmetic */
+/* sample formats of the fxc_*_iq entry points: complex64 (what the path computes in), the receivers' interleaved
+ * unsigned 8-bit I,Q (pyrtlsdr's packed bytes, effex.py:652), and complex128 (the reference's own sample type,
+ * effex.py:109-110: narrowed to complex64 on the device, after the DC removal when that is asked for) */
+enum fxc_iq_format { FXC_IQ_C64 = 0, FXC_IQ_U8 = 1, FXC_IQ_C128 = 2 };
 enum fxc_path {
     FXC_PATH_GENERIC = 0, /* any shape: FIR / FFT / X kernels through a workspace                          */
     FXC_PATH_FUSED = 1,   /* nchan 4096, ntaps 4, 2 antennas (one kernel) or 4/6/8 (F-only kernel + X-engine) */
@@ -173,6 +177,26 @@ int fxc_fx_rows_u8(fxc_plan* plan, const void* iq_u8, void* out, int64_t n_chunk
                    double bandwidth, int remove_dc);
 int fxc_fx_accumulate_u8(fxc_plan* plan, const void* iq_u8, int64_t n_chunks, int mem_kind, int remove_dc);
 
+/* The same two calls for any sample format, with the per-chunk DC removal of effex.py:394-395 on the device:
+ * x = [n_chunks][n_ant][num_samp] samples of `iq_format` (fxc_iq_format); remove_dc != 0 subtracts, per chunk and antenna,
+ * the mean of the real and of the imaginary parts (float64 sums) before the path.  FXC_IQ_U8 = fxc_fx_rows_u8;
+ * FXC_IQ_C64 with remove_dc == 0 = fxc_fx_rows.  complex64 / complex128 with DC removal run the sums and the subtraction
+ * (complex128: subtraction in float64, then one rounding to complex64) as a pre-pass -- in place on the library's own
+ * staging copy for host buffers, into a staging buffer for device buffers (the caller's samples are never written).
+ * Replaces the host lines effex.py:394-395 (+ the narrowing copy of a complex128 source) in front of _pfb_xcorr. */
+int fxc_fx_rows_iq(fxc_plan* plan, const void* x, void* out, int64_t n_chunks, int mem_kind, int mode, double bandwidth,
+                   int iq_format, int remove_dc);
+int fxc_fx_accumulate_iq(fxc_plan* plan, const void* x, int64_t n_chunks, int mem_kind, int iq_format, int remove_dc);
+
+/* Pinned host memory for FXC_MEM_HOST buffers -- the counterpart of the reference's mapped pinned staging buffers
+ * (cusignal.get_shared_mem, effex.py:109-110).  Buffers from fxc_host_alloc cross PCIe by direct DMA (pageable memory goes
+ * through the runtime's bounce buffers at about half the rate), and an `out` buffer inside such an allocation is written by
+ * the finishing kernel itself through the device's mapping of it: no copy back.  Any host pointer is still accepted
+ * everywhere; these only make it fast.  fxc_host_free(NULL) is a no-op; FXC_ERR_ARG for a pointer fxc_host_alloc did not
+ * return.  Process-wide, thread-safe; the memory is usable with every device. */
+int fxc_host_alloc(void** out, int64_t bytes);
+int fxc_host_free(void* ptr);
+
 /* Delay calibration — replaces Correlator._estimate_delay_gaussian, effex.py:583-627:
  * zero-pad both streams, FFT, f0*conj(f1), inverse FFT, arg-max of |xcorr|, 3-point log-Gaussian peak;
  * *delay_s = (n - (imax + delta)) / rate.  iq0, iq1: n complex64 samples each (host or device), any n.
@@ -194,6 +218,10 @@ int fxc_pipe_create(fxc_pipe** out, fxc_plan* plan, int64_t chunks_per_batch, in
  * through fxc_fx_rows_u8 (a quarter of the PCIe traffic of complex64 samples) */
 int fxc_pipe_create_u8(fxc_pipe** out, fxc_plan* plan, int64_t chunks_per_batch, int depth, int mode, double bandwidth,
                        int remove_dc);
+/* any sample format (fxc_iq_format), batches through fxc_fx_rows_iq: complex64 / complex128 recordings with the DC
+ * removal of effex.py:394-395 on the device instead of a host pass per chunk */
+int fxc_pipe_create_iq(fxc_pipe** out, fxc_plan* plan, int64_t chunks_per_batch, int depth, int mode, double bandwidth,
+                       int iq_format, int remove_dc);
 int fxc_pipe_acquire(fxc_pipe* pipe, void** in_host);
 int fxc_pipe_submit(fxc_pipe* pipe);
 int fxc_pipe_push(fxc_pipe* pipe, const void* x_host);

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.fxc_version() == 103
+    assert lib.fxc_version() == 104
     assert lib.fxc_status_string(0) == b"ok"
     assert b"unsupported" in lib.fxc_status_string(_lib.FXC_ERR_UNSUPPORTED)
 
@@ -61,6 +61,12 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.fxc_comm_destroy(None) == _lib.FXC_OK
     assert b"RCCL" in lib.fxc_status_string(_lib.FXC_ERR_COMM)
     assert lib.fxc_plan_destroy(None) == _lib.FXC_OK
+    assert lib.fxc_fx_rows_iq(None, None, None, 1, 0, 0, 1.0, _lib.FXC_IQ_C128, 1) == _lib.FXC_ERR_ARG
+    assert lib.fxc_fx_rows_iq(None, None, None, 1, 0, 0, 1.0, 7, 0) == _lib.FXC_ERR_ARG          # no such sample format
+    assert lib.fxc_fx_accumulate_iq(None, None, 1, 0, _lib.FXC_IQ_C64, 1) == _lib.FXC_ERR_ARG
+    assert lib.fxc_pipe_create_iq(None, None, 1, 2, 0, 1.0, _lib.FXC_IQ_C64, 1) == _lib.FXC_ERR_ARG
+    assert lib.fxc_host_alloc(None, 64) == _lib.FXC_ERR_ARG
+    assert lib.fxc_host_free(None) == _lib.FXC_OK
 
 
 def test_no_cpu_backend(lib):
@@ -74,9 +80,20 @@ def test_no_cpu_backend(lib):
     rc = lib.fxc_plan_create(ctypes.byref(h), 0, 2, 64, 4, 4096, win, None, -1)
     assert rc == _lib.FXC_ERR_NODEVICE
     assert b"no CPU backend" in lib.fxc_last_error(None)
-    from effex_amd.plan import FxPlan
+    from effex_amd.plan import FxPlan, pinned_empty
     with pytest.raises(_lib.FxcError):
         FxPlan(2, 64, 4, 4096)
+    # pinned staging memory is the HIP runtime's to give: without a device there is none, and the drop-in class falls back
+    # to ordinary arrays for its *buffers* (never for arithmetic)
+    ptr = ctypes.c_void_p()
+    assert lib.fxc_host_alloc(ctypes.byref(ptr), 4096) == _lib.FXC_ERR_NODEVICE and not ptr.value
+    with pytest.raises(_lib.FxcError):
+        pinned_empty((16,), "complex64")
+    from effex_amd.correlator import Correlator, SyntheticSource
+    cor = Correlator(source=SyntheticSource())
+    assert not cor._pinned and cor.gpu_iq_0.dtype == "complex64" and len(cor.gpu_iq_0) == 2 ** 18
+    with pytest.raises(_lib.FxcError):
+        cor._run_task()
 
 
 def test_bench_refuses_a_foreign_library(monkeypatch, tmp_path):

@@ -208,6 +208,122 @@ def test_sharded_integrator_finalize_over_gloo(world, to_all):
                 assert out is None
 
 
+class OracleRowsPlan(object):
+    """Stands in for FxPlan.fx_rows on a machine without a GPU (the oracle does the arithmetic; rows rounded to the
+    device's complex64)."""
+    n_baselines, nchan = 1, NCHAN
+
+    def __init__(self, window, rot_args):
+        self.window, self.rot_args = window, rot_args
+        self.calls = []
+
+    def fx_rows(self, x, mode="SPECTRUM", bandwidth=1.0, remove_dc=False, out=None):
+        import fx_oracle
+        bw, fc, tau = self.rot_args
+        self.calls.append(len(x))
+        rows = []
+        for pair in x:
+            a, b = (fx_oracle.remove_dc(pair[0]), fx_oracle.remove_dc(pair[1])) if remove_dc else (pair[0], pair[1])
+            rows.append(fx_oracle.pfb_xcorr(a, b, NTAPS, NCHAN, self.window, bw, fc, tau, mode))
+        if mode == "SPECTRUM":
+            res = np.stack(rows).astype(np.complex64)[:, None, :]
+        else:
+            res = np.asarray(rows, dtype=np.complex128)[:, None]
+        if out is not None:
+            out[...] = res
+            return out
+        return res
+
+
+def _rows_worker(rank, world, port, path, mode, n_chunks, batch, queue):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from effex_amd import rowsink, sharding, synth
+    from effex_amd.window import design_window
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = OracleRowsPlan(design_window(NTAPS, NCHAN), (2.4e6, 1.4204e9, 1e-6))
+        rows = sharding.ShardedRows(plan, rank, world, batch=batch)
+        header = rowsink.header_line(1, 2.4e6, 1.4204e9, NUM_SAMP, NCHAN, 49.6, mode)
+        freqs = rowsink.spectrum_freqs(NCHAN, 2.4e6, 1.4204e9)
+
+        def read_chunks(lo, hi):       # each rank generates only its own chunks of the synthetic stream
+            return synth.synth_iq(1234, hi - lo, 2, NUM_SAMP, first_chunk=lo) + np.complex64(0.05 - 0.02j)
+
+        lo, hi = rows.run(path, header, freqs, read_chunks, n_chunks, mode, 2.4e6, remove_dc=True)
+        # after run() every rank sees the whole, committed file
+        queue.put((rank, lo, hi, plan.calls, len(rowsink.RowFile(path).rows)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,n_chunks,batch", [(2, "SPECTRUM", 7, 2), (3, "SPECTRUM", 11, 3), (3, "CONTINUUM", 5, 1),
+                                                       (8, "SPECTRUM", 9, 1)])
+def test_sharded_rows_write_one_file_over_gloo(tmp_path, world, mode, n_chunks, batch):
+    """SURVEY.md 8e, time-series mode: ranks own disjoint rows of one shared row file, no collective.  The file of
+    `world` ranks equals the single-rank file byte for byte, its rows are the oracle's (DC removal included), nothing is
+    visible to a reader before the count is published, and tools/rows_to_csv.py's conversion gives the csv the reference's
+    writer produces for those rows (effex.py:667-696)."""
+    import torch.multiprocessing as mp
+    import fx_oracle
+    from effex_amd import rowsink, sharding, synth
+    from effex_amd.window import design_window
+    path = str(tmp_path / "shared.fxb")
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, path, mode, n_chunks, batch, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(queue.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(g[1], g[2]) for g in got] == [sharding.batch_range(r, world, n_chunks, batch) for r in range(world)]
+    assert got[0][1] == 0 and got[-1][2] == n_chunks and all(got[i][2] == got[i + 1][1] for i in range(world - 1))
+    assert all(g[4] == n_chunks for g in got)
+    assert all(c <= batch for g in got for c in g[3])
+    # the single-rank file, written by the same class in this process
+    window = design_window(NTAPS, NCHAN)
+    single = str(tmp_path / "single.fxb")
+    header = rowsink.header_line(1, 2.4e6, 1.4204e9, NUM_SAMP, NCHAN, 49.6, mode)
+    freqs = rowsink.spectrum_freqs(NCHAN, 2.4e6, 1.4204e9)
+    x = synth.synth_iq(1234, n_chunks, 2, NUM_SAMP) + np.complex64(0.05 - 0.02j)
+    sharding.ShardedRows(OracleRowsPlan(window, (2.4e6, 1.4204e9, 1e-6)), batch=batch).run(
+        single, header, freqs, lambda lo, hi: x[lo:hi], n_chunks, mode, 2.4e6, remove_dc=True)
+    assert open(path, "rb").read() == open(single, "rb").read()
+    back = rowsink.RowFile(path)
+    assert back.rows.shape == (n_chunks, NCHAN if mode == "SPECTRUM" else 1)
+    ref = np.stack([np.atleast_1d(fx_oracle.pfb_xcorr(fx_oracle.remove_dc(x[c, 0]), fx_oracle.remove_dc(x[c, 1]), NTAPS, NCHAN,
+                                                      window, 2.4e6, 1.4204e9, 1e-6, mode)) for c in range(n_chunks)])
+    np.testing.assert_array_equal(np.asarray(back.rows), ref.astype(back.row_dtype))
+    out_csv, ref_csv = str(tmp_path / "back.csv"), str(tmp_path / "ref.csv")
+    assert rowsink.to_csv(path, out_csv) == n_chunks
+    with rowsink.CsvSink(ref_csv, header, freqs if mode == "SPECTRUM" else None) as sink:
+        sink.write_rows(ref.astype(back.row_dtype))
+    assert open(out_csv, "rb").read() == open(ref_csv, "rb").read()
+    loaded = np.loadtxt(out_csv, dtype=np.complex128, delimiter=',', skiprows=2 if mode == "SPECTRUM" else 1)   # post_process.py:201-219
+    np.testing.assert_allclose(loaded.reshape(ref.shape), ref, rtol=1e-6)
+
+
+def test_shared_row_file_shows_nothing_before_the_count_is_published(tmp_path):
+    from effex_amd import rowsink
+    path = str(tmp_path / "s.fxb")
+    rowsink.create_shared(path, "h:1", None, 4, np.complex64, 6)
+    with rowsink.RowWindow(path, 2, 5) as win:
+        win.rows[...] = 3
+        assert len(rowsink.RowFile(path).rows) == 0          # a live reader, a killed writer's leftover
+    with pytest.raises(ValueError):
+        rowsink.RowWindow(path, 4, 9)                        # outside the file
+    rowsink.commit_shared(path, 6)
+    rows = np.asarray(rowsink.RowFile(path).rows)
+    assert rows.shape == (6, 4) and (rows[2:5] == 3).all() and not rows[:2].any() and not rows[5:].any()
+
+
 def _dry_run(n_ranks, *extra):
     import json
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
@@ -231,6 +347,17 @@ def test_bench_dry_run_dist_two_ranks():
     assert line["mean_chunk_index"] == 99.5      # mean over both ranks' chunk ranges: the reduce reached the root
     assert [r["rank"] for r in line["ranks"]["per_rank"]] == [0, 1]
     assert line["ranks"]["ms_per_step_this_rank"]["max"] <= line["ms_per_step"] * 1.5 + 1.0
+
+
+def test_bench_dry_run_dist_eight_ranks():
+    """The size the driver launches: 8 ranks, weak (the default) and strong with an uneven split."""
+    line = _dry_run(8)
+    assert line["n_gpus"] == 8 and line["frames_per_rank"] == [100] * 8 and line["frames_total"] == 800
+    assert line["first_chunk_last_rank"] == 700 and line["mean_chunk_index"] == 399.5
+    assert [r["rank"] for r in line["ranks"]["per_rank"]] == list(range(8))
+    line = _dry_run(8, "--scaling", "strong", "--frames", "1001")
+    assert line["frames_total"] == 1001 and sum(line["frames_per_rank"]) == 1001
+    assert max(line["frames_per_rank"]) - min(line["frames_per_rank"]) == 1 and line["mean_chunk_index"] == 500.0
 
 
 def test_bench_dry_run_dist_strong_scaling_three_ranks():

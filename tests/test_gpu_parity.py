@@ -1210,6 +1210,180 @@ def test_fx_straight_from_rtlsdr_bytes(plan_mod, torch, nchan, frames, n_chunks,
         assert rel_err(integ[0], rows[:, 0].astype(np.complex128).mean(axis=0)) < 2e-6
 
 
+def _offset_iq(seed, n_chunks, num_samp, dtype):
+    """Synthetic chunk pairs with a different complex DC offset on every stream (the receivers' I/Q imbalance that
+    effex.py:394-395 removes), in the source's sample type."""
+    x = synth.synth_iq(seed, n_chunks, 2, num_samp).astype(np.complex128)
+    rng = np.random.default_rng(seed)
+    x += (rng.uniform(-0.3, 0.3, size=(n_chunks, 2, 1)) + 1j * rng.uniform(-0.3, 0.3, size=(n_chunks, 2, 1)))
+    if dtype == np.complex128:
+        x += 1e-9 * rng.standard_normal(x.shape)          # bits a complex64 does not hold
+    return x.astype(dtype)
+
+
+@pytest.mark.parametrize("nchan,frames,n_chunks,dtype", [(4096, 9, 3, np.complex64), (4096, 5, 300, np.complex64),
+                                                         (4096, 7, 2, np.complex128), (1024, 12, 4, np.complex64),
+                                                         (64, 40, 2, np.complex128), (96, 21, 2, np.complex64),
+                                                         (1, 3000, 2, np.complex64)])
+def test_fx_with_dc_removal_on_the_device(plan_mod, torch, nchan, frames, n_chunks, dtype):
+    """fxc_fx_rows_iq / fxc_fx_accumulate_iq: effex.py:394-395 (per chunk, per antenna: x - mean(x.real) - 1j mean(x.imag))
+    in front of _pfb_xcorr, on the device, for complex64 and complex128 samples, host and device buffers -- against the
+    oracle chain remove_dc -> pfb_xcorr.  Tolerance: 1e-5 of max|vis| (TOL_VIS)."""
+    num_samp = nchan * frames + (37 if nchan > 1 else 0)
+    x = _offset_iq(77 + nchan, n_chunks, num_samp, dtype)
+    c128 = dtype == np.complex128
+    rng = np.random.default_rng(nchan)
+    window = design_window(4, nchan) if nchan > 1 else rng.standard_normal(4)
+    xd = torch.from_numpy(x).cuda()
+    keep = xd.clone()
+    with plan_mod.FxPlan(2, nchan, 4, num_samp, window=window) as p:
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-7)
+        rows = p.fx_rows(xd, "SPECTRUM", remove_dc=True, c128=c128).cpu().numpy()
+        assert torch.equal(xd, keep)                      # the caller's samples are never written
+        rows_host = p.fx_rows(x, "SPECTRUM", remove_dc=True, c128=c128)
+        np.testing.assert_array_equal(rows_host, rows)
+        pinned_in = plan_mod.pinned_empty(x.shape, dtype)
+        pinned_in[...] = x
+        pinned_out = plan_mod.pinned_empty(rows.shape, np.complex64)
+        got = p.fx_rows(pinned_in, "SPECTRUM", remove_dc=True, c128=c128, out=pinned_out)
+        assert got is pinned_out
+        np.testing.assert_array_equal(pinned_out, rows)   # written by the device through the mapping
+        for c in range(min(n_chunks, 2)):
+            ref = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(x[c, 0]), fx_oracle.remove_dc(x[c, 1]), 4, nchan, window,
+                                      gi.BANDWIDTH, gi.FREQUENCY, 1e-7, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        with_mean = p.fx_rows(xd, "SPECTRUM", c128=c128).cpu().numpy()
+        ref_mean = fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], 4, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 1e-7, "SPECTRUM")
+        assert rel_err(with_mean[0, 0], ref_mean) < TOL_VIS
+        assert rel_err(with_mean[0, 0], rows[0, 0]) > 1e-3     # the offset matters: the flag is not a no-op
+        cont = p.fx_rows(xd, "CONTINUUM", gi.BANDWIDTH, remove_dc=True, c128=c128).cpu().numpy()
+        np.testing.assert_allclose(cont[:, 0], rows[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH,
+                                   rtol=2e-5, atol=1e-7 * np.abs(cont).max())
+        p.fx_accumulate(xd[: n_chunks // 2], remove_dc=True, c128=c128)
+        p.fx_accumulate(x[n_chunks // 2:], remove_dc=True, c128=c128)
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ[0], rows[:, 0].astype(np.complex128).mean(axis=0)) < 2e-6
+
+
+def test_dc_removal_with_a_small_workspace(plan_mod, torch):
+    """Device buffers are de-meaned into a staging buffer in passes bounded by the workspace target: many passes give the
+    rows of one pass (float32 summation order aside)."""
+    num_samp, n_chunks = 4096 * 3, 37
+    x = _offset_iq(5, n_chunks, num_samp, np.complex64)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        one = p.fx_rows(xd, remove_dc=True).cpu().numpy()
+    import subprocess, sys, os      # the workspace target is read once per process: the 1 MiB run is a child
+    code = ("import numpy as np, torch, sys; sys.path.insert(0, %r); from effex_amd import plan\n"
+            "x = torch.from_numpy(np.load(sys.argv[1])).cuda()\n"
+            "with plan.FxPlan(2, 4096, 4, x.shape[2]) as p: np.save(sys.argv[2], p.fx_rows(x, remove_dc=True).cpu().numpy())\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "x.npy"), x)
+        subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "x.npy"), os.path.join(tmp, "r.npy")], check=True,
+                       env=dict(os.environ, FXC_WS_MB="1"), timeout=600)
+        many = np.load(os.path.join(tmp, "r.npy"))
+    # (not bit for bit: a pass of 5 chunk pairs splits its frames over the workgroups differently from one of 37)
+    assert many.shape == one.shape and rel_err(many, one) < TOL_VIS
+
+
+def test_pinned_host_memory(plan_mod, torch):
+    """fxc_host_alloc / fxc_host_free (effex.py:109-110: cusignal.get_shared_mem): buffers are ordinary host memory to the
+    caller, results are bit-identical to the pageable route, a pointer the library did not hand out is refused."""
+    import ctypes
+    from effex_amd import _lib
+    lib = _lib.load()
+    num_samp = 4096 * 6
+    x = synth.synth_iq(3, 2, 2, num_samp)
+    a = plan_mod.pinned_empty(x.shape, np.complex64)
+    a[...] = x
+    np.testing.assert_array_equal(a, x)
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        ref = p.fx_rows(x, "CONTINUUM", gi.BANDWIDTH)
+        out = plan_mod.pinned_empty(ref.shape, np.complex128)
+        np.testing.assert_array_equal(p.fx_rows(a, "CONTINUUM", gi.BANDWIDTH, out=out), ref)
+        inner = plan_mod.pinned_empty((4, 1, 4096), np.complex64)      # rows into the middle of a pinned block
+        inner[...] = 7
+        p.fx_rows(a, "SPECTRUM", out=inner[1:3])
+        np.testing.assert_array_equal(inner[1:3], p.fx_rows(x, "SPECTRUM"))
+        assert (inner[0] == 7).all() and (inner[3] == 7).all()
+        with pytest.raises(ValueError):
+            p.fx_rows(a, "SPECTRUM", out=np.empty((2, 1, 4095), np.complex64))
+    assert lib.fxc_host_free(None) == 0
+    assert lib.fxc_host_free(ctypes.c_void_p(a.ctypes.data + 64)) == _lib.FXC_ERR_ARG   # inside a block, not its start
+    ptr = ctypes.c_void_p()
+    assert lib.fxc_host_alloc(ctypes.byref(ptr), 0) == _lib.FXC_ERR_ARG
+    assert lib.fxc_host_alloc(ctypes.byref(ptr), 1 << 20) == 0 and ptr.value
+    assert lib.fxc_host_free(ptr) == 0
+    assert lib.fxc_host_free(ptr) == _lib.FXC_ERR_ARG                                    # freed once
+
+
+@pytest.mark.parametrize("fmt,dtype", [("c64", np.complex64), ("c128", np.complex128)])
+def test_host_fed_pipeline_with_dc_removal(plan_mod, torch, fmt, dtype):
+    """fxc_pipe_create_iq: complex recordings through the double-buffered front end with effex.py:394-395 on the device
+    == the blocking call, batch for batch."""
+    num_samp, chunks, n_batches = 4096 * 5, 3, 4
+    x = _offset_iq(21, chunks * n_batches, num_samp, dtype).reshape(n_batches, chunks, 2, num_samp)
+    c128 = fmt == "c128"
+    with plan_mod.FxPlan(2, 4096, 4, num_samp) as p:
+        ref = [p.fx_rows(x[b], remove_dc=True, c128=c128) for b in range(n_batches)]
+        with plan_mod.FxPipeline(p, chunks, depth=2, fmt=fmt, remove_dc=True) as pipe:
+            got = []
+            pipe.push(x[0])
+            for b in range(1, n_batches):
+                view = pipe.acquire()
+                assert view.dtype == dtype
+                view[...] = x[b]
+                pipe.submit()
+                got.append(pipe.pop())
+            got.append(pipe.pop())
+    for g, r in zip(got, ref):
+        np.testing.assert_array_equal(g, r)
+    ref0 = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(x[0, 0, 0]), fx_oracle.remove_dc(x[0, 0, 1]), 4, 4096,
+                               design_window(4, 4096), gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+    assert rel_err(got[0][0, 0], ref0) < TOL_VIS
+
+
+@pytest.mark.parametrize("mode", ["SPECTRUM", "CONTINUUM"])
+def test_drop_in_stage_then_run_task(torch, mode):
+    """The drop-in's own per-pair call path (effex.py:391-395, 402-410): _stage narrows the source's complex128 chunk pair
+    into the pinned gpu_iq buffers, _run_task hands them over and the mean comes off on the device -- equal to the
+    reference's host de-mean followed by _pfb_xcorr (oracle chain), and unchanged by a second call or by rebinding."""
+    from effex_amd.correlator import Correlator, SyntheticSource
+    num_samp = 2 ** 16
+    x = _offset_iq(31, 3, num_samp, np.complex128)
+    cor = Correlator(num_samp=num_samp, source=SyntheticSource(), mode=mode)
+    try:
+        assert cor._pinned
+        cor._state = 'RUN'
+        for c in range(3):
+            cor._stage((x[c, 0], x[c, 1]))
+            assert cor.gpu_iq_0.dtype == np.complex64 and np.shares_memory(cor.gpu_iq_0, cor._pair_buf)
+            vis = cor._run_task()
+            ref = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(x[c, 0]), fx_oracle.remove_dc(x[c, 1]), 4, 4096, cor.window,
+                                      cor.bandwidth, cor.frequency, 0.0, mode)
+            assert rel_err(vis, ref) < TOL_VIS
+            np.testing.assert_array_equal(cor._run_task(), vis)
+        # rebinding (effex.py:394-395 style) hands over exactly what was bound: no DC removal behind the caller's back
+        cor.gpu_iq_0, cor.gpu_iq_1 = x[0, 0], x[0, 1]
+        ref = fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], 4, 4096, cor.window, cor.bandwidth, cor.frequency, 0.0, mode)
+        assert rel_err(cor._run_task(), ref) < TOL_VIS
+        # ... and so does writing into the staging buffers in place after a rebind to them
+        cor.gpu_iq_0, cor.gpu_iq_1 = cor._pair_buf[0, 0], cor._pair_buf[0, 1]
+        cor.gpu_iq_0[:] = x[1, 0]
+        cor.gpu_iq_1[:] = x[1, 1]
+        ref = fx_oracle.pfb_xcorr(x[1, 0].astype(np.complex64), x[1, 1].astype(np.complex64), 4, 4096, cor.window,
+                                  cor.bandwidth, cor.frequency, 0.0, mode)
+        assert rel_err(cor._run_task(), ref) < TOL_VIS
+        cor.remove_dc = False
+        cor._stage((x[2, 0], x[2, 1]))
+        ref = fx_oracle.pfb_xcorr(x[2, 0], x[2, 1], 4, 4096, cor.window, cor.bandwidth, cor.frequency, 0.0, mode)
+        assert rel_err(cor._run_task(), ref) < TOL_VIS
+    finally:
+        cor.close()
+
+
 @pytest.mark.parametrize("mode", ["SPECTRUM", "CONTINUUM"])
 def test_host_fed_pipeline(plan_mod, torch, mode):
     """SURVEY.md §8f #4: double-buffered host-fed front end == the blocking host path, batch for batch."""

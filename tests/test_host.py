@@ -442,6 +442,38 @@ def test_binary_sidecar_round_trips_to_the_reference_csv(tmp_path, golden, mode)
     assert open(out, 'rb').read() == open(ref_csv, 'rb').read()
 
 
+def test_binary_sidecar_shows_committed_rows_only(tmp_path):
+    """The file is extended before rows are committed (reserve): a reader must not take the zero-filled tail for
+    visibilities -- the preamble carries the committed-row count, rewritten by commit / write_rows / close.  Round-3
+    files (FXB1, no count) are still read by size."""
+    import struct
+    from effex_amd import rowsink
+    path = str(tmp_path / "live.fxb")
+    sink = rowsink.BinSink(path, "h:1", None, 4, np.complex64)
+    view = sink.reserve(6)
+    assert len(rowsink.RowFile(path).rows) == 0              # reserved, nothing committed
+    view[:3] = 1
+    sink.commit(3)
+    assert np.asarray(rowsink.RowFile(path).rows).shape == (3, 4)
+    view[3:5] = 2                                            # (a writer killed here leaves six rows' worth of file)
+    assert len(rowsink.RowFile(path).rows) == 3
+    sink.commit(2)
+    sink.write(np.full(4, 5, np.complex64))
+    assert len(rowsink.RowFile(path).rows) == 6
+    sink.close()
+    rows = np.asarray(rowsink.RowFile(path).rows)
+    assert rows.shape == (6, 4) and (rows[:3] == 1).all() and (rows[3:5] == 2).all() and (rows[5] == 5).all()
+    # an FXB1 file: the same head without the count
+    old = str(tmp_path / "old.fxb")
+    head = b"h:1\n"
+    data_offset = (len(head) + rowsink._PRE_V1.size + 63) // 64 * 64
+    with open(old, "wb") as fh:
+        fh.write(head + rowsink._PRE_V1.pack(rowsink.MAGIC_V1, 8, 4, data_offset, 0))
+        fh.write(b"\0" * (data_offset - len(head) - rowsink._PRE_V1.size))
+        fh.write(rows[:2].tobytes())
+    np.testing.assert_array_equal(np.asarray(rowsink.RowFile(old).rows), rows[:2])
+
+
 def test_binary_sidecar_rejects_other_files(tmp_path):
     from effex_amd import rowsink
     p = tmp_path / "not.fxb"

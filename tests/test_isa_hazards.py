@@ -22,13 +22,51 @@ from effex_amd import build as fx_build
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "effex_amd", "csrc")
 
 
-@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not found")
-def test_no_wide_buffer_store_with_a_scalar_offset(tmp_path):
-    asm = tmp_path / "fxcorr.s"
+needs_hipcc = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not found")
+
+
+@pytest.fixture(scope="module")
+def asm_listing(tmp_path_factory):
+    """Device-only assembly of the library with the build's own flags (one compile for the whole module)."""
+    asm = tmp_path_factory.mktemp("asm") / "fxcorr.s"
     flags = [f for f in fx_build.FLAGS if f not in ("-shared", "-fPIC")]
     subprocess.run([fx_build.hipcc_path()] + flags + ["-S", "--cuda-device-only", "-o", str(asm), "fxcorr.hip"],
                    cwd=CSRC, check=True, stderr=subprocess.DEVNULL)
-    wide = [line.strip() for line in open(asm) if re.search(r"\bbuffer_store_(dwordx3|dwordx4)\b", line)]
+    return open(asm).read()
+
+
+@needs_hipcc
+def test_no_wide_buffer_store_with_a_scalar_offset(asm_listing):
+    wide = [line.strip() for line in asm_listing.split("\n") if re.search(r"\bbuffer_store_(dwordx3|dwordx4)\b", line)]
     # operands: vdata, vaddr, srsrc, soffset [modifiers]
     bad = [line for line in wide if re.match(r"s\d+|m0|s\[", line.split(",")[3].split()[0])]
     assert not bad, "wide buffer stores with an SGPR offset:\n" + "\n".join(bad[:8])
+
+
+def kernel_resources(asm_text):
+    """{mangled kernel name: (VGPRs, AGPR offset, SGPRs, scratch bytes, static LDS bytes)} from the .amdhsa_kernel blocks."""
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm_text, re.S):
+        body = m.group(2)
+
+        def field(name, default=0):
+            f = re.search(r"\.amdhsa_" + name + r" (\d+)", body)
+            return int(f.group(1)) if f else default
+        out[m.group(1)] = (field("next_free_vgpr"), field("accum_offset"), field("next_free_sgpr"),
+                           field("private_segment_fixed_size"), field("group_segment_fixed_size"))
+    return out
+
+
+@needs_hipcc
+def test_no_kernel_spills_to_scratch(asm_listing):
+    """Round 3 shipped three kernels with scratch (the uint8 kernel with in-kernel DC removal 56 B per lane, the 16-channel
+    F-only kernel 24 B, the 1024-thread 8192-channel kernels 168 / 172 B): every kernel of the library must compile to
+    .amdhsa_private_segment_fixed_size 0 -- a spill in a frame loop is a scratch round trip per step, and the ones outside
+    cost the wave its scratch set-up.  Also: nothing uses the dynamic-stack or the flat-scratch path."""
+    res = kernel_resources(asm_listing)
+    assert len(res) >= 80, len(res)
+    spilled = {name: r[3] for name, r in res.items() if r[3] != 0}
+    assert not spilled, "kernels with scratch: {}".format(spilled)
+    assert not re.search(r"\bscratch_(load|store)", asm_listing)
+    # the two-waves-per-SIMD kernels stay within the 256 registers that occupancy leaves them
+    assert max(r[0] for r in res.values()) <= 256
