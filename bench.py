@@ -245,8 +245,14 @@ def dry_run_dist(args):
     import torch.distributed as dist
     from effex_amd import sharding
     rank, local_rank, world = rank_env(args)
+    if args.supervise and world > 1 and not os.environ.get(CHILD_ENV):
+        raise SystemExit(supervise(args, rank, world))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.supervise and args.reduce != "torch":     # stands in for the real run's communicator window
+        milestone("comm:start")
+        _fake_comm_hang()
+        milestone("comm:done")
     if args.scaling == "weak":                        # every rank owns `frames` frames
         first_chunk, frames = rank * args.frames, args.frames
     else:                                             # `frames` in all, contiguous ranges
@@ -290,7 +296,8 @@ def dry_run_dist(args):
         print(json.dumps({"dry_run": True, "backend": "gloo", "n_gpus": world, "steps": args.steps, "scaling": args.scaling,
                           "warmup": args.warmup, "frames_per_rank": [r["frames"] for r in ranks], "frames_total": total,
                           "first_chunk_last_rank": ranks[-1]["first_frame"],
-                          "transport": integ.transport, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+                          "transport": integ.transport, "fallback": os.environ.get(NOTE_ENV),
+                          "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
                           "ranks": {"per_rank": ranks, "ms_per_step_this_rank": spread(ranks, "ms_per_step_this_rank")},
                           "mean_chunk_index": want.real}))
     else:
@@ -419,6 +426,95 @@ def rccl_preflight(gpu, rank, world, timeout_s):
     return (not bad), ("; ".join(bad) if bad else None)
 
 
+# ----------------------------------------------------------------------------------------------
+# Watchdog around the REAL communicator (N > 1, fxc_reduce): the preflight above proves in a throw-away child that
+# fxc_comm_create / fxc_reduce work; the measuring process then has to call ncclCommInitRank itself, and a collective
+# that hangs there cannot be abandoned from inside the process that is stuck in it.  So with N > 1 every rank started by
+# the launcher is a *supervisor* that never touches the GPU: it runs the measurement in a child process (a fresh child,
+# never an exec of a process that holds the GPU), watches the child's milestones ("comm:start" / "comm:done" in a status
+# file), and if the communicator is not up within --comm-timeout seconds -- or the child dies inside that window -- kills
+# exactly that child and starts another one on the torch.distributed transport (--reduce torch) with a rendezvous of its
+# own (a fresh port published by rank 0's supervisor through a file; the launcher's store still holds the first
+# attempt's keys).  The fall-back is recorded in the line (config.reduce_transport).
+# ----------------------------------------------------------------------------------------------
+STATUS_ENV, CHILD_ENV, NOTE_ENV = "FXC_BENCH_STATUS", "FXC_BENCH_CHILD", "FXC_BENCH_FALLBACK_NOTE"
+
+
+def milestone(text):
+    path = os.environ.get(STATUS_ENV)
+    if path:
+        with open(path, "a") as fh:
+            fh.write("%s %.3f\n" % (text, time.time()))
+
+
+def _fake_comm_hang():
+    """Test hook (tests/test_dist_gloo.py): the first attempt never gets its communicator."""
+    if os.environ.get("FXC_BENCH_TEST_COMM_HANG") == "1" and not os.environ.get(NOTE_ENV):
+        time.sleep(3600)
+
+
+def supervise(args, rank, world):
+    import socket
+    import subprocess
+    import tempfile
+    status = tempfile.NamedTemporaryFile(prefix="fxbench_status_r%d_" % rank, suffix=".txt", delete=False)
+    status.close()
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]      # (the child knows it is one: CHILD_ENV)
+
+    def start(extra_args, extra_env):
+        env = dict(os.environ, **{CHILD_ENV: "1", STATUS_ENV: status.name})
+        env.update(extra_env)
+        open(status.name, "w").close()
+        return subprocess.Popen(argv + extra_args, env=env)
+
+    def state():
+        with open(status.name) as fh:
+            text = fh.read()
+        begun = [ln for ln in text.splitlines() if ln.startswith("comm:start")]
+        return (float(begun[-1].split()[1]) if begun else None), "comm:done" in text
+
+    proc = start([], {})
+    why = None
+    while True:
+        rc = proc.poll()
+        begun, done = state()
+        if rc is not None:
+            if rc != 0 and begun is not None and not done:
+                why = "the measuring process of rank %d exited %s while the RCCL communicator was being made" % (rank, rc)
+                break
+            os.unlink(status.name)
+            return rc
+        if begun is not None and not done and time.time() - begun > args.comm_timeout:
+            proc.kill()                      # exactly the child this supervisor started
+            proc.wait()
+            why = "no RCCL communicator on rank %d within %.0f s (measuring process killed)" % (rank, args.comm_timeout)
+            break
+        time.sleep(0.2)
+    # fall back: a fresh child on the torch.distributed transport, with a rendezvous the first attempt never touched
+    port_file = os.path.join(tempfile.gettempdir(), "fxbench_fallback_port_%s" % os.environ.get("MASTER_PORT", "0"))
+    if rank == 0:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        with open(port_file + ".tmp", "w") as fh:
+            fh.write(str(port))
+        os.replace(port_file + ".tmp", port_file)
+    else:
+        t_end = time.time() + args.comm_timeout + 120
+        while not os.path.exists(port_file):
+            if time.time() > t_end:
+                raise SystemExit("bench.py: rank %d fell back (%s) but rank 0 never published a rendezvous port" % (rank, why))
+            time.sleep(0.2)
+        port = int(open(port_file).read())
+    sys.stderr.write("bench.py rank %d: %s -- falling back to --reduce torch on port %d\n" % (rank, why, port))
+    proc = start(["--reduce", "torch"], {NOTE_ENV: why, "MASTER_PORT": str(port), "TORCHELASTIC_USE_AGENT_STORE": "False"})
+    rc = proc.wait()
+    os.unlink(status.name)
+    if rank == 0 and os.path.exists(port_file):
+        os.unlink(port_file)
+    return rc
+
+
 def gather_rank_stats(stats, world):
     """Every rank's dict on rank 0 (list indexed by rank)."""
     if world == 1:
@@ -434,6 +530,88 @@ def spread(rows, key):
     if not vals:
         return None
     return {"min": min(vals), "max": max(vals), "mean": round(sum(vals) / len(vals), 4), "argmax_rank": max(range(len(vals)), key=lambda i: vals[i])}
+
+
+def rows_mode(args, plan, x, dev, rank, world, first_frame, frames, total_frames, check_rows):
+    """--rows: K timed passes; in each, every rank turns its resident frames into visibility rows (fxc_fx_rows, --rows-batch
+    frames per call) and writes them into its own window of one shared row file -- the reference's product, one row per
+    chunk pair (effex.py:402-410, 687-696), with no collective on the data path.  Barrier + synchronize on both sides of the
+    timed region, max over ranks; afterwards (untimed) rank 0 reads the file back and checks it."""
+    import tempfile
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from effex_amd import rowsink, sharding
+    box = [None]
+    if rank == 0:
+        box[0] = args.rows_file or os.path.join(tempfile.mkdtemp(prefix="fxrows_"), "visibilities.fxb")
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    path = box[0]
+    header = rowsink.header_line(1, BANDWIDTH, FREQUENCY, NUM_SAMP, NCHAN, 49.6, "SPECTRUM")
+    freqs = rowsink.spectrum_freqs(NCHAN, BANDWIDTH, FREQUENCY)
+    writer = sharding.ShardedRows(plan, rank, world, batch=args.rows_batch)
+    assert writer.my_range(total_frames) == (first_frame, first_frame + frames)
+
+    def read_chunks(lo, hi):
+        return x[lo - first_frame:hi - first_frame]
+
+    def one_pass():
+        writer.run(path, header, freqs, read_chunks, total_frames, "SPECTRUM", BANDWIDTH)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_pass()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    fence()
+    elapsed_rank = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_rank, world, dev)
+    ranks = gather_rank_stats({"rank": rank, "frames": frames, "first_frame": first_frame,
+                               "ms_per_step_this_rank": round(elapsed_rank / max(args.steps, 1) * 1e3, 4),
+                               "rows_per_s_this_rank": round(frames * args.steps / elapsed_rank, 1)}, world)
+    if rank == 0:
+        back = rowsink.RowFile(path)
+        assert back.rows.shape == (total_frames, NCHAN) and back.header == header, (back.rows.shape, back.header)
+        assert sum(r["frames"] for r in ranks) == total_frames
+        # sampled rows of the file against a direct call on the same frames, and rank 0's against the oracle (N = 1)
+        probe = sorted(set([0, frames // 2, frames - 1])) if frames > 0 else []
+        err_direct = 0.0
+        if probe:
+            direct = plan.fx_rows(x[probe], "SPECTRUM")[:, 0].cpu().numpy()
+            err_direct = float(np.abs(np.asarray(back.rows[[first_frame + f for f in probe]]) - direct).max() / np.abs(direct).max())
+        err_oracle = {str(f): float(np.abs(np.asarray(back.rows[f]) - ref).max() / np.abs(ref).max())
+                      for f, ref in sorted(check_rows.items()) if f < frames}
+        assert err_direct < TOL_VIS and all(e < TOL_VIS for e in err_oracle.values()), (err_direct, err_oracle)
+        assert np.abs(np.asarray(back.rows[-1])).max() > 0          # the last rank's last row arrived
+        rows_s = total_frames * args.steps / elapsed
+        print(json.dumps({
+            "metric": "2-ant FX correlator time series (PFB+FFT+X, one visibility row per frame into one shared row file)",
+            "value": round(rows_s, 1), "unit": "rows/s", "Msamples_per_s": round(rows_s * NUM_SAMP / 1e6, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1] frames as a time series: 2-antenna FX, num_samp=262144, ntaps=4, nchan=4096, "
+                                   "%d frames %s, one complex64 row of 4096 bins per frame" % (args.frames, "per GPU" if args.scaling == "weak" else "in all"),
+                       "frames_total": total_frames, "rows_batch": args.rows_batch, "row_bytes": NCHAN * 8,
+                       "parallelism": "frames sharded over %d GPU(s) in whole batches, disjoint windows of one row file, no collective" % world,
+                       "dist_backend": args.dist_backend if world > 1 else None, "path": plan.path},
+            "verify": {"rows_in_file": int(back.rows.shape[0]), "file_vs_direct_call": err_direct, "rows_vs_oracle": err_oracle,
+                       "tolerance": TOL_VIS, "checked_after_timed_region": True},
+            "ranks": {"per_rank": ranks, "rows_per_s_this_rank": spread(ranks, "rows_per_s_this_rank"),
+                      "ms_per_step_this_rank": spread(ranks, "ms_per_step_this_rank")}}))
+        del back
+        if not args.rows_file:
+            import shutil
+            shutil.rmtree(os.path.dirname(path), ignore_errors=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -462,9 +640,19 @@ def main():
     ap.add_argument("--strict-rccl", action="store_true",
                     help="exit non-zero instead of falling back to torch.distributed when fxc_reduce cannot be used")
     ap.add_argument("--rccl-timeout", type=float, default=120.0, help="seconds the RCCL preflight child of a rank may take")
+    ap.add_argument("--comm-timeout", type=float, default=180.0,
+                    help="N > 1: seconds the measuring process may spend making the real RCCL communicator before its supervisor "
+                         "kills it and falls back to --reduce torch from a fresh child")
+    ap.add_argument("--supervise", action="store_true", help="(tests) run the supervisor in --dry-run-dist mode too")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend for N > 1.  gloo + fewer GPUs than ranks (ranks share GPUs round-robin) "
                          "runs the real multi-rank flow on a one-GPU box for testing; its timing means nothing")
+    ap.add_argument("--rows", action="store_true",
+                    help="the reference-faithful time-series mode instead of the integration (SURVEY.md 8e, second paragraph): one "
+                         "visibility row per frame, every rank writes the rows of its own frames into its window of ONE shared "
+                         "row file (effex_amd.sharding.ShardedRows), no collective; prints rows/s")
+    ap.add_argument("--rows-batch", type=int, default=64, help="--rows: frames per device call")
+    ap.add_argument("--rows-file", default=None, help="--rows: the shared row file (default: a temporary file, removed)")
     ap.add_argument("--dry-run-dist", action="store_true",
                     help="run the multi-rank control flow on gloo / CPU tensors with a stand-in plan (no GPU)")
     args = ap.parse_args()
@@ -475,6 +663,9 @@ def main():
         return dry_run_dist(args)
 
     rank, local_rank, world = rank_env(args)
+    if (world > 1 and args.reduce != "torch" and args.dist_backend == "nccl" and not args.rows
+            and not os.environ.get(CHILD_ENV)):
+        raise SystemExit(supervise(args, rank, world))      # this process never touches the GPU
 
     from effex_amd import _lib
     if not _lib.is_in_tree():
@@ -503,13 +694,16 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # --- this rank's frames of the synthetic stream, device resident if they fit ------------------------
-    if args.scaling == "weak":
+    total_frames = args.frames * world if args.scaling == "weak" else args.frames
+    if args.rows:      # whole batches of the global frame index per rank: the file is a single rank's, byte for byte
+        lo, hi = sharding.batch_range(rank, world, total_frames, args.rows_batch)
+        first_frame, frames = lo, hi - lo
+    elif args.scaling == "weak":
         first_frame, frames = rank * args.frames, args.frames
     else:
         lo, hi = sharding.chunk_range(rank, world, args.frames)
         first_frame, frames = lo, hi - lo
-    total_frames = args.frames * world if args.scaling == "weak" else args.frames
-    if frames < 1:
+    if frames < 1 and not args.rows:      # (--rows: a rank without a batch writes an empty window and joins the barriers)
         raise SystemExit("rank %d has no frames: --frames %d over %d ranks" % (rank, args.frames, world))
     free_b, _total_b = torch.cuda.mem_get_info(dev)
     need = frames * BYTES_PER_FRAME
@@ -521,6 +715,10 @@ def main():
     plan = FxPlan(N_ANT, NCHAN, NTAPS, NUM_SAMP, device=gpu)
     assert plan.path == "fused", "headline workload must run on the fused HIP kernel"
     plan.set_delay(BANDWIDTH, FREQUENCY, 0.0)
+    if args.rows:
+        if pool_frames < frames:
+            raise SystemExit("--rows needs this rank's %d frames resident (%d fit)" % (frames, pool_frames))
+        return rows_mode(args, plan, x, dev, rank, world, first_frame, frames, total_frames, check_rows)
     comm, comm_note = None, None
     if world > 1 and args.reduce != "torch":
         if args.dist_backend != "nccl":
@@ -528,7 +726,9 @@ def main():
         else:
             ok, why = rccl_preflight(gpu, rank, world, args.rccl_timeout)
             if ok:
+                milestone("comm:start")          # from here the supervisor's clock runs (--comm-timeout)
                 try:
+                    _fake_comm_hang()
                     comm = sharding.make_comm(gpu, rank, world)
                 except Exception as exc:
                     comm, why = None, "rank %d: %s" % (rank, exc)
@@ -537,10 +737,13 @@ def main():
                 if int(flag.item()) == 0 and comm is not None:
                     comm.close()
                     comm = None
+                milestone("comm:done")
             if comm is None:
                 comm_note = "no RCCL communicator (%s)" % (why or "another rank failed")
         if comm is None and args.strict_rccl:
             raise SystemExit("bench.py --strict-rccl: fxc_reduce is not usable: %s" % comm_note)
+    if os.environ.get(NOTE_ENV):
+        comm_note = "fell back from fxc_reduce: " + os.environ[NOTE_ENV]
     integ = sharding.ShardedIntegrator(plan, rank, world, comm=comm)
 
     def issue():

@@ -141,12 +141,13 @@ int fxc_plan_destroy(fxc_plan* p) {
         return fail(p, FXC_ERR_STATE, "%d pipe(s) still use this plan: destroy them first", p->live_pipes);
     DeviceGuard device_guard__(p->device);
     (void)hipStreamSynchronize(p->stream);
+    if (p->s_copy) (void)hipStreamSynchronize(p->s_copy);   // an uncollected large result may still be on its way to h_res[]
     for (auto& e : p->kev) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
     void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_tw_small, p->d_stamps,
-                    p->d_acc, p->d_sums, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
+                    p->d_acc, p->d_sums, p->d_cont, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
                     p->d_ones, p->d_pre, p->d_tw8192};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -734,10 +735,12 @@ int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth
         // SPECTRUM: one kernel.  CONTINUUM needs the mean over the bins of the finished accumulator: export, then reduce
         FoldFinish fin = {nullptr, out, p->d_rot, p->spectra_count, reset ? 1 : 0};
         if (mode == FXC_MODE_CONTINUUM) {
-            fin.sums = p->d_sums;
+            // into a buffer of its own: d_sums may hold reduced sums (fxc_reduce) that fxc_finalize_sums(plan, NULL) has yet
+            // to read, and only fxc_reduce makes that copy valid
+            if (!p->d_cont) FXC_HIP(p, hipMalloc(&p->d_cont, ((size_t)n + 1) * sizeof(cd)));
+            fin.sums = p->d_cont;
             fin.out = nullptr;
-            p->sums_valid = true;
-            sums_src = p->d_sums;
+            sums_src = p->d_cont;
         }
         // the slot's event rides on the last kernel's own completion (hipExtLaunchKernelGGL): an event recorded behind it is
         // a packet of its own in the stream, and the next F+X kernel starts 11 us later for it
@@ -893,8 +896,10 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
         // streams, the default work split, one launch for the pass and at least two rounds of chunks.
         int64_t spec_b, raw_b;
         const int64_t g = p->fused_grid_max;
+        // (num_samp <= 2^26: a wave's byte sums are reduced in 32 bits, 16384 frames x 4080 x 64 lanes < 2^32)
         const bool dck = remove_dc && fused_ingest && p->path == FXC_PATH_FUSED && p->fused_seg == 1 &&
-                         (p->num_samp % fxc::fused::kN) == 0 && (reinterpret_cast<uintptr_t>(xb) % 16) == 0 &&
+                         (p->num_samp % fxc::fused::kN) == 0 && p->num_samp <= (1ll << 26) &&
+                         (reinterpret_cast<uintptr_t>(xb) % 16) == 0 &&
                          fused_chunks_per_pass(p, nc, &spec_b, &raw_b) >= nc && nc >= 2 * g;
         if (remove_dc && fused_ingest) {
             const int64_t n_full = dck ? nc / g * g : nc;

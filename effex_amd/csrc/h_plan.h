@@ -85,6 +85,7 @@ struct fxc_plan {
     int64_t fused_seg = 1;         // chunks per round-robin segment of the fused kernel (fx_fused4096.h::RangeWalk)
     cd* d_acc = nullptr;           // [n_base*nchan]
     cd* d_sums = nullptr;          // [n_base*nchan + 1]
+    cd* d_cont = nullptr;          // [n_base*nchan + 1] the export a CONTINUUM finalize of the accumulator reduces (lazy)
     bool sums_valid = false;       // d_sums holds exported sums (fxc_reduce): fxc_finalize_sums(plan, NULL, ...) may read it
     // raw rows of the last fx_accumulate pass whose fold into the accumulator is still to be launched: it is launched
     // by whatever needs the accumulator or the workspace next (flush_pending) -- by a finalize together with the

@@ -253,17 +253,6 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
     return FXC_OK;
 }
 
-bool h2d_by_kernel() {
-    static const bool v = [] { const char* e = std::getenv("FXC_H2D"); return e && std::string(e) == "kernel"; }();
-    return v;
-}
-
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void host_fetch_kernel(const v4f_t* __restrict__ src, v4f_t* __restrict__ dst, int64_t n16) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += stride) dst[k] = __builtin_nontemporal_load(src + k);
-}
-
 // host-buffer helper: stage in, run, stage out (synchronous)
 // Pageable buffers go through the runtime's bounce buffers inside hipMemcpyAsync; buffers from fxc_host_alloc are pinned, so
 // the same call is one DMA -- and an `out` inside such a block is handed to fn as the device's mapping of it: the finishing
@@ -281,17 +270,9 @@ int with_host_staging(fxc_plan* p, const void* x, size_t x_bytes, void* out, siz
     void* dx = p->d_stage[0];
     void* dout = out_bytes ? (out_mapped ? out_mapped : p->d_stage[1]) : nullptr;
     int rc = FXC_OK;
-    hipError_t e = hipSuccess;
-    const void* x_mapped = h2d_by_kernel() ? pinned_device_ptr(x, x_bytes) : nullptr;
-    if (x_mapped && x_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(x_mapped) % 16 == 0) {
-        // developer knob FXC_H2D=kernel: the CUs fetch the pinned block over PCIe themselves instead of the copy engine
-        const int64_t n16 = (int64_t)(x_bytes / 16);
-        hipLaunchKernelGGL(host_fetch_kernel, dim3((unsigned)std::min<int64_t>((n16 + 255) / 256, (int64_t)p->cu_count * 8)), dim3(256),
-                           0, p->stream, static_cast<const v4f_t*>(x_mapped), static_cast<v4f_t*>(dx), n16);
-        e = hipGetLastError();
-    } else {
-        e = hipMemcpyAsync(dx, x, x_bytes, hipMemcpyHostToDevice, p->stream);
-    }
+    // (a kernel fetching the pinned block over PCIe itself instead of the copy engine was measured: 0.149 against 0.133 ms per
+    // reference-sized call, profiles/r04/experiments.md)
+    hipError_t e = hipMemcpyAsync(dx, x, x_bytes, hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) rc = fn(static_cast<const cf*>(dx), dout);
     if (e == hipSuccess && rc == FXC_OK && out_bytes && !out_mapped)
         e = hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, p->stream);

@@ -215,7 +215,7 @@ __device__ __forceinline__ cf dck_offset(unsigned* acc, unsigned* red, int tid, 
     }
     __syncthreads();
     const int ant = (tid >> 8) & 1;        // waves 0-3 summed antenna 0, waves 4-7 antenna 1
-    unsigned long long ti = 0, tq = 0;     // exact: at most 2^27 samples of 255
+    unsigned long long ti = 0, tq = 0;     // exact: the launcher keeps num_samp <= 2^26, so a wave's 32-bit sums cannot wrap
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv) {
         ti += red[(4 * ant + wv) * 2];

@@ -324,16 +324,30 @@ def test_shared_row_file_shows_nothing_before_the_count_is_published(tmp_path):
     assert rows.shape == (6, 4) and (rows[2:5] == 3).all() and not rows[:2].any() and not rows[5:].any()
 
 
-def _dry_run(n_ranks, *extra):
+def _dry_run(n_ranks, *extra, env=None):
     import json
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--steps", "3",
            "--warmup", "1", "--dry-run-dist"] + list(extra)
-    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                       # rank 0 alone prints the line
     return json.loads(lines[0])
+
+
+def test_bench_supervisor_falls_back_when_the_communicator_hangs():
+    """The watchdog around the real RCCL communicator (bench.py::supervise): every rank is a supervisor that runs the
+    measurement in a child; a child stuck between "comm:start" and "comm:done" (here: the test hook, on every rank) is
+    killed after --comm-timeout and a fresh child takes the torch.distributed transport on a rendezvous of its own.  The
+    run completes, exits 0, and says what happened."""
+    env = dict(os.environ, FXC_BENCH_TEST_COMM_HANG="1")
+    line = _dry_run(3, "--supervise", "--comm-timeout", "3", env=env)
+    assert line["n_gpus"] == 3 and line["frames_total"] == 300 and line["mean_chunk_index"] == 149.5
+    assert "no RCCL communicator on rank 0 within 3 s" in line["fallback"]
+    # without the hang: the same supervised launch finishes on the first attempt
+    line = _dry_run(2, "--supervise", "--comm-timeout", "30")
+    assert line["fallback"] is None and line["frames_total"] == 200
 
 
 def test_bench_dry_run_dist_two_ranks():

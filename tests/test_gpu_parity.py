@@ -1094,8 +1094,25 @@ def test_reduce_through_rccl_on_the_plan_stream(plan_mod, torch):
             np.testing.assert_array_equal(p.finalize_sums(None, "SPECTRUM"), ref)
         p.reduce(None, 0)                              # no communicator: export only
         np.testing.assert_array_equal(p.finalize_sums(None, "SPECTRUM"), ref)
+        # a CONTINUUM finalize of the accumulator in between neither clobbers the reduced sums nor makes them valid
+        p.fx_accumulate(x[:2])
+        cont = p.finalize("CONTINUUM", gi.BANDWIDTH, reset=False)
+        assert np.isfinite(cont).all()
+        np.testing.assert_array_equal(p.finalize_sums(None, "SPECTRUM"), ref)
+        with plan_mod.FxPlan(2, 4096, 4, num_samp) as q:
+            q.fx_accumulate(x)
+            q.finalize("CONTINUUM", gi.BANDWIDTH, reset=False)
+            with pytest.raises(plan_mod._lib.FxcError):
+                q.finalize_sums(None, "SPECTRUM")       # no fxc_reduce has run on this plan
         p.acc_reset()
         integ = sharding.ShardedIntegrator(p, 0, 1, comm=comm)
+        with pytest.raises(plan_mod._lib.FxcError):
+            integ.finalize_wait()                      # nothing queued
+        integ.accumulate(x)
+        integ.finalize_async("SPECTRUM", gi.BANDWIDTH)
+        with pytest.raises(plan_mod._lib.FxcError):
+            integ.finalize("SPECTRUM", gi.BANDWIDTH)   # an asynchronous result is outstanding (as fxc_finalize refuses)
+        np.testing.assert_array_equal(integ.finalize_wait(), ref)
         integ.accumulate(x)
         np.testing.assert_array_equal(integ.finalize("SPECTRUM", gi.BANDWIDTH), ref)
         with pytest.raises(ValueError):
@@ -1487,3 +1504,75 @@ def test_bench_two_ranks_share_one_gpu():
     ranks = line["ranks"]
     assert [r["rank"] for r in ranks["per_rank"]] == [0, 1] and [r["first_frame"] for r in ranks["per_rank"]] == [0, 600]
     assert ranks["avg_kernel_ms"]["min"] > 0 and ranks["reduce_us"]["max"] > 0
+
+
+def _launch_bench(n_ranks, *extra, timeout=900):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--dist-backend",
+           "gloo"] + list(extra)
+    proc = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=timeout)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]                       # rank 0 alone prints, every child exited cleanly
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling,frames", [("weak", 64), ("strong", 530)])
+def test_bench_eight_ranks_share_one_gpu(scaling, frames):
+    """The launch the driver makes for the scaling curve -- torch.distributed.run with 8 ranks -- rehearsed on this one GPU
+    over gloo (ranks share the GPU, so RCCL is out and the run takes the torch.distributed transport): the per-rank table,
+    the frame bookkeeping, the all-reduced check after the timed region and a clean exit of all eight children."""
+    line = _launch_bench(8, "--steps", "2", "--warmup", "1", "--frames", str(frames), "--scaling", scaling, "--no-power")
+    total = frames * 8 if scaling == "weak" else frames
+    assert line["n_gpus"] == 8 and line["scaling"] == scaling and line["config"]["frames_total"] == total
+    assert line["verify"]["frames"] == total and line["verify"]["integration_vs_float64_mean_of_rows"] < 1e-6
+    ranks = line["ranks"]["per_rank"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and sum(r["frames"] for r in ranks) == total
+    assert [r["first_frame"] for r in ranks] == [sum(q["frames"] for q in ranks[:k]) for k in range(8)]
+    assert max(r["frames"] for r in ranks) - min(r["frames"] for r in ranks) <= (0 if scaling == "weak" else 1)
+    assert all(r["avg_kernel_ms"] > 0 and r["launches"] == 2 for r in ranks) and line["ranks"]["reduce_us"]["max"] > 0
+    assert line["config"]["reduce_transport"].startswith("torch.distributed; ranks share GPUs")
+    assert line["value"] > 0 and line["roofline"]["launches"] == 2
+
+
+def test_bench_rows_mode_two_ranks_write_the_single_rank_file(tmp_path):
+    """bench.py --rows (the time-series mode; effex.py:687-696): two ranks sharing this GPU fill disjoint
+    windows of one row file through ShardedRows; the file is byte-identical to the one a single rank writes, and
+    tools/rows_to_csv.py turns it into the csv the reference's writer produces for those rows."""
+    import subprocess
+    import sys
+    import os
+    from effex_amd import rowsink
+    two, one = str(tmp_path / "two.fxb"), str(tmp_path / "one.fxb")
+    line = _launch_bench(2, "--rows", "--rows-batch", "16", "--rows-file", two, "--steps", "1", "--warmup", "0", "--frames", "72",
+                         "--scaling", "strong")
+    assert line["unit"] == "rows/s" and line["n_gpus"] == 2 and line["verify"]["rows_in_file"] == 72
+    assert [r["frames"] for r in line["ranks"]["per_rank"]] == [32, 40]          # whole batches of 16: 2 + 3 (the last one short)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", "--rows-batch", "16", "--rows-file", one,
+                           "--steps", "1", "--warmup", "0", "--frames", "72", "--no-cpu-baseline"], cwd=root,
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert open(two, "rb").read() == open(one, "rb").read()
+    back = rowsink.RowFile(two)
+    out_csv, ref_csv = str(tmp_path / "two.csv"), str(tmp_path / "ref.csv")
+    subprocess.run([sys.executable, os.path.join(root, "tools", "rows_to_csv.py"), two, out_csv], check=True, capture_output=True)
+    with rowsink.CsvSink(ref_csv, back.header, back.freqs) as sink:          # the reference's writer (golden-tested in test_host.py)
+        sink.write_rows(np.asarray(back.rows))
+    assert open(out_csv, "rb").read() == open(ref_csv, "rb").read()
+    # the rows themselves: frame 3 and the last one against the oracle
+    window = design_window(4, 4096)
+    for f in (3, 71):
+        x = synth.synth_iq(1234, 1, 2, 262144, first_chunk=f)[0]
+        ref = fx_oracle.pfb_xcorr(x[0], x[1], 4, 4096, window, 2.4e6, 1.4204e9, 0.0, "SPECTRUM")
+        assert rel_err(np.asarray(back.rows[f]), ref) < TOL_VIS
