@@ -312,7 +312,7 @@ def other_configs(x, dev, reps=5):
     28 baselines, nchan 4096), plus two three-pass shapes (32 taps, 8192 channels).  HIP events around four calls back to
     back (results collected one call behind, as the headline loop does), per call, median of `reps`."""
     import numpy as np
-    from effex_amd.plan import FxPlan
+    from effex_amd.plan import FxPlan, pinned_empty
     out = []
     flat = x.view(-1)
 
@@ -322,6 +322,10 @@ def other_configs(x, dev, reps=5):
             return
         xv = flat[:need].view(n_chunks, n_ant, num_samp)
         with FxPlan(n_ant, nchan, ntaps, num_samp, window=window, device=dev.index) as plan:
+            # integrations are delivered into pinned buffers named when they are queued (fxc_finalize_async_to)
+            outs = [pinned_empty((plan.n_baselines, nchan) if mode == "SPECTRUM" else (plan.n_baselines,), np.complex128)
+                    for _ in range(2)]
+
             def many(k):
                 """k calls back to back; an integration's result is collected while the next one runs, as in main()"""
                 for j in range(k):
@@ -329,7 +333,7 @@ def other_configs(x, dev, reps=5):
                         plan.fx_rows(xv, mode, BANDWIDTH)
                     else:
                         plan.fx_accumulate(xv)
-                        plan.finalize_async(mode, BANDWIDTH, reset=True)
+                        plan.finalize_async(mode, BANDWIDTH, reset=True, out=outs[j & 1])
                         if j > 0:
                             plan.finalize_wait()
                 if not rows and k > 0:

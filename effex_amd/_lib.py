@@ -71,6 +71,7 @@ SIGNATURES = {
     "fxc_finalize_sums": (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_double]),
     "fxc_finalize": (_c.c_int, [_vp, _vp, _c.c_int, _c.c_double, _c.c_int]),
     "fxc_finalize_async": (_c.c_int, [_vp, _c.c_int, _c.c_double, _c.c_int]),
+    "fxc_finalize_async_to": (_c.c_int, [_vp, _vp, _c.c_int, _c.c_double, _c.c_int]),
     "fxc_finalize_sums_async": (_c.c_int, [_vp, _vp, _c.c_int, _c.c_double]),
     "fxc_finalize_wait": (_c.c_int, [_vp, _vp]),
     "fxc_finalize_pending": (_c.c_int, [_vp]),

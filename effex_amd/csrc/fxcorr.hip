@@ -90,6 +90,7 @@ int64_t ws_target() {
 
 #include "k_generic.h"
 #include "k_finish.h"
+#include "k_xmfma.h"
 #include "k_fused4096.h"
 #include "k_tiled.h"
 #include "k_small.h"
@@ -421,6 +422,21 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             case 8: xfn = reinterpret_cast<const void*>(&xengine_kernel<8>); break;
             default: xfn = reinterpret_cast<const void*>(&xengine_block_kernel); break;
         }
+        // more than 8 antennas: the matrix-core X-engine (k_xmfma.h) unless FXC_XENGINE=block (developer knob: the vector
+        // kernel over blocks of 8 antennas it replaced)
+        const char* xe = std::getenv("FXC_XENGINE");
+        p->x_mfma = p->n_ant > kXB && !(xe && std::string(xe) == "block");
+        if (p->x_mfma) {
+            int per_cu = 0, threads = 0, lds = 0;
+            FXC_XMFMA_DISPATCH(p, {
+                xfn = reinterpret_cast<const void*>(&xengine_mfma_kernel<XT>);
+                threads = XMfmaGeo<XT>::kThreads;
+                lds = XMfmaGeo<XT>::kLdsBytes;
+            });
+            FXC_HIP(p, hipFuncSetAttribute(xfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            FXC_HIP(p, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xfn, threads, lds));
+            p->x_resident = (int64_t)std::max(per_cu, 1) * p->cu_count;
+        } else {
         // one-wave workgroups resident per CU: the occupancy API, bounded by the register file (512 VGPRs per SIMD lane in
         // granules of 8, at most 8 waves per SIMD) -- the API has been seen one block per CU high (MI355X_MICROARCH.md),
         // and a launch sized one wave per CU too large would run a second round for that sliver
@@ -431,6 +447,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8);
         per_cu = std::min(per_cu, 4 * std::min(8, 512 / regs));
         p->x_resident = (int64_t)std::max(per_cu, 1) * p->cu_count;
+        }
     }
     if (N > 1) {
         const int lds = N * (int)sizeof(cf);
@@ -712,7 +729,10 @@ namespace {
 // Queue the finalize of `sums_src` (exported, possibly cross-rank reduced sums) or, sums_src == nullptr, of the plan's
 // accumulator -- then together with the fold of the rows still pending and with the reset, in one kernel -- into the
 // next result slot; the slot's event marks the host copy complete.
-int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth, int reset) {
+// user_out != nullptr (fxc_finalize_async_to): the result goes to that host buffer instead of the plan's pinned slot -- by
+// the finishing kernel itself when it is small and lies in fxc_host_alloc memory, by the side-stream copy when it is large
+// (a direct DMA for pinned memory) -- and fxc_finalize_wait copies nothing.
+int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth, int reset, void* user_out = nullptr) {
     if (mode != FXC_MODE_SPECTRUM && mode != FXC_MODE_CONTINUUM) return fail(p, FXC_ERR_ARG, "bad mode %d", mode);
     if (mode == FXC_MODE_CONTINUUM && !(bandwidth > 0.0)) return fail(p, FXC_ERR_ARG, "bandwidth must be > 0");
     if (p->res_head - p->res_tail >= fxc_plan::kResSlots)
@@ -731,6 +751,11 @@ int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth
         for (int k = 0; k < fxc_plan::kResSlots; ++k) FXC_HIP(p, hipMalloc(&p->d_res_big[k], (size_t)n * sizeof(cd)));
     }
     cd* out = big ? p->d_res_big[slot] : p->d_res[slot];
+    cd* const user_mapped = (user_out && !big) ? static_cast<cd*>(pinned_device_ptr(user_out, bytes)) : nullptr;
+    if (user_mapped) out = user_mapped;
+    // where fxc_finalize_wait finds the bytes: the caller's buffer (nothing to copy) or the plan's slot
+    p->res_user[slot] = (user_out && (big || user_mapped)) ? user_out : nullptr;
+    p->res_dst[slot] = user_out;
     if (!sums_src) {
         // SPECTRUM: one kernel.  CONTINUUM needs the mean over the bins of the finished accumulator: export, then reduce
         FoldFinish fin = {nullptr, out, p->d_rot, p->spectra_count, reset ? 1 : 0};
@@ -760,7 +785,7 @@ int finalize_enqueue(fxc_plan* p, const cd* sums_src, int mode, double bandwidth
     if (big) {
         FXC_HIP(p, hipEventRecord(p->ev_fin, p->stream));
         FXC_HIP(p, hipStreamWaitEvent(p->s_copy, p->ev_fin, 0));
-        FXC_HIP(p, hipMemcpyAsync(p->h_res[slot], out, bytes, hipMemcpyDeviceToHost, p->s_copy));
+        FXC_HIP(p, hipMemcpyAsync(user_out ? user_out : static_cast<void*>(p->h_res[slot]), out, bytes, hipMemcpyDeviceToHost, p->s_copy));
         FXC_HIP(p, hipEventRecord(p->ev_res[slot], p->s_copy));
     }
     p->res_bytes[slot] = bytes;
@@ -776,6 +801,12 @@ int fxc_finalize_async(fxc_plan* p, int mode, double bandwidth, int reset) {
     return finalize_enqueue(p, nullptr, mode, bandwidth, reset);
 }
 
+int fxc_finalize_async_to(fxc_plan* p, void* out_host, int mode, double bandwidth, int reset) {
+    if (!p || !out_host) return fail(p, FXC_ERR_ARG, "NULL argument");
+    FXC_DEVICE(p, p->device);
+    return finalize_enqueue(p, nullptr, mode, bandwidth, reset, out_host);
+}
+
 int fxc_finalize_sums_async(fxc_plan* p, const void* sums_dev, int mode, double bandwidth) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     if (!sums_dev) {                         // what fxc_reduce left in the plan
@@ -787,12 +818,15 @@ int fxc_finalize_sums_async(fxc_plan* p, const void* sums_dev, int mode, double 
 }
 
 int fxc_finalize_wait(fxc_plan* p, void* out_host) {
-    if (!p || !out_host) return fail(p, FXC_ERR_ARG, "NULL argument");
+    if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     if (p->res_head == p->res_tail) return fail(p, FXC_ERR_STATE, "no finalize result outstanding");
-    FXC_DEVICE(p, p->device);
     const int slot = (int)(p->res_tail % fxc_plan::kResSlots);
+    void* const dst = p->res_dst[slot];       // fxc_finalize_async_to: the buffer named when the result was queued
+    if (dst ? (out_host && out_host != dst) : !out_host)
+        return fail(p, FXC_ERR_ARG, dst ? "this result was queued with fxc_finalize_async_to: pass that buffer or NULL" : "out_host is NULL");
+    FXC_DEVICE(p, p->device);
     FXC_HIP(p, hipEventSynchronize(p->ev_res[slot]));
-    std::memcpy(out_host, p->h_res[slot], p->res_bytes[slot]);
+    if (!p->res_user[slot]) std::memcpy(dst ? dst : out_host, p->h_res[slot], p->res_bytes[slot]);
     p->res_tail += 1;
     return FXC_OK;
 }

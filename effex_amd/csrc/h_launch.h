@@ -198,10 +198,23 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
 // chunks per X-engine workgroup (= per raw row) for an integration over nc chunks.  The kernel's one-wave workgroups
 // all do the same work, so the launch is cut into exactly as many as are resident at once (p->x_resident, from the
 // occupancy API: one round, no tail) unless a float32 row (fused_unit) allows fewer chunks than that: then many rounds
+// antenna tiles of 16 of the matrix-core X-engine: XT = 1 .. 4
+#define FXC_XMFMA_DISPATCH(p, ...)                       \
+    do {                                                 \
+        switch (((p)->n_ant + 15) / 16) {                \
+            case 1: { constexpr int XT = 1; __VA_ARGS__; } break; \
+            case 2: { constexpr int XT = 2; __VA_ARGS__; } break; \
+            case 3: { constexpr int XT = 3; __VA_ARGS__; } break; \
+            default: { constexpr int XT = 4; __VA_ARGS__; } break; \
+        }                                                \
+    } while (0)
+
 int64_t xengine_group(const fxc_plan* p, int64_t nc, int64_t unit) {
-    // more than 8 antennas: a column is shared by the G (G + 1) / 2 pairs of antenna blocks (xengine_block_kernel)
+    // more than 8 antennas: a column of 16 bins with all antennas per workgroup (xengine_mfma_kernel), or -- the vector
+    // kernel it replaced -- a column of 64 shared by the G (G + 1) / 2 pairs of antenna blocks (xengine_block_kernel)
     const int64_t gb = (p->n_ant + kXB - 1) / kXB;
-    const int64_t cols = std::max<int64_t>(1, p->nchan / kXThreads) * (p->n_ant > kXB ? gb * (gb + 1) / 2 : 1);
+    const int64_t cols = p->x_mfma ? std::max<int64_t>(1, p->nchan / 16)
+                                   : std::max<int64_t>(1, p->nchan / kXThreads) * (p->n_ant > kXB ? gb * (gb + 1) / 2 : 1);
     const int64_t groups = std::max<int64_t>(1, p->x_resident / cols);
     return std::max<int64_t>(1, std::min<int64_t>(unit, (nc + groups - 1) / groups));
 }
@@ -256,7 +269,11 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
         case 6: FXC_X_LAUNCH(6); break;
         case 7: FXC_X_LAUNCH(7); break;
         case 8: FXC_X_LAUNCH(8); break;
-        default: {
+        default: if (p->x_mfma) {
+            FXC_XMFMA_DISPATCH(p, hipLaunchKernelGGL(xengine_mfma_kernel<XT>, dim3((unsigned)(p->nchan / XMfmaGeo<XT>::kCH), grid.y),
+                                                     dim3(XMfmaGeo<XT>::kThreads), XMfmaGeo<XT>::kLdsBytes, p->stream, spec, raw,
+                                                     p->n_pts, p->nchan, nc, cg, p->n_ant, xr, std::getenv("FXC_XMFMA_ABL") ? std::atoi(std::getenv("FXC_XMFMA_ABL")) : 0));
+        } else {
             const unsigned gb = (unsigned)((p->n_ant + kXB - 1) / kXB);
             hipLaunchKernelGGL(xengine_block_kernel, dim3(grid.x, grid.y, gb * (gb + 1) / 2), dim3(kXThreads), 0, p->stream, spec,
                                raw, p->n_pts, p->nchan, nc, cg, p->n_ant, xr);

@@ -81,7 +81,8 @@ struct fxc_plan {
     cf* d_tw8192 = nullptr;        // [4096] w8192^(4095 - n')
     unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int fused_grid_max = 0;
-    int64_t x_resident = 0;        // one-wave workgroups of xengine_kernel<n_ant> the device holds at once
+    int64_t x_resident = 0;        // workgroups of the X-engine kernel the device holds at once
+    bool x_mfma = false;           // more than 8 antennas: xengine_mfma_kernel (k_xmfma.h)
     int64_t fused_seg = 1;         // chunks per round-robin segment of the fused kernel (fx_fused4096.h::RangeWalk)
     cd* d_acc = nullptr;           // [n_base*nchan]
     cd* d_sums = nullptr;          // [n_base*nchan + 1]
@@ -104,6 +105,8 @@ struct fxc_plan {
     cd* d_res[kResSlots] = {nullptr, nullptr};     // the same memory as the device sees it
     hipEvent_t ev_res[kResSlots] = {nullptr, nullptr};
     size_t res_bytes[kResSlots] = {0, 0};
+    void* res_dst[kResSlots] = {nullptr, nullptr};    // fxc_finalize_async_to: the caller's buffer for this result
+    void* res_user[kResSlots] = {nullptr, nullptr};   // ... and whether the device delivers into it (else via the slot + a copy)
     int64_t res_head = 0, res_tail = 0;            // results queued / collected
     // results too large to be worth a kernel's time on PCIe (28 baselines: 1.8 MB, 35 us inside the finishing kernel):
     // the kernel writes device memory and a copy on a side stream carries it to the slot while the next F+X runs

@@ -298,13 +298,22 @@ class FxPlan(object):
         shape = (self.n_baselines, self.nchan) if mode_code == _lib.FXC_MODE_SPECTRUM else (self.n_baselines,)
         return np.empty(shape, dtype=np.complex128)
 
-    def finalize_async(self, mode="SPECTRUM", bandwidth=1.0, reset=True):
+    def finalize_async(self, mode="SPECTRUM", bandwidth=1.0, reset=True, out=None):
         """Queue ``finalize`` on the plan's stream and return at once (``fxc_finalize_async``): on the 2-antenna fast
         paths the fold of the last ``fx_accumulate``'s partial sums, the finalize, the reset and the write into pinned
         host memory are one kernel.  Collect with ``finalize_wait()``; up to two results may be outstanding, so the
-        next integration can be queued before the host waits for this one."""
+        next integration can be queued before the host waits for this one.  ``out``: a complex128 array of the result's
+        shape (best: ``pinned_empty``) the device delivers the result into (``fxc_finalize_async_to``);
+        ``finalize_wait()`` then returns that array without copying anything."""
         self._sync_stream()
         m = MODES[mode.upper()]
+        if out is not None:
+            want = self._result(m).shape
+            if out.dtype != np.complex128 or out.shape != want or not out.flags.c_contiguous or not out.flags.writeable:
+                raise ValueError("out must be a writable C-contiguous complex128 array of shape {}".format(want))
+            self._check(self._lib.fxc_finalize_async_to(self._h, out.ctypes.data, m, float(bandwidth), int(bool(reset))))
+            self._queued.append((m, out))
+            return
         self._check(self._lib.fxc_finalize_async(self._h, m, float(bandwidth), int(bool(reset))))
         self._queued.append(m)
 
@@ -320,7 +329,8 @@ class FxPlan(object):
         """The oldest queued finalize result as numpy complex128 (blocks on that result's event only)."""
         if not self._queued:
             raise _lib.FxcError(_lib.FXC_ERR_STATE, "no finalize result outstanding")
-        out = self._result(self._queued[0])
+        head = self._queued[0]
+        out = head[1] if isinstance(head, tuple) else self._result(head)
         self._check(self._lib.fxc_finalize_wait(self._h, out.ctypes.data))
         self._queued.pop(0)
         return out

@@ -151,6 +151,13 @@ int fxc_finalize(fxc_plan* plan, void* out_host, int mode, double bandwidth, int
  * finalize calls while any is); they are collected in the order they were queued.
  * fxc_finalize_sums_async: the multi-GPU form (sums as for fxc_finalize_sums; the accumulator is not touched). */
 int fxc_finalize_async(fxc_plan* plan, int mode, double bandwidth, int reset);
+/* fxc_finalize_async with the destination named up front: the result is delivered into out_host (same layout as
+ * fxc_finalize) by the device -- written by the finishing kernel itself when it is small and out_host lies in
+ * fxc_host_alloc memory, by the side-stream copy when it is large (28 baselines and more: a direct DMA into pinned memory) --
+ * so that fxc_finalize_wait(plan, out_host or NULL) only waits: with 496 baselines of 4 096 bins the copy out of the plan's
+ * slot is 32 MB of host memcpy per integration, more than the integration's kernels take.  The buffer must stay valid until
+ * the wait returns. */
+int fxc_finalize_async_to(fxc_plan* plan, void* out_host, int mode, double bandwidth, int reset);
 int fxc_finalize_sums_async(fxc_plan* plan, const void* sums_dev, int mode, double bandwidth);
 int fxc_finalize_wait(fxc_plan* plan, void* out_host);
 int fxc_finalize_pending(const fxc_plan* plan); /* results queued and not yet collected */

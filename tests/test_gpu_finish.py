@@ -99,6 +99,41 @@ def test_two_integrations_in_flight(plan_mod, torch):
             p.finalize_wait()
 
 
+@pytest.mark.parametrize("n_ant,nchan,mode", [(2, 4096, "SPECTRUM"), (2, 4096, "CONTINUUM"), (8, 4096, "SPECTRUM"), (12, 1024, "SPECTRUM")])
+def test_finalize_delivered_into_the_callers_buffer(plan_mod, torch, n_ant, nchan, mode):
+    """fxc_finalize_async_to: the destination is named when the finalize is queued and the device delivers into it -- the
+    finishing kernel itself for small results in fxc_host_alloc memory, the side-stream copy for large ones (28 baselines and
+    more) -- so the wait copies nothing.  Same bits as the blocking finalize, for pinned and for ordinary arrays, with two
+    results in flight; the wait refuses another buffer."""
+    import ctypes
+    num_samp = nchan * 5
+    xa = torch.from_numpy(synth.synth_iq(21, 6, n_ant, num_samp, delays=np.arange(n_ant) % 5)).cuda()
+    xb = torch.from_numpy(synth.synth_iq(22, 3, n_ant, num_samp, delays=np.arange(n_ant) % 5)).cuda()
+    with plan_mod.FxPlan(n_ant, nchan, 4, num_samp) as p:
+        p.fx_accumulate(xa)
+        ref_a = p.finalize(mode, gi.BANDWIDTH)
+        p.fx_accumulate(xb)
+        ref_b = p.finalize(mode, gi.BANDWIDTH)
+        pinned = plan_mod.pinned_empty(ref_a.shape, np.complex128)
+        plain = np.empty(ref_a.shape, dtype=np.complex128)
+        pinned[...] = 0
+        p.fx_accumulate(xa)
+        p.finalize_async(mode, gi.BANDWIDTH, out=pinned)
+        p.fx_accumulate(xb)
+        p.finalize_async(mode, gi.BANDWIDTH, out=plain)
+        assert p.finalize_pending == 2
+        other = np.empty(ref_a.shape, dtype=np.complex128)
+        assert p._lib.fxc_finalize_wait(p._h, ctypes.c_void_p(other.ctypes.data)) == _lib.FXC_ERR_ARG   # not the buffer it was queued with
+        got_a = p.finalize_wait()
+        assert got_a is pinned
+        np.testing.assert_array_equal(got_a, ref_a)
+        got_b = p.finalize_wait()
+        assert got_b is plain
+        np.testing.assert_array_equal(got_b, ref_b)
+        with pytest.raises(ValueError):
+            p.finalize_async(mode, gi.BANDWIDTH, out=np.empty(3, dtype=np.complex128))
+
+
 def test_fold_is_bit_reproducible(plan_mod, torch):
     """The fold sums rows, phases and partials in a fixed order:
     repeated integrations of the same frames are identical bit for bit (700 chunk pairs: every split in use)."""

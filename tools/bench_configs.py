@@ -33,7 +33,7 @@ def main():
     args = ap.parse_args()
     import numpy as np
     import torch
-    from effex_amd.plan import FxPlan, synth_fill
+    from effex_amd.plan import FxPlan, pinned_empty, synth_fill
     from effex_amd.window import design_window
     bw = 2.4e6
     out = []
@@ -42,6 +42,9 @@ def main():
         x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")
         synth_fill(x, 1234, delays=None if n_ant <= 8 else [a % 7 for a in range(n_ant)])
         plan = FxPlan(n_ant, nchan, ntaps, num_samp, window=window)
+        # results are delivered into pinned buffers named up front (fxc_finalize_async_to): nothing is copied on the host
+        shape = (plan.n_baselines, nchan) if mode == "SPECTRUM" else (plan.n_baselines,)
+        outs = [pinned_empty(shape, np.complex128) for _ in range(2)]
         if rows:
             def fn(k):
                 for _ in range(k):
@@ -50,7 +53,7 @@ def main():
             def fn(k):
                 for j in range(k):
                     plan.fx_accumulate(x)
-                    plan.finalize_async(mode, bw, reset=True)
+                    plan.finalize_async(mode, bw, reset=True, out=outs[j & 1])
                     if j > 0:
                         plan.finalize_wait()
                 plan.finalize_wait()
@@ -76,7 +79,8 @@ def main():
     report("8 antennas, 28 baselines, N=2048 (tiled F-only kernel + X-engine)", 8, 2048, 4, 2 ** 18, 512, "SPECTRUM")
     report("8 antennas, 28 baselines, N=1024 (tiled F-only kernel + X-engine)", 8, 1024, 4, 2 ** 18, 512, "SPECTRUM")
     report("4 antennas, 6 baselines, N=4096", 4, 4096, 4, 2 ** 18, 1024, "SPECTRUM")
-    report("16 antennas, 120 baselines, N=4096 (tiled F-only kernel + X-engine over blocks of 8)", 16, 4096, 4, 2 ** 18, 128, "SPECTRUM")
+    report("16 antennas, 120 baselines, N=4096 (tiled F-only kernel + matrix-core X-engine)", 16, 4096, 4, 2 ** 18, 128, "SPECTRUM")
+    report("32 antennas, 496 baselines, N=4096 (tiled F-only kernel + matrix-core X-engine)", 32, 4096, 4, 2 ** 18, 64, "SPECTRUM")
     report("N=2048 T=32 (reference test shape), 2 antennas", 2, 2048, 32, 2 ** 18, 256, "SPECTRUM")
     for nfft in (16, 64, 256, 512, 1024, 2048):   # the reference's --nfft at its fixed ntaps = 4 (effex.py:115,778)
         report("--nfft %d, integrate" % nfft, 2, nfft, 4, 2 ** 18, 4096, "SPECTRUM")
