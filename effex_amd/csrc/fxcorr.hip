@@ -193,7 +193,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     // half empty) + X-engine
     // 16 .. 256 channels, up to four taps: the wave-local variant of the tiled design (k_small.h) -- 2 antennas in one
     // F+X kernel, 3 .. 64 through its F-only variant + X-engine
-    const bool small_n = small_nchan(N) && T <= 4 && p->num_samp / N < (1ll << 31);   // (32-bit frame counters in the kernel)
+    // (32-bit frame counters in the kernel; more than four taps: behind the pre-filter pass, whose buffer descriptors bound the stream)
+    const bool small_n = small_nchan(N) && p->num_samp / N < (1ll << 31) && (T <= 4 || p->num_samp <= (1ll << 27));
     const bool small_shape = small_n && p->n_ant >= 2 && p->n_ant <= kMaxXAnt;
     const bool tiled_shape = small_shape || (p->n_ant >= 2 && p->n_ant <= kMaxXAnt && tiled_nchan(N) && p->num_samp <= (1ll << 27));
     if (force_path == FXC_PATH_TILED && !tiled_shape)
@@ -289,15 +290,27 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     p->small_f = small_n && force_path != FXC_PATH_GENERIC;
     if (p->small || p->small_f) {
         const int P = N / 16;
+        // more than four taps: pfb_prefilter_kernel applies the FIR first (k_prepass.h), the wave-local kernel then runs with
+        // one unit tap -- the route the tiled channel counts take (FXC_PREFILTER=1: developer knob, the same at <= 4 taps)
+        const char* pre_env_s = std::getenv("FXC_PREFILTER");
+        p->prefilter = (T > 4 || (pre_env_s && std::atoi(pre_env_s) == 1));
+        if (p->prefilter) {
+            p->pre_tp = T <= 8 ? 8 : (T <= 16 ? 16 : 32);
+            std::vector<float> hp((size_t)p->pre_tp * N, 0.f);
+            for (int t = 0; t < T; ++t)
+                for (int n = 0; n < N; ++n) hp[(size_t)t * N + n] = wf[(size_t)t * N + (N - 1 - n)];
+            FXC_HIP(p, hipMalloc(&p->d_hpre, hp.size() * sizeof(float)));
+            FXC_HIP(p, hipMemcpy(p->d_hpre, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         std::vector<f4> w4((size_t)N);          // window quads [r P + u] = h[t N + u + P r], t = x, y, z, w (zero beyond ntaps)
         for (int r = 0; r < 16; ++r)
             for (int u = 0; u < P; ++u) {
                 const int m = u + P * r;
                 f4 w;
-                w.x = wf[m];
-                w.y = T > 1 ? wf[(size_t)1 * N + m] : 0.f;
-                w.z = T > 2 ? wf[(size_t)2 * N + m] : 0.f;
-                w.w = T > 3 ? wf[(size_t)3 * N + m] : 0.f;
+                w.x = p->prefilter ? 1.f : wf[m];
+                w.y = (T > 1 && !p->prefilter) ? wf[(size_t)1 * N + m] : 0.f;
+                w.z = (T > 2 && !p->prefilter) ? wf[(size_t)2 * N + m] : 0.f;
+                w.w = (T > 3 && !p->prefilter) ? wf[(size_t)3 * N + m] : 0.f;
                 w4[(size_t)r * P + u] = w;
             }
         FXC_HIP(p, hipMalloc(&p->d_win4, w4.size() * sizeof(f4)));
@@ -909,7 +922,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
     const size_t row_elems = mode == FXC_MODE_SPECTRUM ? (size_t)p->n_base * p->nchan * sizeof(cf) : (size_t)p->n_base * sizeof(cd);
     // chunks per pass: dc_sum_u8_kernel carries the stream index in grid.y (<= 65535 streams), and plans without the
     // fused ingest convert a pass into a complex64 staging buffer that stays within the workspace target
-    const bool fused_in = p->n_ant == 2 && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && ((p->tiled_ring && !p->prefilter) || p->small)));
+    const bool fused_in = p->n_ant == 2 && !p->prefilter && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && (p->tiled_ring || p->small)));
     int64_t per_pass = std::min<int64_t>(16384, 65535 / p->n_ant);
     if (!fused_in) per_pass = std::min<int64_t>(per_pass, ws_target() / ((int64_t)p->n_ant * p->num_samp * (int64_t)sizeof(cf)));
     per_pass = std::max<int64_t>(1, per_pass);

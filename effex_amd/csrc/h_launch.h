@@ -405,14 +405,29 @@ int small_launch(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, co
 int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false);
 
 // F-stage only (see tiled_channelize): n_streams consecutive streams -> natural-order spectra, pairs of streams per item
+int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only);
+int64_t prefilter_streams_per_pass(const fxc_plan* p);
+int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_out);
+
 int small_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a) {
     KernelTimer kt(p);
-    const int64_t pairs = (n_streams + 1) / 2;
-    const int n_splits = tiled_splits(p, pairs, true);
-    const int grid = small_grid(p, pairs * n_splits);
-    FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P, false, true>), dim3(grid), dim3(256), 0, p->stream, x,
-                                             p->num_samp, p->n_pts, pairs, n_splits, p->d_win4, p->d_tw_small, spec,
-                                             (const cf*)nullptr, n_streams, spec_a, (int64_t)0));
+    const int64_t per_pass = prefilter_streams_per_pass(p);      // everything at once unless the pre-filter bounds a pass
+    for (int64_t s0 = 0; s0 < n_streams; s0 += per_pass) {
+        const int64_t ns = std::min(per_pass, n_streams - s0);
+        const cf* xs = x + s0 * p->num_samp;
+        if (p->prefilter) {
+            const int rc = tiled_prefilter(p, xs, ns, &xs);
+            if (rc) return rc;
+        }
+        const int64_t pairs = (ns + 1) / 2;
+        const int n_splits = tiled_splits(p, pairs, true);
+        const int grid = small_grid(p, pairs * n_splits);
+        // spec_a == 0: this pass's streams start at row s0 * n_pts; by frame: rows are placed from the global stream index
+        FXC_SMALL_DISPATCH(p, hipLaunchKernelGGL((fx_small_ring_kernel<P, false, true>), dim3(grid), dim3(256), 0, p->stream, xs,
+                                                 p->num_samp, p->n_pts, pairs, n_splits, p->d_win4, p->d_tw_small,
+                                                 spec_a ? spec : spec + s0 * p->n_pts * p->nchan, (const cf*)nullptr, ns, spec_a,
+                                                 spec_a ? s0 : (int64_t)0));
+    }
     kt.stop();
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
@@ -435,7 +450,7 @@ int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only) {
 int64_t prefilter_streams_per_pass(const fxc_plan* p) {
     if (!p->prefilter) return INT64_MAX;
     int64_t n = ws_target() / (p->num_samp * (int64_t)sizeof(cf));
-    n = std::min<int64_t>(n, 65534) & ~(int64_t)1;      // grid.y carries the stream; whole pairs
+    n = std::min<int64_t>(n, 65534) & ~(int64_t)1;      // grid.y carries the stream (or a row of them); whole pairs
     return std::max<int64_t>(2, n);
 }
 
@@ -450,15 +465,18 @@ int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_ou
     // streams of odd length are not 16-byte aligned one after the other.  FXC_PRE_W=1: developer knob, 8-byte accesses
     static const bool narrow = [] { const char* e = std::getenv("FXC_PRE_W"); return e && std::atoi(e) == 1; }();
     const int w = (!narrow && tp == 8 && (p->num_samp % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0) ? 2 : 1;
+    // channel counts below 256 w: several streams side by side in a workgroup
+    const int spb = std::max(1, 256 * w / p->nchan);
+    const int64_t rows = (n_streams + spb - 1) / spb;
     // frame splits so that a few-stream call still fills the chip; each split reloads one block of history
-    const int64_t blocks = (int64_t)(p->nchan / (256 * w)) * n_streams;
+    const int64_t blocks = std::max<int64_t>(1, p->nchan / (256 * w)) * rows;
     int64_t fs = std::max<int64_t>(1, (2 * (int64_t)p->cu_count + blocks - 1) / blocks);
     fs = std::min<int64_t>(fs, std::max<int64_t>(1, p->n_pts / (4 * tp)));
     const int64_t per = ((p->n_pts + fs - 1) / fs + 2 * tp - 1) / (2 * tp) * (2 * tp);
-    const dim3 grid((unsigned)(p->nchan / (256 * w)), (unsigned)n_streams, (unsigned)((p->n_pts + per - 1) / per));
+    const dim3 grid((unsigned)std::max(1, p->nchan / (256 * w)), (unsigned)rows, (unsigned)((p->n_pts + per - 1) / per));
 #define FXC_PRE_LAUNCH(TP, W)                                                                                             \
     hipLaunchKernelGGL((pfb_prefilter_kernel<TP, W>), grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, \
-                       p->n_pts, per)
+                       p->n_pts, per, spb, n_streams)
     if (tp == 8) {
         if (w == 2) FXC_PRE_LAUNCH(8, 2);
         else FXC_PRE_LAUNCH(8, 1);
@@ -477,6 +495,10 @@ int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_ou
 int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
     KernelTimer kt(p);
     if (p->small) {
+        if (p->prefilter && !dc_u8) {       // more than four taps: the FIR as its own pass, the wave-local kernel with one unit tap
+            const int rp = tiled_prefilter(p, x, 2 * nc, &x);
+            if (rp) return rp;
+        }
         const int rc = small_launch(p, x, nc, n_splits, raw, dc_u8);
         if (rc) return rc;
         kt.stop();

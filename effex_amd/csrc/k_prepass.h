@@ -81,12 +81,17 @@ __device__ __forceinline__ void prefilter_load(cf (&xr)[TP][W], __amdgpu_buffer_
 
 // hcoef[t][n] = h[t N + (N - 1 - n)] for t < ntaps, zero rows up to TP; grid (N / (256 W), streams, frame splits)
 // (asking for 3 waves per SIMD at TP = 32 makes the compiler spill and the pass 3 % slower: measured)
+// Channel counts below 256 W (16 .. 256, in front of the wave-local kernels of k_small.h): a workgroup takes
+// streams_per_block = 256 W / nchan streams side by side, grid (1, ceil(streams / streams_per_block), frame splits).
 template <int TP, int W>
 __global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict__ x, cf* __restrict__ y,
                                                            const float* __restrict__ hcoef, int64_t num_samp, int nchan,
-                                                           int64_t n_pts, int64_t per_split) {
-    const int n = (blockIdx.x * 256 + threadIdx.x) * W;      // first of this thread's W adjacent positions
-    const int64_t s = blockIdx.y;
+                                                           int64_t n_pts, int64_t per_split, int streams_per_block,
+                                                           int64_t n_streams) {
+    const int lin = (blockIdx.x * 256 + threadIdx.x) * W;    // first of this thread's W adjacent positions, streams side by side
+    const int n = streams_per_block > 1 ? lin % nchan : lin;
+    const int64_t s = (int64_t)blockIdx.y * streams_per_block + (streams_per_block > 1 ? lin / nchan : 0);
+    if (s >= n_streams) return;
     const int64_t i_begin = (int64_t)blockIdx.z * per_split;
     const int64_t i_end = (i_begin + per_split < n_pts) ? i_begin + per_split : n_pts;
     if (i_begin >= i_end) return;

@@ -627,11 +627,14 @@ def test_tiled_path_matches_oracle(plan_mod, torch, nchan, ntaps, n_chunks, fram
 @pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [
     (256, 4, 3, 40, 7), (256, 4, 1, 1024, 0), (128, 4, 5, 33, 100), (64, 4, 2, 500, 3), (32, 4, 9, 70, 1), (16, 4, 4, 300, 0),
     (256, 3, 2, 9, 0), (128, 1, 7, 5, 2), (64, 2, 300, 3, 0), (16, 4, 1, 16384, 5), (32, 4, 1, 1, 0), (256, 4, 700, 2, 0),
-    (16, 4, 1, 3, 0)])
+    (16, 4, 1, 3, 0),
+    # more than four taps: the pre-filter pass (streams side by side in a workgroup below 256 channels) + one unit tap
+    (256, 8, 3, 40, 7), (64, 16, 5, 300, 3), (16, 32, 4, 100, 1), (128, 5, 2, 33, 0), (32, 9, 70, 20, 2), (256, 32, 1, 2000, 5),
+    (64, 8, 1, 3, 0)])
 def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
     """--nfft 16 ... 256 (a free integer in the reference, effex.py:733-739) on the wave-local kernel (k_small.h): several
     work items per wave, items beyond the last one, ranges of one frame and empty ranges, ragged tails, integration in
-    uneven calls, continuum, bytes in -- against the oracle and against the generic kernels."""
+    uneven calls, continuum, bytes in, up to 32 taps -- against the oracle and against the generic kernels."""
     num_samp = nchan * frames + extra
     x = synth.synth_iq(4321, n_chunks, 2, num_samp)
     window = design_window(ntaps, nchan)
@@ -662,18 +665,20 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
 
 
 def test_small_channel_counts_outside_the_kernel_fall_back(plan_mod, torch):
-    """More than four taps, or fewer than 16 channels: the generic kernels, as before."""
-    with plan_mod.FxPlan(2, 256, 8, 256 * 20) as p, plan_mod.FxPlan(3, 32, 5, 32 * 20) as q, \
-            plan_mod.FxPlan(9, 8, 4, 8 * 20) as r:
-        assert p.path == "generic" and q.path == "generic" and r.path == "generic"
+    """Fewer than 16 channels, or channel counts that are not 16 x a power of two: the generic kernels, as before (more
+    than four taps no longer: the pre-filter pass serves them, test_small_channel_counts_match_oracle)."""
+    with plan_mod.FxPlan(2, 8, 4, 8 * 20) as p, plan_mod.FxPlan(3, 48, 5, 48 * 20) as q, \
+            plan_mod.FxPlan(9, 8, 4, 8 * 20) as r, plan_mod.FxPlan(2, 256, 8, 256 * 20) as t:
+        assert p.path == "generic" and q.path == "generic" and r.path == "generic" and t.path == "tiled"
     with pytest.raises(NotImplementedError):
-        plan_mod.FxPlan(2, 256, 8, 256 * 20, path="tiled")
+        plan_mod.FxPlan(2, 48, 8, 48 * 20, path="tiled")
 
 
 @pytest.mark.parametrize("n_ant,nchan,ntaps,n_chunks,frames,extra", [
     (3, 256, 4, 3, 40, 7), (8, 64, 4, 5, 200, 3), (4, 128, 4, 1, 700, 0), (5, 256, 2, 2, 9, 100), (8, 256, 4, 40, 16, 0),
     (7, 64, 4, 2, 1, 0), (3, 64, 4, 2, 2500, 7), (6, 128, 4, 3, 1025, 0),    # the last two: more than 1024 frames per chunk
-    (3, 32, 4, 2, 300, 5), (8, 16, 4, 3, 90, 0), (11, 32, 4, 2, 40, 1)])     # part of a wave in the X-engine; blocks of 8
+    (3, 32, 4, 2, 300, 5), (8, 16, 4, 3, 90, 0), (11, 32, 4, 2, 40, 1),      # part of a wave in the X-engine; more than 8 antennas
+    (5, 64, 8, 3, 50, 3), (12, 128, 16, 2, 40, 0), (3, 16, 6, 2, 200, 1)])   # more than four taps: pre-filter pass first
 def test_small_channel_counts_multi_antenna(plan_mod, torch, n_ant, nchan, ntaps, n_chunks, frames, extra):
     """3 and more antennas at 16 ... 256 channels: the F-only variant of the wave-local kernel (odd stream counts leave the
     last pair half empty) + the X-engine, against the oracle and the generic kernels."""
@@ -698,7 +703,8 @@ def test_small_channel_counts_multi_antenna(plan_mod, torch, n_ant, nchan, ntaps
 
 
 @pytest.mark.parametrize("nchan,ntaps,n_streams,frames,extra", [(256, 4, 5, 33, 9), (128, 4, 2, 900, 0), (64, 3, 1, 50, 3),
-                                                                (16, 4, 7, 300, 1), (32, 1, 4, 4, 0)])
+                                                                (16, 4, 7, 300, 1), (32, 1, 4, 4, 0),
+                                                                (256, 32, 3, 70, 5), (64, 8, 5, 300, 0), (16, 12, 2, 90, 3)])
 def test_small_channel_counts_channelize(plan_mod, torch, nchan, ntaps, n_streams, frames, extra):
     """fxc_channelize (the _spectrometer_poly drop-in, effex.py:530-555) at 16 ... 256 branches: natural-order spectra
     from the F-only variant of the wave-local kernel, against the oracle."""

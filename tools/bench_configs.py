@@ -82,7 +82,7 @@ def main():
     report("16 antennas, 120 baselines, N=4096 (tiled F-only kernel + matrix-core X-engine)", 16, 4096, 4, 2 ** 18, 128, "SPECTRUM")
     report("32 antennas, 496 baselines, N=4096 (tiled F-only kernel + matrix-core X-engine)", 32, 4096, 4, 2 ** 18, 64, "SPECTRUM")
     report("N=2048 T=32 (reference test shape), 2 antennas", 2, 2048, 32, 2 ** 18, 256, "SPECTRUM")
-    for nfft in (16, 64, 256, 512, 1024, 2048):   # the reference's --nfft at its fixed ntaps = 4 (effex.py:115,778)
+    for nfft in (16, 32, 64, 128, 256, 512, 1024, 2048):   # the reference's --nfft at its fixed ntaps = 4 (effex.py:115,778)
         report("--nfft %d, integrate" % nfft, 2, nfft, 4, 2 ** 18, 4096, "SPECTRUM")
     report("--nfft 8192, integrate (split into two 4096-channel problems)", 2, 8192, 4, 2 ** 18, 1024, "SPECTRUM")
     report("headline shape, one chunk pair per call (the reference's call pattern)", 2, 4096, 4, 2 ** 18, 1, "SPECTRUM",
