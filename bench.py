@@ -111,14 +111,21 @@ def cpu_baseline(seconds=8.0, frames=FRAMES):
     frames2, dt2 = _cpu_worker((2.0, 0, True))
     single_c128 = frames2 * NUM_SAMP / dt2 / 1e6
     ctx = mp.get_context("spawn")
+    t_pool = time.perf_counter()
     with ctx.Pool(workers) as pool:
         res = pool.map(_cpu_worker, [(seconds, k) for k in range(workers)])
+    wall = time.perf_counter() - t_pool
     multi = sum(f * NUM_SAMP / dt for f, dt in res) / 1e6
     total_frames = sum(f for f, _ in res)
+    worker_seconds = sum(dt for _, dt in res)
     check = _oracle_rows([f for f in CHECK_FRAMES if f < frames])
     return {"value": round(multi, 2), "unit": "Msamples/s", "cores": workers, "kind": "port",
             "single_core_value": round(single, 2), "single_core_complex128_value": round(single_c128, 2),
             "cpu_count_logical": logical, "cpu_count_usable": usable,
+            # what the workers got: their own timed seconds, and the wall clock of the pool (start-up included) -- on a shared
+            # host 256 workers obtain far fewer than 256 cores' worth of frames (multi / single_core says how many)
+            "worker_seconds_obtained": round(worker_seconds, 1), "pool_wall_seconds": round(wall, 1),
+            "frames_done": int(total_frames), "effective_cores": round(multi / single, 1) if single > 0 else None,
             "cpu_model": cpu_model(),
             "sample": "%d frames of the same workload (S=%d, N=%d, T=%d, 2 ant, complex64 numpy/scipy oracle), "
                       "%d single-threaded worker processes (one per usable core) x %.0f s on independent frames"

@@ -144,3 +144,63 @@ def test_fused_work_split(emul_sched, n_chunks, n_pts, grid, seg, unit, rows_are
     if rows_are_chunks:
         assert n_rows.value == n_chunks + grid
         assert np.array_equal(per_chunk, w.reshape(n_chunks, n_pts).sum(axis=1))
+
+
+def test_emulation_sources_under_address_and_undefined_sanitizers(tmp_path):
+    """Sanitizers belong on the CPU build (GPU AddressSanitizer is not available on the pool): the kernels' own phase headers
+    (fx_math.h, fx_fused4096.h, fx_tiled.h, fx_small.h), compiled by g++ for the host emulation, run a representative set of
+    shapes under -fsanitize=address,undefined in a child process (libasan preloaded).  Index maps that step outside an LDS
+    image, a ring slot or a raw row show up here as reports, not as silently wrong spectra."""
+    import shutil
+    import sys
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    libasan = subprocess.run([gxx, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("no libasan for this g++")
+    libs = {}
+    for name in ("emul_fused", "emul_tiled", "emul_small", "emul_sched"):
+        out = str(tmp_path / ("lib%s_san.so" % name))
+        subprocess.run([gxx, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared", "-fPIC",
+                        "-o", out, os.path.join(HERE, "emul", name + ".cpp")], check=True)
+        libs[name] = out
+    driver = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from effex_amd import synth
+from effex_amd.window import design_window
+libs = %(libs)r
+vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+f = ctypes.CDLL(libs["emul_fused"])
+a = (np.arange(16) + 1j * np.arange(16)[::-1]).astype(np.complex64); o = np.zeros(16, np.complex64)
+f.emul_dft16(vp(a), vp(o))
+assert f.emul_layout_check() == 0
+for num_samp in (4096, 4096 * 3 + 17):
+    x = synth.synth_iq(1234, 1, 2, num_samp)[0]; w = design_window(4, 4096); out = np.zeros(4096, np.complex128)
+    assert f.emul_fused4096(vp(x), ctypes.c_int64(num_samp), vp(w), vp(out)) == 0
+t = ctypes.CDLL(libs["emul_tiled"])
+for nchan, ntaps, frames, ring in ((512, 4, 9, 1), (1024, 4, 6, 1), (2048, 32, 3, 0), (4096, 4, 6, 1), (8192, 4, 3, 0), (512, 7, 12, 0)):
+    num_samp = nchan * frames + 13
+    x = synth.synth_iq(99, 1, 2, num_samp)[0]; w = design_window(ntaps, nchan); out = np.zeros(nchan, np.complex128)
+    assert t.emul_tiled(vp(x), ctypes.c_int64(num_samp), nchan, ntaps, vp(w), vp(out), ring) == 0
+s = ctypes.CDLL(libs["emul_small"])
+for nchan, ntaps, frames in ((16, 4, 40), (32, 4, 33), (64, 4, 21), (128, 4, 12), (256, 3, 5)):
+    num_samp = nchan * frames + 5
+    x = synth.synth_iq(77, 1, 2, num_samp)[0]; w = design_window(ntaps, nchan); out = np.zeros(nchan, np.complex128)
+    assert s.emul_small(vp(x), ctypes.c_int64(num_samp), nchan, ntaps, vp(w), vp(out)) == 0
+c = ctypes.CDLL(libs["emul_sched"])
+for n_chunks, n_pts, grid, seg, unit, rac in ((10000, 64, 256, 1, 4, 0), (257, 64, 256, 1, 1, 1), (23, 5, 8, 1, 3, 0), (5, 3, 256, 1, 1, 1), (103, 1, 25, 2, 64, 0)):
+    w = np.arange(1, n_chunks * n_pts + 1, dtype=np.float64); per = np.zeros(n_chunks); tot = ctypes.c_double()
+    fmin, fmax, nr = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    assert c.emul_fused_schedule(n_chunks, n_pts, grid, seg, unit, rac, vp(w), vp(per), ctypes.byref(tot), ctypes.byref(fmin),
+                                 ctypes.byref(fmax), ctypes.byref(nr)) == 0
+    assert tot.value == w.sum()
+print("sanitized emulation ok")
+""" % {"root": os.path.dirname(HERE), "libs": libs}
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    proc = subprocess.run([sys.executable, "-c", driver], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert "sanitized emulation ok" in proc.stdout
+    assert "AddressSanitizer" not in proc.stderr and "runtime error" not in proc.stderr, proc.stderr[-3000:]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: one named workload a few times, for rocprofv3 (kernel trace / PMC passes; tools/collect_profiles.sh).
 
-    python3 tools/prof_workload.py 8ant | stream1 | nfft2048 | taps32 | nfft256 [reps]
+    python3 tools/prof_workload.py 8ant | stream1 | nfft2048 | taps32 | nfft256 | nfft16 | 16ant | 32ant [reps]
 """
 import os
 import sys
@@ -18,6 +18,9 @@ WORKLOADS = {
     "nfft2048": (2, 2048, 4, 2 ** 18, 10000, "SPECTRUM", False),     # --nfft 2048, tiled ring kernel
     "taps32": (2, 2048, 32, 2 ** 18, 1024, "SPECTRUM", False),       # the reference test's taps = 32 shape
     "nfft256": (2, 256, 4, 2 ** 18, 10000, "SPECTRUM", False),       # --nfft 256, the wave-local kernel (k_small.h)
+    "nfft16": (2, 16, 4, 2 ** 18, 10000, "SPECTRUM", False),         # --nfft 16, one lane per work item
+    "16ant": (16, 4096, 4, 2 ** 18, 128, "SPECTRUM", False),         # 120 baselines: F-only tiled kernel + matrix-core X-engine
+    "32ant": (32, 4096, 4, 2 ** 18, 64, "SPECTRUM", False),          # 496 baselines
 }
 
 
@@ -26,7 +29,7 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     n_ant, nchan, ntaps, num_samp, n_chunks, mode, rows = WORKLOADS[name]
     x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")
-    synth_fill(x, 1234)
+    synth_fill(x, 1234, delays=None if n_ant <= 8 else [a % 7 for a in range(n_ant)])
     window = np.array([0.4, 0.3, 0.2, 0.1]) if nchan == 1 else None
     with FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as plan:
         for _ in range(reps):
