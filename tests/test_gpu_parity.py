@@ -590,6 +590,34 @@ def test_eight_antennas_full_size(plan_mod, torch):
         assert rel_err(rev[:, idx], np.conj(rows[:, pairs.index((n_ant - 1 - b, n_ant - 1 - a))])) < 1e-6
 
 
+@pytest.mark.parametrize("n_ant,n_chunks", [(16, 3), (32, 2), (40, 2), (64, 1)])
+def test_many_antennas_full_size(plan_mod, torch, n_ant, n_chunks):
+    """The matrix-core X-engine (k_xmfma.h) at the headline frame size -- nchan 4096, num_samp 262144 -- with 1, 2, 3 and 4
+    antenna tiles: one chunk against the oracle (fx_integrate, every baseline), the integration against the float64 mean of
+    the rows, exact linearity, and conjugate symmetry under reversal of the antenna order (which moves every baseline to
+    another place of another tile pair)."""
+    num_samp = 2 ** 18
+    x = synth.synth_iq(900 + n_ant, n_chunks, n_ant, num_samp, delays=np.arange(n_ant) % 11)
+    window = design_window(4, 4096)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(n_ant, 4096, 4, num_samp) as p:
+        assert p.path == "tiled" and p.n_baselines == n_ant * (n_ant - 1) // 2
+        rows = p.fx_rows(xd).cpu().numpy().astype(np.complex128)
+        out = plan_mod.pinned_empty((p.n_baselines, 4096), np.complex128)
+        p.fx_accumulate(xd)
+        p.finalize_async("SPECTRUM", out=out)
+        integ = p.finalize_wait()
+        assert integ is out
+        np.testing.assert_array_equal(p.fx_rows(xd * 2.0).cpu().numpy().astype(np.complex128), 4.0 * rows)
+        rev = p.fx_rows(xd[:1].flip(1).contiguous()).cpu().numpy().astype(np.complex128)
+    ref = fx_oracle.fx_integrate(x[n_chunks - 1:n_chunks], 4096, window)
+    assert rel_err(rows[n_chunks - 1], ref) < TOL_VIS
+    assert rel_err(integ, rows.mean(axis=0)) < 2e-6
+    pairs = {(a, b): idx for idx, (a, b) in enumerate((a, b) for a in range(n_ant) for b in range(a + 1, n_ant))}
+    for (a, b), idx in pairs.items():
+        assert rel_err(rev[0, idx], np.conj(rows[0, pairs[(n_ant - 1 - b, n_ant - 1 - a)]])) < 1e-6, (a, b)
+
+
 @pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [
     (512, 4, 7, 20, 5), (1024, 4, 3, 9, 0), (2048, 4, 5, 33, 100), (2048, 32, 2, 40, 0), (4096, 8, 2, 11, 7),
     (8192, 4, 3, 6, 1), (4096, 3, 2, 11, 7), (1024, 1, 4, 5, 0), (512, 7, 300, 3, 0), (2048, 4, 1, 128, 0),

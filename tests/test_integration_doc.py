@@ -29,7 +29,7 @@ def _stub_namespace():
         from effex_amd import build
         build.build()
     blocks = _python_blocks()
-    assert len(blocks) >= 3, "INTEGRATION.md lost its code blocks"
+    assert len(blocks) >= 4, "INTEGRATION.md lost its code blocks"
     first = blocks[0].replace('"/path/to/effex_amd/csrc/libfxcorr.so"', repr(_lib.LIB_PATH))
     parts = re.split(r"^# --- ", first, flags=re.M)
     src = []
@@ -39,7 +39,7 @@ def _stub_namespace():
             src.append("def _init_plan(self):\n" + "".join("    " + line + "\n" for line in body.splitlines()))
         else:
             src.append(part if not part or part[0] in "#\n" else "# " + part)
-    src += blocks[1:3]            # _estimate_delay_gaussian, _pfb_xcorr_bytes
+    src += blocks[1:4]            # _estimate_delay_gaussian, _pfb_xcorr_bytes, pinned staging + _pfb_xcorr_staged
     ns = {}
     exec(compile("\n".join(src), "INTEGRATION.md", "exec"), ns)
     return ns
@@ -48,7 +48,8 @@ def _stub_namespace():
 def _bare_correlator(ns, nbins, ntaps, num_samp, mode):
     cor = types.SimpleNamespace(nbins=nbins, ntaps=ntaps, num_samp=num_samp, mode=mode, bandwidth=gi.BANDWIDTH,
                                 frequency=gi.FREQUENCY, calibrated_delay=0.0, window=design_window(ntaps, nbins))
-    for name in ("_init_plan", "_pfb_xcorr", "_spectrometer_poly", "_estimate_delay_gaussian", "_pfb_xcorr_bytes"):
+    for name in ("_init_plan", "_pfb_xcorr", "_spectrometer_poly", "_estimate_delay_gaussian", "_pfb_xcorr_bytes", "_init_staging",
+                 "_pfb_xcorr_staged"):
         setattr(cor, name, types.MethodType(ns[name], cor))
     return cor
 
@@ -57,7 +58,7 @@ def test_integration_md_parses_without_a_gpu():
     """CPU half: the document still has its blocks and they still compile against the in-tree library's symbols."""
     ns = _stub_namespace()
     for name in ("_fx", "_fxc", "_init_plan", "_pfb_xcorr", "_spectrometer_poly", "_estimate_delay_gaussian",
-                 "_pfb_xcorr_bytes"):
+                 "_pfb_xcorr_bytes", "_pinned", "_init_staging", "_pfb_xcorr_staged"):
         assert name in ns, name
 
 
@@ -102,4 +103,14 @@ def test_integration_md_spectrometer_and_delay(golden):
     d = cor._estimate_delay_gaussian(a[37:37 + n], a[:n], 2.4e6)
     want = fx_oracle.estimate_delay_gaussian(a[37:37 + n], a[:n], 2.4e6)
     assert abs(d - want) < 2e-3 / 2.4e6
+    # pinned staging + the DC removal of effex.py:394-395 on the device: the staged pair with an offset on each stream
+    cor._init_staging()
+    iq = gi.xcorr_input()
+    cor.gpu_iq_0[:] = iq[0] + (0.2 - 0.1j)
+    cor.gpu_iq_1[:] = iq[1] - (0.05 + 0.3j)
+    got = cor._pfb_xcorr_staged()
+    a0 = fx_oracle.remove_dc(np.asarray(cor.gpu_iq_0))
+    a1 = fx_oracle.remove_dc(np.asarray(cor.gpu_iq_1))
+    ref = fx_oracle.pfb_xcorr(a0, a1, 4, 4096, cor.window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+    assert np.abs(got - ref).max() < TOL_VIS * np.abs(ref).max()
     ns["_fx"].fxc_plan_destroy(cor._plan)
