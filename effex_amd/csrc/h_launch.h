@@ -465,8 +465,10 @@ int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_ou
     // streams of odd length are not 16-byte aligned one after the other.  FXC_PRE_W=1: developer knob, 8-byte accesses
     static const bool narrow = [] { const char* e = std::getenv("FXC_PRE_W"); return e && std::atoi(e) == 1; }();
     const int w = (!narrow && tp == 8 && (p->num_samp % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0) ? 2 : 1;
-    // channel counts below 256 w: several streams side by side in a workgroup
-    const int spb = std::max(1, 256 * w / p->nchan);
+    // channel counts below 256 w: several streams side by side in a workgroup, while their span fits a buffer descriptor
+    const int64_t stream_bytes = p->num_samp * (int64_t)sizeof(cf);
+    const int spb = (int)std::max<int64_t>(1, std::min<int64_t>(256 * w / p->nchan, (1ll << 31) / stream_bytes));
+    const bool pack = p->nchan < 256 * w;
     const int64_t rows = (n_streams + spb - 1) / spb;
     // frame splits so that a few-stream call still fills the chip; each split reloads one block of history
     const int64_t blocks = std::max<int64_t>(1, p->nchan / (256 * w)) * rows;
@@ -474,9 +476,15 @@ int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_ou
     fs = std::min<int64_t>(fs, std::max<int64_t>(1, p->n_pts / (4 * tp)));
     const int64_t per = ((p->n_pts + fs - 1) / fs + 2 * tp - 1) / (2 * tp) * (2 * tp);
     const dim3 grid((unsigned)std::max(1, p->nchan / (256 * w)), (unsigned)rows, (unsigned)((p->n_pts + per - 1) / per));
-#define FXC_PRE_LAUNCH(TP, W)                                                                                             \
-    hipLaunchKernelGGL((pfb_prefilter_kernel<TP, W>), grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp, p->nchan, \
-                       p->n_pts, per, spb, n_streams)
+#define FXC_PRE_LAUNCH(TP, W)                                                                                                    \
+    do {                                                                                                                         \
+        if (pack)                                                                                                                \
+            hipLaunchKernelGGL((pfb_prefilter_kernel<TP, W, true>), grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp,    \
+                               p->nchan, p->n_pts, per, spb, n_streams);                                                         \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((pfb_prefilter_kernel<TP, W, false>), grid, dim3(256), 0, p->stream, x, y, p->d_hpre, p->num_samp,   \
+                               p->nchan, p->n_pts, per, spb, n_streams);                                                         \
+    } while (0)
     if (tp == 8) {
         if (w == 2) FXC_PRE_LAUNCH(8, 2);
         else FXC_PRE_LAUNCH(8, 1);

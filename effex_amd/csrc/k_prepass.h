@@ -81,17 +81,22 @@ __device__ __forceinline__ void prefilter_load(cf (&xr)[TP][W], __amdgpu_buffer_
 
 // hcoef[t][n] = h[t N + (N - 1 - n)] for t < ntaps, zero rows up to TP; grid (N / (256 W), streams, frame splits)
 // (asking for 3 waves per SIMD at TP = 32 makes the compiler spill and the pass 3 % slower: measured)
-// Channel counts below 256 W (16 .. 256, in front of the wave-local kernels of k_small.h): a workgroup takes
-// streams_per_block = 256 W / nchan streams side by side, grid (1, ceil(streams / streams_per_block), frame splits).
-template <int TP, int W>
+// PACK (channel counts below 256 W: 16 .. 256, in front of the wave-local kernels of k_small.h): a workgroup takes
+// streams_per_block = 256 W / nchan consecutive streams side by side, grid (1, ceil(streams / streams_per_block), frame
+// splits); the buffer descriptors span those streams and a lane's stream rides in its byte offset, so the descriptors stay
+// wave-uniform (a per-lane stream index in the descriptor costs a readfirstlane loop around every access: +27 % on the
+// 32-tap pass when the unpacked kernel was written that way).  The launcher packs only while the span fits 2^31 bytes.
+template <int TP, int W, bool PACK = false>
 __global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict__ x, cf* __restrict__ y,
                                                            const float* __restrict__ hcoef, int64_t num_samp, int nchan,
                                                            int64_t n_pts, int64_t per_split, int streams_per_block,
                                                            int64_t n_streams) {
-    const int lin = (blockIdx.x * 256 + threadIdx.x) * W;    // first of this thread's W adjacent positions, streams side by side
-    const int n = streams_per_block > 1 ? lin % nchan : lin;
-    const int64_t s = (int64_t)blockIdx.y * streams_per_block + (streams_per_block > 1 ? lin / nchan : 0);
-    if (s >= n_streams) return;
+    const int lin = (blockIdx.x * 256 + threadIdx.x) * W;    // first of this thread's W adjacent positions
+    const int n = PACK ? lin % nchan : lin;
+    const int sl = PACK ? lin / nchan : 0;                   // this lane's stream among the workgroup's
+    const int64_t s = PACK ? (int64_t)blockIdx.y * streams_per_block : (int64_t)blockIdx.y;      // (first) stream: uniform
+    const int64_t span = PACK ? (n_streams - s < streams_per_block ? n_streams - s : streams_per_block) : 1;
+    if (PACK && sl >= span) return;
     const int64_t i_begin = (int64_t)blockIdx.z * per_split;
     const int64_t i_end = (i_begin + per_split < n_pts) ? i_begin + per_split : n_pts;
     if (i_begin >= i_end) return;
@@ -101,9 +106,10 @@ __global__ __launch_bounds__(256) void pfb_prefilter_kernel(const cf* __restrict
 #pragma unroll
         for (int w = 0; w < W; ++w) hc[t][w] = hcoef[(int64_t)t * nchan + n + w];
     const unsigned stream_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf));       // num_samp <= 2^27
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x + s * num_samp), 0, (int)stream_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + s * num_samp, 0, (int)stream_bytes, 0x00020000);
-    const unsigned voff = (unsigned)n * (unsigned)sizeof(cf);
+    const unsigned span_bytes = stream_bytes * (unsigned)span;                        // PACK: <= 2^31 (the launcher)
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(x + s * num_samp), 0, (int)span_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + s * num_samp, 0, (int)span_bytes, 0x00020000);
+    const unsigned voff = (unsigned)sl * stream_bytes + (unsigned)n * (unsigned)sizeof(cf);
     const unsigned frame_bytes = (unsigned)nchan * (unsigned)sizeof(cf);
     cf xa[TP][W], xb[TP][W];
     prefilter_load<TP, W>(xa, rx, voff, i_begin - TP, n_pts, frame_bytes);     // history (zeros before the stream's start)
