@@ -154,7 +154,8 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
         // F-only with an odd stream count: the missing second stream of the last pair re-reads the first
         const bool valid = !SPEC || (2 * c + ant) < n_streams;
         const int ant_ld = valid ? ant : 0;
-        const unsigned chunk_bytes = (unsigned)((SPEC && 2 * c + 1 >= n_streams ? 1 : 2) * num_samp * (int64_t)sizeof(cf));
+        const int pair_streams = SPEC ? min(2, (int)n_streams - 2 * (int)c) : 2;      // a scalar minimum: see fx_tiled_ring_kernel
+        const unsigned chunk_bytes = (unsigned)(pair_streams * num_samp * (int64_t)sizeof(cf));
         const unsigned xoff = (unsigned)((ant_ld * num_samp + (G::P - 1 - u)) * (int64_t)sizeof(cf));
         cf acc[G::kAccPerThread];
 #pragma unroll
@@ -359,7 +360,11 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
         const cf* chunk_base = reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c * 2 * num_samp * kSampleBytes);
         const bool valid = !SPEC || (2 * c + ant) < n_streams;   // see fx_tiled_kernel
         const int ant_ld = valid ? ant : 0;
-        const unsigned chunk_bytes = (unsigned)((SPEC && 2 * c + 1 >= n_streams ? 1 : 2) * num_samp * kSampleBytes);
+        // streams of this pair that exist, as a scalar minimum.  Written as `2 c + 1 >= n_streams ? 1 : 2` the compiler tied the
+        // test to the per-lane `valid` above, formed the descriptor's size word with a v_cndmask and put every one of the F-only
+        // kernel's buffer loads into a readfirstlane loop (520 v_readfirstlane in the kernel; the F+X variant: 6).
+        const int pair_streams = SPEC ? min(2, (int)n_streams - 2 * (int)c) : 2;
+        const unsigned chunk_bytes = (unsigned)(pair_streams * num_samp * kSampleBytes);
         const unsigned xoff = (unsigned)((ant_ld * num_samp + (G::P - 1 - u)) * kSampleBytes);
         if (U8) s.u8.off = dc[c * 2 + ant];
         // SPEC: row of this stream's frame 0 and the rows from frame to frame (spec_row)

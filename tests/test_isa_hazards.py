@@ -70,3 +70,27 @@ def test_no_kernel_spills_to_scratch(asm_listing):
     assert not re.search(r"\bscratch_(load|store)", asm_listing)
     # the two-waves-per-SIMD kernels stay within the 256 registers that occupancy leaves them
     assert max(r[0] for r in res.values()) <= 256
+
+
+@needs_hipcc
+def test_no_buffer_access_inside_a_readfirstlane_loop(asm_listing):
+    """A buffer descriptor the compiler takes for divergent is served by a "waterfall": v_readfirstlane x 4, two 64-bit
+    compares, s_and_saveexec, the access, s_cbranch_execnz -- a dozen instructions and a loop around every single load.
+    Round 4 found the F-only tiled kernels written that way (520 v_readfirstlane per kernel: the descriptor's size word was
+    `2 c + 1 >= n_streams ? 1 : 2` times the stream size, which the compiler tied to a per-lane test and formed with a
+    v_cndmask) and, for one commit, the pre-filter pass (a per-lane stream index in the descriptor base: the 32-tap pass
+    1.7 -> 2.15 ms).  Every descriptor of this library is wave-uniform by construction: no kernel may contain the pattern."""
+    bad = {}
+    kernels = list(re.finditer(r"^(_Z\S+):[^\n]*\n(.*?)s_endpgm", asm_listing, re.S | re.M))
+    assert len(kernels) >= 80, len(kernels)
+    for m in kernels:
+        lines = [ln.strip() for ln in m.group(2).split("\n")]
+        hits = 0
+        for i, ln in enumerate(lines):
+            if ln.startswith(("buffer_load", "buffer_store")):
+                before, after = lines[max(0, i - 12):i], lines[i + 1:i + 4]
+                if any(b.startswith("v_readfirstlane_b32") for b in before) and any(a.startswith("s_cbranch_execnz") for a in after):
+                    hits += 1
+        if hits:
+            bad[m.group(1)] = hits
+    assert not bad, "buffer accesses inside readfirstlane loops: {}".format(bad)
