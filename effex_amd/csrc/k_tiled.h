@@ -164,9 +164,17 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
         auto finish = [&](cf (&v)[16], int64_t i) {
             if (G::R0 > 1) {
                 if (kReloadTw) {
-                    const cf* t0 = tw0_g;
-                    asm volatile("" : "+s"(t0));      // a fresh pointer per frame: the loads stay here
-                    G::load_tw0(tw0, t0, u);
+                    // a fresh pointer per frame (the loads stay here), typed global: behind the asm a plain pointer has lost its
+                    // address space and loads through it are flat -- they count as LDS operations too, and every LDS wait of the
+                    // frame would wait for them
+                    typedef const __attribute__((address_space(1))) unsigned long long* gu64_t;
+                    gu64_t t0 = (gu64_t)tw0_g;
+                    asm volatile("" : "+s"(t0));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {                                // = G::load_tw0
+                        const unsigned long long w = t0[r * G::P + u];
+                        tw0[r] = fxc::mk(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+                    }
                 }
                 G::prestage(v, tw0);
             }
@@ -178,9 +186,14 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
                     G::loadA(reg, u, v);
                 }
                 if (kReloadTw) {
-                    const cf* tA = twA_g;
+                    typedef const __attribute__((address_space(1))) unsigned long long* gu64_t;
+                    gu64_t tA = (gu64_t)twA_g;
                     asm volatile("" : "+s"(tA));
-                    G::load_twA(twA, tA, u);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {                                // = G::load_twA
+                        const unsigned long long w = tA[k * 256 + (u & 255)];
+                        twA[k] = fxc::mk(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+                    }
                 }
                 fxc::dft16(v);
                 __syncthreads();

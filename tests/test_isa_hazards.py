@@ -94,3 +94,13 @@ def test_no_buffer_access_inside_a_readfirstlane_loop(asm_listing):
         if hits:
             bad[m.group(1)] = hits
     assert not bad, "buffer accesses inside readfirstlane loops: {}".format(bad)
+
+
+@needs_hipcc
+def test_no_flat_memory_instructions(asm_listing):
+    """Every pointer this library dereferences on the device is global or LDS, and the compiler must know which: a `flat_`
+    access counts against BOTH the vector-memory and the LDS counters, so a wait for LDS operands becomes a wait for HBM
+    (round 4: a pointer passed through an asm barrier, or selected from an array of pointers, lost its address space --
+    23 flat loads per frame in the 8192-channel kernel, 35 in the first matrix-core X-engine)."""
+    flat = [ln.strip() for ln in asm_listing.split("\n") if re.match(r"\s+flat_(load|store|atomic)", ln)]
+    assert not flat, flat[:8]
