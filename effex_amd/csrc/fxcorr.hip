@@ -148,7 +148,7 @@ int fxc_plan_destroy(fxc_plan* p) {
         (void)hipEventDestroy(e.second);
     }
     void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_tw_small, p->d_stamps,
-                    p->d_acc, p->d_sums, p->d_cont, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
+                    p->d_acc, p->d_sums, p->d_cont, p->d_rowpart, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
                     p->d_ones, p->d_pre, p->d_tw8192};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -865,7 +865,12 @@ int fxc_finalize(fxc_plan* p, void* out_host, int mode, double bandwidth, int re
 // workgroups per stream of the subtract / narrow pass: enough to fill the chip when a call has few streams (one chunk
 // pair: the reference's own call), a handful when it has thousands
 static int cond_slices(const fxc_plan* p, int64_t n_streams) {
-    return (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)p->cu_count * 8 + n_streams - 1) / n_streams));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(256, ((int64_t)p->cu_count * 8 + n_streams - 1) / n_streams));
+}
+// slice sums per stream (each a workgroup): 32 for batches, up to 256 when a call has a handful of streams (one chunk pair:
+// 64 workgroups of 32 sequential loads each took 7 us for 4 MiB)
+static int sum_slices(const fxc_plan* p, int64_t n_streams) {
+    return (int)std::max<int64_t>(32, std::min<int64_t>(256, (int64_t)p->cu_count * 4 / n_streams));
 }
 
 static int conditioning_common(fxc_plan* p, int64_t n_streams, const void* x, void* out) {
@@ -1022,7 +1027,6 @@ namespace {
 // host buffer (x_is_scratch) -- then the plan's usual kernels.  The caller's device buffers are never written.
 int fx_cond_dev(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mode, double bandwidth, int fmt, int remove_dc,
                 bool rows, bool x_is_scratch) {
-    constexpr int kSlices = 32;
     const size_t in_elem = fmt == FXC_IQ_C128 ? sizeof(cd) : sizeof(cf);
     const size_t row_bytes = mode == FXC_MODE_SPECTRUM ? (size_t)p->n_base * p->nchan * sizeof(cf) : (size_t)p->n_base * sizeof(cd);
     const bool in_place = x_is_scratch && fmt == FXC_IQ_C64;
@@ -1035,6 +1039,7 @@ int fx_cond_dev(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mod
         const int64_t n_streams = nc * p->n_ant;
         const char* xb = static_cast<const char*>(x) + (size_t)c0 * p->n_ant * p->num_samp * in_elem;
         void* ob = rows ? static_cast<char*>(out) + (size_t)c0 * row_bytes : nullptr;
+        const int kSlices = sum_slices(p, n_streams);
         int rc = grow(p, &p->d_dc, &p->dc_bytes, (size_t)n_streams * kSlices * 2 * sizeof(double));
         if (rc) return rc;
         double* part = static_cast<double*>(p->d_dc);

@@ -119,6 +119,8 @@ struct fxc_plan {
     int64_t ws_bytes = 0;
     void* d_stage[3] = {nullptr, nullptr, nullptr};   // host-buffer calls: device copies of x and out; uint8 calls on
     size_t stage_bytes[3] = {0, 0, 0};                // plans without the fused ingest: the converted samples
+    void* d_rowpart = nullptr;                       // continuum rows of a few-row call: float64 partial sums per bin slice
+    size_t rowpart_bytes = 0;
     void* d_dc = nullptr;                            // uint8 ingest: byte sums + conversion offsets per stream
     bool u8_dck = false;                             // this uint8 call: the fused kernel sums its later chunks' bytes itself
     size_t dc_bytes = 0;

@@ -115,6 +115,26 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
     return FXC_OK;
 }
 
+// CONTINUUM rows: one workgroup per row when there are rows enough to fill the chip, else bin slices + a second small kernel
+int launch_rows_continuum(fxc_plan* p, const cf* raw, cd* out, int nchan, int64_t rows, int n_splits, int64_t split_stride,
+                          double scale, int slots, LeadRows lead) {
+    const int slices = (int)std::min<int64_t>(32, nchan / 128);
+    if (slices >= 2 && rows * 2 <= p->cu_count && rows <= 65535) {
+        const int rg = grow(p, &p->d_rowpart, &p->rowpart_bytes, (size_t)rows * slices * sizeof(cd));
+        if (rg) return rg;
+        cd* part = static_cast<cd*>(p->d_rowpart);
+        hipLaunchKernelGGL(rows_continuum_part_kernel, dim3(slices, (unsigned)rows), dim3(256), 0, p->stream, raw, part, p->d_rot, nchan,
+                           rows, n_splits, split_stride, slots, lead, slices);
+        hipLaunchKernelGGL(rows_continuum_fin_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, p->stream, part, out, rows, slices,
+                           scale);
+    } else {
+        hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
+                           dim3(continuum_threads(nchan)), 0, p->stream, raw, out, p->d_rot, nchan, rows, n_splits, split_stride, scale,
+                           slots, lead);
+    }
+    return FXC_OK;
+}
+
 // device-resident implementation of fx_rows; out = cf[n_chunks][n_base][nchan] or cd[n_chunks][n_base]
 int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode, double bandwidth,
                 const cf* dc_u8 = nullptr) {
@@ -135,10 +155,10 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
             if (mode == FXC_MODE_SPECTRUM)
                 hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc, 256, p->cu_count)), dim3(256), 0, p->stream, raw,
                                    static_cast<cf*>(out) + c0, p->d_rot, 1, nc, nb, nc, inv_pts, 0, kNoLead);
-            else
-                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
-                                   dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, 1, nc, nb, nc,
-                                   cscale, 0, kNoLead);
+            else {
+                rc = launch_rows_continuum(p, raw, static_cast<cd*>(out) + c0, 1, nc, nb, nc, cscale, 0, kNoLead);
+                if (rc) return rc;
+            }
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;
@@ -165,10 +185,10 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
                 hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(rows * p->nchan, 256, p->cu_count)), dim3(256), 0,
                                    p->stream, raw, static_cast<cf*>(out) + c0 * p->n_base * p->nchan, p->d_rot, p->nchan,
                                    rows, xr, xr_stride, inv_pts, fused_layout(p), lead);
-            else
-                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
-                                   dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot,
-                                   p->nchan, rows, xr, xr_stride, cscale, fused_layout(p), lead);
+            else {
+                rc = launch_rows_continuum(p, raw, static_cast<cd*>(out) + c0 * p->n_base, p->nchan, rows, xr, xr_stride, cscale, fused_layout(p), lead);
+                if (rc) return rc;
+            }
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;
@@ -187,10 +207,10 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
             if (mode == FXC_MODE_SPECTRUM)
                 hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc * N, 256, p->cu_count)), dim3(256), 0, p->stream,
                                    raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, 1, (int64_t)0, inv_pts, 3, lead);
-            else
-                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
-                                   dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, 1, (int64_t)0,
-                                   cscale, 3, lead);
+            else {
+                rc = launch_rows_continuum(p, raw, static_cast<cd*>(out) + c0, N, nc, 1, (int64_t)0, cscale, 3, lead);
+                if (rc) return rc;
+            }
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;
@@ -213,10 +233,10 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
             if (mode == FXC_MODE_SPECTRUM)
                 hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(nc * N, 256, p->cu_count)), dim3(256), 0, p->stream,
                                    raw, static_cast<cf*>(out) + c0 * N, p->d_rot, N, nc, n_splits, nc * N, inv_pts, 0, kNoLead);
-            else
-                hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(nc, (int64_t)p->cu_count * 8)),
-                                   dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0, p->d_rot, N, nc, n_splits,
-                                   nc * N, cscale, 0, kNoLead);
+            else {
+                rc = launch_rows_continuum(p, raw, static_cast<cd*>(out) + c0, N, nc, n_splits, nc * N, cscale, 0, kNoLead);
+                if (rc) return rc;
+            }
             FXC_HIP(p, hipGetLastError());
         }
         return FXC_OK;
@@ -244,10 +264,10 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
             hipLaunchKernelGGL(rows_spectrum_kernel, dim3(grid_for(rows * p->nchan, 256, p->cu_count)), dim3(256), 0,
                                p->stream, raw, static_cast<cf*>(out) + c0 * p->n_base * p->nchan, p->d_rot, p->nchan,
                                rows, g.n_splits, split_stride, inv_pts, 0, kNoLead);
-        else
-            hipLaunchKernelGGL(rows_continuum_kernel, dim3((int)std::min<int64_t>(rows, (int64_t)p->cu_count * 8)),
-                               dim3(continuum_threads(p->nchan)), 0, p->stream, raw, static_cast<cd*>(out) + c0 * p->n_base, p->d_rot, p->nchan,
-                               rows, g.n_splits, split_stride, cscale, 0, kNoLead);
+        else {
+            rc = launch_rows_continuum(p, raw, static_cast<cd*>(out) + c0 * p->n_base, p->nchan, rows, g.n_splits, split_stride, cscale, 0, kNoLead);
+            if (rc) return rc;
+        }
         FXC_HIP(p, hipGetLastError());
     }
     return FXC_OK;

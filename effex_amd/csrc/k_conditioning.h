@@ -17,8 +17,20 @@ __global__ __launch_bounds__(256) void dc_sum_c64_kernel(const cf* __restrict__ 
     const int64_t per = (num_samp + n_slices - 1) / n_slices;
     const int64_t lo = slice * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
     double ar = 0.0, ai = 0.0;
-    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
-        const cf v = x[s * num_samp + n];
+    const cf* __restrict__ xs = x + s * num_samp;
+    int64_t n = lo + threadIdx.x;
+    for (; n + 3 * (int64_t)blockDim.x < hi; n += 4 * (int64_t)blockDim.x) {       // four loads in flight, added in index order
+        cf v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = xs[n + q * (int64_t)blockDim.x];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ar += v[q].x;
+            ai += v[q].y;
+        }
+    }
+    for (; n < hi; n += blockDim.x) {
+        const cf v = xs[n];
         ar += v.x;
         ai += v.y;
     }
@@ -124,14 +136,14 @@ __global__ __launch_bounds__(256) void dc_sum_c128_kernel(const cd* __restrict__
     }
 }
 
-// mean of stream s from its slice sums, the same fixed order in every thread
+// mean of stream s from its slice sums (at most 256 of them): one partial per thread, summed by the workgroup's fixed tree
 __device__ __forceinline__ void dc_mean(const double* __restrict__ part, int64_t s, int n_slices, int64_t num_samp,
-                                        double* mr, double* mi) {
-    double ar = 0.0, ai = 0.0;
-    for (int k = 0; k < n_slices; ++k) {
-        ar += part[(s * n_slices + k) * 2];
-        ai += part[(s * n_slices + k) * 2 + 1];
-    }
+                                        double* mr, double* mi, double* red) {
+    const int k = threadIdx.x;
+    double ar = k < n_slices ? part[(s * n_slices + k) * 2] : 0.0;
+    double ai = k < n_slices ? part[(s * n_slices + k) * 2 + 1] : 0.0;
+    ar = block_sum(ar, red);
+    ai = block_sum(ai, red);
     *mr = ar / (double)num_samp;
     *mi = ai / (double)num_samp;
 }
@@ -141,14 +153,26 @@ __device__ __forceinline__ void dc_mean(const double* __restrict__ part, int64_t
 __global__ __launch_bounds__(256) void dc_apply_c64_kernel(const cf* __restrict__ x, cf* __restrict__ out,
                                                           const double* __restrict__ part, int64_t num_samp, int n_slices,
                                                           int part_slices, int remove_dc) {
+    __shared__ double red[256];
     const int64_t s = blockIdx.y;
     double mr = 0.0, mi = 0.0;
-    if (remove_dc) dc_mean(part, s, part_slices, num_samp, &mr, &mi);
+    if (remove_dc) dc_mean(part, s, part_slices, num_samp, &mr, &mi, red);
     const int64_t per = (num_samp + n_slices - 1) / n_slices;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
-    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
-        const cf v = x[s * num_samp + n];
-        out[s * num_samp + n] = fxc::mk((float)((double)v.x - mr), (float)((double)v.y - mi));
+    const cf* __restrict__ xs = x + s * num_samp;
+    cf* __restrict__ os = out + s * num_samp;
+    int64_t n = lo + threadIdx.x;
+    for (; n + 3 * (int64_t)blockDim.x < hi; n += 4 * (int64_t)blockDim.x) {       // four loads in flight
+        cf v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = xs[n + q * (int64_t)blockDim.x];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            os[n + q * (int64_t)blockDim.x] = fxc::mk((float)((double)v[q].x - mr), (float)((double)v[q].y - mi));
+    }
+    for (; n < hi; n += blockDim.x) {
+        const cf v = xs[n];
+        os[n] = fxc::mk((float)((double)v.x - mr), (float)((double)v.y - mi));
     }
 }
 
@@ -157,9 +181,10 @@ __global__ __launch_bounds__(256) void dc_apply_c64_kernel(const cf* __restrict_
 __global__ __launch_bounds__(256) void narrow_c128_kernel(const cd* __restrict__ x, cf* __restrict__ out,
                                                          const double* __restrict__ part, int64_t num_samp, int n_slices,
                                                          int part_slices, int remove_dc) {
+    __shared__ double red[256];
     const int64_t s = blockIdx.y;
     double mr = 0.0, mi = 0.0;
-    if (remove_dc) dc_mean(part, s, part_slices, num_samp, &mr, &mi);
+    if (remove_dc) dc_mean(part, s, part_slices, num_samp, &mr, &mi, red);
     const int64_t per = (num_samp + n_slices - 1) / n_slices;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
     for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {

@@ -125,6 +125,57 @@ __global__ __launch_bounds__(kContinuumThreads) void rows_continuum_kernel(const
     }
 }
 
+// The same for a call of few rows (the reference's own call is ONE: effex.py:490-494): a row's bins are cut into `slices`
+// workgroups (grid = slices x rows) that leave float64 partial sums, and rows_continuum_fin_kernel adds them in slice
+// order -- one workgroup per row gathered a chunk pair's up to 255 leading-part rows for all 4096 bins in 33 us, the largest
+// item of that call.
+__global__ __launch_bounds__(256) void rows_continuum_part_kernel(const cf* __restrict__ raw, cd* __restrict__ part,
+                                                                 const cd* __restrict__ rot, int nchan, int64_t rows, int n_splits,
+                                                                 int64_t split_stride, int slots, LeadRows lead, int slices) {
+    __shared__ double red[256];
+    const int64_t row = blockIdx.y;
+    const int per = (nchan + slices - 1) / slices;
+    const int k_lo = blockIdx.x * per, k_hi = k_lo + per < nchan ? k_lo + per : nchan;
+    double ar = 0.0, ai = 0.0;
+    for (int k = k_lo + threadIdx.x; k < k_hi; k += blockDim.x) {
+        double xr = 0.0, xi = 0.0;
+        for (int s = 0; s < n_splits; ++s) {
+            const cf r = raw[s * split_stride + row * nchan + raw_index(k, slots)];
+            xr += r.x;
+            xi += r.y;
+        }
+        float lr_re = 0.f, lr_im = 0.f;
+        add_lead_rows(raw, lead, row, nchan, k, slots, lr_re, lr_im);
+        xr += lr_re;
+        xi += lr_im;
+        const cd w = rot[k];
+        ar += xr * w.x + xi * w.y;
+        ai += xi * w.x - xr * w.y;
+    }
+    ar = block_sum(ar, red);
+    ai = block_sum(ai, red);
+    if (threadIdx.x == 0) {
+        cd o;
+        o.x = ar;
+        o.y = ai;
+        part[row * slices + blockIdx.x] = o;
+    }
+}
+
+__global__ void rows_continuum_fin_kernel(const cd* __restrict__ part, cd* __restrict__ out, int64_t rows, int slices, double scale) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    double ar = 0.0, ai = 0.0;
+    for (int s = 0; s < slices; ++s) {
+        ar += part[row * slices + s].x;
+        ai += part[row * slices + s].y;
+    }
+    cd o;
+    o.x = ar * scale;
+    o.y = ai * scale;
+    out[row] = o;
+}
+
 // What the kernel that finishes an integration does with an accumulator element besides updating it: export it for the
 // cross-rank reduce, finalise it, clear it -- in the same launch instead of export + finalize + device-to-host copy +
 // memset (round 2: four commands and 50 us of gaps per integration).
