@@ -59,6 +59,7 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
 #include "fx_fused4096.h"
 #include "fx_tiled.h"
 #include "fx_small.h"
+#include "fx_mixed.h"
 #include "fx_math.h"
 
 using fxc::cd;
@@ -71,6 +72,7 @@ constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 channeliser kernels only
 constexpr int kMaxXAnt = 64;         // antennas the F-only + X-engine route takes (fxc_plan_create's own limit)
 constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
+constexpr int kMixedMaxN = 10240;    // two rows of complex64 in the 160 KiB of LDS (pfb_fft_mixed_kernel)
 size_t res_direct_bytes() {      // finalize results up to this size are written to host memory by the kernel (FXC_RES_DIRECT: developer knob, bytes)
     static const size_t v = [] { const char* e = std::getenv("FXC_RES_DIRECT"); return e ? (size_t)std::atoll(e) : (size_t)(256 << 10); }();
     return v;
@@ -211,9 +213,21 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     FXC_HIP(p, hipMalloc(&p->d_win, wf.size() * sizeof(float)));
     FXC_HIP(p, hipMemcpy(p->d_win, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
 
-    // generic FFT twiddles exp(+2 pi i j / N): [N/2] for the radix-2 kernel, [N] for the direct DFT
+    // generic F stage: every channel count that is not a power of two (and fits two LDS rows) takes the mixed-radix kernel;
+    // FXC_GENERIC_FFT=mixed|radix2 moves the powers of two onto it / everything off it (developer knob)
+    {
+        const char* gf = std::getenv("FXC_GENERIC_FFT");
+        const bool force_mixed = gf && !std::strcmp(gf, "mixed"), force_old = gf && !std::strcmp(gf, "radix2");
+        p->mixed = N > 1 && N <= kMixedMaxN && !force_old && (!p->pow2 || force_mixed);
+        if (p->mixed) {
+            p->mixed_plan = fxc::mixed_factor(N);
+            p->mixed_tpr = fxc::mixed_threads_per_row(N);
+            if (p->mixed_plan.n_stages < 0) p->mixed = false;
+        }
+    }
+    // generic FFT twiddles exp(+2 pi i j / N): [N/2] for the radix-2 kernel, [N] for the mixed-radix kernel and the direct DFT
     if (N > 1) {
-        const int cnt = p->pow2 ? N / 2 : N;
+        const int cnt = (p->pow2 && !p->mixed) ? N / 2 : N;
         std::vector<cf> tw((size_t)cnt);
         for (int jx = 0; jx < cnt; ++jx) {
             const double ph = kTwoPi * (double)jx / (double)N;
@@ -462,7 +476,10 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         p->x_resident = (int64_t)std::max(per_cu, 1) * p->cu_count;
         }
     }
-    if (N > 1) {
+    if (p->mixed) {
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMixedMaxN * (int)sizeof(cf)));
+    } else if (N > 1) {
         const int lds = N * (int)sizeof(cf);
         if (p->pow2)
             FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_pow2_kernel),

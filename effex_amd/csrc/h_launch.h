@@ -15,6 +15,19 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
     if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
     // the F-only tiled kernel writes natural-order spectra straight to `spec` (no workspace): any caller may use it
     if (p->tiled_f) return tiled_channelize(p, x, spec, n_streams);
+    if (p->mixed) {
+        const int64_t n_rows = n_streams * p->n_pts;
+        const int rpw = 256 / p->mixed_tpr;
+        const int64_t n_groups = (n_rows + rpw - 1) / rpw;
+        const size_t lds = (size_t)rpw * 2 * p->nchan * sizeof(cf);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
+        // a few row groups per workgroup at least (the FIR's re-reads stay in one L2), and no more workgroups than fit at once
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + 3) / 4, (int64_t)p->cu_count * per_cu));
+        hipLaunchKernelGGL(pfb_fft_mixed_kernel, dim3(grid), dim3(256), lds, p->stream, x, p->d_win, spec, p->d_tw,
+                           p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_rows, p->mixed_tpr);
+        FXC_HIP(p, hipGetLastError());
+        return FXC_OK;
+    }
     const int64_t total = n_streams * p->n_pts * p->nchan;
     hipLaunchKernelGGL(pfb_fir_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream, x, p->d_win,
                        spec, p->num_samp, p->nchan, p->ntaps, p->n_pts, total);
@@ -213,7 +226,9 @@ int64_t xengine_group(const fxc_plan* p, int64_t nc, int64_t unit) {
     // more than 8 antennas: a column of 16 bins with all antennas per workgroup (xengine_mfma_kernel), or -- the vector
     // kernel it replaced -- a column of 64 shared by the G (G + 1) / 2 pairs of antenna blocks (xengine_block_kernel)
     const int64_t gb = (p->n_ant + kXB - 1) / kXB;
-    const int64_t cols = p->x_mfma ? std::max<int64_t>(1, p->nchan / 16)
+    int x_ch = 16;
+    if (p->x_mfma) FXC_XMFMA_DISPATCH(p, x_ch = XMfmaGeo<XT>::kCH);
+    const int64_t cols = p->x_mfma ? std::max<int64_t>(1, p->nchan / x_ch)
                                    : std::max<int64_t>(1, p->nchan / kXThreads) * (p->n_ant > kXB ? gb * (gb + 1) / 2 : 1);
     const int64_t groups = std::max<int64_t>(1, p->x_resident / cols);
     return std::max<int64_t>(1, std::min<int64_t>(unit, (nc + groups - 1) / groups));

@@ -51,6 +51,9 @@ struct fxc_plan {
     int path = FXC_PATH_GENERIC;
     bool pow2 = false;
     int lg2n = 0;
+    bool mixed = false;            // generic F stage = pfb_fft_mixed_kernel (FIR + mixed-radix FFT in one pass)
+    fxc::MixedPlan mixed_plan{};
+    int mixed_tpr = 256;           // threads per row
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev_order = nullptr;   // orders the old stream's work before the new one's (fxc_set_stream)

@@ -95,6 +95,59 @@ __global__ __launch_bounds__(256) void dft_any_kernel(cf* __restrict__ data, con
     }
 }
 
+// FIR + FFT for any nchan whose two LDS rows fit (kMixedMaxN): the polyphase FIR runs on the way into LDS, the mixed-radix
+// Stockham stages of fx_mixed.h ping-pong between the two rows, and the natural-order spectrum goes out once.  256 / tpr
+// rows share a workgroup when nchan is small; a workgroup owns a contiguous run of rows, so the ntaps re-reads of a frame
+// come from its own L2.
+__global__ __launch_bounds__(256) void pfb_fft_mixed_kernel(const cf* __restrict__ x, const float* __restrict__ h,
+                                                           cf* __restrict__ spec, const cf* __restrict__ tw,
+                                                           const fxc::MixedPlan mp, int64_t num_samp, int nchan, int ntaps,
+                                                           int64_t n_pts, int64_t n_rows, int tpr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int rpw = 256 / tpr;
+    const int sub = (int)threadIdx.x / tpr, lt = (int)threadIdx.x % tpr;
+    cf* row_a = reinterpret_cast<cf*>(smem) + (int64_t)sub * 2 * nchan;
+    cf* row_b = row_a + nchan;
+    const int64_t n_groups = (n_rows + rpw - 1) / rpw;
+    const int64_t g0 = (int64_t)blockIdx.x * n_groups / gridDim.x, g1 = ((int64_t)blockIdx.x + 1) * n_groups / gridDim.x;
+    for (int64_t g = g0; g < g1; ++g) {
+        const int64_t row = g * rpw + sub;
+        const bool active = row < n_rows;
+        if (active) {
+            const int64_t s = row / n_pts, i = row - s * n_pts;
+            const cf* xs = x + s * num_samp + i * nchan + (nchan - 1);
+            const int tmax = (i + 1 < (int64_t)ntaps) ? (int)(i + 1) : ntaps;
+            for (int m = lt; m < nchan; m += tpr) {
+                float ar = 0.f, ai = 0.f;
+                for (int t = 0; t < tmax; ++t) {
+                    const cf xv = xs[-(int64_t)t * nchan - m];
+                    const float w = h[(int64_t)t * nchan + m];
+                    ar = fmaf(w, xv.x, ar);
+                    ai = fmaf(w, xv.y, ai);
+                }
+                row_a[m] = fxc::mk(ar, ai);
+            }
+        }
+        __syncthreads();
+        cf *src = row_a, *dst = row_b;
+        int ns = 1;
+        for (int st = 0; st < mp.n_stages; ++st) {
+            const int radix = mp.radix[st];
+            if (active) fxc::mixed_stage(src, dst, tw, nchan, radix, ns, lt, tpr);
+            __syncthreads();
+            ns *= radix;
+            cf* t = src;
+            src = dst;
+            dst = t;
+        }
+        if (active) {
+            cf* d = spec + row * nchan;
+            for (int n = lt; n < nchan; n += tpr) d[n] = src[n];
+        }
+        __syncthreads();
+    }
+}
+
 // raw[split][c][p][k] = sum_{i in split} spec[c][a][i][k] * conj(spec[c][b][i][k]); block = kx x iy threads
 __global__ __launch_bounds__(256) void xmul_kernel(const cf* __restrict__ spec, cf* __restrict__ raw, int n_ant,
                                                   int n_base, int nchan, int64_t n_pts, int kx, int n_splits,

@@ -45,10 +45,14 @@ struct XMfmaGeo {
 #endif
     static constexpr int kWaves = T == 1 ? FXC_XMFMA_W1 : (T == 2 ? FXC_XMFMA_W2 : (T == 3 ? FXC_XMFMA_W3 : FXC_XMFMA_W4));
     static constexpr int kThreads = 64 * kWaves;
-    static constexpr int kCH = 16;                       // bins per workgroup: 128-byte row segments
+#ifndef FXC_XMFMA_CH34
+#define FXC_XMFMA_CH34 16
+#endif
+    static constexpr int kCH = T <= 2 ? 16 : FXC_XMFMA_CH34;   // bins per workgroup: 128-byte row segments
+    static constexpr int kSegLanes = kCH / 2;             // lanes per row segment (16 bytes each)
     static constexpr int kCPW = kCH / kWaves;            // bins per wave: 4 (T <= 2) or 2
     static constexpr int kPairs = T * (T + 1) / 2;
-    static constexpr int kRowsPerPass = kThreads / 8;    // 8 lanes x 16 bytes per row segment: 32 or 64 rows per load instruction
+    static constexpr int kRowsPerPass = kThreads / kSegLanes;   // rows per load instruction
     static constexpr int kFPPmax = kRowsPerPass / kAP;   // whole frames per pass (48 antennas: rows idle)
     static constexpr int kFPP = kFPPmax >= 4 ? 4 : (kFPPmax >= 2 ? 2 : 1);
 #ifndef FXC_XMFMA_FT1
@@ -61,15 +65,17 @@ struct XMfmaGeo {
     static_assert(kFT % kFPP == 0 && kFT % 4 == 0, "whole passes per tile, two halves of whole frame pairs");
     static constexpr int kPasses = kFT / kFPP;           // loads per thread and tile
     static constexpr int kRows = kFT * kAP;              // LDS rows of a tile
-    static constexpr int kPitch = 17;                    // complex per LDS row
+    static constexpr int kPitch = kCH + 1;               // complex per LDS row
     static constexpr int kTileCf = kRows * kPitch;       // complex per tile buffer
-    static constexpr int kLdsBytes = 2 * kTileCf * (int)sizeof(cf);
     static_assert(kFPP * kAP <= kRowsPerPass, "a pass covers whole frames");
-    static_assert(256 * kPitch * (int)sizeof(cf) <= kLdsBytes, "the epilogue's [16][16][bin] tile must fit");
+    static constexpr int kLdsBytes = (2 * kTileCf > 256 * kPitch ? 2 * kTileCf : 256 * kPitch) * (int)sizeof(cf);   // two tiles, or the epilogue's [16][16][bin]
 };
 
+#ifndef FXC_XMFMA_LB34
+#define FXC_XMFMA_LB34 2
+#endif
 template <int T>
-__global__ __launch_bounds__(XMfmaGeo<T>::kThreads, (T == 1 ? 4 : (T == 2 ? 3 : 2))) void xengine_mfma_kernel(const cf* __restrict__ spec, cf* __restrict__ raw,
+__global__ __launch_bounds__(XMfmaGeo<T>::kThreads, (T == 1 ? 4 : (T == 2 ? 3 : FXC_XMFMA_LB34))) void xengine_mfma_kernel(const cf* __restrict__ spec, cf* __restrict__ raw,
                                                                                int64_t n_pts, int nchan, int64_t n_chunks, int cg,
                                                                                int A, int n_ranges, int abl) {
     using G = XMfmaGeo<T>;
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(XMfmaGeo<T>::kThreads, (T == 1 ? 4 : (T == 2 ? 3 : 
 
     // ---- load side: thread -> (frame of the pass, antenna, 16-byte piece of the 128-byte segment).  Everything about a frame
     // is wave-uniform (scalar registers): the walk over (chunk, frame in chunk) is two counters, no division.
-    const int lrow = tid >> 3, lsub = tid & 7;
+    const int lrow = tid / G::kSegLanes, lsub = tid % G::kSegLanes;
     const int la = lrow % G::kAP, lf = lrow / G::kAP;          // lf < kFPP for the rows that load
     const bool loads = lf < G::kFPP && la < A;
     // complex, inside a frame's A rows of nchan bins.  (Measured and dropped: spectra as [bin >> 4][antenna][bin & 15], a

@@ -692,6 +692,52 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
         assert rel_err(rows_u8, g.fx_rows_u8(u8).cpu().numpy()) < TOL_VIS
 
 
+@pytest.mark.parametrize("n_ant,nchan,ntaps,n_chunks,frames,extra", [
+    (2, 1000, 4, 3, 40, 7), (2, 3000, 4, 2, 21, 0), (2, 96, 4, 5, 300, 5), (2, 1536, 8, 2, 33, 100), (2, 100, 3, 7, 9, 0),
+    (2, 997, 4, 2, 10, 3), (2, 6, 4, 4, 1000, 1), (2, 12, 1, 3, 50, 0), (3, 48, 5, 2, 77, 2), (2, 2310, 2, 1, 12, 0),
+    (2, 5000, 4, 1, 9, 11), (4, 10240, 4, 1, 5, 0), (2, 3, 4, 2, 4000, 2), (2, 7, 32, 2, 500, 0), (2, 1001, 4, 1, 3, 0),
+    (2, 6561, 4, 1, 4, 0), (2, 250, 4, 1, 1, 0), (5, 360, 4, 2, 30, 1)])
+def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, nchan, ntaps, n_chunks, frames, extra):
+    """`--resolution` is a free integer (effex.py:733-739): channel counts that are not a power of two run the FIR + mixed-radix
+    Stockham kernel (fx_mixed.h: radices 4, 2, 3, 5, 7, 11, 13 in registers, any other prime factor from the LDS row) -- against
+    the oracle, and against the direct O(N^2) DFT kernel it replaced."""
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(777 + nchan, n_chunks, n_ant, num_samp)
+    window = design_window(ntaps, nchan)
+    rot = plan_mod.rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, -2e-7)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as p:
+        assert p.path == "generic"
+        p.set_rot(rot)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        for c in range(min(n_chunks, 3)):
+            ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, -2e-7, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        p.fx_accumulate(xd[: n_chunks // 3 + 1])
+        p.fx_accumulate(xd[n_chunks // 3 + 1:])
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ, rows.astype(np.complex128).mean(axis=0)) < 2e-6
+        spec = p.channelize(xd[0, 0]).cpu().numpy()
+        assert rel_err(spec.reshape(-1, nchan), fx_oracle.spectrometer_poly(x[0, 0], ntaps, nchan, window)) < TOL_VIS
+    monkeypatch.setenv("FXC_GENERIC_FFT", "radix2")            # the direct DFT (developer knob, read when the plan is built)
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as d:
+        d.set_rot(rot)
+        assert rel_err(rows, d.fx_rows(xd, "SPECTRUM").cpu().numpy()) < 4e-6
+
+
+@pytest.mark.parametrize("nchan", [8, 64, 1024, 4096, 8192])
+def test_mixed_radix_kernel_on_powers_of_two(plan_mod, torch, monkeypatch, nchan):
+    """The same kernel with only fours and a two (FXC_GENERIC_FFT=mixed moves the generic path's powers of two onto it)."""
+    num_samp = nchan * 23 + 5
+    x = synth.synth_iq(55, 2, 2, num_samp)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, nchan, 3, num_samp, path="generic") as g:
+        ref = g.fx_rows(xd).cpu().numpy()
+    monkeypatch.setenv("FXC_GENERIC_FFT", "mixed")
+    with plan_mod.FxPlan(2, nchan, 3, num_samp, path="generic") as m:
+        assert rel_err(m.fx_rows(xd).cpu().numpy(), ref) < 4e-6
+
+
 def test_small_channel_counts_outside_the_kernel_fall_back(plan_mod, torch):
     """Fewer than 16 channels, or channel counts that are not 16 x a power of two: the generic kernels, as before (more
     than four taps no longer: the pre-filter pass serves them, test_small_channel_counts_match_oracle)."""
