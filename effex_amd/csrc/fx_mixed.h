@@ -50,97 +50,179 @@ inline MixedPlan mixed_factor(int n) {
     return mp;
 }
 
-// R-point DFT, kernel exp(+2 pi i q r / R), in place; `root` = tw + the stride N/R of the R-th roots in the table
+// Two floats in one register pair: gfx950 runs v_pk_add/mul/fma_f32 at the rate of the scalar forms, so complex
+// arithmetic written on pairs costs half the issue slots (the stages are issue-bound, not LDS- or HBM-bound).
+typedef float pk2 __attribute__((vector_size(8)));
+FXC_HD pk2 pk(cf a) { pk2 r = {a.x, a.y}; return r; }
+FXC_HD cf unpk(pk2 a) { return mk(a[0], a[1]); }
+FXC_HD pk2 pk_splat(float s) { pk2 r = {s, s}; return r; }
+FXC_HD pk2 pk_muli(pk2 a) { pk2 r = {-a[1], a[0]}; return r; }     // times +i
+FXC_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) {
+#if defined(__clang__)
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+// a * w = a.x (w.x, w.y) + a.y (-w.y, w.x)
+FXC_HD pk2 pk_cmul(pk2 a, pk2 w) { return pk_fma(pk_splat(a[1]), pk_muli(w), pk_splat(a[0]) * w); }
+
+// the R-th roots of unity the odd butterflies need: w[m] = exp(+2 pi i m / R), m = 1 .. (R-1)/2, at stride N/R in the table
 template <int R>
-FXC_HD void dft_reg(cf (&v)[R], const cf* root, int root_stride) {
+struct Roots {
+    pk2 w[(R - 1) / 2 + 1];
+};
+template <int R>
+FXC_HD Roots<R> load_roots(const cf* tw, int root_stride) {
+    Roots<R> rt;
+    rt.w[0] = pk_splat(1.f);
+    if constexpr (R != 2 && R != 4) {
+#pragma unroll
+        for (int m = 1; m <= (R - 1) / 2; ++m) rt.w[m] = pk(tw[m * root_stride]);
+    }
+    return rt;
+}
+
+// R-point DFT, kernel exp(+2 pi i q r / R), of v[0..R) straight into d[q * ds].  Odd R: inputs r and R - r enter as a sum
+// and an i-times-difference, outputs q and R - q leave as P +- Q with P = v0 + sum a_r cos(2 pi q r / R),
+// Q = sum b_r sin(2 pi q r / R) -- half the multiplies of the plain sum.
+template <int R>
+FXC_HD void dft_store(pk2 (&v)[R], const Roots<R>& rt, cf* d, int ds) {
     if constexpr (R == 2) {
-        const cf a = v[0], b = v[1];
-        v[0] = cadd(a, b);
-        v[1] = csub(a, b);
+        d[0] = unpk(v[0] + v[1]);
+        d[ds] = unpk(v[0] - v[1]);
     } else if constexpr (R == 4) {
-        dft4(v[0], v[1], v[2], v[3]);
+        const pk2 t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], t3 = pk_muli(v[1] - v[3]);
+        d[0] = unpk(t0 + t2);
+        d[ds] = unpk(t1 + t3);
+        d[2 * ds] = unpk(t0 - t2);
+        d[3 * ds] = unpk(t1 - t3);
     } else {
-        cf w[R];
+        static_assert(R % 2 == 1, "odd radix");
+        constexpr int H = (R - 1) / 2;
+        pk2 sum = v[0];
 #pragma unroll
-        for (int m = 1; m < R; ++m) w[m] = root[m * root_stride];
-        cf out[R];
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            cf acc = v[0];
-#pragma unroll
-            for (int r = 1; r < R; ++r) {
-                if ((q * r) % R == 0) {
-                    acc = cadd(acc, v[r]);
-                } else {
-                    const cf ww = w[(q * r) % R];
-                    acc = mk(__builtin_fmaf(-v[r].y, ww.y, __builtin_fmaf(v[r].x, ww.x, acc.x)),
-                             __builtin_fmaf(v[r].y, ww.x, __builtin_fmaf(v[r].x, ww.y, acc.y)));
-                }
-            }
-            out[q] = acc;
+        for (int r = 1; r <= H; ++r) {
+            const pk2 a = v[r] + v[R - r], b = pk_muli(v[r] - v[R - r]);
+            v[r] = a;
+            v[R - r] = b;
+            sum = sum + a;
         }
+        d[0] = unpk(sum);
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = out[q];
+        for (int q = 1; q <= H; ++q) {
+            pk2 pacc = v[0], qacc = {0.f, 0.f};
+#pragma unroll
+            for (int r = 1; r <= H; ++r) {
+                const int m = (q * r) % R;                     // cos(2 pi m / R), sin(2 pi m / R) from the half table
+                const pk2 ww = rt.w[m <= H ? m : R - m];
+                pacc = pk_fma(pk_splat(ww[0]), v[r], pacc);
+                const pk2 sb = pk_splat(ww[1]) * v[R - r];
+                if (r == 1)
+                    qacc = m <= H ? sb : -sb;
+                else
+                    qacc = m <= H ? qacc + sb : qacc - sb;
+            }
+            d[q * ds] = unpk(pacc + qacc);
+            d[(R - q) * ds] = unpk(pacc - qacc);
+        }
     }
 }
 
-// one stage, register butterflies: "thread" lt of tpr walks the butterflies lt, lt + tpr, ...
-template <int R>
-FXC_HD void mixed_stage_reg(const cf* src, cf* dst, const cf* tw, int n, int ns, int lt, int tpr) {
+// a / d for 0 <= a < 2^15 and 1 <= d < 2^15 with inv = 1.0f / d: (a + 1/2) / d is at least 1/(2d) away from an integer, and
+// the rounding of the product is below a / d * 2^-22 <= 2^-7 / d -- the truncation cannot land on the wrong side
+FXC_HD int small_div(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
+
+// one stage, register butterflies: "thread" lt of tpr walks the butterflies lt, lt + tpr, ... of U rows that stand
+// row_stride elements apart in src and in dst -- one index computation and one set of twiddles for all of them
+template <int R, int U>
+FXC_HD void mixed_stage_reg(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int ns, int lt, int tpr) {
     const int nb = n / R;
     const int tmul = nb / ns;          // N / (Ns R)
+    const float inv_ns = 1.0f / (float)ns;
+    const Roots<R> rt = load_roots<R>(tw, nb);
     for (int b = lt; b < nb; b += tpr) {
-        const int k = b % ns;
+        const int k = b - small_div(b, inv_ns) * ns;
         const int e = k * tmul;        // < N/R, so r e < N for every r < R: the index never wraps
-        cf v[R];
-        v[0] = src[b];
+        pk2 w[R];
 #pragma unroll
-        for (int r = 1; r < R; ++r) v[r] = cmul(src[b + r * nb], tw[r * e]);
-        dft_reg<R>(v, tw, nb);
-        cf* d = dst + (b - k) * R + k;
+        for (int r = 1; r < R; ++r) w[r] = pk(tw[r * e]);
+        const int o = (b - k) * R + k;
+#pragma unroll R >= 7 ? 1 : U                  // the big butterflies one row at a time: U of them at once spill
+        for (int u = 0; u < U; ++u) {
+            pk2 v[R];
+            v[0] = pk(src[u * row_stride + b]);
 #pragma unroll
-        for (int q = 0; q < R; ++q) d[q * ns] = v[q];
+            for (int r = 1; r < R; ++r) v[r] = pk_cmul(pk(src[u * row_stride + b + r * nb]), w[r]);
+            dft_store<R>(v, rt, dst + u * row_stride + o, ns);
+        }
     }
 }
 
 // one stage, any radix: item (b, q) = one output of one butterfly; the R inputs are read from the row each time
-FXC_HD void mixed_stage_any(const cf* src, cf* dst, const cf* tw, int n, int radix, int ns, int lt, int tpr) {
+template <int U>
+FXC_HD void mixed_stage_any(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int radix, int ns, int lt, int tpr) {
     const int nb = n / radix;
     const int tmul = nb / ns;
+    const float inv_ns = 1.0f / (float)ns, inv_nb = 1.0f / (float)nb;
     for (int item = lt; item < n; item += tpr) {
-        const int q = item / nb, b = item - q * nb;
-        const int k = b % ns;
+        const int q = small_div(item, inv_nb), b = item - q * nb;
+        const int k = b - small_div(b, inv_ns) * ns;
         const int e = k * tmul + q * nb;     // < N/R + (R-1) N/R = N
-        cf acc = src[b];
+        pk2 acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = pk(src[u * row_stride + b]);
         int idx = e;
         for (int r = 1; r < radix; ++r) {
-            const cf a = src[b + r * nb], w = tw[idx];
-            acc = mk(__builtin_fmaf(-a.y, w.y, __builtin_fmaf(a.x, w.x, acc.x)),
-                     __builtin_fmaf(a.y, w.x, __builtin_fmaf(a.x, w.y, acc.y)));
+            const pk2 w = pk(tw[idx]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const pk2 a = pk(src[u * row_stride + b + r * nb]);
+                acc[u] = pk_fma(pk_splat(a[1]), pk_muli(w), pk_fma(pk_splat(a[0]), w, acc[u]));
+            }
             idx += e;
             if (idx >= n) idx -= n;
         }
-        dst[(b - k) * radix + k + q * ns] = acc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[u * row_stride + (b - k) * radix + k + q * ns] = unpk(acc[u]);
     }
 }
 
-FXC_HD void mixed_stage(const cf* src, cf* dst, const cf* tw, int n, int radix, int ns, int lt, int tpr) {
+template <int U>
+FXC_HD void mixed_stage(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int radix, int ns, int lt, int tpr) {
     switch (radix) {
-        case 2: mixed_stage_reg<2>(src, dst, tw, n, ns, lt, tpr); break;
-        case 3: mixed_stage_reg<3>(src, dst, tw, n, ns, lt, tpr); break;
-        case 4: mixed_stage_reg<4>(src, dst, tw, n, ns, lt, tpr); break;
-        case 5: mixed_stage_reg<5>(src, dst, tw, n, ns, lt, tpr); break;
-        case 7: mixed_stage_reg<7>(src, dst, tw, n, ns, lt, tpr); break;
-        case 11: mixed_stage_reg<11>(src, dst, tw, n, ns, lt, tpr); break;
-        case 13: mixed_stage_reg<13>(src, dst, tw, n, ns, lt, tpr); break;
-        default: mixed_stage_any(src, dst, tw, n, radix, ns, lt, tpr); break;
+        case 2: mixed_stage_reg<2, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
+        case 3: mixed_stage_reg<3, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
+        case 4: mixed_stage_reg<4, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
+        case 5: mixed_stage_reg<5, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
+        case 7: mixed_stage_reg<7, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
+        case 11:        // the two big register butterflies only one row at a time (more rows: spills); the host picks U = 1
+        case 13:        // for channel counts with these factors (mixed_rows_per_slot_cap)
+            if constexpr (U == 1) {
+                if (radix == 11)
+                    mixed_stage_reg<11, U>(src, dst, row_stride, tw, n, ns, lt, tpr);
+                else
+                    mixed_stage_reg<13, U>(src, dst, row_stride, tw, n, ns, lt, tpr);
+                break;
+            }
+            [[fallthrough]];
+        default: mixed_stage_any<U>(src, dst, row_stride, tw, n, radix, ns, lt, tpr); break;
     }
 }
 
-// threads of the 256-thread workgroup that share one row: the power of two at or above N/4, within [4, 256]
-inline int mixed_threads_per_row(int n) {
+// most rows per slot the kernel should take for this factorisation
+inline int mixed_rows_per_slot_cap(const MixedPlan& mp) {
+    for (int s = 0; s < mp.n_stages; ++s)
+        if (mp.radix[s] == 11 || mp.radix[s] == 13) return 1;
+    return 2;
+}
+
+// threads that share one row: the power of two at or above N/4 within [4, 256], and 512 or 1024 of them only beyond 2048
+// channels (the workgroup has max(256, that) threads)
+inline int mixed_threads_per_row(int n, int cap = 1024) {
     int t = 4;
     while (t < 256 && t * 4 < n) t <<= 1;
+    while (n > 2048 && t < cap && t * 4 < n) t <<= 1;
     return t;
 }
 

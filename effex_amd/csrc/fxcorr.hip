@@ -221,7 +221,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         p->mixed = N > 1 && N <= kMixedMaxN && !force_old && (!p->pow2 || force_mixed);
         if (p->mixed) {
             p->mixed_plan = fxc::mixed_factor(N);
-            p->mixed_tpr = fxc::mixed_threads_per_row(N);
+            p->mixed_tpr = fxc::mixed_threads_per_row(N, env_int("FXC_MIXED_TPR", 1024));
             if (p->mixed_plan.n_stages < 0) p->mixed = false;
         }
     }
@@ -477,8 +477,10 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         }
     }
     if (p->mixed) {
-        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMixedMaxN * (int)sizeof(cf)));
+        const int lds_max = 160 * 1024;
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     } else if (N > 1) {
         const int lds = N * (int)sizeof(cf);
         if (p->pow2)

@@ -11,20 +11,47 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a = 0);
 
+// developer knobs: an integer from the environment, read once
+int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+
 int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
     if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
     // the F-only tiled kernel writes natural-order spectra straight to `spec` (no workspace): any caller may use it
     if (p->tiled_f) return tiled_channelize(p, x, spec, n_streams);
     if (p->mixed) {
-        const int64_t n_rows = n_streams * p->n_pts;
-        const int rpw = 256 / p->mixed_tpr;
-        const int64_t n_groups = (n_rows + rpw - 1) / rpw;
-        const size_t lds = (size_t)rpw * 2 * p->nchan * sizeof(cf);
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
-        // a few row groups per workgroup at least (the FIR's re-reads stay in one L2), and no more workgroups than fit at once
-        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + 3) / 4, (int64_t)p->cu_count * per_cu));
-        hipLaunchKernelGGL(pfb_fft_mixed_kernel, dim3(grid), dim3(256), lds, p->stream, x, p->d_win, spec, p->d_tw,
-                           p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_rows, p->mixed_tpr);
+        const int threads = std::max(256, p->mixed_tpr);
+        const int rpw = threads / p->mixed_tpr;
+        static const int tw_knob = env_int("FXC_MIXED_TWLDS", 1), u_knob = env_int("FXC_MIXED_U", 0);
+        // U = 2 frames per slot where the measurements favour it (tools/bench_channelize.py, r04 experiments.md §7): up to 1280
+        // channels (four 256-thread workgroups still fit a CU's LDS) and from 2049 to 4096 (one 1024-thread workgroup per
+        // CU either way); never with a factor 11 or 13 (register butterflies one row at a time)
+        const size_t row_bytes = (size_t)p->nchan * sizeof(cf);
+        int u = (p->nchan <= 1280 || (p->nchan > 2048 && p->nchan <= 4096)) ? 2 : 1;
+        u = std::min(u, fxc::mixed_rows_per_slot_cap(p->mixed_plan));
+        if (u_knob == 1 || u_knob == 2) u = u_knob;
+        const bool twl = tw_knob && (1 + (size_t)rpw * 2 * u) * row_bytes <= (size_t)(160 * 1024);
+        if (!twl) u = 1;
+        const size_t lds = ((size_t)rpw * 2 * u + (twl ? 1 : 0)) * row_bytes;
+        const int fpg = rpw * u;
+        const int64_t n_groups = n_streams * ((p->n_pts + fpg - 1) / fpg);
+        // runs of up to 16 frame groups per workgroup (the FIR's re-reads of a frame stay in one L2), many more workgroups than
+        // fit at once when there are rows for it (no second, part-filled round of resident workgroups)
+        static const int run_knob = env_int("FXC_MIXED_RUN", 16);
+        const int64_t run = std::max<int64_t>(1, std::min<int64_t>(run_knob, n_groups / ((int64_t)p->cu_count * 8)));
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
+#define FXC_MIXED_LAUNCH(TWL, UU)                                                                                              \
+    hipLaunchKernelGGL((pfb_fft_mixed_kernel<TWL, UU>), dim3(grid), dim3(threads), lds, p->stream, x, p->d_win, spec, p->d_tw, \
+                       p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams, p->mixed_tpr)
+        if (!twl)
+            FXC_MIXED_LAUNCH(false, 1);
+        else if (u == 2)
+            FXC_MIXED_LAUNCH(true, 2);
+        else
+            FXC_MIXED_LAUNCH(true, 1);
+#undef FXC_MIXED_LAUNCH
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
     }

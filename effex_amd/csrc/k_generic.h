@@ -96,55 +96,95 @@ __global__ __launch_bounds__(256) void dft_any_kernel(cf* __restrict__ data, con
 }
 
 // FIR + FFT for any nchan whose two LDS rows fit (kMixedMaxN): the polyphase FIR runs on the way into LDS, the mixed-radix
-// Stockham stages of fx_mixed.h ping-pong between the two rows, and the natural-order spectrum goes out once.  256 / tpr
-// rows share a workgroup when nchan is small; a workgroup owns a contiguous run of rows, so the ntaps re-reads of a frame
-// come from its own L2.
-__global__ __launch_bounds__(256) void pfb_fft_mixed_kernel(const cf* __restrict__ x, const float* __restrict__ h,
-                                                           cf* __restrict__ spec, const cf* __restrict__ tw,
-                                                           const fxc::MixedPlan mp, int64_t num_samp, int nchan, int ntaps,
-                                                           int64_t n_pts, int64_t n_rows, int tpr) {
+// Stockham stages of fx_mixed.h ping-pong between the two rows, and the natural-order spectrum goes out once.
+//   workgroup = rpw slots of tpr threads (rpw = 256 / tpr when nchan is small; up to 1024 threads share a slot when it is
+//   large); a slot carries U consecutive frames through every step together: one index computation, one set of twiddles
+//   and one barrier serve U rows, and the FIR's taps of neighbouring frames are the same loads (U + 3 per four taps, not 4 U).
+//   A workgroup owns a contiguous run of frame groups of one stream after another, so tap re-reads across groups hit its L2.
+// TWL: the twiddle table sits in LDS in front of the rows.  The kernel is bound by instruction issue (index arithmetic and
+// LDS traffic of five-odd short stages), not by HBM: hence the packed-pair arithmetic and the shared indices.
+template <bool TWL, int U>
+__global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restrict__ x, const float* __restrict__ h,
+                                                            cf* __restrict__ spec, const cf* __restrict__ tw_table,
+                                                            const fxc::MixedPlan mp, int64_t num_samp, int nchan, int ntaps,
+                                                            int64_t n_pts, int64_t n_streams, int tpr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int rpw = 256 / tpr;
+    const int rpw = (int)blockDim.x / tpr;
     const int sub = (int)threadIdx.x / tpr, lt = (int)threadIdx.x % tpr;
-    cf* row_a = reinterpret_cast<cf*>(smem) + (int64_t)sub * 2 * nchan;
-    cf* row_b = row_a + nchan;
-    const int64_t n_groups = (n_rows + rpw - 1) / rpw;
+    const int fpg = rpw * U;                                        // frames per group
+    const int64_t gps = (n_pts + fpg - 1) / fpg;                    // groups per stream
+    const int64_t n_groups = n_streams * gps;
+    cf* tw_lds = reinterpret_cast<cf*>(smem);
+    if (TWL)
+        for (int n = threadIdx.x; n < nchan; n += blockDim.x) tw_lds[n] = tw_table[n];     // the first barrier below covers it
+    const cf* tw = TWL ? tw_lds : tw_table;
     const int64_t g0 = (int64_t)blockIdx.x * n_groups / gridDim.x, g1 = ((int64_t)blockIdx.x + 1) * n_groups / gridDim.x;
+    int64_t s = g0 / gps, gi = g0 - s * gps;
     for (int64_t g = g0; g < g1; ++g) {
-        const int64_t row = g * rpw + sub;
-        const bool active = row < n_rows;
-        if (active) {
-            const int64_t s = row / n_pts, i = row - s * n_pts;
-            const cf* xs = x + s * num_samp + i * nchan + (nchan - 1);
-            const int tmax = (i + 1 < (int64_t)ntaps) ? (int)(i + 1) : ntaps;
-            for (int m = lt; m < nchan; m += tpr) {
-                float ar = 0.f, ai = 0.f;
-                for (int t = 0; t < tmax; ++t) {
-                    const cf xv = xs[-(int64_t)t * nchan - m];
-                    const float w = h[(int64_t)t * nchan + m];
-                    ar = fmaf(w, xv.x, ar);
-                    ai = fmaf(w, xv.y, ai);
+        // per-lane and per-shape index math stays inside the group loop: hoisted (the compiler would hoist every radix's
+        // share of it), it is a hundred live registers and spills
+        int lt_g = lt, sub_g = sub, nch = nchan, tpr_g = tpr;
+        asm volatile("" : "+v"(lt_g), "+v"(sub_g), "+s"(nch), "+s"(tpr_g));
+        cf* rows = reinterpret_cast<cf*>(smem) + (TWL ? nch : 0) + sub_g * U * 2 * nch;     // [u][a|b][nchan]
+        const int row_stride = 2 * nch;
+        // ---- FIR: v[f][m] = sum_t h[t][m] x[(f - t) nchan + nchan - 1 - m], frames f = f0 .. f0 + U - 1 of stream s
+        const int64_t gf = gi * fpg;                                            // the group's first frame
+        const int64_t frame_lo = gf > ntaps - 1 ? gf - (ntaps - 1) : 0;         // the earliest frame any tap reaches
+        const cf* xg = x + s * num_samp + frame_lo * nch;                       // uniform base; lane offsets stay small
+        const int f0 = (int)(gf - frame_lo) + sub_g * U;                        // relative to frame_lo
+        const int f_end = (int)std::min<int64_t>(n_pts - frame_lo, 1 << 30);    // frames that exist, relative
+        for (int m = lt_g; m < nch; m += tpr_g) {
+            fxc::pk2 acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = fxc::pk_splat(0.f);
+            for (int t0 = 0; t0 < ntaps; t0 += 4) {
+                fxc::pk2 xv[U + 3];
+                float hw[4];
+#pragma unroll
+                for (int j = 0; j < U + 3; ++j) {
+                    const int f = f0 - t0 - 3 + j;                              // frame f0 + u - (t0 + v) at j = u - v + 3
+                    const bool ok = f >= 0 && f < f_end;
+                    const unsigned off = ok ? (unsigned)(f * nch + nch - 1 - m) : 0u;
+                    const fxc::pk2 ld = fxc::pk(xg[off]);
+                    xv[j] = ok ? ld : fxc::pk_splat(0.f);
                 }
-                row_a[m] = fxc::mk(ar, ai);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const bool ok = t0 + v < ntaps;
+                    const float ld = h[(unsigned)(ok ? (t0 + v) * nch + m : m)];
+                    hw[v] = ok ? ld : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u] = fxc::pk_fma(fxc::pk_splat(hw[v]), xv[u - v + 3], acc[u]);
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) rows[u * row_stride + m] = fxc::unpk(acc[u]);
         }
         __syncthreads();
-        cf *src = row_a, *dst = row_b;
-        int ns = 1;
+        int so = 0, ns = 1;
         for (int st = 0; st < mp.n_stages; ++st) {
             const int radix = mp.radix[st];
-            if (active) fxc::mixed_stage(src, dst, tw, nchan, radix, ns, lt, tpr);
+            int nst = nch;
+            asm volatile("" : "+s"(nst));                                       // ... and inside the stage loop
+            fxc::mixed_stage<U>(rows + so, rows + (nst - so), row_stride, tw, nst, radix, ns, lt_g, tpr_g);
             __syncthreads();
             ns *= radix;
-            cf* t = src;
-            src = dst;
-            dst = t;
+            so = nst - so;
         }
-        if (active) {
-            cf* d = spec + row * nchan;
-            for (int n = lt; n < nchan; n += tpr) d[n] = src[n];
+        cf* out = spec + (s * n_pts + gf) * nch;                                // uniform base of the group's rows
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int fr = sub_g * U + u;
+            if (gf + fr < n_pts)
+                for (int n = lt_g; n < nch; n += tpr_g) out[(unsigned)(fr * nch + n)] = rows[u * row_stride + so + n];
         }
         __syncthreads();
+        if (++gi == gps) {
+            gi = 0;
+            ++s;
+        }
     }
 }
 

@@ -29,7 +29,7 @@ extern "C" int emul_mixed_fft(const float* in, float* out, int n, int tpr, int* 
     cf *src = a.data(), *dst = b.data();
     int ns = 1;
     for (int s = 0; s < mp.n_stages; ++s) {
-        for (int lt = 0; lt < tpr; ++lt) mixed_stage(src, dst, tw.data(), n, mp.radix[s], ns, lt, tpr);
+        for (int lt = 0; lt < tpr; ++lt) mixed_stage<1>(src, dst, 0, tw.data(), n, mp.radix[s], ns, lt, tpr);
         ns *= mp.radix[s];
         cf* t = src;
         src = dst;

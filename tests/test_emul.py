@@ -111,6 +111,33 @@ def test_small_phases_match_oracle(emul_small, nchan, ntaps, frames):
 
 
 @pytest.fixture(scope="module")
+def emul_mixed():
+    src = os.path.join(HERE, "emul", "emul_mixed.cpp")
+    lib = os.path.join(HERE, "emul", "libemul_mixed.so")
+    deps = [src] + [os.path.join(HERE, "..", "effex_amd", "csrc", h) for h in ("fx_mixed.h", "fx_math.h")]
+    if not os.path.isfile(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", lib, src], check=True)
+    return ctypes.CDLL(lib)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 15, 30, 96, 100, 125, 127, 210, 500, 997, 1000, 1001, 1536, 2000,
+                               2310, 2431, 3000, 4096, 5000, 6561, 8190, 10240, 13122, 16383, 16384])
+def test_mixed_radix_stages_match_numpy(emul_mixed, n):
+    """The generic path's FFT for any channel count (fx_mixed.h): the factorisation multiplies back to n, and the Stockham
+    stages run thread by thread give numpy's transform (kernel exp(+2 pi i n k / N), natural order out) -- for the register
+    radices, for prime factors walked from the row (127, 997, 17) and for the row-sharing thread counts of small n."""
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    ref = np.fft.ifft(x.astype(np.complex128)) * n
+    radices = (ctypes.c_int * 16)()
+    for tpr in sorted({emul_mixed.emul_mixed_threads_per_row(n), 1, 256}):
+        out = np.zeros(n, np.complex64)
+        stages = emul_mixed.emul_mixed_fft(x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n, tpr, radices)
+        assert stages >= 0 and int(np.prod(list(radices)[:stages], dtype=np.int64)) == n
+        assert np.abs(out - ref).max() <= 4e-6 * max(np.abs(ref).max(), 1e-30), (n, tpr)
+
+
+@pytest.fixture(scope="module")
 def emul_sched():
     src = os.path.join(HERE, "emul", "emul_sched.cpp")
     lib = os.path.join(HERE, "emul", "libemul_sched.so")
@@ -148,7 +175,7 @@ def test_fused_work_split(emul_sched, n_chunks, n_pts, grid, seg, unit, rows_are
 
 def test_emulation_sources_under_address_and_undefined_sanitizers(tmp_path):
     """Sanitizers belong on the CPU build (GPU AddressSanitizer is not available on the pool): the kernels' own phase headers
-    (fx_math.h, fx_fused4096.h, fx_tiled.h, fx_small.h), compiled by g++ for the host emulation, run a representative set of
+    (fx_math.h, fx_fused4096.h, fx_tiled.h, fx_small.h, fx_mixed.h), compiled by g++ for the host emulation, run a representative set of
     shapes under -fsanitize=address,undefined in a child process (libasan preloaded).  Index maps that step outside an LDS
     image, a ring slot or a raw row show up here as reports, not as silently wrong spectra."""
     import shutil
@@ -160,7 +187,7 @@ def test_emulation_sources_under_address_and_undefined_sanitizers(tmp_path):
     if not os.path.isabs(libasan) or not os.path.exists(libasan):
         pytest.skip("no libasan for this g++")
     libs = {}
-    for name in ("emul_fused", "emul_tiled", "emul_small", "emul_sched"):
+    for name in ("emul_fused", "emul_tiled", "emul_small", "emul_sched", "emul_mixed"):
         out = str(tmp_path / ("lib%s_san.so" % name))
         subprocess.run([gxx, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared", "-fPIC",
                         "-o", out, os.path.join(HERE, "emul", name + ".cpp")], check=True)
@@ -197,6 +224,10 @@ for n_chunks, n_pts, grid, seg, unit, rac in ((10000, 64, 256, 1, 4, 0), (257, 6
     assert c.emul_fused_schedule(n_chunks, n_pts, grid, seg, unit, rac, vp(w), vp(per), ctypes.byref(tot), ctypes.byref(fmin),
                                  ctypes.byref(fmax), ctypes.byref(nr)) == 0
     assert tot.value == w.sum()
+m = ctypes.CDLL(libs["emul_mixed"])
+for n in (1, 2, 6, 96, 100, 127, 1000, 1001, 3000, 6561, 10240):
+    a = (np.arange(n) + 1j * np.arange(n)[::-1]).astype(np.complex64); o = np.zeros(n, np.complex64)
+    assert m.emul_mixed_fft(vp(a), vp(o), n, m.emul_mixed_threads_per_row(n), None) >= 0
 print("sanitized emulation ok")
 """ % {"root": os.path.dirname(HERE), "libs": libs}
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")

@@ -12,7 +12,10 @@ def main():
     import torch
     from effex_amd.plan import FxPlan, synth_fill
     num_samp = 262144
-    for nchan, ntaps in ((4096, 4), (2048, 4), (1024, 4), (256, 4), (64, 4), (16, 4), (2048, 32), (4096, 32), (8192, 4)):
+    cases = ((4096, 4), (2048, 4), (1024, 4), (256, 4), (64, 4), (16, 4), (2048, 32), (4096, 32), (8192, 4))
+    if len(sys.argv) > 1:       # "1000:4,96:4"
+        cases = tuple(tuple(int(v) for v in c.split(":")) for c in sys.argv[1].split(","))
+    for nchan, ntaps in cases:
         n_streams = 1024
         x = torch.empty((n_streams // 2, 2, num_samp), dtype=torch.complex64, device="cuda")
         synth_fill(x, 1234)
