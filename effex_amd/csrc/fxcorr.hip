@@ -72,6 +72,8 @@ constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 channeliser kernels only
 constexpr int kMaxXAnt = 64;         // antennas the F-only + X-engine route takes (fxc_plan_create's own limit)
 constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
+constexpr int kBluMinPrime = 61;      // larger prime factors: the chirp-z form (see pfb_fft_mixed_kernel, BLU)
+constexpr int kBluMaxNfft = 8192;     // two chirp-z rows in LDS
 constexpr int kMixedMaxN = 10240;    // two rows of complex64 in the 160 KiB of LDS (pfb_fft_mixed_kernel)
 size_t res_direct_bytes() {      // finalize results up to this size are written to host memory by the kernel (FXC_RES_DIRECT: developer knob, bytes)
     static const size_t v = [] { const char* e = std::getenv("FXC_RES_DIRECT"); return e ? (size_t)std::atoll(e) : (size_t)(256 << 10); }();
@@ -151,7 +153,7 @@ int fxc_plan_destroy(fxc_plan* p) {
     }
     void* bufs[] = {p->d_win, p->d_tw, p->d_rot, p->d_win4, p->d_tw1, p->d_tw2, p->d_tw0, p->d_tw_small, p->d_stamps,
                     p->d_acc, p->d_sums, p->d_cont, p->d_rowpart, p->d_ws, p->d_stage[0], p->d_stage[1], p->d_stage[2], p->d_dc, p->d_hpre,
-                    p->d_ones, p->d_pre, p->d_tw8192};
+                    p->d_ones, p->d_pre, p->d_tw8192, p->d_chirp, p->d_blud};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -224,17 +226,80 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             p->mixed_tpr = fxc::mixed_threads_per_row(N, env_int("FXC_MIXED_TPR", 1024));
             if (p->mixed_plan.n_stages < 0) p->mixed = false;
         }
+        if (p->mixed) {
+            // a prime factor beyond kBluMinPrime costs more as an O(N p) stage than the whole transform as a chirp-z convolution
+            int pmax = 1;
+            for (int st = 0; st < p->mixed_plan.n_stages; ++st) pmax = std::max(pmax, p->mixed_plan.radix[st]);
+            int m = 1;
+            while (m < 2 * N - 1) m <<= 1;
+            if (pmax > env_int("FXC_BLU_MIN_PRIME", kBluMinPrime) && m <= kBluMaxNfft) {
+                p->mixed_blu = true;
+                p->blu_nfft = m;
+                p->mixed_plan = fxc::mixed_factor(m);
+                p->mixed_tpr = fxc::mixed_threads_per_row(m, 1024);
+            }
+        }
+        if (p->mixed && !p->mixed_blu && p->n_ant == 2 && env_int("FXC_MIXED_XF", 1)) {
+            const size_t rpw = (size_t)(std::max(256, p->mixed_tpr) / p->mixed_tpr);
+            p->mixed_xf = (rpw * 4 + 1) * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && N <= kMixedXPoints * p->mixed_tpr;
+        }
     }
     // generic FFT twiddles exp(+2 pi i j / N): [N/2] for the radix-2 kernel, [N] for the mixed-radix kernel and the direct DFT
     if (N > 1) {
-        const int cnt = (p->pow2 && !p->mixed) ? N / 2 : N;
+        const int tn = p->mixed_blu ? p->blu_nfft : N;         // the chirp-z rows transform blu_nfft points
+        const int cnt = (p->pow2 && !p->mixed) ? N / 2 : tn;
         std::vector<cf> tw((size_t)cnt);
         for (int jx = 0; jx < cnt; ++jx) {
-            const double ph = kTwoPi * (double)jx / (double)N;
+            const double ph = kTwoPi * (double)jx / (double)tn;
             tw[jx] = fxc::mk((float)std::cos(ph), (float)std::sin(ph));
         }
         FXC_HIP(p, hipMalloc(&p->d_tw, tw.size() * sizeof(cf)));
         FXC_HIP(p, hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+    }
+
+    if (p->mixed_blu) {
+        // chirp c[n] = exp(+i pi n^2 / N) with n^2 reduced mod 2N (exact), and D = FFT_M(d) / M for d[m] = d[M - m] = conj(c[m]),
+        // m < N, zero elsewhere; kernel exp(+2 pi i j k / M), float64 radix-2 on the host
+        const int M = p->blu_nfft;
+        std::vector<cd> c((size_t)N);
+        for (int n = 0; n < N; ++n) {
+            const double ph = kTwoPi / 2.0 * (double)(((int64_t)n * n) % (2 * (int64_t)N)) / (double)N;
+            c[n].x = std::cos(ph);
+            c[n].y = std::sin(ph);
+        }
+        std::vector<cd> d((size_t)M);
+        for (auto& v : d) v.x = v.y = 0.0;
+        for (int m = 0; m < N; ++m) {
+            d[m].x = c[m].x;
+            d[m].y = -c[m].y;
+            if (m) d[M - m] = d[m];
+        }
+        int lg = 0;
+        while ((1 << lg) < M) ++lg;
+        for (int i = 0; i < M; ++i) {
+            int r = 0;
+            for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
+            if (r > i) std::swap(d[i], d[r]);
+        }
+        for (int half = 1; half < M; half <<= 1)
+            for (int i0 = 0; i0 < M; i0 += 2 * half)
+                for (int j = 0; j < half; ++j) {
+                    const double ph = kTwoPi * (double)j / (double)(2 * half);
+                    const double wr = std::cos(ph), wi = std::sin(ph);
+                    const cd a = d[i0 + j], b = d[i0 + j + half];
+                    const double tr = b.x * wr - b.y * wi, ti = b.x * wi + b.y * wr;
+                    d[i0 + j].x = a.x + tr;
+                    d[i0 + j].y = a.y + ti;
+                    d[i0 + j + half].x = a.x - tr;
+                    d[i0 + j + half].y = a.y - ti;
+                }
+        std::vector<cf> cfl((size_t)N), dfl((size_t)M);
+        for (int n = 0; n < N; ++n) cfl[n] = fxc::mk((float)c[n].x, (float)c[n].y);
+        for (int k = 0; k < M; ++k) dfl[k] = fxc::mk((float)(d[k].x / M), (float)(d[k].y / M));
+        FXC_HIP(p, hipMalloc(&p->d_chirp, cfl.size() * sizeof(cf)));
+        FXC_HIP(p, hipMemcpy(p->d_chirp, cfl.data(), cfl.size() * sizeof(cf), hipMemcpyHostToDevice));
+        FXC_HIP(p, hipMalloc(&p->d_blud, dfl.size() * sizeof(cf)));
+        FXC_HIP(p, hipMemcpy(p->d_blud, dfl.data(), dfl.size() * sizeof(cf), hipMemcpyHostToDevice));
     }
 
     std::vector<cd> rot((size_t)N);
@@ -478,9 +543,12 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     }
     if (p->mixed) {
         const int lds_max = 160 * 1024;
-        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     } else if (N > 1) {
         const int lds = N * (int)sizeof(cf);
         if (p->pow2)

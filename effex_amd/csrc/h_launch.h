@@ -21,9 +21,29 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
     if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
     // the F-only tiled kernel writes natural-order spectra straight to `spec` (no workspace): any caller may use it
     if (p->tiled_f) return tiled_channelize(p, x, spec, n_streams);
+    if (p->mixed && p->mixed_blu) {
+        // a large prime factor: chirp-z rows of nfft = 2^j >= 2 nchan - 1, one row per workgroup pass
+        const int threads = std::max(256, p->mixed_tpr);
+        const int rpw = threads / p->mixed_tpr;
+        const bool twl = p->blu_nfft <= 4096;
+        const size_t lds = ((size_t)rpw * 2 + (twl ? 1 : 0)) * p->blu_nfft * sizeof(cf);
+        const int64_t n_groups = n_streams * ((p->n_pts + rpw - 1) / rpw);
+        const int64_t run = std::max<int64_t>(1, std::min<int64_t>(16, n_groups / ((int64_t)p->cu_count * 8)));
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
+        const MixedBlu blu = {p->blu_nfft, p->d_chirp, p->d_blud};
+        if (twl)
+            hipLaunchKernelGGL((pfb_fft_mixed_kernel<true, 1, false, true>), dim3(grid), dim3(threads), lds, p->stream, x, p->d_win,
+                               spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams, p->mixed_tpr, 1, blu);
+        else
+            hipLaunchKernelGGL((pfb_fft_mixed_kernel<false, 1, false, true>), dim3(grid), dim3(threads), lds, p->stream, x, p->d_win,
+                               spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams, p->mixed_tpr, 1, blu);
+        FXC_HIP(p, hipGetLastError());
+        return FXC_OK;
+    }
     if (p->mixed) {
         const int threads = std::max(256, p->mixed_tpr);
         const int rpw = threads / p->mixed_tpr;
+        const MixedBlu no_blu = {p->nchan, nullptr, nullptr};
         static const int tw_knob = env_int("FXC_MIXED_TWLDS", 1), u_knob = env_int("FXC_MIXED_U", 0);
         // U = 2 frames per slot where the measurements favour it (tools/bench_channelize.py, r04 experiments.md §7): up to 1280
         // channels (four 256-thread workgroups still fit a CU's LDS) and from 2049 to 4096 (one 1024-thread workgroup per
@@ -42,9 +62,9 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
         static const int run_knob = env_int("FXC_MIXED_RUN", 16);
         const int64_t run = std::max<int64_t>(1, std::min<int64_t>(run_knob, n_groups / ((int64_t)p->cu_count * 8)));
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
-#define FXC_MIXED_LAUNCH(TWL, UU)                                                                                              \
-    hipLaunchKernelGGL((pfb_fft_mixed_kernel<TWL, UU>), dim3(grid), dim3(threads), lds, p->stream, x, p->d_win, spec, p->d_tw, \
-                       p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams, p->mixed_tpr)
+#define FXC_MIXED_LAUNCH(TWL, UU)                                                                                                     \
+    hipLaunchKernelGGL((pfb_fft_mixed_kernel<TWL, UU, false>), dim3(grid), dim3(threads), lds, p->stream, x, p->d_win, spec, p->d_tw, \
+                       p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams, p->mixed_tpr, 1, no_blu)
         if (!twl)
             FXC_MIXED_LAUNCH(false, 1);
         else if (u == 2)
@@ -72,12 +92,35 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
     return FXC_OK;
 }
 
+// two antennas on the mixed-radix kernel: F and X in one pass, raw[split][chunk][nchan] out (xmul_kernel's layout)
+int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, cf* raw) {
+    const int threads = std::max(256, p->mixed_tpr);
+    const int rpw = threads / p->mixed_tpr;
+    const size_t lds = ((size_t)rpw * 4 + 1) * p->nchan * sizeof(cf);
+    const int64_t grid = n_chunks * n_splits;
+    if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
+    hipLaunchKernelGGL((pfb_fft_mixed_kernel<true, 2, true>), dim3((unsigned)grid), dim3(threads), lds, p->stream, x, p->d_win, raw,
+                       p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_chunks, p->mixed_tpr, n_splits,
+                       MixedBlu{p->nchan, nullptr, nullptr});
+    FXC_HIP(p, hipGetLastError());
+    return FXC_OK;
+}
+
 struct XGeom {
     int kx, n_splits;
 };
 
-XGeom x_geometry(const fxc_plan* p) {
+XGeom x_geometry(const fxc_plan* p, int64_t n_chunks) {
     XGeom g;
+    if (p->mixed_xf) {
+        // workgroups = chunks x splits: eight per CU when the frames allow it, runs of four frame groups at least
+        const int rpw = std::max(256, p->mixed_tpr) / p->mixed_tpr;
+        const int64_t gps = (p->n_pts + rpw - 1) / rpw;
+        const int64_t want = ((int64_t)p->cu_count * 8 + n_chunks - 1) / std::max<int64_t>(n_chunks, 1);
+        g.kx = 1;
+        g.n_splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 256), gps / 4));
+        return g;
+    }
     g.kx = 1;
     while (g.kx < 256 && g.kx < p->nchan) g.kx <<= 1;
     const int iy = 256 / g.kx;
@@ -91,7 +134,7 @@ XGeom x_geometry(const fxc_plan* p) {
 // chunks per pass on the generic path so that spectra + raw sums fit the workspace target
 int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom& g, int64_t* spec_bytes,
                                 int64_t* raw_bytes) {
-    const int64_t spec_per_chunk = (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
+    const int64_t spec_per_chunk = p->mixed_xf ? 0 : (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
     const int64_t raw_per_chunk = (int64_t)g.n_splits * p->n_base * p->nchan * (int64_t)sizeof(cf);
     int64_t cb = ws_target() / std::max<int64_t>(1, spec_per_chunk + raw_per_chunk);
     if (cb < 1) cb = 1;

@@ -54,6 +54,11 @@ struct fxc_plan {
     bool mixed = false;            // generic F stage = pfb_fft_mixed_kernel (FIR + mixed-radix FFT in one pass)
     fxc::MixedPlan mixed_plan{};
     int mixed_tpr = 256;           // threads per row
+    bool mixed_blu = false;        // a prime factor beyond kBluMinPrime: chirp-z rows of blu_nfft points (F only)
+    int blu_nfft = 0;
+    cf* d_chirp = nullptr;         // [nchan] exp(+i pi n^2 / nchan)
+    cf* d_blud = nullptr;          // [blu_nfft] FFT of the wrapped conjugate chirp / blu_nfft
+    bool mixed_xf = false;         // two antennas: the same kernel multiplies and integrates too (no spectra in HBM)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev_order = nullptr;   // orders the old stream's work before the new one's (fxc_set_stream)

@@ -86,7 +86,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             if (rc) return rc;
         }
     } else {
-        const XGeom g = x_geometry(p);
+        const XGeom g = x_geometry(p, n_chunks);
         int64_t spec_bytes, raw_bytes;
         const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes);
         raw_bytes = (raw_bytes + 255) / 256 * 256;
@@ -98,12 +98,17 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
             KernelTimer kt(p);
-            rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);
-            if (rc) return rc;
-            const int kblocks = (p->nchan + g.kx - 1) / g.kx;
-            const int64_t wgs = nc * p->n_base * kblocks * g.n_splits;
-            hipLaunchKernelGGL(xmul_kernel, dim3((int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8)), dim3(256), 0,
-                               p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
+            if (p->mixed_xf) {
+                rc = mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
+                if (rc) return rc;
+            } else {
+                rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);
+                if (rc) return rc;
+                const int kblocks = (p->nchan + g.kx - 1) / g.kx;
+                const int64_t wgs = nc * p->n_base * kblocks * g.n_splits;
+                hipLaunchKernelGGL(xmul_kernel, dim3((int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8)), dim3(256), 0,
+                                   p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
+            }
             kt.stop();
             FXC_HIP(p, hipGetLastError());
             // raw[split][chunk] = nc * n_splits rows of [n_base][nchan], natural bin order
@@ -241,7 +246,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         }
         return FXC_OK;
     }
-    const XGeom g = x_geometry(p);
+    const XGeom g = x_geometry(p, n_chunks);
     int64_t spec_bytes, raw_bytes;
     const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes);
     int rc = ensure_ws(p, spec_bytes + raw_bytes);
@@ -251,12 +256,17 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
     for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
         const int64_t nc = std::min(cb, n_chunks - c0);
         KernelTimer kt(p);
-        rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);
-        if (rc) return rc;
-        const int kblocks = (p->nchan + g.kx - 1) / g.kx;
-        const int64_t wgs = nc * p->n_base * kblocks * g.n_splits;
-        hipLaunchKernelGGL(xmul_kernel, dim3((int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8)), dim3(256), 0,
-                           p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
+        if (p->mixed_xf) {
+            rc = mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
+            if (rc) return rc;
+        } else {
+            rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);
+            if (rc) return rc;
+            const int kblocks = (p->nchan + g.kx - 1) / g.kx;
+            const int64_t wgs = nc * p->n_base * kblocks * g.n_splits;
+            hipLaunchKernelGGL(xmul_kernel, dim3((int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8)), dim3(256), 0,
+                               p->stream, spec, raw, p->n_ant, p->n_base, p->nchan, p->n_pts, g.kx, g.n_splits, nc);
+        }
         kt.stop();
         const int64_t rows = nc * p->n_base;
         const int64_t split_stride = rows * p->nchan;

@@ -98,92 +98,217 @@ __global__ __launch_bounds__(256) void dft_any_kernel(cf* __restrict__ data, con
 // FIR + FFT for any nchan whose two LDS rows fit (kMixedMaxN): the polyphase FIR runs on the way into LDS, the mixed-radix
 // Stockham stages of fx_mixed.h ping-pong between the two rows, and the natural-order spectrum goes out once.
 //   workgroup = rpw slots of tpr threads (rpw = 256 / tpr when nchan is small; up to 1024 threads share a slot when it is
-//   large); a slot carries U consecutive frames through every step together: one index computation, one set of twiddles
-//   and one barrier serve U rows, and the FIR's taps of neighbouring frames are the same loads (U + 3 per four taps, not 4 U).
-//   A workgroup owns a contiguous run of frame groups of one stream after another, so tap re-reads across groups hit its L2.
+//   large); a slot carries U rows through every step together: one index computation, one set of twiddles and one barrier
+//   serve U rows.
+//   XF = false (F only): the U rows are consecutive frames of one stream -- the FIR's taps of neighbouring frames are the
+//   same loads (U + 3 per four taps, not 4 U); a workgroup owns a contiguous run of frame groups of one stream after
+//   another (tap re-reads across groups hit its L2); the natural-order spectra go to `out` = spec[stream][frame][nchan].
+//   XF = true (two antennas, F + X): the U = 2 rows are the two antennas' spectra of one frame; their product
+//   s0 conj(s1) adds up in registers over the workgroup's run of frames of chunk c = blockIdx / n_splits, and the run's
+//   sum goes to `out` = raw[split][chunk][nchan] -- xmul_kernel's layout, with no spectrum ever written.
 // TWL: the twiddle table sits in LDS in front of the rows.  The kernel is bound by instruction issue (index arithmetic and
 // LDS traffic of five-odd short stages), not by HBM: hence the packed-pair arithmetic and the shared indices.
-template <bool TWL, int U>
+constexpr int kMixedXPoints = 8;    // bins per thread of the XF accumulator: nchan <= 8 tpr (mixed_threads_per_row up to 4096)
+//   BLU = true (a prime factor too large for a butterfly, F only, U = 1): Bluestein's chirp-z form of the same transform.
+//   With c[n] = exp(+i pi n^2 / N):  X[k] = c[k] sum_n (v[n] c[n]) conj(c[k - n])  -- a convolution, done as a cyclic one
+//   of length nfft = 2^j >= 2 N - 1 in the row: u = v c zero-padded, Z = FFT(conj(FFT(u) D)), X[k] = c[k] conj(Z[k]),
+//   D = FFT(conj(c) wrapped) / nfft from the host (float64).  Both FFTs are the same radix-4/2 stages (mp, tw for nfft).
+struct MixedBlu {
+    int nfft;               // == nchan when BLU is false
+    const cf* chirp;        // [nchan]
+    const cf* d;            // [nfft]
+};
+template <bool TWL, int U, bool XF, bool BLU = false>
 __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restrict__ x, const float* __restrict__ h,
-                                                            cf* __restrict__ spec, const cf* __restrict__ tw_table,
+                                                            cf* __restrict__ out, const cf* __restrict__ tw_table,
                                                             const fxc::MixedPlan mp, int64_t num_samp, int nchan, int ntaps,
-                                                            int64_t n_pts, int64_t n_streams, int tpr) {
+                                                            int64_t n_pts, int64_t n_streams, int tpr, int n_splits,
+                                                            const MixedBlu blu) {
+    static_assert(!XF || U == 2, "the fused X stage pairs two antennas");
+    static_assert(!BLU || (U == 1 && !XF), "the chirp-z rows go one at a time, F only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nfft = BLU ? blu.nfft : nchan;
     const int rpw = (int)blockDim.x / tpr;
     const int sub = (int)threadIdx.x / tpr, lt = (int)threadIdx.x % tpr;
-    const int fpg = rpw * U;                                        // frames per group
+    const int fpg = XF ? rpw : rpw * U;                             // frames per group
     const int64_t gps = (n_pts + fpg - 1) / fpg;                    // groups per stream
-    const int64_t n_groups = n_streams * gps;
     cf* tw_lds = reinterpret_cast<cf*>(smem);
     if (TWL)
-        for (int n = threadIdx.x; n < nchan; n += blockDim.x) tw_lds[n] = tw_table[n];     // the first barrier below covers it
+        for (int n = threadIdx.x; n < nfft; n += blockDim.x) tw_lds[n] = tw_table[n];      // the first barrier below covers it
     const cf* tw = TWL ? tw_lds : tw_table;
-    const int64_t g0 = (int64_t)blockIdx.x * n_groups / gridDim.x, g1 = ((int64_t)blockIdx.x + 1) * n_groups / gridDim.x;
-    int64_t s = g0 / gps, gi = g0 - s * gps;
+    int64_t g0, g1, s, gi;          // XF: s = chunk, the run stays inside it; else s = stream, the run walks on
+    if (XF) {
+        const int sp = (int)(blockIdx.x % (unsigned)n_splits);
+        s = blockIdx.x / (unsigned)n_splits;
+        g0 = (int64_t)sp * gps / n_splits;
+        g1 = ((int64_t)sp + 1) * gps / n_splits;
+        gi = g0;
+    } else {
+        const int64_t n_groups = n_streams * gps;
+        g0 = (int64_t)blockIdx.x * n_groups / gridDim.x;
+        g1 = ((int64_t)blockIdx.x + 1) * n_groups / gridDim.x;
+        s = g0 / gps;
+        gi = g0 - s * gps;
+    }
+    fxc::pk2 xacc[XF ? kMixedXPoints : 1];
+#pragma unroll
+    for (int q = 0; q < (XF ? kMixedXPoints : 1); ++q) xacc[q] = fxc::pk_splat(0.f);
     for (int64_t g = g0; g < g1; ++g) {
         // per-lane and per-shape index math stays inside the group loop: hoisted (the compiler would hoist every radix's
         // share of it), it is a hundred live registers and spills
-        int lt_g = lt, sub_g = sub, nch = nchan, tpr_g = tpr;
-        asm volatile("" : "+v"(lt_g), "+v"(sub_g), "+s"(nch), "+s"(tpr_g));
-        cf* rows = reinterpret_cast<cf*>(smem) + (TWL ? nch : 0) + sub_g * U * 2 * nch;     // [u][a|b][nchan]
-        const int row_stride = 2 * nch;
-        // ---- FIR: v[f][m] = sum_t h[t][m] x[(f - t) nchan + nchan - 1 - m], frames f = f0 .. f0 + U - 1 of stream s
+        int lt_g = lt, sub_g = sub, nch = nchan, tpr_g = tpr, nf = nfft;
+        asm volatile("" : "+v"(lt_g), "+v"(sub_g), "+s"(nch), "+s"(tpr_g), "+s"(nf));
+        if (!BLU) nf = nch;
+        cf* rows = reinterpret_cast<cf*>(smem) + (TWL ? nf : 0) + sub_g * U * 2 * nf;       // [u][a|b][nfft]
+        const int row_stride = 2 * nf;
+        // ---- FIR: v[f][m] = sum_t h[t][m] x[(f - t) nchan + nchan - 1 - m]
         const int64_t gf = gi * fpg;                                            // the group's first frame
         const int64_t frame_lo = gf > ntaps - 1 ? gf - (ntaps - 1) : 0;         // the earliest frame any tap reaches
-        const cf* xg = x + s * num_samp + frame_lo * nch;                       // uniform base; lane offsets stay small
-        const int f0 = (int)(gf - frame_lo) + sub_g * U;                        // relative to frame_lo
-        const int f_end = (int)std::min<int64_t>(n_pts - frame_lo, 1 << 30);    // frames that exist, relative
-        for (int m = lt_g; m < nch; m += tpr_g) {
-            fxc::pk2 acc[U];
+        const int f_end = (int)std::min<int64_t>(n_pts - frame_lo, 1 << 30);    // frames that exist, relative to frame_lo
+        if constexpr (XF) {
+            const cf* xg0 = x + (2 * s) * num_samp + frame_lo * nch;             // uniform bases; lane offsets stay small
+            const cf* xg1 = xg0 + num_samp;
+            const int f0 = (int)(gf - frame_lo) + sub_g;
+            for (int m = lt_g; m < nch; m += tpr_g) {
+                fxc::pk2 acc0 = fxc::pk_splat(0.f), acc1 = acc0;
+                for (int t0 = 0; t0 < ntaps; t0 += 4) {
+                    fxc::pk2 xv0[4], xv1[4];
+                    float hw[4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] = fxc::pk_splat(0.f);
-            for (int t0 = 0; t0 < ntaps; t0 += 4) {
-                fxc::pk2 xv[U + 3];
-                float hw[4];
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = f0 - t0 - 3 + j;                          // frame f0 - (t0 + v) at j = 3 - v
+                        const bool ok = f >= 0 && f < f_end;
+                        const unsigned off = ok ? (unsigned)(f * nch + nch - 1 - m) : 0u;
+                        const fxc::pk2 l0 = fxc::pk(xg0[off]), l1 = fxc::pk(xg1[off]);
+                        xv0[j] = ok ? l0 : fxc::pk_splat(0.f);
+                        xv1[j] = ok ? l1 : fxc::pk_splat(0.f);
+                    }
 #pragma unroll
-                for (int j = 0; j < U + 3; ++j) {
-                    const int f = f0 - t0 - 3 + j;                              // frame f0 + u - (t0 + v) at j = u - v + 3
-                    const bool ok = f >= 0 && f < f_end;
-                    const unsigned off = ok ? (unsigned)(f * nch + nch - 1 - m) : 0u;
-                    const fxc::pk2 ld = fxc::pk(xg[off]);
-                    xv[j] = ok ? ld : fxc::pk_splat(0.f);
+                    for (int v = 0; v < 4; ++v) {
+                        const bool ok = t0 + v < ntaps;
+                        const float ld = h[(unsigned)(ok ? (t0 + v) * nch + m : m)];
+                        hw[v] = ok ? ld : 0.f;
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        acc0 = fxc::pk_fma(fxc::pk_splat(hw[v]), xv0[3 - v], acc0);
+                        acc1 = fxc::pk_fma(fxc::pk_splat(hw[v]), xv1[3 - v], acc1);
+                    }
                 }
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const bool ok = t0 + v < ntaps;
-                    const float ld = h[(unsigned)(ok ? (t0 + v) * nch + m : m)];
-                    hw[v] = ok ? ld : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u] = fxc::pk_fma(fxc::pk_splat(hw[v]), xv[u - v + 3], acc[u]);
+                rows[m] = fxc::unpk(acc0);
+                rows[row_stride + m] = fxc::unpk(acc1);
             }
+        } else {
+            const cf* xg = x + s * num_samp + frame_lo * nch;                   // uniform base; lane offsets stay small
+            const int f0 = (int)(gf - frame_lo) + sub_g * U;                    // frames f0 .. f0 + U - 1, relative to frame_lo
+            for (int m = lt_g; m < nch; m += tpr_g) {
+                fxc::pk2 acc[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) rows[u * row_stride + m] = fxc::unpk(acc[u]);
+                for (int u = 0; u < U; ++u) acc[u] = fxc::pk_splat(0.f);
+                for (int t0 = 0; t0 < ntaps; t0 += 4) {
+                    fxc::pk2 xv[U + 3];
+                    float hw[4];
+#pragma unroll
+                    for (int j = 0; j < U + 3; ++j) {
+                        const int f = f0 - t0 - 3 + j;                          // frame f0 + u - (t0 + v) at j = u - v + 3
+                        const bool ok = f >= 0 && f < f_end;
+                        const unsigned off = ok ? (unsigned)(f * nch + nch - 1 - m) : 0u;
+                        const fxc::pk2 ld = fxc::pk(xg[off]);
+                        xv[j] = ok ? ld : fxc::pk_splat(0.f);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const bool ok = t0 + v < ntaps;
+                        const float ld = h[(unsigned)(ok ? (t0 + v) * nch + m : m)];
+                        hw[v] = ok ? ld : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[u] = fxc::pk_fma(fxc::pk_splat(hw[v]), xv[u - v + 3], acc[u]);
+                }
+                if constexpr (BLU) acc[0] = fxc::pk_cmul(acc[0], fxc::pk(blu.chirp[m]));
+#pragma unroll
+                for (int u = 0; u < U; ++u) rows[u * row_stride + m] = fxc::unpk(acc[u]);
+            }
+            if constexpr (BLU)
+                for (int m = nch + lt_g; m < nf; m += tpr_g) rows[m] = fxc::mk(0.f, 0.f);
         }
         __syncthreads();
-        int so = 0, ns = 1;
-        for (int st = 0; st < mp.n_stages; ++st) {
-            const int radix = mp.radix[st];
-            int nst = nch;
-            asm volatile("" : "+s"(nst));                                       // ... and inside the stage loop
-            fxc::mixed_stage<U>(rows + so, rows + (nst - so), row_stride, tw, nst, radix, ns, lt_g, tpr_g);
-            __syncthreads();
-            ns *= radix;
-            so = nst - so;
+        int so = 0;
+        for (int pass = 0; pass < (BLU ? 2 : 1); ++pass) {
+            int ns = 1;
+            for (int st = 0; st < mp.n_stages; ++st) {
+                const int radix = mp.radix[st];
+                int nst = nf;
+                asm volatile("" : "+s"(nst));                                   // ... and inside the stage loop
+                fxc::mixed_stage<U>(rows + so, rows + (nst - so), row_stride, tw, nst, radix, ns, lt_g, tpr_g);
+                __syncthreads();
+                ns *= radix;
+                so = nst - so;
+            }
+            if (BLU && pass == 0) {
+                for (int k = lt_g; k < nf; k += tpr_g) {
+                    const fxc::pk2 t = fxc::pk_cmul(fxc::pk(rows[so + k]), fxc::pk(blu.d[k]));
+                    rows[so + k] = fxc::mk(t[0], -t[1]);
+                }
+                __syncthreads();
+            }
         }
-        cf* out = spec + (s * n_pts + gf) * nch;                                // uniform base of the group's rows
+        if constexpr (XF) {
+            if (gf + sub_g < n_pts) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int fr = sub_g * U + u;
-            if (gf + fr < n_pts)
-                for (int n = lt_g; n < nch; n += tpr_g) out[(unsigned)(fr * nch + n)] = rows[u * row_stride + so + n];
+                for (int q = 0; q < kMixedXPoints; ++q) {
+                    const int m = lt_g + q * tpr_g;
+                    if (m < nch) {
+                        const fxc::pk2 a = fxc::pk(rows[so + m]), b = fxc::pk(rows[row_stride + so + m]);
+                        const fxc::pk2 ar = {a[1], -a[0]};                      // a conj(b) = b.x (a.x, a.y) + b.y (a.y, -a.x)
+                        xacc[q] = fxc::pk_fma(fxc::pk_splat(b[1]), ar, fxc::pk_fma(fxc::pk_splat(b[0]), a, xacc[q]));
+                    }
+                }
+            }
+        } else {
+            cf* o = out + (s * n_pts + gf) * nch;                               // uniform base of the group's rows
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int fr = sub_g * U + u;
+                if (gf + fr < n_pts)
+                    for (int n = lt_g; n < nch; n += tpr_g) {
+                        cf v = rows[u * row_stride + so + n];
+                        if constexpr (BLU) v = fxc::unpk(fxc::pk_cmul(fxc::pk(fxc::mk(v.x, -v.y)), fxc::pk(blu.chirp[n])));
+                        o[(unsigned)(fr * nch + n)] = v;
+                    }
+            }
         }
         __syncthreads();
-        if (++gi == gps) {
+        if (++gi == gps && !XF) {
             gi = 0;
             ++s;
+        }
+    }
+    if constexpr (XF) {
+        // the slots of a workgroup (rpw > 1) hold sums over different frames of the same bins: add them up through LDS
+        cf* red = reinterpret_cast<cf*>(smem) + (TWL ? nchan : 0);              // [rpw][nchan], free after the last barrier
+        if (rpw > 1) {
+#pragma unroll
+            for (int q = 0; q < kMixedXPoints; ++q) {
+                const int m = lt + q * tpr;
+                if (m < nchan) red[sub * nchan + m] = fxc::unpk(xacc[q]);
+            }
+            __syncthreads();
+        }
+        const int sp = (int)(blockIdx.x % (unsigned)n_splits);
+        cf* o = out + ((int64_t)sp * n_streams + s) * nchan;                    // n_streams = chunks here
+        if (sub == 0) {
+#pragma unroll
+            for (int q = 0; q < kMixedXPoints; ++q) {
+                const int m = lt + q * tpr;
+                if (m < nchan) {
+                    fxc::pk2 t = xacc[q];
+                    for (int r = 1; r < rpw; ++r) t = t + fxc::pk(red[r * nchan + m]);
+                    o[m] = fxc::unpk(t);
+                }
+            }
         }
     }
 }

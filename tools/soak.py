@@ -37,20 +37,38 @@ def main():
         n_ant = int(rng.choice([2, 2, 2, 2, 3, 4, 8, 11, 16]))
         if nchan == 1:
             n_ant, ntaps = 2, int(rng.choice([1, 3, 4, 7]))
+        # one case in five: a channel count that is not a power of two (mixed-radix kernel; with two antennas F and X in one pass)
+        # against the direct O(N^2) DFT kernels (FXC_GENERIC_FFT=radix2 when the reference plan is built)
+        any_n = nchan != 1 and rng.random() < 0.2
+        if any_n:
+            nchan = int(rng.choice([int(rng.integers(2, 400)), int(rng.integers(400, 3000)), int(rng.integers(3000, 10241)),
+                                    int(rng.choice([96, 100, 360, 1000, 1536, 2000, 3000, 5000, 6000, 10000]))]))
+            if nchan & (nchan - 1) == 0:
+                nchan += 1
+            n_ant = int(rng.choice([2, 2, 2, 3, 5]))
         frames = int(rng.integers(1, 3000 if 1 < nchan <= 256 else (80 if nchan <= 1024 else 30)))
         n_chunks = int(rng.choice([1, 2, 3, 5, 17, 64, 255, 257, 300, 600]))
         budget = 3.0e7          # complex samples per case
         num_samp = max(nchan, 1) * frames + int(rng.integers(0, max(nchan, 2)))
         if nchan == 1:
             num_samp = int(rng.integers(ntaps + 1, 70000))
+        if any_n:
+            frames = int(rng.integers(1, 600 if nchan <= 256 else (40 if nchan <= 1024 else 8)))
+            num_samp = nchan * frames + int(rng.integers(0, nchan))
+            budget = 3.0e6 if nchan > 256 else 1.0e7      # the reference side is O(N^2) per frame
         n_chunks = max(1, min(n_chunks, int(budget // (n_ant * num_samp))))
         x = torch.from_numpy(synth.synth_iq(int(rng.integers(1, 1 << 30)), n_chunks, n_ant, num_samp,
                                              delays=np.arange(n_ant) % 8)).cuda()
         window = np.linspace(0.4, 0.1, ntaps) if nchan == 1 else None
         tag = dict(nchan=nchan, ntaps=ntaps, n_ant=n_ant, frames=frames, n_chunks=n_chunks, num_samp=num_samp)
         try:
-            with FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as f, \
-                    FxPlan(n_ant, nchan, ntaps, num_samp, window=window, path="generic") as g:
+            if any_n:
+                os.environ["FXC_GENERIC_FFT"] = "radix2"
+            try:
+                g_plan = FxPlan(n_ant, nchan, ntaps, num_samp, window=window, path="generic")
+            finally:
+                os.environ.pop("FXC_GENERIC_FFT", None)
+            with FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as f, g_plan as g:
                 rf, rg = f.fx_rows(x).cpu().numpy(), g.fx_rows(x).cpu().numpy()
                 e_rows = rel_err(rf, rg)
                 f.fx_accumulate(x[: n_chunks // 2])
@@ -82,6 +100,8 @@ def main():
                 raise SystemExit(1)
         tol = 2e-5 if nchan == 1 else 6e-6
         key = (path, nchan if nchan in (1, 4096, 8192) else (256 if nchan <= 256 else 0), ntaps > 4)
+        if any_n:
+            key = ("mixed-radix", n_ant == 2, ntaps > 4)
         worst[key] = max(worst.get(key, 0.0), e_rows, e_int)
         if not (e_rows < tol and e_int < tol and e_cont < 5e-5):
             print(json.dumps({"MISMATCH": [e_rows, e_int, e_cont], "path": path, **tag}), flush=True)
