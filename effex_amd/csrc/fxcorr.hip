@@ -72,7 +72,7 @@ constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 channeliser kernels only
 constexpr int kMaxXAnt = 64;         // antennas the F-only + X-engine route takes (fxc_plan_create's own limit)
 constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
-constexpr int kBluMinPrime = 61;      // larger prime factors: the chirp-z form (see pfb_fft_mixed_kernel, BLU)
+constexpr int kBluPrimePerRatio = 45;  // prime factors beyond 45 nfft / N: the chirp-z form (see pfb_fft_mixed_kernel, BLU)
 constexpr int kBluMaxNfft = 8192;     // two chirp-z rows in LDS
 constexpr int kMixedMaxN = 10240;    // two rows of complex64 in the 160 KiB of LDS (pfb_fft_mixed_kernel)
 size_t res_direct_bytes() {      // finalize results up to this size are written to host memory by the kernel (FXC_RES_DIRECT: developer knob, bytes)
@@ -227,12 +227,14 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             if (p->mixed_plan.n_stages < 0) p->mixed = false;
         }
         if (p->mixed) {
-            // a prime factor beyond kBluMinPrime costs more as an O(N p) stage than the whole transform as a chirp-z convolution
+            // a large prime factor costs more as an O(N p) stage than the whole transform as a chirp-z convolution
             int pmax = 1;
             for (int st = 0; st < p->mixed_plan.n_stages; ++st) pmax = std::max(pmax, p->mixed_plan.radix[st]);
             int m = 1;
             while (m < 2 * N - 1) m <<= 1;
-            if (pmax > env_int("FXC_BLU_MIN_PRIME", kBluMinPrime) && m <= kBluMaxNfft) {
+            // measured (profiles/r04/experiments.md §7): the stage costs ~p, the chirp-z rows ~nfft / N; they cross near p = 45 nfft / N
+            const int p_min = env_int("FXC_BLU_MIN_PRIME", (int)((int64_t)kBluPrimePerRatio * m / N));
+            if (pmax > p_min && m <= kBluMaxNfft) {
                 p->mixed_blu = true;
                 p->blu_nfft = m;
                 p->mixed_plan = fxc::mixed_factor(m);

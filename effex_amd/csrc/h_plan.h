@@ -54,7 +54,7 @@ struct fxc_plan {
     bool mixed = false;            // generic F stage = pfb_fft_mixed_kernel (FIR + mixed-radix FFT in one pass)
     fxc::MixedPlan mixed_plan{};
     int mixed_tpr = 256;           // threads per row
-    bool mixed_blu = false;        // a prime factor beyond kBluMinPrime: chirp-z rows of blu_nfft points (F only)
+    bool mixed_blu = false;        // a large prime factor (plan_build): chirp-z rows of blu_nfft points (F only)
     int blu_nfft = 0;
     cf* d_chirp = nullptr;         // [nchan] exp(+i pi n^2 / nchan)
     cf* d_blud = nullptr;          // [blu_nfft] FFT of the wrapped conjugate chirp / blu_nfft

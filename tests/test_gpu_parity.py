@@ -697,12 +697,12 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
     (2, 997, 4, 2, 10, 3), (2, 6, 4, 4, 1000, 1), (2, 12, 1, 3, 50, 0), (3, 48, 5, 2, 77, 2), (2, 2310, 2, 1, 12, 0),
     (2, 5000, 4, 1, 9, 11), (4, 10240, 4, 1, 5, 0), (2, 3, 4, 2, 4000, 2), (2, 7, 32, 2, 500, 0), (2, 1001, 4, 1, 3, 0),
     (2, 6561, 4, 1, 4, 0), (2, 250, 4, 1, 1, 0), (5, 360, 4, 2, 30, 1),
-    # a prime factor beyond 61: chirp-z rows (Bluestein), table in LDS up to 4096 points, from global at 8192
-    (2, 1002, 4, 2, 12, 5), (3, 4093, 4, 1, 5, 0), (2, 2049, 2, 2, 7, 1), (2, 67, 5, 3, 200, 3), (2, 127, 4, 1, 1, 0),
+    # a prime factor beyond 45 nfft / nchan: chirp-z rows (Bluestein), table in LDS up to 4096 points, from global at 8192
+    (2, 1002, 4, 2, 12, 5), (3, 4093, 4, 1, 5, 0), (2, 2049, 2, 2, 7, 1), (2, 97, 5, 3, 200, 3), (2, 127, 4, 1, 1, 0), (2, 67, 4, 2, 50, 0),
     (2, 4096 + 1, 4, 1, 3, 0), (2, 8190 // 2 + 4, 4, 1, 2, 0)])
 def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, nchan, ntaps, n_chunks, frames, extra):
     """`--resolution` is a free integer (effex.py:733-739): channel counts that are not a power of two run the FIR + mixed-radix
-    Stockham kernel (fx_mixed.h: radices 4, 2, 3, 5, 7, 11, 13 in registers, other prime factors up to 61 from the LDS row,
+    Stockham kernel (fx_mixed.h: radices 4, 2, 3, 5, 7, 11, 13 in registers, other prime factors from the LDS row up to about 90,
     larger ones as a chirp-z convolution; with two antennas the same kernel multiplies and integrates) -- against the oracle,
     and against the direct O(N^2) DFT kernel it replaced."""
     num_samp = nchan * frames + extra
