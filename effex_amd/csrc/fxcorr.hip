@@ -220,7 +220,10 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     {
         const char* gf = std::getenv("FXC_GENERIC_FFT");
         const bool force_mixed = gf && !std::strcmp(gf, "mixed"), force_old = gf && !std::strcmp(gf, "radix2");
-        p->mixed = N > 1 && N <= kMixedMaxN && !force_old && (!p->pow2 || force_mixed);
+        // powers of two on the automatic path that no tuned kernel takes -- 4, 8 and 16384 channels -- ride along; a forced
+        // generic path keeps the radix-2 kernels (the tests' independent reference)
+        const bool auto_pow2 = force_path == -1 && (N == 4 || N == 8 || N == 16384);
+        p->mixed = N > 1 && N <= kMaxLdsFftN && !force_old && (!p->pow2 || force_mixed || auto_pow2);
         if (p->mixed) {
             p->mixed_plan = fxc::mixed_factor(N);
             p->mixed_tpr = fxc::mixed_threads_per_row(N, env_int("FXC_MIXED_TPR", 1024));
@@ -549,6 +552,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     } else if (N > 1) {

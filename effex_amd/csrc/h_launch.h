@@ -40,6 +40,17 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
     }
+    if (p->mixed && p->nchan > kMixedMaxN) {
+        // one LDS row, the other in the output (pfb_fft_mixed_kernel, BIG): one frame per workgroup pass, 1024 threads
+        const int64_t n_groups = n_streams * p->n_pts;
+        const int64_t run = std::max<int64_t>(1, std::min<int64_t>(16, n_groups / ((int64_t)p->cu_count * 8)));
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
+        hipLaunchKernelGGL((pfb_fft_mixed_kernel<false, 1, false, false, true>), dim3(grid), dim3(1024), (size_t)p->nchan * sizeof(cf),
+                           p->stream, x, p->d_win, spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams,
+                           1024, 1, MixedBlu{p->nchan, nullptr, nullptr});
+        FXC_HIP(p, hipGetLastError());
+        return FXC_OK;
+    }
     if (p->mixed) {
         const int threads = std::max(256, p->mixed_tpr);
         const int rpw = threads / p->mixed_tpr;

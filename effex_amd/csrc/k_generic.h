@@ -118,7 +118,10 @@ struct MixedBlu {
     const cf* chirp;        // [nchan]
     const cf* d;            // [nfft]
 };
-template <bool TWL, int U, bool XF, bool BLU = false>
+//   BIG = true (10240 < nchan <= 16384: one row is all the LDS holds; F only, U = 1, 1024 threads): the stages go back and
+//   forth between the LDS row and the frame's own row of `out` (L2-resident; __syncthreads() orders global memory within the
+//   workgroup), and the spectrum ends in `out` either way.
+template <bool TWL, int U, bool XF, bool BLU = false, bool BIG = false>
 __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restrict__ x, const float* __restrict__ h,
                                                             cf* __restrict__ out, const cf* __restrict__ tw_table,
                                                             const fxc::MixedPlan mp, int64_t num_samp, int nchan, int ntaps,
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                                                             const MixedBlu blu) {
     static_assert(!XF || U == 2, "the fused X stage pairs two antennas");
     static_assert(!BLU || (U == 1 && !XF), "the chirp-z rows go one at a time, F only");
+    static_assert(!BIG || (U == 1 && !XF && !BLU && !TWL), "one LDS row: plain F stage, twiddles from the table");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nfft = BLU ? blu.nfft : nchan;
     const int rpw = (int)blockDim.x / tpr;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
         int lt_g = lt, sub_g = sub, nch = nchan, tpr_g = tpr, nf = nfft;
         asm volatile("" : "+v"(lt_g), "+v"(sub_g), "+s"(nch), "+s"(tpr_g), "+s"(nf));
         if (!BLU) nf = nch;
-        cf* rows = reinterpret_cast<cf*>(smem) + (TWL ? nf : 0) + sub_g * U * 2 * nf;       // [u][a|b][nfft]
+        cf* rows = reinterpret_cast<cf*>(smem) + (TWL ? nf : 0) + sub_g * U * (BIG ? 1 : 2) * nf;       // [u][a|b][nfft]
         const int row_stride = 2 * nf;
         // ---- FIR: v[f][m] = sum_t h[t][m] x[(f - t) nchan + nchan - 1 - m]
         const int64_t gf = gi * fpg;                                            // the group's first frame
@@ -236,7 +240,24 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
         }
         __syncthreads();
         int so = 0;
-        for (int pass = 0; pass < (BLU ? 2 : 1); ++pass) {
+        if constexpr (BIG) {
+            cf* orow = out + (s * n_pts + gf) * nch;                            // fpg = 1: the group is one frame
+            int ns = 1;
+            for (int st = 0; st < mp.n_stages; ++st) {
+                const int radix = mp.radix[st];
+                int nst = nf;
+                asm volatile("" : "+s"(nst));
+                if ((st & 1) == 0)
+                    fxc::mixed_stage<1>(rows, orow, 0, tw, nst, radix, ns, lt_g, tpr_g);
+                else
+                    fxc::mixed_stage<1>(orow, rows, 0, tw, nst, radix, ns, lt_g, tpr_g);
+                __syncthreads();
+                ns *= radix;
+            }
+            if ((mp.n_stages & 1) == 0)
+                for (int n = lt_g; n < nch; n += tpr_g) orow[n] = rows[n];
+        }
+        for (int pass = 0; pass < (BIG ? 0 : (BLU ? 2 : 1)); ++pass) {
             int ns = 1;
             for (int st = 0; st < mp.n_stages; ++st) {
                 const int radix = mp.radix[st];
@@ -267,7 +288,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                     }
                 }
             }
-        } else {
+        } else if constexpr (!BIG) {
             cf* o = out + (s * n_pts + gf) * nch;                               // uniform base of the group's rows
 #pragma unroll
             for (int u = 0; u < U; ++u) {

@@ -699,7 +699,9 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
     (2, 6561, 4, 1, 4, 0), (2, 250, 4, 1, 1, 0), (5, 360, 4, 2, 30, 1),
     # a prime factor beyond 45 nfft / nchan: chirp-z rows (Bluestein), table in LDS up to 4096 points, from global at 8192
     (2, 1002, 4, 2, 12, 5), (3, 4093, 4, 1, 5, 0), (2, 2049, 2, 2, 7, 1), (2, 97, 5, 3, 200, 3), (2, 127, 4, 1, 1, 0), (2, 67, 4, 2, 50, 0),
-    (2, 4096 + 1, 4, 1, 3, 0), (2, 8190 // 2 + 4, 4, 1, 2, 0)])
+    (2, 4096 + 1, 4, 1, 3, 0), (2, 8190 // 2 + 4, 4, 1, 2, 0),
+    # beyond 10240 channels one row is all the LDS holds: the stages alternate between it and the output row
+    (2, 12000, 4, 2, 3, 7), (3, 15000, 2, 1, 2, 0), (2, 10241, 4, 1, 2, 0), (2, 16380, 4, 1, 1, 0)])
 def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, nchan, ntaps, n_chunks, frames, extra):
     """`--resolution` is a free integer (effex.py:733-739): channel counts that are not a power of two run the FIR + mixed-radix
     Stockham kernel (fx_mixed.h: radices 4, 2, 3, 5, 7, 11, 13 in registers, other prime factors from the LDS row up to about 90,
@@ -726,7 +728,8 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
     monkeypatch.setenv("FXC_GENERIC_FFT", "radix2")            # the direct DFT (developer knob, read when the plan is built)
     with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as d:
         d.set_rot(rot)
-        assert rel_err(rows, d.fx_rows(xd, "SPECTRUM").cpu().numpy()) < 4e-6
+        # (the direct DFT's own float32 sums of nchan terms are the larger share of the difference at the top sizes)
+        assert rel_err(rows, d.fx_rows(xd, "SPECTRUM").cpu().numpy()) < (4e-6 if nchan <= 8192 else 1e-5)
 
 
 @pytest.mark.parametrize("nchan", [8, 64, 1024, 4096, 8192])
@@ -740,6 +743,27 @@ def test_mixed_radix_kernel_on_powers_of_two(plan_mod, torch, monkeypatch, nchan
     monkeypatch.setenv("FXC_GENERIC_FFT", "mixed")
     with plan_mod.FxPlan(2, nchan, 3, num_samp, path="generic") as m:
         assert rel_err(m.fx_rows(xd).cpu().numpy(), ref) < 4e-6
+
+
+@pytest.mark.parametrize("n_ant,nchan,ntaps,n_chunks,frames", [(2, 4, 4, 5, 3000), (2, 8, 4, 3, 777), (3, 8, 7, 2, 100), (2, 16384, 4, 2, 3),
+                                                               (3, 16384, 2, 1, 2), (2, 2, 4, 3, 500)])
+def test_powers_of_two_no_tuned_kernel_takes(plan_mod, torch, n_ant, nchan, ntaps, n_chunks, frames):
+    """--nfft 4, 8 and 16384 on the automatic path ride the mixed-radix kernel (two antennas: F and X in one pass; 16384: one LDS
+    row, the other in the output); a forced generic path keeps the radix-2 kernels, the reference here besides the oracle."""
+    num_samp = nchan * frames + 1
+    x = synth.synth_iq(91 + nchan, n_chunks, n_ant, num_samp)
+    xd = torch.from_numpy(x).cuda()
+    window = design_window(ntaps, nchan)
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as p, \
+            plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window, path="generic") as g:
+        assert p.path == "generic"
+        rows = p.fx_rows(xd).cpu().numpy()
+        assert rel_err(rows, g.fx_rows(xd).cpu().numpy()) < 4e-6
+        ref = fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+        assert rel_err(rows[0, 0], ref) < TOL_VIS
+        p.fx_accumulate(xd)
+        assert rel_err(p.finalize("SPECTRUM"), rows.astype(np.complex128).mean(axis=0)) < 2e-6
+        assert rel_err(p.channelize(xd[0]).cpu().numpy(), g.channelize(xd[0]).cpu().numpy()) < 4e-6
 
 
 def test_small_channel_counts_outside_the_kernel_fall_back(plan_mod, torch):
