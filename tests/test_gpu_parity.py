@@ -194,6 +194,30 @@ def test_drop_in_nbins_changed_after_construction(torch, golden):
             cor.close()
 
 
+@pytest.mark.parametrize("nbins", [1000, 1536, 997, 12000])
+def test_drop_in_any_resolution(torch, nbins):
+    """Correlator(nbins=...) with a channel count that is not a power of two (effex.py:733-739: --resolution is a free
+    integer): _run_task() on staged buffers against the oracle's pfb_xcorr, both output modes."""
+    from effex_amd.correlator import Correlator, SyntheticSource
+    num_samp = 2 ** 16
+    x = synth.synth_iq(31 + nbins, 1, 2, num_samp, delays=[0, 3])[0]
+    cor = Correlator(source=SyntheticSource(), nbins=nbins, num_samp=num_samp)
+    try:
+        assert cor.ntaps * nbins == len(cor.window)
+        cor.calibrated_delay = 1.25e-6
+        cor.gpu_iq_0, cor.gpu_iq_1 = x[0], x[1]
+        for mode in ("SPECTRUM", "CONTINUUM"):
+            cor.mode = mode
+            vis = cor._run_task()
+            ref = fx_oracle.pfb_xcorr(x[0], x[1], cor.ntaps, nbins, cor.window, cor.bandwidth, cor.frequency, 1.25e-6, mode)
+            if mode == "SPECTRUM":
+                assert vis.shape == (nbins,) and rel_err(vis, ref) < TOL_VIS
+            else:
+                assert abs(vis - ref) < 1e-4 * abs(ref) + 1e-9 * np.abs(x).max() ** 2
+    finally:
+        cor.close()
+
+
 @pytest.mark.parametrize("path", ["tiled", "generic"])
 def test_small_multichunk_rows(plan_mod, torch, golden, path):
     _, arrays = golden
