@@ -316,7 +316,8 @@ def dry_run_dist(args):
 def other_configs(x, dev, reps=5):
     """Short, untimed-region runs of the other single-GPU BASELINE configs on the resident synthetic bytes (viewed with
     their own shapes): configs[2] continuum streaming limit (nchan = 1, num_samp = 2^20) and configs[4] (8 antennas,
-    28 baselines, nchan 4096), plus two three-pass shapes (32 taps, 8192 channels).  HIP events around four calls back to
+    28 baselines, nchan 4096), plus two three-pass shapes (32 taps, 8192 channels) and a channel count that is not a power
+    of two (1000).  HIP events around four calls back to
     back (results collected one call behind, as the headline loop does), per call, median of `reps`."""
     import numpy as np
     from effex_amd.plan import FxPlan, pinned_empty
@@ -369,6 +370,10 @@ def other_configs(x, dev, reps=5):
     run("reference test shape: 2 antennas, nchan=2048, ntaps=32, num_samp=262144, integrated", 2, 2048, NUM_SAMP, 1024, None,
         "SPECTRUM", False, ntaps=32)
     run("--nfft 8192: 2 antennas, nchan=8192, ntaps=4, num_samp=262144, integrated", 2, 8192, NUM_SAMP, 1024, None,
+        "SPECTRUM", False)
+    # --resolution is a free integer in the reference (effex.py:733-739): a channel count that is not a power of two
+    # (mixed-radix Stockham kernel, F and X in one pass)
+    run("--resolution 1000: 2 antennas, nchan=1000, ntaps=4, num_samp=262144, integrated", 2, 1000, NUM_SAMP, 1024, None,
         "SPECTRUM", False)
     return out
 
