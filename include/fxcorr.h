@@ -51,7 +51,11 @@ enum fxc_mode { FXC_MODE_SPECTRUM = 0, FXC_MODE_CONTINUUM = 1 }; /* TEST == CONT
  * effex.py:109-110: narrowed to complex64 on the device, after the DC removal when that is asked for) */
 enum fxc_iq_format { FXC_IQ_C64 = 0, FXC_IQ_U8 = 1, FXC_IQ_C128 = 2 };
 enum fxc_path {
-    FXC_PATH_GENERIC = 0, /* any shape: FIR / FFT / X kernels through a workspace                          */
+    FXC_PATH_GENERIC = 0, /* any shape (nchan <= 16384, ntaps <= 32, 2..64 antennas).  Channel counts that are not a
+                             power of two (effex.py:733-739: --resolution is a free integer) and nchan 4 / 8 / 16384 when the
+                             path is chosen automatically: FIR + mixed-radix Stockham FFT (chirp-z for large prime factors)
+                             in one kernel, which with 2 antennas also multiplies and integrates; otherwise FIR / radix-2
+                             FFT / X kernels through a workspace (the tests' independent reference when forced)      */
     FXC_PATH_FUSED = 1,   /* nchan 4096, ntaps 4, 2 antennas (one kernel) or 4/6/8 (F-only kernel + X-engine) */
     FXC_PATH_STREAM = 2,  /* nchan 1, 2 antennas: the continuum streaming limit                             */
     FXC_PATH_TILED = 3    /* nchan 512/1024/2048/4096/8192, any ntaps: 2 antennas in one fused F+X kernel, 3..64
