@@ -19,5 +19,5 @@ run() {   # name, program args...
 }
 # the driver's own command line (20 timed steps after 5 warm-up steps), minus the CPU leg and the untimed extras
 run bench "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-power --no-other-configs --no-verify
-for w in 8ant stream1 nfft2048 taps32 nfft256 nfft16 16ant 32ant; do run $w "$root/tools/prof_workload.py" $w 10; done
+for w in 8ant stream1 nfft2048 taps32 nfft256 nfft16 16ant 32ant res1000; do run $w "$root/tools/prof_workload.py" $w 10; done
 python3 "$root/tools/summarize_profiles.py" "$root/gpurun_out/$tag"

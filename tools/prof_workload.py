@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: one named workload a few times, for rocprofv3 (kernel trace / PMC passes; tools/collect_profiles.sh).
 
-    python3 tools/prof_workload.py 8ant | stream1 | nfft2048 | taps32 | nfft256 | nfft16 | 16ant | 32ant [reps]
+    python3 tools/prof_workload.py 8ant | stream1 | nfft2048 | taps32 | nfft256 | nfft16 | 16ant | 32ant | res1000 [reps]
 """
 import os
 import sys
@@ -21,6 +21,8 @@ WORKLOADS = {
     "nfft16": (2, 16, 4, 2 ** 18, 10000, "SPECTRUM", False),         # --nfft 16, one lane per work item
     "16ant": (16, 4096, 4, 2 ** 18, 128, "SPECTRUM", False),         # 120 baselines: F-only tiled kernel + matrix-core X-engine
     "32ant": (32, 4096, 4, 2 ** 18, 64, "SPECTRUM", False),          # 496 baselines
+    "res1000": (2, 1000, 4, 2 ** 18, 1024, "SPECTRUM", False),       # --resolution 1000: mixed-radix kernel, F and X in one pass
+    "res1000t1": (2, 1000, 1, 2 ** 18, 1024, "SPECTRUM", False),     # ... with one tap: every sample read once (calibrates FETCH_SIZE)
 }
 
 
