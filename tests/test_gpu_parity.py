@@ -1437,6 +1437,32 @@ def test_dc_removal_with_a_small_workspace(plan_mod, torch):
     assert many.shape == one.shape and rel_err(many, one) < TOL_VIS
 
 
+@pytest.mark.parametrize("n_ant", [2, 3])
+def test_any_channel_count_with_a_small_workspace(plan_mod, torch, n_ant):
+    """The mixed-radix path in passes bounded by the workspace target (1 MiB in a child process: raw sums only with two
+    antennas, spectra + raw sums with three): rows and the integration equal the one-pass run's."""
+    nchan, num_samp, n_chunks = 1000, 1000 * 40 + 3, 23
+    x = synth.synth_iq(17, n_chunks, n_ant, num_samp)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(n_ant, nchan, 4, num_samp) as p:
+        one = p.fx_rows(xd).cpu().numpy()
+        p.fx_accumulate(xd)
+        integ = p.finalize("SPECTRUM")
+    import subprocess, sys, os, tempfile      # the workspace target is read once per process
+    code = ("import numpy as np, torch, sys; sys.path.insert(0, %r); from effex_amd import plan\n"
+            "x = torch.from_numpy(np.load(sys.argv[1])).cuda()\n"
+            "with plan.FxPlan(x.shape[1], 1000, 4, x.shape[2]) as p:\n"
+            "    rows = p.fx_rows(x).cpu().numpy(); p.fx_accumulate(x); np.savez(sys.argv[2], rows=rows, integ=p.finalize('SPECTRUM'))\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "x.npy"), x)
+        subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "x.npy"), os.path.join(tmp, "r.npz")], check=True,
+                       env=dict(os.environ, FXC_WS_MB="1"), timeout=600)
+        many = np.load(os.path.join(tmp, "r.npz"))
+        assert many["rows"].shape == one.shape and rel_err(many["rows"], one) < 2e-6
+        assert rel_err(many["integ"], integ) < 2e-6
+
+
 def test_pinned_host_memory(plan_mod, torch):
     """fxc_host_alloc / fxc_host_free (effex.py:109-110: cusignal.get_shared_mem): buffers are ordinary host memory to the
     caller, results are bit-identical to the pageable route, a pointer the library did not hand out is refused."""
