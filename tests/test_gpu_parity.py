@@ -723,7 +723,7 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
     (2, 6561, 4, 1, 4, 0), (2, 250, 4, 1, 1, 0), (5, 360, 4, 2, 30, 1),
     # a prime factor beyond 45 nfft / nchan: chirp-z rows (Bluestein), table in LDS up to 4096 points, from global at 8192
     (2, 1002, 4, 2, 12, 5), (3, 4093, 4, 1, 5, 0), (2, 2049, 2, 2, 7, 1), (2, 97, 5, 3, 200, 3), (2, 127, 4, 1, 1, 0), (2, 67, 4, 2, 50, 0),
-    (2, 4096 + 1, 4, 1, 3, 0), (2, 8190 // 2 + 4, 4, 1, 2, 0),
+    (2, 4096 + 1, 4, 1, 3, 0), (2, 8190 // 2 + 4, 4, 1, 2, 0), (2, 251, 4, 3, 77, 2), (3, 509, 3, 2, 31, 0),
     # beyond 10240 channels one row is all the LDS holds: the stages alternate between it and the output row
     (2, 12000, 4, 2, 3, 7), (3, 15000, 2, 1, 2, 0), (2, 10241, 4, 1, 2, 0), (2, 16380, 4, 1, 1, 0)])
 def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, nchan, ntaps, n_chunks, frames, extra):
