@@ -749,6 +749,14 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
         assert rel_err(integ, rows.astype(np.complex128).mean(axis=0)) < 2e-6
         spec = p.channelize(xd[0, 0]).cpu().numpy()
         assert rel_err(spec.reshape(-1, nchan), fx_oracle.spectrometer_poly(x[0, 0], ntaps, nchan, window)) < TOL_VIS
+        if n_ant == 2 and nchan <= 4096:       # the steps either side of the path: receiver bytes in, DC removal on the device
+            u8 = torch.from_numpy(np.random.default_rng(nchan).integers(0, 256, size=(2, 2, num_samp, 2), dtype=np.uint8)).cuda()
+            by = p.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()
+            assert rel_err(by, p.fx_rows(p.convert_u8(u8, remove_dc=True)).cpu().numpy()) < 1e-6
+            dc = p.fx_rows(xd[:1] + (0.25 - 0.5j), remove_dc=True).cpu().numpy()
+            ref = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(x[0, 0] + (0.25 - 0.5j)), fx_oracle.remove_dc(x[0, 1] + (0.25 - 0.5j)),
+                                      ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, -2e-7, "SPECTRUM")
+            assert rel_err(dc[0, 0], ref) < TOL_VIS
     monkeypatch.setenv("FXC_GENERIC_FFT", "radix2")            # the direct DFT (developer knob, read when the plan is built)
     with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as d:
         d.set_rot(rot)
