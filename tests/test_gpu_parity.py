@@ -1445,6 +1445,35 @@ def test_dc_removal_with_a_small_workspace(plan_mod, torch):
     assert many.shape == one.shape and rel_err(many, one) < TOL_VIS
 
 
+def test_resolution_1000_at_full_size(plan_mod, torch):
+    """BASELINE configs[1]'s size at a channel count that is not a power of two (nchan 1000, 1 024 chunk pairs of 2^18 samples,
+    4.3 GB resident, generated on the device): properties that do not need the oracle at that size -- the integration is the
+    mean of the rows, doubling the input quadruples every row bit for bit, swapping the antennas conjugates it -- and chunks
+    0 and 1023 against the oracle."""
+    from effex_amd.plan import synth_fill
+    num_samp, n_chunks, nchan = 2 ** 18, 1024, 1000
+    x = torch.empty((n_chunks, 2, num_samp), dtype=torch.complex64, device="cuda")
+    synth_fill(x, 4242)
+    window = design_window(4, nchan)
+    with plan_mod.FxPlan(2, nchan, 4, num_samp, window=window) as p:
+        assert p.path == "generic"
+        rows = p.fx_rows(x).cpu().numpy()
+        p.fx_accumulate(x[:300])
+        p.fx_accumulate(x[300:])
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ, rows.astype(np.complex128).mean(axis=0)) < 2e-6
+        sub = x[500:516]
+        rows16 = p.fx_rows(sub).cpu().numpy()          # (16 chunk pairs split their frames differently from 1 024: not bit for bit)
+        assert rel_err(rows16, rows[500:516]) < 1e-6
+        np.testing.assert_array_equal(p.fx_rows(sub * 2.0).cpu().numpy(), 4.0 * rows16)
+        swapped = p.fx_rows(sub.flip(1).contiguous()).cpu().numpy()
+        assert rel_err(swapped, np.conj(rows16)) < 1e-6
+        for c in (0, n_chunks - 1):
+            xc = x[c].cpu().numpy()
+            ref = fx_oracle.pfb_xcorr(xc[0], xc[1], 4, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+
+
 @pytest.mark.parametrize("n_ant", [2, 3])
 def test_any_channel_count_with_a_small_workspace(plan_mod, torch, n_ant):
     """The mixed-radix path in passes bounded by the workspace target (1 MiB in a child process: raw sums only with two
