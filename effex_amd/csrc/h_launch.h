@@ -17,6 +17,14 @@ int env_int(const char* name, int dflt) {
     return e ? std::atoi(e) : dflt;
 }
 
+// Slots of one wave (tpr <= 64) go without the workgroup barrier between their steps: measured on one box, two antennas
+// 7 - 16 % faster at 8 ... 250 channels, F only 5 - 7 % faster at 96 ... 250 but 17 % slower at 12 (slots of 4 threads) -- so F
+// only from 16 threads per slot.  Developer knob: FXC_MIXED_WAVELOCAL=0 keeps the barrier everywhere.
+int mixed_wave_local(const fxc_plan* p, bool fused_x) {
+    static const int v = env_int("FXC_MIXED_WAVELOCAL", 1);
+    return v && (fused_x || p->mixed_tpr >= 16);
+}
+
 int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
     if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
     // the F-only tiled kernel writes natural-order spectra straight to `spec` (no workspace): any caller may use it
@@ -30,7 +38,7 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
         const int64_t n_groups = n_streams * ((p->n_pts + rpw - 1) / rpw);
         const int64_t run = std::max<int64_t>(1, std::min<int64_t>(16, n_groups / ((int64_t)p->cu_count * 8)));
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
-        const MixedBlu blu = {p->blu_nfft, p->d_chirp, p->d_blud};
+        const MixedBlu blu = {mixed_wave_local(p, false), p->blu_nfft, p->d_chirp, p->d_blud};
         if (twl)
             hipLaunchKernelGGL((pfb_fft_mixed_kernel<true, 1, false, true>), dim3(grid), dim3(threads), lds, p->stream, x, p->d_win,
                                spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams, p->mixed_tpr, 1, blu);
@@ -47,14 +55,14 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
         hipLaunchKernelGGL((pfb_fft_mixed_kernel<false, 1, false, false, true>), dim3(grid), dim3(1024), (size_t)p->nchan * sizeof(cf),
                            p->stream, x, p->d_win, spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams,
-                           1024, 1, MixedBlu{p->nchan, nullptr, nullptr});
+                           1024, 1, MixedBlu{0, p->nchan, nullptr, nullptr});
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
     }
     if (p->mixed) {
         const int threads = std::max(256, p->mixed_tpr);
         const int rpw = threads / p->mixed_tpr;
-        const MixedBlu no_blu = {p->nchan, nullptr, nullptr};
+        const MixedBlu no_blu = {mixed_wave_local(p, false), p->nchan, nullptr, nullptr};
         static const int tw_knob = env_int("FXC_MIXED_TWLDS", 1), u_knob = env_int("FXC_MIXED_U", 0);
         // U = 2 frames per slot where the measurements favour it (tools/bench_channelize.py, r04 experiments.md §7): up to 1280
         // channels (four 256-thread workgroups still fit a CU's LDS) and from 2049 to 4096 (one 1024-thread workgroup per
@@ -112,7 +120,7 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
     if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
     hipLaunchKernelGGL((pfb_fft_mixed_kernel<true, 2, true>), dim3((unsigned)grid), dim3(threads), lds, p->stream, x, p->d_win, raw,
                        p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_chunks, p->mixed_tpr, n_splits,
-                       MixedBlu{p->nchan, nullptr, nullptr});
+                       MixedBlu{mixed_wave_local(p, true), p->nchan, nullptr, nullptr});
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
 }

@@ -114,6 +114,7 @@ constexpr int kMixedXPoints = 8;    // bins per thread of the XF accumulator: nc
 //   of length nfft = 2^j >= 2 N - 1 in the row: u = v c zero-padded, Z = FFT(conj(FFT(u) D)), X[k] = c[k] conj(Z[k]),
 //   D = FFT(conj(c) wrapped) / nfft from the host (float64).  Both FFTs are the same radix-4/2 stages (mp, tw for nfft).
 struct MixedBlu {
+    int wave_local;         // slots of one wave synchronise without the workgroup barrier
     int nfft;               // == nchan when BLU is false
     const cf* chirp;        // [nchan]
     const cf* d;            // [nfft]
@@ -140,6 +141,16 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
     if (TWL)
         for (int n = threadIdx.x; n < nfft; n += blockDim.x) tw_lds[n] = tw_table[n];      // the first barrier below covers it
     const cf* tw = TWL ? tw_lds : tw_table;
+    // a slot of up to 64 threads is one wave (tpr is a power of two): its steps need no workgroup barrier -- LDS operations of
+    // a wave complete in order -- only the compiler kept from moving them across; the waves of the workgroup then drift freely
+    const bool wave_local = blu.wave_local && tpr <= 64;
+    auto slot_sync = [wave_local]() {
+        if (wave_local)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        else
+            __syncthreads();
+    };
+    if (TWL && wave_local) __syncthreads();         // the table is the whole workgroup's work
     int64_t g0, g1, s, gi;          // XF: s = chunk, the run stays inside it; else s = stream, the run walks on
     if (XF) {
         const int sp = (int)(blockIdx.x % (unsigned)n_splits);
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
             if constexpr (BLU)
                 for (int m = nch + lt_g; m < nf; m += tpr_g) rows[m] = fxc::mk(0.f, 0.f);
         }
-        __syncthreads();
+        slot_sync();
         int so = 0;
         if constexpr (BIG) {
             cf* orow = out + (s * n_pts + gf) * nch;                            // fpg = 1: the group is one frame
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                     fxc::mixed_stage<1>(rows, orow, 0, tw, nst, radix, ns, lt_g, tpr_g);
                 else
                     fxc::mixed_stage<1>(orow, rows, 0, tw, nst, radix, ns, lt_g, tpr_g);
-                __syncthreads();
+                slot_sync();
                 ns *= radix;
             }
             if ((mp.n_stages & 1) == 0)
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                 int nst = nf;
                 asm volatile("" : "+s"(nst));                                   // ... and inside the stage loop
                 fxc::mixed_stage<U>(rows + so, rows + (nst - so), row_stride, tw, nst, radix, ns, lt_g, tpr_g);
-                __syncthreads();
+                slot_sync();
                 ns *= radix;
                 so = nst - so;
             }
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                     const fxc::pk2 t = fxc::pk_cmul(fxc::pk(rows[so + k]), fxc::pk(blu.d[k]));
                     rows[so + k] = fxc::mk(t[0], -t[1]);
                 }
-                __syncthreads();
+                slot_sync();
             }
         }
         if constexpr (XF) {
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                     }
             }
         }
-        __syncthreads();
+        slot_sync();
         if (++gi == gps && !XF) {
             gi = 0;
             ++s;
@@ -311,6 +322,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
         // the slots of a workgroup (rpw > 1) hold sums over different frames of the same bins: add them up through LDS
         cf* red = reinterpret_cast<cf*>(smem) + (TWL ? nchan : 0);              // [rpw][nchan], free after the last barrier
         if (rpw > 1) {
+            __syncthreads();                        // every slot is through with its rows (wave-local slots drift apart)
 #pragma unroll
             for (int q = 0; q < kMixedXPoints; ++q) {
                 const int m = lt + q * tpr;
