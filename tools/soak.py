@@ -99,6 +99,8 @@ def main():
                 print(json.dumps({"MISMATCH_BYTES": e_b, "n_chunks": nb, "num_samp": nsb}), flush=True)
                 raise SystemExit(1)
         tol = 2e-5 if nchan == 1 else 6e-6
+        if any_n and nchan > 4096:      # both sides may be O(N) float32 sums per bin there (a large prime factor beyond the chirp-z rows)
+            tol = 1.5e-5
         key = (path, nchan if nchan in (1, 4096, 8192) else (256 if nchan <= 256 else 0), ntaps > 4)
         if any_n:
             key = ("mixed-radix", n_ant == 2, ntaps > 4)
