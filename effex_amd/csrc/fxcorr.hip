@@ -244,6 +244,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                 p->mixed_tpr = fxc::mixed_threads_per_row(m, 1024);
             }
         }
+        p->mixed_xeng = p->mixed && p->n_ant >= 3 && env_int("FXC_MIXED_XENGINE", 1);
         if (p->mixed && !p->mixed_blu && p->n_ant == 2 && env_int("FXC_MIXED_XF", 1)) {
             const size_t rpw = (size_t)(std::max(256, p->mixed_tpr) / p->mixed_tpr);
             p->mixed_xf = (rpw * 4 + 1) * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && N <= kMixedXPoints * p->mixed_tpr;

@@ -25,7 +25,7 @@ int mixed_wave_local(const fxc_plan* p, bool fused_x) {
     return v && (fused_x || p->mixed_tpr >= 16);
 }
 
-int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
+int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int ant = 1) {
     if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
     // the F-only tiled kernel writes natural-order spectra straight to `spec` (no workspace): any caller may use it
     if (p->tiled_f) return tiled_channelize(p, x, spec, n_streams);
@@ -38,7 +38,7 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
         const int64_t n_groups = n_streams * ((p->n_pts + rpw - 1) / rpw);
         const int64_t run = std::max<int64_t>(1, std::min<int64_t>(16, n_groups / ((int64_t)p->cu_count * 8)));
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
-        const MixedBlu blu = {mixed_wave_local(p, false), p->blu_nfft, p->d_chirp, p->d_blud};
+        const MixedBlu blu = {mixed_wave_local(p, false), ant, p->blu_nfft, p->d_chirp, p->d_blud};
         if (twl)
             hipLaunchKernelGGL((pfb_fft_mixed_kernel<true, 1, false, true>), dim3(grid), dim3(threads), lds, p->stream, x, p->d_win,
                                spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams, p->mixed_tpr, 1, blu);
@@ -55,14 +55,14 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams) {
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
         hipLaunchKernelGGL((pfb_fft_mixed_kernel<false, 1, false, false, true>), dim3(grid), dim3(1024), (size_t)p->nchan * sizeof(cf),
                            p->stream, x, p->d_win, spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams,
-                           1024, 1, MixedBlu{0, p->nchan, nullptr, nullptr});
+                           1024, 1, MixedBlu{0, ant, p->nchan, nullptr, nullptr});
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
     }
     if (p->mixed) {
         const int threads = std::max(256, p->mixed_tpr);
         const int rpw = threads / p->mixed_tpr;
-        const MixedBlu no_blu = {mixed_wave_local(p, false), p->nchan, nullptr, nullptr};
+        const MixedBlu no_blu = {mixed_wave_local(p, false), ant, p->nchan, nullptr, nullptr};
         static const int tw_knob = env_int("FXC_MIXED_TWLDS", 1), u_knob = env_int("FXC_MIXED_U", 0);
         // U = 2 frames per slot where the measurements favour it (tools/bench_channelize.py, r04 experiments.md §7): up to 1280
         // channels (four 256-thread workgroups still fit a CU's LDS) and from 2049 to 4096 (one 1024-thread workgroup per
@@ -120,7 +120,7 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
     if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
     hipLaunchKernelGGL((pfb_fft_mixed_kernel<true, 2, true>), dim3((unsigned)grid), dim3(threads), lds, p->stream, x, p->d_win, raw,
                        p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_chunks, p->mixed_tpr, n_splits,
-                       MixedBlu{mixed_wave_local(p, true), p->nchan, nullptr, nullptr});
+                       MixedBlu{mixed_wave_local(p, true), 1, p->nchan, nullptr, nullptr});
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
 }
@@ -158,6 +158,7 @@ int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom
     int64_t cb = ws_target() / std::max<int64_t>(1, spec_per_chunk + raw_per_chunk);
     if (cb < 1) cb = 1;
     if (cb > n_chunks) cb = n_chunks;
+    if (p->mixed_xeng && cb > 65535 / g.n_splits) cb = std::max<int64_t>(1, 65535 / g.n_splits);   // the X-engines carry chunk and range in grid.y
     *spec_bytes = (cb * spec_per_chunk + 255) / 256 * 256;
     *raw_bytes = cb * raw_per_chunk;
     return cb;
@@ -348,6 +349,8 @@ int64_t fused_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, int64_t* spec
     return cb;
 }
 
+int launch_xengine(fxc_plan* p, const cf* spec, cf* raw, int64_t nc, int cg, int xr);
+
 // raw[c][p][layout] for nc chunks starting at x; spec = scratch for the multi-antenna path.  2 antennas: rows of
 // `unit` chunks + leading-part rows (fused_rows() of them in all)
 int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, const cf* dc_u8 = nullptr, int64_t unit = 1,
@@ -361,8 +364,14 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
     int rc = p->path == FXC_PATH_FUSED ? launch_fused(p, x, nc * (p->n_ant / 2), spec, true)
                                        : tiled_channelize(p, x, spec, nc * p->n_ant, p->n_ant);
     if (rc) return rc;
-    const int cg = (int)unit;
-    const int xr = x_ranges(p, unit);
+    return launch_xengine(p, spec, raw, nc, (int)unit, x_ranges(p, unit));
+}
+
+// spec[chunk][frame][antenna][nchan] -> raw[range][group][baseline][nchan] (natural bin order): 3 .. 8 antennas in registers,
+// more on the matrix cores (plans whose nchan the tiles divide) or over blocks of 8
+int launch_xengine(fxc_plan* p, const cf* spec, cf* raw, int64_t nc, int cg, int xr) {
+    int x_ch = 16;
+    if (p->x_mfma) FXC_XMFMA_DISPATCH(p, x_ch = XMfmaGeo<XT>::kCH);
     const dim3 grid((p->nchan + kXThreads - 1) / kXThreads, (unsigned)(((nc + cg - 1) / cg) * xr));
 #define FXC_X_LAUNCH(A) \
     hipLaunchKernelGGL(xengine_kernel<A>, grid, dim3(kXThreads), 0, p->stream, spec, raw, p->n_pts, p->nchan, nc, cg, xr)
@@ -373,7 +382,7 @@ int fused_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* spec, cf* raw, cons
         case 6: FXC_X_LAUNCH(6); break;
         case 7: FXC_X_LAUNCH(7); break;
         case 8: FXC_X_LAUNCH(8); break;
-        default: if (p->x_mfma) {
+        default: if (p->x_mfma && p->nchan % x_ch == 0) {       // (the matrix-core tiles take whole columns of x_ch bins)
             FXC_XMFMA_DISPATCH(p, hipLaunchKernelGGL(xengine_mfma_kernel<XT>, dim3((unsigned)(p->nchan / XMfmaGeo<XT>::kCH), grid.y),
                                                      dim3(XMfmaGeo<XT>::kThreads), XMfmaGeo<XT>::kLdsBytes, p->stream, spec, raw,
                                                      p->n_pts, p->nchan, nc, cg, p->n_ant, xr, std::getenv("FXC_XMFMA_ABL") ? std::atoi(std::getenv("FXC_XMFMA_ABL")) : 0));

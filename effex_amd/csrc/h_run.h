@@ -101,6 +101,12 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             if (p->mixed_xf) {
                 rc = mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
                 if (rc) return rc;
+            } else if (p->mixed_xeng) {
+                // 3 .. 64 antennas off the powers of two: spectra antenna-interleaved, then the X-engines of the tiled paths
+                rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant, p->n_ant);
+                if (rc) return rc;
+                rc = launch_xengine(p, spec, raw, nc, 1, g.n_splits);
+                if (rc) return rc;
             } else {
                 rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);
                 if (rc) return rc;
@@ -258,6 +264,11 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         KernelTimer kt(p);
         if (p->mixed_xf) {
             rc = mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
+            if (rc) return rc;
+        } else if (p->mixed_xeng) {
+            rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant, p->n_ant);
+            if (rc) return rc;
+            rc = launch_xengine(p, spec, raw, nc, 1, g.n_splits);
             if (rc) return rc;
         } else {
             rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant);

@@ -115,6 +115,7 @@ constexpr int kMixedXPoints = 8;    // bins per thread of the XF accumulator: nc
 //   D = FFT(conj(c) wrapped) / nfft from the host (float64).  Both FFTs are the same radix-4/2 stages (mp, tw for nfft).
 struct MixedBlu {
     int wave_local;         // slots of one wave synchronise without the workgroup barrier
+    int ant;                // F only: spectra as out[chunk][frame][ant][nchan] for stream = chunk * ant + a (1: [stream][frame][nchan])
     int nfft;               // == nchan when BLU is false
     const cf* chirp;        // [nchan]
     const cf* d;            // [nfft]
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
         slot_sync();
         int so = 0;
         if constexpr (BIG) {
-            cf* orow = out + (s * n_pts + gf) * nch;                            // fpg = 1: the group is one frame
+            const int64_t oc = s / blu.ant;                                    // fpg = 1: the group is one frame
+            cf* orow = out + (((oc * n_pts + gf) * blu.ant) + (s - oc * blu.ant)) * nch;
             int ns = 1;
             for (int st = 0; st < mp.n_stages; ++st) {
                 const int radix = mp.radix[st];
@@ -300,7 +302,9 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                 }
             }
         } else if constexpr (!BIG) {
-            cf* o = out + (s * n_pts + gf) * nch;                               // uniform base of the group's rows
+            const int64_t oc = s / blu.ant;                                     // chunk and antenna of stream s
+            cf* o = out + (((oc * n_pts + gf) * blu.ant) + (s - oc * blu.ant)) * nch;   // uniform base of the group's rows
+            const int fstride = blu.ant * nch;                                  // from one frame's row to the next
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int fr = sub_g * U + u;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                     for (int n = lt_g; n < nch; n += tpr_g) {
                         cf v = rows[u * row_stride + so + n];
                         if constexpr (BLU) v = fxc::unpk(fxc::pk_cmul(fxc::pk(fxc::mk(v.x, -v.y)), fxc::pk(blu.chirp[n])));
-                        o[(unsigned)(fr * nch + n)] = v;
+                        o[(unsigned)(fr * fstride + n)] = v;
                     }
             }
         }

@@ -724,6 +724,8 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
     # a prime factor beyond 45 nfft / nchan: chirp-z rows (Bluestein), table in LDS up to 4096 points, from global at 8192
     (2, 1002, 4, 2, 12, 5), (3, 4093, 4, 1, 5, 0), (2, 2049, 2, 2, 7, 1), (2, 97, 5, 3, 200, 3), (2, 127, 4, 1, 1, 0), (2, 67, 4, 2, 50, 0),
     (2, 4096 + 1, 4, 1, 3, 0), (2, 8190 // 2 + 4, 4, 1, 2, 0), (2, 251, 4, 3, 77, 2), (3, 509, 3, 2, 31, 0),
+    # 3 .. 64 antennas: spectra antenna-interleaved, then the X-engines of the tiled paths (registers up to 8, blocks of 8 beyond)
+    (8, 1000, 4, 3, 30, 3), (11, 96, 4, 2, 200, 1), (16, 250, 3, 2, 40, 0), (7, 2310, 2, 1, 5, 0), (9, 12, 4, 5, 1000, 2),
     # beyond 10240 channels one row is all the LDS holds: the stages alternate between it and the output row
     (2, 12000, 4, 2, 3, 7), (3, 15000, 2, 1, 2, 0), (2, 10241, 4, 1, 2, 0), (2, 16380, 4, 1, 1, 0)])
 def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, nchan, ntaps, n_chunks, frames, extra):
@@ -732,7 +734,7 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
     larger ones as a chirp-z convolution; with two antennas the same kernel multiplies and integrates) -- against the oracle,
     and against the direct O(N^2) DFT kernel it replaced."""
     num_samp = nchan * frames + extra
-    x = synth.synth_iq(777 + nchan, n_chunks, n_ant, num_samp)
+    x = synth.synth_iq(777 + nchan, n_chunks, n_ant, num_samp, delays=np.arange(n_ant) % 7)
     window = design_window(ntaps, nchan)
     rot = plan_mod.rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, -2e-7)
     xd = torch.from_numpy(x).cuda()
@@ -747,6 +749,11 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
         p.fx_accumulate(xd[n_chunks // 3 + 1:])
         integ = p.finalize("SPECTRUM")
         assert rel_err(integ, rows.astype(np.complex128).mean(axis=0)) < 2e-6
+        if n_ant > 2:                           # every baseline, in the order (0,1),(0,2),...: the oracle's integration of chunk 0
+            p.set_rot(plan_mod.rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, 0.0))
+            all_b = p.fx_rows(xd[:1]).cpu().numpy()[0]
+            assert rel_err(all_b, fx_oracle.fx_integrate(x[:1], nchan, window)) < TOL_VIS
+            p.set_rot(rot)
         spec = p.channelize(xd[0, 0]).cpu().numpy()
         assert rel_err(spec.reshape(-1, nchan), fx_oracle.spectrometer_poly(x[0, 0], ntaps, nchan, window)) < TOL_VIS
         if n_ant == 2 and nchan <= 4096:       # the steps either side of the path: receiver bytes in, DC removal on the device
