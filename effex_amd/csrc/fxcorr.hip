@@ -174,6 +174,54 @@ int fxc_plan_destroy(fxc_plan* p) {
     return FXC_OK;
 }
 
+// float64 transform of any length on the host, kernel exp(+2 pi i j k / n): decimation in time over the smallest prime factor,
+// a direct sum for a prime length (the chirp-z table: 7-smooth lengths up to 8192, built once per plan)
+static std::vector<cd> host_dft(const std::vector<cd>& x) {
+    const int n = (int)x.size();
+    if (n == 1) return x;
+    int p1 = n;
+    for (int q = 2; q * q <= n; ++q)
+        if (n % q == 0) {
+            p1 = q;
+            break;
+        }
+    std::vector<cd> out((size_t)n);
+    if (p1 == n) {
+        for (int k = 0; k < n; ++k) {
+            double ar = 0.0, ai = 0.0;
+            for (int j = 0; j < n; ++j) {
+                const double ph = kTwoPi * (double)(((int64_t)j * k) % n) / (double)n;
+                const double wr = std::cos(ph), wi = std::sin(ph);
+                ar += x[j].x * wr - x[j].y * wi;
+                ai += x[j].x * wi + x[j].y * wr;
+            }
+            out[k].x = ar;
+            out[k].y = ai;
+        }
+        return out;
+    }
+    const int m = n / p1;                                   // x[p1 j + r] -> p1 transforms of m points
+    std::vector<std::vector<cd>> sub((size_t)p1);
+    for (int r = 0; r < p1; ++r) {
+        std::vector<cd> part((size_t)m);
+        for (int j = 0; j < m; ++j) part[j] = x[(size_t)p1 * j + r];
+        sub[r] = host_dft(part);
+    }
+    for (int k = 0; k < n; ++k) {
+        double ar = 0.0, ai = 0.0;
+        for (int r = 0; r < p1; ++r) {
+            const double ph = kTwoPi * (double)(((int64_t)r * k) % n) / (double)n;
+            const double wr = std::cos(ph), wi = std::sin(ph);
+            const cd v = sub[r][k % m];
+            ar += v.x * wr - v.y * wi;
+            ai += v.x * wi + v.y * wr;
+        }
+        out[k].x = ar;
+        out[k].y = ai;
+    }
+    return out;
+}
+
 static int plan_build(fxc_plan* p, const double* window, int force_path) {
     hipDeviceProp_t prop;
     FXC_HIP(p, hipGetDeviceProperties(&prop, p->device));
@@ -233,8 +281,30 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             // a large prime factor costs more as an O(N p) stage than the whole transform as a chirp-z convolution
             int pmax = 1;
             for (int st = 0; st < p->mixed_plan.n_stages; ++st) pmax = std::max(pmax, p->mixed_plan.radix[st]);
-            int m = 1;
-            while (m < 2 * N - 1) m <<= 1;
+            // the convolution length: any 7-smooth number from 2 N - 1 up to the next power of two -- the one whose stages cost
+            // least (points x a weight per stage from the measured stage times), not the power of two itself (2049 channels:
+            // 4116 = 4 3 7 7 7 points instead of 8192)
+            int m_pow2 = 1;
+            while (m_pow2 < 2 * N - 1) m_pow2 <<= 1;
+            int m = m_pow2;
+            if (env_int("FXC_BLU_SMOOTH", 1)) {
+                double best = 1e300;
+                for (int cand = 2 * N - 1; cand <= m_pow2; ++cand) {
+                    int rest = cand;
+                    double w = 0.0;
+                    for (int q : {4, 2, 3, 5, 7}) {
+                        const double wq = q == 4 ? 1.0 : q == 2 ? 0.8 : q == 3 ? 1.0 : q == 5 ? 1.5 : 2.0;
+                        while (rest % q == 0) {
+                            rest /= q;
+                            w += wq;
+                        }
+                    }
+                    if (rest == 1 && w * cand < best) {
+                        best = w * cand;
+                        m = cand;
+                    }
+                }
+            }
             // measured (profiles/r04/experiments.md §7): the stage costs ~p, the chirp-z rows ~nfft / N; they cross near p = 45 nfft / N
             const int p_min = env_int("FXC_BLU_MIN_PRIME", (int)((int64_t)kBluPrimePerRatio * m / N));
             if (pmax > p_min && m <= kBluMaxNfft) {
@@ -280,25 +350,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             d[m].y = -c[m].y;
             if (m) d[M - m] = d[m];
         }
-        int lg = 0;
-        while ((1 << lg) < M) ++lg;
-        for (int i = 0; i < M; ++i) {
-            int r = 0;
-            for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
-            if (r > i) std::swap(d[i], d[r]);
-        }
-        for (int half = 1; half < M; half <<= 1)
-            for (int i0 = 0; i0 < M; i0 += 2 * half)
-                for (int j = 0; j < half; ++j) {
-                    const double ph = kTwoPi * (double)j / (double)(2 * half);
-                    const double wr = std::cos(ph), wi = std::sin(ph);
-                    const cd a = d[i0 + j], b = d[i0 + j + half];
-                    const double tr = b.x * wr - b.y * wi, ti = b.x * wi + b.y * wr;
-                    d[i0 + j].x = a.x + tr;
-                    d[i0 + j].y = a.y + ti;
-                    d[i0 + j + half].x = a.x - tr;
-                    d[i0 + j + half].y = a.y - ti;
-                }
+        d = host_dft(d);
         std::vector<cf> cfl((size_t)N), dfl((size_t)M);
         for (int n = 0; n < N; ++n) cfl[n] = fxc::mk((float)c[n].x, (float)c[n].y);
         for (int k = 0; k < M; ++k) dfl[k] = fxc::mk((float)(d[k].x / M), (float)(d[k].y / M));
