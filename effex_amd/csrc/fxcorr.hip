@@ -73,7 +73,7 @@ constexpr int kMaxTaps = 32;         // cusignal ships 8x8 / 16x16 / 32x32 chann
 constexpr int kMaxXAnt = 64;         // antennas the F-only + X-engine route takes (fxc_plan_create's own limit)
 constexpr int kMaxLdsFftN = 16384;   // 128 KiB of complex64 in LDS
 constexpr int kBluPrimePerRatio = 45;  // prime factors beyond 45 nfft / N: the chirp-z form (see pfb_fft_mixed_kernel, BLU)
-constexpr int kBluMaxNfft = 8192;     // two chirp-z rows in LDS
+constexpr int kBluMaxNfft = 10240;    // two chirp-z rows in the 160 KiB of LDS: up to 5120 channels
 constexpr int kMixedMaxN = 10240;    // two rows of complex64 in the 160 KiB of LDS (pfb_fft_mixed_kernel)
 size_t res_direct_bytes() {      // finalize results up to this size are written to host memory by the kernel (FXC_RES_DIRECT: developer knob, bytes)
     static const size_t v = [] { const char* e = std::getenv("FXC_RES_DIRECT"); return e ? (size_t)std::atoll(e) : (size_t)(256 << 10); }();
@@ -289,7 +289,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             int m = m_pow2;
             if (env_int("FXC_BLU_SMOOTH", 1)) {
                 double best = 1e300;
-                for (int cand = 2 * N - 1; cand <= m_pow2; ++cand) {
+                for (int cand = 2 * N - 1; cand <= std::min(m_pow2, kBluMaxNfft); ++cand) {
                     int rest = cand;
                     double w = 0.0;
                     for (int q : {4, 2, 3, 5, 7}) {

@@ -724,6 +724,7 @@ def test_small_channel_counts_match_oracle(plan_mod, torch, nchan, ntaps, n_chun
     # a prime factor beyond 45 nfft / nchan: chirp-z rows (Bluestein), table in LDS up to 4096 points, from global at 8192
     (2, 1002, 4, 2, 12, 5), (3, 4093, 4, 1, 5, 0), (2, 2049, 2, 2, 7, 1), (2, 97, 5, 3, 200, 3), (2, 127, 4, 1, 1, 0), (2, 67, 4, 2, 50, 0),
     (2, 4096 + 1, 4, 1, 3, 0), (2, 8190 // 2 + 4, 4, 1, 2, 0), (2, 251, 4, 3, 77, 2), (3, 509, 3, 2, 31, 0),
+    (2, 5003, 4, 1, 3, 1), (2, 5119, 2, 1, 2, 0),       # 10 080 / 10 240 points: the largest rows that fit
     # 3 .. 64 antennas: spectra antenna-interleaved, then the X-engines of the tiled paths (registers up to 8, blocks of 8 beyond)
     (8, 1000, 4, 3, 30, 3), (11, 96, 4, 2, 200, 1), (16, 250, 3, 2, 40, 0), (7, 2310, 2, 1, 5, 0), (9, 12, 4, 5, 1000, 2),
     # beyond 10240 channels one row is all the LDS holds: the stages alternate between it and the output row
