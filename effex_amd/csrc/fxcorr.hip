@@ -274,7 +274,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         p->mixed = N > 1 && N <= kMaxLdsFftN && !force_old && (!p->pow2 || force_mixed || auto_pow2);
         if (p->mixed) {
             p->mixed_plan = fxc::mixed_factor(N);
-            p->mixed_tpr = fxc::mixed_threads_per_row(N, env_int("FXC_MIXED_TPR", 1024));
+            p->mixed_tpr = fxc::mixed_threads_per_row(N, env_int("FXC_MIXED_TPR", 1024), p->n_ant == 2);
             if (p->mixed_plan.n_stages < 0) p->mixed = false;
         }
         if (p->mixed) {
