@@ -226,6 +226,7 @@ inline int mixed_threads_per_row(int n, int cap = 1024, bool fused_x = false) {
     // 257 .. 384 channels, two antennas: a wave per row (no workgroup barrier) beats 128 part-used threads (300 channels 3.44 ->
     // 2.42 ms); F only it is the other way round (360 channels 1.49 -> 1.65 ms)
     if (fused_x && t == 128 && n <= 384) t = 64;
+    if (fused_x && t == 256 && n <= 640) t = 128;    // 513 .. 640: two slots of 128 (600 channels 3.78 -> 3.51 ms; from 700 on no more)
     return t;
 }
 
