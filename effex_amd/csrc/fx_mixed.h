@@ -144,17 +144,28 @@ FXC_HD void mixed_stage_reg(const cf* src, cf* dst, int row_stride, const cf* tw
     for (int b = lt; b < nb; b += tpr) {
         const int k = b - small_div(b, inv_ns) * ns;
         const int e = k * tmul;        // < N/R, so r e < N for every r < R: the index never wraps
-        pk2 w[R];
-#pragma unroll
-        for (int r = 1; r < R; ++r) w[r] = pk(tw[r * e]);
         const int o = (b - k) * R + k;
-#pragma unroll R >= 7 ? 1 : U                  // the big butterflies one row at a time: U of them at once spill
-        for (int u = 0; u < U; ++u) {
-            pk2 v[R];
-            v[0] = pk(src[u * row_stride + b]);
+        if constexpr (R >= 11 && U > 1) {       // 11, 13 with several rows: the twiddles fetched again per row (kept, they spill)
+#pragma unroll 1
+            for (int u = 0; u < U; ++u) {
+                pk2 v[R];
+                v[0] = pk(src[u * row_stride + b]);
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[r] = pk_cmul(pk(src[u * row_stride + b + r * nb]), w[r]);
-            dft_store<R>(v, rt, dst + u * row_stride + o, ns);
+                for (int r = 1; r < R; ++r) v[r] = pk_cmul(pk(src[u * row_stride + b + r * nb]), pk(tw[r * e]));
+                dft_store<R>(v, rt, dst + u * row_stride + o, ns);
+            }
+        } else {
+            pk2 w[R];
+#pragma unroll
+            for (int r = 1; r < R; ++r) w[r] = pk(tw[r * e]);
+#pragma unroll R >= 7 ? 1 : U                  // the big butterflies one row at a time: U of them at once spill
+            for (int u = 0; u < U; ++u) {
+                pk2 v[R];
+                v[0] = pk(src[u * row_stride + b]);
+#pragma unroll
+                for (int r = 1; r < R; ++r) v[r] = pk_cmul(pk(src[u * row_stride + b + r * nb]), w[r]);
+                dft_store<R>(v, rt, dst + u * row_stride + o, ns);
+            }
         }
     }
 }
@@ -188,7 +199,11 @@ FXC_HD void mixed_stage_any(const cf* src, cf* dst, int row_stride, const cf* tw
     }
 }
 
-template <int U>
+// BIG_REG: the register butterflies for 11 and 13 also with U > 1 (twiddles fetched again per row).  They cost ~8 VGPRs on the
+// whole kernel -- the two-antenna kernel has them to spare (still four workgroups per CU; 1001 channels 5.34 -> 3.44 ms), the
+// F-only kernel with two frames per slot would drop from five to four (360 channels 1.60 -> 1.74 ms) and goes without: the
+// host gives channel counts with these factors one frame per slot there (mixed_rows_per_slot_cap).
+template <int U, bool BIG_REG = (U == 1)>
 FXC_HD void mixed_stage(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int radix, int ns, int lt, int tpr) {
     switch (radix) {
         case 2: mixed_stage_reg<2, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
@@ -196,9 +211,9 @@ FXC_HD void mixed_stage(const cf* src, cf* dst, int row_stride, const cf* tw, in
         case 4: mixed_stage_reg<4, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
         case 5: mixed_stage_reg<5, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
         case 7: mixed_stage_reg<7, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
-        case 11:        // the two big register butterflies only one row at a time (more rows: spills); the host picks U = 1
-        case 13:        // for channel counts with these factors (mixed_rows_per_slot_cap)
-            if constexpr (U == 1) {
+        case 11:
+        case 13:
+            if constexpr (BIG_REG) {
                 if (radix == 11)
                     mixed_stage_reg<11, U>(src, dst, row_stride, tw, n, ns, lt, tpr);
                 else
@@ -210,7 +225,7 @@ FXC_HD void mixed_stage(const cf* src, cf* dst, int row_stride, const cf* tw, in
     }
 }
 
-// most rows per slot the kernel should take for this factorisation
+// most frames per slot the F-only kernel should take for this factorisation (see mixed_stage)
 inline int mixed_rows_per_slot_cap(const MixedPlan& mp) {
     for (int s = 0; s < mp.n_stages; ++s)
         if (mp.radix[s] == 11 || mp.radix[s] == 13) return 1;

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                 const int radix = mp.radix[st];
                 int nst = nf;
                 asm volatile("" : "+s"(nst));                                   // ... and inside the stage loop
-                fxc::mixed_stage<U>(rows + so, rows + (nst - so), row_stride, tw, nst, radix, ns, lt_g, tpr_g);
+                fxc::mixed_stage<U, XF || U == 1>(rows + so, rows + (nst - so), row_stride, tw, nst, radix, ns, lt_g, tpr_g);
                 slot_sync();
                 ns *= radix;
                 so = nst - so;
