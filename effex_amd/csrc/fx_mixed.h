@@ -16,7 +16,6 @@
 namespace fxc {
 
 constexpr int kMixedMaxStages = 16;      // 2^14 = 16384 is the largest N, and fours are taken before twos
-constexpr int kMixedMaxRegRadix = 13;    // primes up to here are register butterflies; larger ones walk the LDS row
 
 struct MixedPlan {
     int n_stages;

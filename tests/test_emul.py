@@ -135,6 +135,13 @@ def test_mixed_radix_stages_match_numpy(emul_mixed, n):
         stages = emul_mixed.emul_mixed_fft(x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), n, tpr, radices)
         assert stages >= 0 and int(np.prod(list(radices)[:stages], dtype=np.int64)) == n
         assert np.abs(out - ref).max() <= 4e-6 * max(np.abs(ref).max(), 1e-30), (n, tpr)
+    # two rows a slot carries through the stages together (one index computation, one set of twiddles)
+    x2 = np.stack([x, x[::-1] * (0.5 - 0.25j)]).astype(np.complex64)
+    out2 = np.zeros_like(x2)
+    assert emul_mixed.emul_mixed_fft_two_rows(x2.ctypes.data_as(ctypes.c_void_p), out2.ctypes.data_as(ctypes.c_void_p), n,
+                                              emul_mixed.emul_mixed_threads_per_row(n)) >= 0
+    ref2 = np.fft.ifft(x2.astype(np.complex128), axis=1) * n
+    assert np.abs(out2 - ref2).max() <= 4e-6 * max(np.abs(ref2).max(), 1e-30), n
 
 
 @pytest.fixture(scope="module")
