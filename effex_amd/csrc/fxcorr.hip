@@ -605,6 +605,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -1065,7 +1066,8 @@ int fxc_convert_u8(fxc_plan* p, const void* iq_u8_dev, void* out_dev, int64_t n_
 
 namespace {
 
-// uint8 I,Q in: fused plans (2 antennas, nchan 4096, ntaps 4) read the bytes in the F+X kernel itself; every other plan
+// uint8 I,Q in: fused plans (2 antennas: nchan 4096 / ntaps 4, the tiled ring and wave-local kernels, the mixed-radix F + X
+// kernel) read the bytes in the F+X kernel itself; every other plan
 // converts into a complex64 staging buffer first.  rows: fxc_fx_rows semantics (out != nullptr) or accumulate.
 int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks, int mode, double bandwidth, int remove_dc,
               bool rows) {
@@ -1073,7 +1075,8 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
     const size_t row_elems = mode == FXC_MODE_SPECTRUM ? (size_t)p->n_base * p->nchan * sizeof(cf) : (size_t)p->n_base * sizeof(cd);
     // chunks per pass: dc_sum_u8_kernel carries the stream index in grid.y (<= 65535 streams), and plans without the
     // fused ingest convert a pass into a complex64 staging buffer that stays within the workspace target
-    const bool fused_in = p->n_ant == 2 && !p->prefilter && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && (p->tiled_ring || p->small)));
+    const bool fused_in = p->n_ant == 2 && !p->prefilter && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && (p->tiled_ring || p->small)) ||
+                                                              (p->path == FXC_PATH_GENERIC && p->mixed_xf && env_int("FXC_MIXED_U8", 1)));
     int64_t per_pass = std::min<int64_t>(16384, 65535 / p->n_ant);
     if (!fused_in) per_pass = std::min<int64_t>(per_pass, ws_target() / ((int64_t)p->n_ant * p->num_samp * (int64_t)sizeof(cf)));
     per_pass = std::max<int64_t>(1, per_pass);

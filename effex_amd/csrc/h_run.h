@@ -99,7 +99,10 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             const int64_t nc = std::min(cb, n_chunks - c0);
             KernelTimer kt(p);
             if (p->mixed_xf) {
-                rc = mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
+                // (bytes in: two per sample, and the offsets of this pass's streams)
+                rc = dc_u8 ? mixed_fx_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * 2 * p->num_samp * 2),
+                                               nc, g.n_splits, raw, dc_u8 + c0 * 2)
+                           : mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
                 if (rc) return rc;
             } else if (p->mixed_xeng) {
                 // 3 .. 64 antennas off the powers of two: spectra antenna-interleaved, then the X-engines of the tiled paths
@@ -263,7 +266,9 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         const int64_t nc = std::min(cb, n_chunks - c0);
         KernelTimer kt(p);
         if (p->mixed_xf) {
-            rc = mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
+            rc = dc_u8 ? mixed_fx_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * 2 * p->num_samp * 2),
+                                           nc, g.n_splits, raw, dc_u8 + c0 * 2)
+                       : mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
             if (rc) return rc;
         } else if (p->mixed_xeng) {
             rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant, p->n_ant);

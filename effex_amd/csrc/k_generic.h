@@ -119,11 +119,15 @@ struct MixedBlu {
     int nfft;               // == nchan when BLU is false
     const cf* chirp;        // [nchan]
     const cf* d;            // [nfft]
+    const cf* dc_u8;        // U8: conversion offsets [stream]
 };
 //   BIG = true (10240 < nchan <= 16384: one row is all the LDS holds; F only, U = 1, 1024 threads): the stages go back and
 //   forth between the LDS row and the frame's own row of `out` (L2-resident; __syncthreads() orders global memory within the
 //   workgroup), and the spectrum ends in `out` either way.
-template <bool TWL, int U, bool XF, bool BLU = false, bool BIG = false>
+//   U8 = true (with XF): x is the receivers' interleaved unsigned bytes [chunk][2][num_samp][2] and blu.dc_u8 the conversion
+//   offsets per stream (k_conditioning.h: sample = byte / 127.5 + offset, one FMA -- pyrtlsdr's conversion behind effex.py:652
+//   and the DC removal of effex.py:394-395); a quarter of the bytes of complex64 through the fabric, and no conversion pass.
+template <bool TWL, int U, bool XF, bool BLU = false, bool BIG = false, bool U8 = false>
 __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restrict__ x, const float* __restrict__ h,
                                                             cf* __restrict__ out, const cf* __restrict__ tw_table,
                                                             const fxc::MixedPlan mp, int64_t num_samp, int nchan, int ntaps,
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
     static_assert(!XF || U == 2, "the fused X stage pairs two antennas");
     static_assert(!BLU || (U == 1 && !XF), "the chirp-z rows go one at a time, F only");
     static_assert(!BIG || (U == 1 && !XF && !BLU && !TWL), "one LDS row: plain F stage, twiddles from the table");
+    static_assert(!U8 || XF, "the byte ingest is the two-antenna kernel's");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nfft = BLU ? blu.nfft : nchan;
     const int rpw = (int)blockDim.x / tpr;
@@ -184,6 +189,14 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
         if constexpr (XF) {
             const cf* xg0 = x + (2 * s) * num_samp + frame_lo * nch;             // uniform bases; lane offsets stay small
             const cf* xg1 = xg0 + num_samp;
+            const unsigned short* xb0 = reinterpret_cast<const unsigned short*>(x) + (2 * s) * num_samp + frame_lo * nch;
+            const unsigned short* xb1 = xb0 + num_samp;
+            const float k8 = 1.0f / 127.5f;
+            fxc::pk2 off0 = fxc::pk_splat(0.f), off1 = off0;
+            if constexpr (U8) {
+                off0 = fxc::pk(blu.dc_u8[2 * s]);
+                off1 = fxc::pk(blu.dc_u8[2 * s + 1]);
+            }
             const int f0 = (int)(gf - frame_lo) + sub_g;
             for (int m = lt_g; m < nch; m += tpr_g) {
                 fxc::pk2 acc0 = fxc::pk_splat(0.f), acc1 = acc0;
@@ -195,7 +208,16 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                         const int f = f0 - t0 - 3 + j;                          // frame f0 - (t0 + v) at j = 3 - v
                         const bool ok = f >= 0 && f < f_end;
                         const unsigned off = ok ? (unsigned)(f * nch + nch - 1 - m) : 0u;
-                        const fxc::pk2 l0 = fxc::pk(xg0[off]), l1 = fxc::pk(xg1[off]);
+                        fxc::pk2 l0, l1;
+                        if constexpr (U8) {
+                            const unsigned r0 = xb0[off], r1 = xb1[off];
+                            const fxc::pk2 b0 = {(float)(r0 & 0xFFu), (float)(r0 >> 8)}, b1 = {(float)(r1 & 0xFFu), (float)(r1 >> 8)};
+                            l0 = fxc::pk_fma(b0, fxc::pk_splat(k8), off0);
+                            l1 = fxc::pk_fma(b1, fxc::pk_splat(k8), off1);
+                        } else {
+                            l0 = fxc::pk(xg0[off]);
+                            l1 = fxc::pk(xg1[off]);
+                        }
                         xv0[j] = ok ? l0 : fxc::pk_splat(0.f);
                         xv1[j] = ok ? l1 : fxc::pk_splat(0.f);
                     }

@@ -759,8 +759,16 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
         assert rel_err(spec.reshape(-1, nchan), fx_oracle.spectrometer_poly(x[0, 0], ntaps, nchan, window)) < TOL_VIS
         if n_ant == 2 and nchan <= 4096:       # the steps either side of the path: receiver bytes in, DC removal on the device
             u8 = torch.from_numpy(np.random.default_rng(nchan).integers(0, 256, size=(2, 2, num_samp, 2), dtype=np.uint8)).cuda()
-            by = p.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()
-            assert rel_err(by, p.fx_rows(p.convert_u8(u8, remove_dc=True)).cpu().numpy()) < 1e-6
+            by = p.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()      # (bytes converted inside the F + X kernel)
+            assert rel_err(by, p.fx_rows(p.convert_u8(u8, remove_dc=True)).cpu().numpy()) < TOL_VIS
+            a = fx_oracle.u8_to_complex(u8[:1].cpu().numpy())[0]
+            p.set_rot(plan_mod.rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, 0.0))
+            by0 = p.fx_rows_u8(u8[:1], "SPECTRUM", remove_dc=True).cpu().numpy()
+            p.set_rot(rot)
+            assert rel_err(by0[0, 0], fx_oracle.pfb_xcorr(fx_oracle.remove_dc(a[0]), fx_oracle.remove_dc(a[1]), ntaps, nchan, window,
+                                                          gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")) < TOL_VIS
+            p.fx_accumulate_u8(u8, remove_dc=True)
+            assert rel_err(p.finalize("SPECTRUM"), by.astype(np.complex128).mean(axis=0)) < 2e-6
             dc = p.fx_rows(xd[:1] + (0.25 - 0.5j), remove_dc=True).cpu().numpy()
             ref = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(x[0, 0] + (0.25 - 0.5j)), fx_oracle.remove_dc(x[0, 1] + (0.25 - 0.5j)),
                                       ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, -2e-7, "SPECTRUM")
@@ -1341,11 +1349,13 @@ def test_input_conditioning_on_device(plan_mod, torch):
 
 @pytest.mark.parametrize("nchan,frames,n_chunks,remove_dc", [(4096, 9, 3, True), (4096, 5, 300, True), (4096, 6, 2, False),
                                                              (1024, 12, 4, True), (2048, 7, 3, True), (512, 300, 1, True),
-                                                             (8192, 3, 2, True), (64, 40, 2, True)])
+                                                             (8192, 3, 2, True), (64, 40, 2, True),
+                                                             (1000, 12, 4, True), (96, 50, 3, False), (360, 9, 300, True), (6, 2000, 2, True)])
 def test_fx_straight_from_rtlsdr_bytes(plan_mod, torch, nchan, frames, n_chunks, remove_dc):
     """fxc_fx_rows_u8 / fxc_fx_accumulate_u8: the byte stream of the reference's receivers (pyrtlsdr conversion behind
-    effex.py:652, DC removal of effex.py:394-395) straight into F+X.  The headline shape and the tiled ring kernels read
-    the bytes inside the kernel (also across frame-range splits); other plans convert first.  Checked against the oracle chain and against the two-step device path."""
+    effex.py:652, DC removal of effex.py:394-395) straight into F+X.  The headline shape, the tiled ring kernels and the mixed-radix
+    F + X kernel (channel counts that are not a power of two) read the bytes inside the kernel (also across frame-range splits);
+    other plans convert first.  Checked against the oracle chain and against the two-step device path."""
     num_samp = nchan * frames + 37
     rng = np.random.default_rng(2024 + nchan)
     u8 = rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)
