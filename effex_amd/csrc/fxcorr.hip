@@ -1045,6 +1045,17 @@ int fxc_remove_dc(fxc_plan* p, const void* x_dev, void* out_dev, int64_t n_strea
     return FXC_OK;
 }
 
+namespace {
+// bytes -> complex64 of n_streams streams: a few thousand workgroups, each on one slice of a stream at a time
+void launch_convert_u8(fxc_plan* p, const unsigned char* x8, cf* out, const double* part, int n_slices, int64_t n_streams, int remove_dc) {
+    const unsigned gy = (unsigned)std::min<int64_t>(n_streams, 65535);
+    const int64_t per_stream = std::max<int64_t>(1, ((int64_t)p->cu_count * 16 + gy - 1) / gy);
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(per_stream, (p->num_samp + 1023) / 1024));
+    hipLaunchKernelGGL(convert_u8_kernel, dim3(gx, gy), dim3(256), 0, p->stream, x8, out, part, p->num_samp, n_slices, n_streams,
+                       remove_dc ? 1 : 0);
+}
+}  // namespace
+
 int fxc_convert_u8(fxc_plan* p, const void* iq_u8_dev, void* out_dev, int64_t n_streams, int remove_dc) {
     int rc = conditioning_common(p, n_streams, iq_u8_dev, out_dev);
     if (rc || n_streams == 0) return rc;
@@ -1053,13 +1064,10 @@ int fxc_convert_u8(fxc_plan* p, const void* iq_u8_dev, void* out_dev, int64_t n_
     rc = ensure_ws(p, n_streams * n_slices * 2 * (int64_t)sizeof(double));
     if (rc) return rc;
     double* part = static_cast<double*>(p->d_ws);
-    const int64_t total = n_streams * p->num_samp;
     if (remove_dc)
-        hipLaunchKernelGGL(dc_sum_u8_kernel, dim3(n_slices, (unsigned)n_streams), dim3(256), 0, p->stream,
-                           static_cast<const unsigned char*>(iq_u8_dev), part, p->num_samp, n_slices);
-    hipLaunchKernelGGL(convert_u8_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream,
-                       static_cast<const unsigned char*>(iq_u8_dev), static_cast<cf*>(out_dev), part, p->num_samp,
-                       n_slices, total, remove_dc ? 1 : 0);
+        hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(n_streams * n_slices, (int64_t)p->cu_count * 16)),
+                           dim3(256), 0, p->stream, static_cast<const unsigned char*>(iq_u8_dev), part, p->num_samp, n_streams, n_slices);
+    launch_convert_u8(p, static_cast<const unsigned char*>(iq_u8_dev), static_cast<cf*>(out_dev), part, n_slices, n_streams, remove_dc);
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
 }
@@ -1073,7 +1081,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
               bool rows) {
     constexpr int kSlices = 32;
     const size_t row_elems = mode == FXC_MODE_SPECTRUM ? (size_t)p->n_base * p->nchan * sizeof(cf) : (size_t)p->n_base * sizeof(cd);
-    // chunks per pass: dc_sum_u8_kernel carries the stream index in grid.y (<= 65535 streams), and plans without the
+    // chunks per pass: at most 65535 streams (a grid dimension of the conditioning kernels), and plans without the
     // fused ingest convert a pass into a complex64 staging buffer that stays within the workspace target
     const bool fused_in = p->n_ant == 2 && !p->prefilter && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && (p->tiled_ring || p->small)) ||
                                                               (p->path == FXC_PATH_GENERIC && p->mixed_xf && env_int("FXC_MIXED_U8", 1)));
@@ -1118,8 +1126,8 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
                                    part + lo[r] * p->n_ant * 2 * sl, dc + lo[r] * p->n_ant, ns, sl, p->num_samp, 1);
             }
         } else if (remove_dc) {
-            hipLaunchKernelGGL(dc_sum_u8_kernel, dim3(kSlices, (unsigned)n_streams), dim3(256), 0, p->stream, xb, part,
-                               p->num_samp, kSlices);
+            hipLaunchKernelGGL(dc_sum_u8_stream_kernel, dim3((unsigned)std::min<int64_t>(n_streams * kSlices, (int64_t)p->cu_count * 16)),
+                               dim3(256), 0, p->stream, xb, part, p->num_samp, n_streams, kSlices);
         }
         if (fused_ingest) {
             if (!remove_dc)
@@ -1135,8 +1143,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
             rc = grow(p, &p->d_stage[2], &p->stage_bytes[2], (size_t)total * sizeof(cf));
             if (rc) return rc;
             cf* xc = static_cast<cf*>(p->d_stage[2]);
-            hipLaunchKernelGGL(convert_u8_kernel, dim3(grid_for(total, 256, p->cu_count)), dim3(256), 0, p->stream, xb, xc,
-                               part, p->num_samp, kSlices, total, remove_dc ? 1 : 0);
+            launch_convert_u8(p, xb, xc, part, kSlices, n_streams, remove_dc);
             FXC_HIP(p, hipGetLastError());
             rc = rows ? fx_rows_dev(p, xc, ob, nc, mode, bandwidth) : fx_accumulate_dev(p, xc, nc);
         }

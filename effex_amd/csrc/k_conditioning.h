@@ -42,28 +42,7 @@ __global__ __launch_bounds__(256) void dc_sum_c64_kernel(const cf* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void dc_sum_u8_kernel(const unsigned char* __restrict__ x, double* __restrict__ part,
-                                                       int64_t num_samp, int n_slices) {
-    __shared__ double red[256];
-    const int64_t s = blockIdx.y;
-    const int slice = blockIdx.x;
-    const int64_t per = (num_samp + n_slices - 1) / n_slices;
-    const int64_t lo = slice * per, hi = (lo + per < num_samp) ? lo + per : num_samp;
-    unsigned long long ar = 0, ai = 0;      // byte sums are exact
-    for (int64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
-        const unsigned short v = reinterpret_cast<const unsigned short*>(x)[s * num_samp + n];
-        ar += v & 0xFF;
-        ai += v >> 8;
-    }
-    const double sr = block_sum((double)ar, red);
-    const double si = block_sum((double)ai, red);
-    if (threadIdx.x == 0) {
-        part[(s * n_slices + slice) * 2] = sr;
-        part[(s * n_slices + slice) * 2 + 1] = si;
-    }
-}
-
-// fused uint8 ingest: exact byte sums of streams, 16-byte loads (8 samples per lane).  n_slices == 1: one workgroup per
+// uint8 ingest (fused and through the conversion pass): exact byte sums of streams, 16-byte loads (8 samples per lane).  n_slices == 1: one workgroup per
 // stream, part[s * 2] = sum of I bytes, part[s * 2 + 1] = sum of Q bytes.  n_slices > 1 (calls of a few streams -- the
 // reference hands over one chunk pair at a time, effex.py:490-494 -- would leave a stream of 512 KiB to one workgroup):
 // workgroup w sums slice w % n_slices of stream w / n_slices into part[(s n_slices + slice) * 2]; the sums are integers,
@@ -193,25 +172,37 @@ __global__ __launch_bounds__(256) void narrow_c128_kernel(const cd* __restrict__
     }
 }
 
-// out = (byte - 127.5) / 127.5 [- mean]; remove_dc == 0 keeps the mean
-__global__ void convert_u8_kernel(const unsigned char* __restrict__ x, cf* __restrict__ out, const double* __restrict__ part,
-                                  int64_t num_samp, int n_slices, int64_t total, int remove_dc) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const int64_t s = idx / num_samp;
-        double mr = 127.5, mi = 127.5;      // without DC removal only the format offset is subtracted
-        if (remove_dc) {
-            mr = mi = 0.0;
-            for (int k = 0; k < n_slices; ++k) {
-                mr += part[(s * n_slices + k) * 2];
-                mi += part[(s * n_slices + k) * 2 + 1];
+// out = (byte - 127.5) / 127.5 [- mean]; remove_dc == 0 keeps the mean.  Workgroup (x, y): slice x of gridDim.x of the streams
+// y, y + gridDim.y, ...; the stream's mean once per workgroup (the byte sums are exact integers: any slicing gives this number)
+__global__ __launch_bounds__(256) void convert_u8_kernel(const unsigned char* __restrict__ x, cf* __restrict__ out,
+                                                        const double* __restrict__ part, int64_t num_samp, int n_slices,
+                                                        int64_t n_streams, int remove_dc) {
+    __shared__ double mean[2];
+    for (int64_t s = blockIdx.y; s < n_streams; s += gridDim.y) {
+        if (threadIdx.x == 0) {
+            double mr = 127.5, mi = 127.5;      // without DC removal only the format offset is subtracted
+            if (remove_dc) {
+                mr = mi = 0.0;
+                for (int k = 0; k < n_slices; ++k) {
+                    mr += part[(s * n_slices + k) * 2];
+                    mi += part[(s * n_slices + k) * 2 + 1];
+                }
+                mr /= (double)num_samp;
+                mi /= (double)num_samp;
             }
-            mr /= (double)num_samp;
-            mi /= (double)num_samp;
+            mean[0] = mr;
+            mean[1] = mi;
         }
-        const unsigned short v = reinterpret_cast<const unsigned short*>(x)[idx];
-        // ((b - 127.5) - (mean_b - 127.5)) / 127.5 = (b - mean_b) / 127.5, formed in float64, rounded once
-        out[idx] = fxc::mk((float)(((double)(v & 0xFF) - mr) / 127.5), (float)(((double)(v >> 8) - mi) / 127.5));
+        __syncthreads();
+        const double mr = mean[0], mi = mean[1];
+        const unsigned short* in = reinterpret_cast<const unsigned short*>(x) + s * num_samp;
+        cf* o = out + s * num_samp;
+        for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < num_samp; n += (int64_t)gridDim.x * 256) {
+            const unsigned short v = in[n];
+            // ((b - 127.5) - (mean_b - 127.5)) / 127.5 = (b - mean_b) / 127.5, formed in float64, rounded once
+            o[n] = fxc::mk((float)(((double)(v & 0xFF) - mr) / 127.5), (float)(((double)(v >> 8) - mi) / 127.5));
+        }
+        __syncthreads();
     }
 }
 
