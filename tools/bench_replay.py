@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batches", type=int, nargs="+", default=[1, 4, 16, 64])
     ap.add_argument("--mode", default="SPECTRUM")
     ap.add_argument("--fmt", default="u8", choices=["u8", "c64"])
+    ap.add_argument("--nbins", type=int, default=2 ** 12, help="--resolution of the reference (any integer)")
     args = ap.parse_args()
     from effex_amd.correlator import Correlator, FileSource
     rng = np.random.default_rng(7)
@@ -35,13 +36,13 @@ def main():
             paths.append(path)
         for batch in args.batches:
             out = os.path.join(tmp, "rows_%d.fxb" % batch)
-            cor = Correlator(num_samp=args.num_samp, source=FileSource(paths[0], paths[1], fmt=args.fmt), output_file=out,
+            cor = Correlator(num_samp=args.num_samp, nbins=args.nbins, source=FileSource(paths[0], paths[1], fmt=args.fmt), output_file=out,
                              output_format='bin', mode=args.mode, batch=batch)
             cor._plan()                       # plan creation is not part of the replay
             t0 = time.perf_counter()
             rows = cor.run_state_machine()
             dt = time.perf_counter() - t0
-            print(json.dumps({"fmt": args.fmt, "batch": batch, "rows": rows, "seconds": round(dt, 4), "rows_per_s": round(rows / dt, 1),
+            print(json.dumps({"fmt": args.fmt, "nbins": args.nbins, "batch": batch, "rows": rows, "seconds": round(dt, 4), "rows_per_s": round(rows / dt, 1),
                               "Msamples_per_s": round(rows * args.num_samp / dt / 1e6, 1),
                               "x_realtime_at_2.4Msps": round(rows * args.num_samp / dt / 2.4e6, 1)}))
             os.remove(out)
