@@ -317,7 +317,10 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         p->mixed_xeng = p->mixed && p->n_ant >= 3 && env_int("FXC_MIXED_XENGINE", 1);
         if (p->mixed && !p->mixed_blu && p->n_ant == 2 && env_int("FXC_MIXED_XF", 1)) {
             const size_t rpw = (size_t)(std::max(256, p->mixed_tpr) / p->mixed_tpr);
-            p->mixed_xf = (rpw * 4 + 1) * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && N <= kMixedXPoints * p->mixed_tpr;
+            // four rows (two antennas x ping-pong) must fit the LDS, with the twiddle table beside them (up to 4096 channels) or
+            // without (up to 5120)
+            p->mixed_xf = rpw * 4 * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && N <= kMixedXPoints * p->mixed_tpr;
+            p->mixed_xf_twl = (rpw * 4 + 1) * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024);
         }
     }
     // generic FFT twiddles exp(+2 pi i j / N): [N/2] for the radix-2 kernel, [N] for the mixed-radix kernel and the direct DFT
@@ -606,6 +609,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 2, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 2, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<true, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_fft_mixed_kernel<false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));

@@ -116,17 +116,26 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
 int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
     const int threads = std::max(256, p->mixed_tpr);
     const int rpw = threads / p->mixed_tpr;
-    const size_t lds = ((size_t)rpw * 4 + 1) * p->nchan * sizeof(cf);
+    const size_t lds = ((size_t)rpw * 4 + (p->mixed_xf_twl ? 1 : 0)) * p->nchan * sizeof(cf);
     const int64_t grid = n_chunks * n_splits;
     if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
     const MixedBlu ex = {mixed_wave_local(p, true), 1, p->nchan, nullptr, nullptr, dc_u8};
-    if (dc_u8)
-        hipLaunchKernelGGL((pfb_fft_mixed_kernel<true, 2, true, false, false, true>), dim3((unsigned)grid), dim3(threads), lds, p->stream,
-                           x, p->d_win, raw, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_chunks, p->mixed_tpr,
-                           n_splits, ex);
-    else
-        hipLaunchKernelGGL((pfb_fft_mixed_kernel<true, 2, true>), dim3((unsigned)grid), dim3(threads), lds, p->stream, x, p->d_win, raw,
-                           p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_chunks, p->mixed_tpr, n_splits, ex);
+#define FXC_MIXED_XF_LAUNCH(TWL, BYTES)                                                                                            \
+    hipLaunchKernelGGL((pfb_fft_mixed_kernel<TWL, 2, true, false, false, BYTES>), dim3((unsigned)grid), dim3(threads), lds, p->stream, \
+                       x, p->d_win, raw, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_chunks, p->mixed_tpr,    \
+                       n_splits, ex)
+    if (p->mixed_xf_twl) {
+        if (dc_u8)
+            FXC_MIXED_XF_LAUNCH(true, true);
+        else
+            FXC_MIXED_XF_LAUNCH(true, false);
+    } else {
+        if (dc_u8)
+            FXC_MIXED_XF_LAUNCH(false, true);
+        else
+            FXC_MIXED_XF_LAUNCH(false, false);
+    }
+#undef FXC_MIXED_XF_LAUNCH
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;
 }

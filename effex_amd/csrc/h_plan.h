@@ -59,6 +59,7 @@ struct fxc_plan {
     cf* d_chirp = nullptr;         // [nchan] exp(+i pi n^2 / nchan)
     cf* d_blud = nullptr;          // [blu_nfft] FFT of the wrapped conjugate chirp / blu_nfft
     bool mixed_xeng = false;       // 3 .. 64 antennas: F-only mixed kernel (antenna-interleaved spectra) + the X-engines
+    bool mixed_xf_twl = true;      // ... with the twiddle table in LDS (up to 4096 channels; from L2 up to 5120)
     bool mixed_xf = false;         // two antennas: the same kernel multiplies and integrates too (no spectra in HBM)
     hipStream_t stream = nullptr;
     bool own_stream = false;
