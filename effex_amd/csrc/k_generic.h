@@ -298,7 +298,8 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                 const int radix = mp.radix[st];
                 int nst = nf;
                 asm volatile("" : "+s"(nst));                                   // ... and inside the stage loop
-                fxc::mixed_stage<U, XF || U == 1>(rows + so, rows + (nst - so), row_stride, tw, nst, radix, ns, lt_g, tpr_g);
+                // (the register butterflies for 11 / 13 with two rows: not with the twiddles in L2 too -- 64-bit addresses, spills)
+                fxc::mixed_stage<U, (XF && TWL) || U == 1>(rows + so, rows + (nst - so), row_stride, tw, nst, radix, ns, lt_g, tpr_g);
                 slot_sync();
                 ns *= radix;
                 so = nst - so;
