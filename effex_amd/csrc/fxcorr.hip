@@ -321,6 +321,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             // without (up to 5120)
             p->mixed_xf = rpw * 4 * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && N <= kMixedXPoints * p->mixed_tpr;
             p->mixed_xf_twl = (rpw * 4 + 1) * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024);
+            // (without the table in LDS that kernel has no register butterflies for 11 / 13: such channel counts go through the
+            // F-only kernel, which has, and xmul_kernel)
+            if (!p->mixed_xf_twl && fxc::mixed_rows_per_slot_cap(p->mixed_plan) == 1) p->mixed_xf = false;
         }
     }
     // generic FFT twiddles exp(+2 pi i j / N): [N/2] for the radix-2 kernel, [N] for the mixed-radix kernel and the direct DFT
