@@ -98,12 +98,26 @@ def main():
             if not e_b < 1e-5:
                 print(json.dumps({"MISMATCH_BYTES": e_b, "n_chunks": nb, "num_samp": nsb}), flush=True)
                 raise SystemExit(1)
+        # ... and off the powers of two (bytes converted inside the mixed-radix F + X kernel up to 5120 channels, through the
+        # conversion pass beyond and for 3 + antennas)
+        if any_n and rng.random() < 0.5:
+            nb = max(1, min(int(rng.choice([1, 3, 40, 300])), int(6.0e6 // (n_ant * num_samp))))
+            u8 = torch.randint(0, 256, (nb, n_ant, num_samp, 2), dtype=torch.uint8, device="cuda")
+            with FxPlan(n_ant, nchan, ntaps, num_samp) as b:
+                rb = b.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()
+                r2 = b.fx_rows(b.convert_u8(u8, remove_dc=True)).cpu().numpy()
+                b.fx_accumulate_u8(u8, remove_dc=True)
+                e_b = max(rel_err(rb, r2), rel_err(b.finalize("SPECTRUM"), r2.astype(np.complex128).mean(axis=0)))
+            worst[("bytes mixed-radix", int(n_ant == 2), False)] = max(worst.get(("bytes mixed-radix", int(n_ant == 2), False), 0.0), e_b)
+            if not e_b < 1e-5:
+                print(json.dumps({"MISMATCH_BYTES": e_b, "n_chunks": nb, **tag}), flush=True)
+                raise SystemExit(1)
         tol = 2e-5 if nchan == 1 else 6e-6
         if any_n and nchan > 4096:      # both sides may be O(N) float32 sums per bin there (a large prime factor beyond the chirp-z rows)
             tol = 1.5e-5
         key = (path, nchan if nchan in (1, 4096, 8192) else (256 if nchan <= 256 else 0), ntaps > 4)
         if any_n:
-            key = ("mixed-radix", n_ant == 2, ntaps > 4)
+            key = ("mixed-radix", int(n_ant == 2), ntaps > 4)
         worst[key] = max(worst.get(key, 0.0), e_rows, e_int)
         if not (e_rows < tol and e_int < tol and e_cont < 5e-5):
             print(json.dumps({"MISMATCH": [e_rows, e_int, e_cont], "path": path, **tag}), flush=True)
