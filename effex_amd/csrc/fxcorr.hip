@@ -1,16 +1,17 @@
 // fxcorr.hip — MI355X (gfx950) F/X hot path: the C ABI of include/fxcorr.h over the kernels.
 //
 // One translation unit.  This file holds the ABI entry points; it includes
-//   fx_math.h, fx_fused4096.h, fx_tiled.h, fx_small.h   index maps, butterflies and kernel phases (also compiled by g++ for the
-//                                           host emulation under tests/emul)
+//   fx_math.h, fx_fused4096.h, fx_tiled.h, fx_small.h, fx_mixed.h   index maps, butterflies and kernel phases (also compiled by
+//                                           g++ for the host emulation under tests/emul)
 //   k_generic.h k_finish.h k_fused4096.h k_tiled.h k_small.h k_prepass.h k_stream.h k_conditioning.h k_delay.h k_synth.h
 //                                           the __global__ kernels, one file per path / step
 //   h_plan.h h_launch.h h_run.h h_rccl.h    fxc_plan, the per-path launchers and workspace passes, the device-resident
 //                                           fx_accumulate / fx_rows, the run-time binding of librccl
 //
 // Replaces, for effex's hot path:
-//   cusignal.filtering.channelize_poly FIR half   effex/effex.py:553   -> pfb_fir_kernel / fused phase 1
-//   cusignal channelize_poly FFT half + conj      effex/effex.py:553   -> fft_pow2_kernel / dft_any_kernel / fused phases 1-3
+//   cusignal.filtering.channelize_poly FIR half   effex/effex.py:553   -> pfb_fir_kernel / pfb_fft_mixed_kernel / fused phase 1
+//   cusignal channelize_poly FFT half + conj      effex/effex.py:553   -> pfb_fft_mixed_kernel (any channel count: mixed radix,
+//                                                                          chirp-z) / fft_pow2_kernel / dft_any_kernel / fused phases 1-3
 //   f0 * conj(f1 * rot), mean(axis=0), fftshift   effex/effex.py:516-521 -> xmul_kernel / fused X + finish kernels
 //   continuum tail mean_k / bandwidth             effex/effex.py:523-524 -> continuum kernels
 // and the steps either side of the path:
@@ -19,7 +20,8 @@
 //   per-chunk blocking copies                     effex/effex.py:391-392, 508-509, 693 -> fxc_pipe_* (host side)
 // Paths: fused (nchan 4096, ntaps 4; 2 antennas in one kernel, 4/6/8 via F-only + X-engine), tiled (2 antennas,
 // nchan 512..8192, any ntaps: the fused design generalised, fx_tiled.h; nchan 16..256, ntaps <= 4: the same inside one
-// wave, k_small.h), stream (nchan 1), generic (everything else).  Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap, buffer loads.
+// wave, k_small.h), stream (nchan 1), generic (everything else: channel counts that are not a power of two on the mixed-radix
+// kernel of k_generic.h / fx_mixed.h -- with two antennas F and X in one pass --, the rest on plain FIR / FFT / X kernels).  Written for gfx950 only: wave64, 160 KiB LDS, v_permlane32_swap, buffer loads.
 // No CPU fallback.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
