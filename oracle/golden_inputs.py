@@ -27,7 +27,9 @@ SMALL_N = 512
 SMALL_CHUNKS = 5
 
 # the other --nfft values (effex.py:778) at the reference's fixed ntaps = 4: (nbins, num_samp, chunk pairs, delay)
-NFFT_CASES = ((1024, 1024 * 12, 2, 1e-6), (2048, 2048 * 9 + 5, 2, -3e-7), (8192, 8192 * 5, 1, 1e-6))
+NFFT_CASES = ((1024, 1024 * 12, 2, 1e-6), (2048, 2048 * 9 + 5, 2, -3e-7), (8192, 8192 * 5, 1, 1e-6),
+              # --resolution is a free integer (effex.py:733-739): counts that are not a power of two, one of them prime
+              (1000, 1000 * 12 + 3, 2, 1e-6), (96, 96 * 300, 1, -3e-7), (997, 997 * 9, 1, 0.0), (1536, 1536 * 7, 1, 2e-7))
 SEED_NFFT = 4321
 
 # nbins changed AFTER construction (tests/test_effex.py:142-144): the window built once by the constructor for 4096 bins

@@ -892,13 +892,14 @@ def test_headline_shape_small_calls_split_frames(plan_mod, torch, n_chunks):
 
 
 def test_other_nfft_against_reference_goldens(plan_mod, torch, golden):
-    """--nfft 1024 / 2048 / 8192 rows produced by the reference's own _run_task (tests/golden), tiled kernels."""
+    """--nfft 1024 / 2048 / 8192 (tiled kernels) and --resolution 1000 / 96 / 997 / 1536 (not powers of two: the mixed-radix and
+    chirp-z kernel) rows produced by the reference's own constructor + _run_task (tests/golden)."""
     meta, arrays = golden
     for case in meta["nfft"]:
         nbins, num_samp, chunks, delay = case["nbins"], case["num_samp"], case["chunks"], case["delay"]
         x = gi.nfft_input(nbins, num_samp, chunks)
         with plan_mod.FxPlan(2, nbins, 4, num_samp) as p:
-            assert p.path == "tiled"
+            assert p.path == ("tiled" if nbins & (nbins - 1) == 0 else "generic")
             p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, delay)
             rows = p.fx_rows(x, "SPECTRUM")                  # host buffers in, host rows out
             assert rel_err(rows[:, 0], arrays[case["key"]]) < TOL_VIS, nbins

@@ -132,7 +132,8 @@ def test_delay_estimator(golden):
 
 
 def test_other_nfft_rows_match_reference(golden):
-    """The reference's constructor + _run_task at --nfft 1024 / 2048 / 8192 (effex.py:778), ragged num_samp."""
+    """The reference's constructor + _run_task at --nfft 1024 / 2048 / 8192 and at 1000 / 96 / 997 / 1536 channels (effex.py:733-739,
+    778: a free integer), ragged num_samp."""
     meta, arrays = golden
     for case in meta["nfft"]:
         nbins, num_samp, chunks, delay = case["nbins"], case["num_samp"], case["chunks"], case["delay"]
