@@ -38,7 +38,7 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
         const int64_t n_groups = n_streams * ((p->n_pts + rpw - 1) / rpw);
         const int64_t run = std::max<int64_t>(1, std::min<int64_t>(16, n_groups / ((int64_t)p->cu_count * 8)));
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
-        const MixedBlu blu = {mixed_wave_local(p, false), ant, p->blu_nfft, p->d_chirp, p->d_blud, nullptr};
+        const MixedExtras blu = {mixed_wave_local(p, false), ant, p->blu_nfft, p->d_chirp, p->d_blud, nullptr};
         if (twl)
             hipLaunchKernelGGL((pfb_fft_mixed_kernel<true, 1, false, true>), dim3(grid), dim3(threads), lds, p->stream, x, p->d_win,
                                spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams, p->mixed_tpr, 1, blu);
@@ -55,14 +55,14 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
         hipLaunchKernelGGL((pfb_fft_mixed_kernel<false, 1, false, false, true>), dim3(grid), dim3(1024), (size_t)p->nchan * sizeof(cf),
                            p->stream, x, p->d_win, spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams,
-                           1024, 1, MixedBlu{0, ant, p->nchan, nullptr, nullptr, nullptr});
+                           1024, 1, MixedExtras{0, ant, p->nchan, nullptr, nullptr, nullptr});
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
     }
     if (p->mixed) {
         const int threads = std::max(256, p->mixed_tpr);
         const int rpw = threads / p->mixed_tpr;
-        const MixedBlu no_blu = {mixed_wave_local(p, false), ant, p->nchan, nullptr, nullptr, nullptr};
+        const MixedExtras no_blu = {mixed_wave_local(p, false), ant, p->nchan, nullptr, nullptr, nullptr};
         static const int tw_knob = env_int("FXC_MIXED_TWLDS", 1), u_knob = env_int("FXC_MIXED_U", 0);
         // U = 2 frames per slot where the measurements favour it (tools/bench_channelize.py, r04 experiments.md §7): up to 1280
         // channels (four 256-thread workgroups still fit a CU's LDS) and from 2049 to 4096 (one 1024-thread workgroup per
@@ -119,7 +119,7 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
     const size_t lds = ((size_t)rpw * 4 + (p->mixed_xf_twl ? 1 : 0)) * p->nchan * sizeof(cf);
     const int64_t grid = n_chunks * n_splits;
     if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
-    const MixedBlu ex = {mixed_wave_local(p, true), 1, p->nchan, nullptr, nullptr, dc_u8};
+    const MixedExtras ex = {mixed_wave_local(p, true), 1, p->nchan, nullptr, nullptr, dc_u8};
 #define FXC_MIXED_XF_LAUNCH(TWL, BYTES)                                                                                            \
     hipLaunchKernelGGL((pfb_fft_mixed_kernel<TWL, 2, true, false, false, BYTES>), dim3((unsigned)grid), dim3(threads), lds, p->stream, \
                        x, p->d_win, raw, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_chunks, p->mixed_tpr,    \

@@ -107,13 +107,15 @@ __global__ __launch_bounds__(256) void dft_any_kernel(cf* __restrict__ data, con
 //   s0 conj(s1) adds up in registers over the workgroup's run of frames of chunk c = blockIdx / n_splits, and the run's
 //   sum goes to `out` = raw[split][chunk][nchan] -- xmul_kernel's layout, with no spectrum ever written.
 // TWL: the twiddle table sits in LDS in front of the rows.  The kernel is bound by instruction issue (index arithmetic and
-// LDS traffic of five-odd short stages), not by HBM: hence the packed-pair arithmetic and the shared indices.
+// LDS traffic of five-odd short stages) -- hence the packed-pair arithmetic and the shared indices -- and, with four taps, by
+// the fabric traffic of the taps' re-reads a few per cent behind it.
 constexpr int kMixedXPoints = 8;    // bins per thread of the XF accumulator: nchan <= 8 tpr (mixed_threads_per_row up to 4096)
 //   BLU = true (a prime factor too large for a butterfly, F only, U = 1): Bluestein's chirp-z form of the same transform.
 //   With c[n] = exp(+i pi n^2 / N):  X[k] = c[k] sum_n (v[n] c[n]) conj(c[k - n])  -- a convolution, done as a cyclic one
-//   of length nfft = 2^j >= 2 N - 1 in the row: u = v c zero-padded, Z = FFT(conj(FFT(u) D)), X[k] = c[k] conj(Z[k]),
-//   D = FFT(conj(c) wrapped) / nfft from the host (float64).  Both FFTs are the same radix-4/2 stages (mp, tw for nfft).
-struct MixedBlu {
+//   of length nfft >= 2 N - 1 (7-smooth, chosen by the host) in the row: u = v c zero-padded, Z = FFT(conj(FFT(u) D)),
+//   X[k] = c[k] conj(Z[k]), D = FFT(conj(c) wrapped) / nfft from the host (float64).  Both FFTs are the stages of mp (tw for nfft).
+// what the variants need beyond the common arguments
+struct MixedExtras {
     int wave_local;         // slots of one wave synchronise without the workgroup barrier
     int ant;                // F only: spectra as out[chunk][frame][ant][nchan] for stream = chunk * ant + a (1: [stream][frame][nchan])
     int nfft;               // == nchan when BLU is false
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(1024) void pfb_fft_mixed_kernel(const cf* __restric
                                                             cf* __restrict__ out, const cf* __restrict__ tw_table,
                                                             const fxc::MixedPlan mp, int64_t num_samp, int nchan, int ntaps,
                                                             int64_t n_pts, int64_t n_streams, int tpr, int n_splits,
-                                                            const MixedBlu blu) {
+                                                            const MixedExtras blu) {
     static_assert(!XF || U == 2, "the fused X stage pairs two antennas");
     static_assert(!BLU || (U == 1 && !XF), "the chirp-z rows go one at a time, F only");
     static_assert(!BIG || (U == 1 && !XF && !BLU && !TWL), "one LDS row: plain F stage, twiddles from the table");
