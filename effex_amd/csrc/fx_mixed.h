@@ -232,11 +232,11 @@ inline int mixed_rows_per_slot_cap(const MixedPlan& mp) {
 }
 
 // threads that share one row: the power of two at or above N/4 within [4, 256] (one wave up to 384 channels with two antennas), and 512 or 1024
-// of them only beyond 2048 channels (the workgroup has max(256, that) threads)
-inline int mixed_threads_per_row(int n, int cap = 1024, bool fused_x = false) {
+// of them only beyond `wide_from` channels (2048; with two antennas 1320) (the workgroup has max(256, that) threads)
+inline int mixed_threads_per_row(int n, int cap = 1024, bool fused_x = false, int wide_from = 2048) {
     int t = 4;
     while (t < 256 && t < cap && t * 4 < n) t <<= 1;
-    while (n > 2048 && t < cap && t * 4 < n) t <<= 1;
+    while (n > wide_from && t < cap && t * 4 < n) t <<= 1;
     // 257 .. 384 channels, two antennas: a wave per row (no workgroup barrier) beats 128 part-used threads (300 channels 3.44 ->
     // 2.42 ms); F only it is the other way round (360 channels 1.49 -> 1.65 ms)
     if (fused_x && t == 128 && n <= 384) t = 64;
