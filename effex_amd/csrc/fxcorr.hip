@@ -324,7 +324,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             // four rows (two antennas x ping-pong) must fit the LDS, with the twiddle table beside them (up to 4096 channels) or
             // without (up to 5120)
             p->mixed_xf = rpw * 4 * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && N <= kMixedXPoints * p->mixed_tpr;
-            p->mixed_xf_twl = (rpw * 4 + 1) * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024);
+            p->mixed_xf_twl = (rpw * 4 + 1) * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && env_int("FXC_MIXED_TWLDS", 1);
             // (without the table in LDS that kernel has no register butterflies for 11 / 13: such channel counts go through the
             // F-only kernel, which has, and xmul_kernel)
             if (!p->mixed_xf_twl && fxc::mixed_rows_per_slot_cap(p->mixed_plan) == 1) p->mixed_xf = false;
