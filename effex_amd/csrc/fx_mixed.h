@@ -232,8 +232,8 @@ inline int mixed_rows_per_slot_cap(const MixedPlan& mp) {
 }
 
 // threads that share one row: the power of two at or above N/4 within [4, 256] (one wave up to 384 channels with two antennas), and 512 or 1024
-// of them only beyond `wide_from` channels (2048; with two antennas 1320) (the workgroup has max(256, that) threads)
-inline int mixed_threads_per_row(int n, int cap = 1024, bool fused_x = false, int wide_from = 2048) {
+// of them only beyond `wide_from` = 1320 channels (the workgroup has max(256, that) threads)
+inline int mixed_threads_per_row(int n, int cap = 1024, bool fused_x = false, int wide_from = 1320) {
     int t = 4;
     while (t < 256 && t < cap && t * 4 < n) t <<= 1;
     while (n > wide_from && t < cap && t * 4 < n) t <<= 1;

@@ -276,9 +276,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         p->mixed = N > 1 && N <= kMaxLdsFftN && !force_old && (!p->pow2 || force_mixed || auto_pow2);
         if (p->mixed) {
             p->mixed_plan = fxc::mixed_factor(N);
-            // (two antennas: 512 threads per row already beyond 1320 channels, where three 256-thread workgroups stop fitting a CU's LDS -- 1350 ... 2000 channels 18 - 20 % faster, 1120 ... 1300 slower)
-            p->mixed_tpr = fxc::mixed_threads_per_row(N, env_int("FXC_MIXED_TPR", 1024), p->n_ant == 2,
-                                                      env_int("FXC_MIXED_WIDE_FROM", p->n_ant == 2 ? 1320 : 2048));
+            // (512 threads per row beyond 1320 channels, where three 256-thread workgroups stop fitting a CU's LDS: two antennas
+            // 1350 ... 2000 channels 18 - 20 % faster, F only with two frames per slot 10 - 25 %; 1120 ... 1300 slower)
+            p->mixed_tpr = fxc::mixed_threads_per_row(N, env_int("FXC_MIXED_TPR", 1024), p->n_ant == 2, env_int("FXC_MIXED_WIDE_FROM", 1320));
             if (p->mixed_plan.n_stages < 0) p->mixed = false;
         }
         if (p->mixed) {

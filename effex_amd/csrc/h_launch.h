@@ -65,10 +65,10 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
         const MixedExtras no_blu = {mixed_wave_local(p, false), ant, p->nchan, nullptr, nullptr, nullptr};
         static const int tw_knob = env_int("FXC_MIXED_TWLDS", 1), u_knob = env_int("FXC_MIXED_U", 0);
         // U = 2 frames per slot where the measurements favour it (tools/bench_channelize.py, r04 experiments.md §7): up to 1280
-        // channels (four 256-thread workgroups still fit a CU's LDS) and from 2049 to 4096 (one 1024-thread workgroup per
-        // CU either way)
+        // channels (three or more 256-thread workgroups still fit a CU's LDS) and, with 512 or 1024 threads per row, from 1321 to
+        // 4096 (1440 ... 2000 channels: 10 - 25 % faster than one frame per slot on 256 threads)
         const size_t row_bytes = (size_t)p->nchan * sizeof(cf);
-        int u = (p->nchan <= 1280 || (p->nchan > 2048 && p->nchan <= 4096)) ? 2 : 1;
+        int u = (p->nchan <= 1280 || (p->mixed_tpr >= 512 && p->nchan <= 4096)) ? 2 : 1;
         u = std::min(u, fxc::mixed_rows_per_slot_cap(p->mixed_plan));     // 11 / 13: register butterflies one frame at a time here
         if (u_knob == 1 || u_knob == 2) u = u_knob;
         const bool twl = tw_knob && (1 + (size_t)rpw * 2 * u) * row_bytes <= (size_t)(160 * 1024);
