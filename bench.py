@@ -49,6 +49,12 @@ CHECK_FRAMES = (0, 7777)       # frames of rank 0 whose rows are checked against
 def _cpu_worker(args):
     seconds, seed_offset = args[:2]
     c128 = len(args) > 2 and args[2]          # the reference's own precision (effex.py:109-110, 551), single core once
+    pin = args[3] if len(args) > 3 else None  # the logical CPU this worker is bound to (one per physical core), or None
+    if pin is not None:
+        try:
+            os.sched_setaffinity(0, {pin})
+        except OSError:
+            pass
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, ROOT)
     os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -63,13 +69,13 @@ def _cpu_worker(args):
         x = x.astype(np.complex128)
     fx_oracle.pfb_xcorr(x[0], x[1], NTAPS, NCHAN, window, BANDWIDTH, FREQUENCY, 0.0, "SPECTRUM", dtype=dtype)
     frames = 0
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     while True:
         fx_oracle.pfb_xcorr(x[0], x[1], NTAPS, NCHAN, window, BANDWIDTH, FREQUENCY, 0.0, "SPECTRUM", dtype=dtype)
         frames += 1
         dt = time.perf_counter() - t0
         if dt >= seconds:
-            return frames, dt
+            return frames, dt, time.process_time() - c0      # wall seconds and the CPU seconds this process was given in them
 
 
 def _oracle_rows(frame_ids):
@@ -97,39 +103,110 @@ def cpu_model():
     return None
 
 
+def cgroup_quota_cores():
+    """CPU quota of this process's cgroup in cores (cgroup v2 cpu.max, v1 cfs_quota/period), None = unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        return None if quota == "max" else round(float(quota) / float(period), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+            quota, period = float(fq.read()), float(fp.read())
+        return None if quota <= 0 else round(quota / period, 2)
+    except (OSError, ValueError):
+        return None
+
+
+def physical_core_map(usable):
+    """{(package, core): [logical CPUs of it that this process may run on]} from sysfs; one entry per CPU if unreadable."""
+    cores = {}
+    for cpu in sorted(usable):
+        base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
+        try:
+            with open(base + "physical_package_id") as fh:
+                pkg = int(fh.read())
+            with open(base + "core_id") as fh:
+                core = int(fh.read())
+        except (OSError, ValueError):
+            pkg, core = -1, cpu
+        cores.setdefault((pkg, core), []).append(cpu)
+    return cores
+
+
+def _cpu_pool_arm(ctx, seconds, pins, single):
+    """One pool of single-threaded workers on independent frames for `seconds`; pins[k] = the CPU worker k is bound to or None."""
+    t_pool = time.perf_counter()
+    with ctx.Pool(len(pins)) as pool:
+        res = pool.map(_cpu_worker, [(seconds, k, False, pin) for k, pin in enumerate(pins)])
+    wall = time.perf_counter() - t_pool
+    multi = sum(f * NUM_SAMP / dt for f, dt, _ in res) / 1e6
+    worker_seconds = sum(dt for _, dt, _ in res)
+    cpu_seconds = sum(c for _, _, c in res)
+    eff = cpu_seconds / worker_seconds * len(pins) if worker_seconds > 0 else None     # cores' worth of CPU time obtained
+    speedup = multi / single if single > 0 else None
+    return {"value": round(multi, 2), "workers": len(pins), "pinned": pins[0] is not None,
+            "frames_done": int(sum(f for f, _, _ in res)),
+            "worker_seconds_obtained": round(worker_seconds, 1), "cpu_seconds_obtained": round(cpu_seconds, 1),
+            "pool_wall_seconds": round(wall, 1),
+            # effective_cores: CPU seconds the workers were given per second of their timed loops (scheduler / cgroup quota /
+            # oversubscription show up here); speedup_over_single_core: what those cores delivered in units of the single-core
+            # rate; their quotient is the rate of one obtained core against a lone worker's (shared memory bandwidth and
+            # last-level cache, SMT siblings, all-core clock)
+            "effective_cores": round(eff, 1) if eff is not None else None,
+            "speedup_over_single_core": round(speedup, 1) if speedup is not None else None,
+            "rate_per_obtained_core_vs_single": round(speedup / eff, 3) if speedup and eff else None}
+
+
 def cpu_baseline(seconds=8.0, frames=FRAMES):
     import multiprocessing as mp
     logical = os.cpu_count() or 1
-    usable = logical
     try:
-        usable = len(os.sched_getaffinity(0))
+        usable_set = set(os.sched_getaffinity(0))
     except Exception:
-        pass
-    workers = max(1, usable)                 # one single-threaded worker per usable core, no cap
-    frames1, dt1 = _cpu_worker((min(seconds, 4.0), 0))
+        usable_set = set(range(logical))
+    usable = len(usable_set)
+    cores = physical_core_map(usable_set)
+    physical = len(cores)
+    quota = cgroup_quota_cores()
+    frames1, dt1, cpu1 = _cpu_worker((min(seconds, 4.0), 0))
     single = frames1 * NUM_SAMP / dt1 / 1e6
-    frames2, dt2 = _cpu_worker((2.0, 0, True))
+    frames2, dt2, _ = _cpu_worker((2.0, 0, True))
     single_c128 = frames2 * NUM_SAMP / dt2 / 1e6
     ctx = mp.get_context("spawn")
-    t_pool = time.perf_counter()
-    with ctx.Pool(workers) as pool:
-        res = pool.map(_cpu_worker, [(seconds, k) for k in range(workers)])
-    wall = time.perf_counter() - t_pool
-    multi = sum(f * NUM_SAMP / dt for f, dt in res) / 1e6
-    total_frames = sum(f for f, _ in res)
-    worker_seconds = sum(dt for _, dt in res)
+    # two arms over independent frames (SURVEY.md 8d config 1): one worker per usable logical CPU, and one worker per
+    # physical core, each bound to one CPU of its core (skipped when the two are the same set)
+    arms = {"per_logical_cpu": _cpu_pool_arm(ctx, seconds, [None] * max(1, usable), single)}
+    if physical < usable:
+        arms["per_physical_core"] = _cpu_pool_arm(ctx, seconds, [cpus[0] for _, cpus in sorted(cores.items())], single)
+    best_name = max(arms, key=lambda k: arms[k]["value"])
+    best = arms[best_name]
     check = _oracle_rows([f for f in CHECK_FRAMES if f < frames])
-    return {"value": round(multi, 2), "unit": "Msamples/s", "cores": workers, "kind": "port",
-            "single_core_value": round(single, 2), "single_core_complex128_value": round(single_c128, 2),
-            "cpu_count_logical": logical, "cpu_count_usable": usable,
-            # what the workers got: their own timed seconds, and the wall clock of the pool (start-up included) -- on a shared
-            # host 256 workers obtain far fewer than 256 cores' worth of frames (multi / single_core says how many)
-            "worker_seconds_obtained": round(worker_seconds, 1), "pool_wall_seconds": round(wall, 1),
-            "frames_done": int(total_frames), "effective_cores": round(multi / single, 1) if single > 0 else None,
-            "cpu_model": cpu_model(),
-            "sample": "%d frames of the same workload (S=%d, N=%d, T=%d, 2 ant, complex64 numpy/scipy oracle), "
-                      "%d single-threaded worker processes (one per usable core) x %.0f s on independent frames"
-                      % (total_frames, NUM_SAMP, NCHAN, NTAPS, workers, seconds)}, check
+    limits = []
+    if quota is not None and quota < best["workers"]:
+        limits.append("cgroup quota of %.1f cores" % quota)
+    if best["effective_cores"] is not None and best["effective_cores"] < 0.9 * best["workers"]:
+        limits.append("the workers were given %.1f cores' worth of CPU time" % best["effective_cores"])
+    if best["rate_per_obtained_core_vs_single"] is not None and best["rate_per_obtained_core_vs_single"] < 0.8:
+        limits.append("each obtained core ran at %.2f of a lone worker's rate (8 MB of streams and spectra per frame per worker: "
+                      "shared memory bandwidth / last-level cache, SMT, all-core clock)" % best["rate_per_obtained_core_vs_single"])
+    out = {"value": best["value"], "unit": "Msamples/s", "cores": best["workers"], "kind": "port", "arm": best_name,
+           "single_core_value": round(single, 2), "single_core_complex128_value": round(single_c128, 2),
+           "single_core_cpu_fraction": round(cpu1 / dt1, 3),
+           "cpu_count_logical": logical, "cpu_count_usable": usable, "physical_cores": physical,
+           "cgroup_quota_cores": quota,
+           "worker_seconds_obtained": best["worker_seconds_obtained"], "cpu_seconds_obtained": best["cpu_seconds_obtained"],
+           "pool_wall_seconds": best["pool_wall_seconds"], "frames_done": best["frames_done"],
+           "effective_cores": best["effective_cores"], "speedup_over_single_core": best["speedup_over_single_core"],
+           "rate_per_obtained_core_vs_single": best["rate_per_obtained_core_vs_single"],
+           "limited_by": "; ".join(limits) if limits else None,
+           "arms": arms, "cpu_model": cpu_model(),
+           "sample": "%d frames of the same workload (S=%d, N=%d, T=%d, 2 ant, complex64 numpy/scipy oracle), "
+                     "%d single-threaded worker processes (%s) x %.0f s on independent frames"
+                     % (best["frames_done"], NUM_SAMP, NCHAN, NTAPS, best["workers"],
+                        "one per physical core, pinned" if best["pinned"] else "one per usable logical CPU", seconds)}
+    return out, check
 
 
 def pmc_traffic_per_frame():
@@ -304,6 +381,9 @@ def dry_run_dist(args):
                           "warmup": args.warmup, "frames_per_rank": [r["frames"] for r in ranks], "frames_total": total,
                           "first_chunk_last_rank": ranks[-1]["first_frame"],
                           "transport": integ.transport, "fallback": os.environ.get(NOTE_ENV),
+                          "rccl": {"transport": "torch.distributed", "ranks_seen": None, "rank": None, "ranks_summed": None,
+                                   "version": None, "strict": False, "torch_backend": "gloo",
+                                   "fallback_reason": os.environ.get(NOTE_ENV) or "dry run on gloo / CPU tensors: no GPU, no RCCL"},
                           "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
                           "ranks": {"per_rank": ranks, "ms_per_step_this_rank": spread(ranks, "ms_per_step_this_rank")},
                           "mean_chunk_index": want.real}))
@@ -405,7 +485,13 @@ def _rccl_child(argv):
                     print("rccl preflight: rank %d root %s: reduced result off by %.3g" % (rank, root, err))
                     return 4
         plan.sync()
-    print("rccl preflight: rank %d of %d on GPU %d ok" % (rank, world, gpu))
+        info, summed = comm.info(), comm.probe()          # what the communicator says of itself; an all-reduce of ones
+        if not (info["ranks_seen"] in (world, None) and info["rank_seen"] in (rank, None) and summed == world):
+            print("rccl preflight: rank %d: the communicator reports %s, %d ranks summed" % (rank, info, summed))
+            return 5
+    print("rccl preflight: rank %d of %d on GPU %d ok %s" % (rank, world, gpu, json.dumps(
+        {"ranks_seen": info["ranks_seen"], "rank": info["rank_seen"], "device_seen": info["device_seen"], "ranks_summed": summed,
+         "version": info["rccl_version"], "reduces": info["reduces"]})))
     return 0
 
 
@@ -464,24 +550,67 @@ def milestone(text):
 
 
 def _fake_comm_hang():
-    """Test hook (tests/test_dist_gloo.py): the first attempt never gets its communicator."""
-    if os.environ.get("FXC_BENCH_TEST_COMM_HANG") == "1" and not os.environ.get(NOTE_ENV):
+    """Test hook (tests/test_dist_gloo.py): the first attempt never gets its communicator -- on every rank ("1") or on
+    one of them ("rank:K"), the others then wait for it in their first collective."""
+    hook = os.environ.get("FXC_BENCH_TEST_COMM_HANG")
+    if hook and not os.environ.get(NOTE_ENV) and hook in ("1", "rank:%s" % os.environ.get("RANK", "0")):
         time.sleep(3600)
 
 
+def one_node_launch(world):
+    """True when every rank of the launch runs on this node (torch.distributed.run exports LOCAL_WORLD_SIZE)."""
+    return int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world
+
+
+def strict_rccl(args):
+    """fxc_reduce or nothing: the default for a launch over the nccl backend (one GPU per rank); the torch.distributed
+    transport takes over only when --allow-torch-fallback says so (or the transport was asked for with --reduce torch)."""
+    if args.reduce == "torch":
+        return False
+    if args.strict_rccl:
+        return True
+    return args.dist_backend == "nccl" and not args.allow_torch_fallback
+
+
 def supervise(args, rank, world):
+    """One per rank, never touches the GPU.  Decisions are all-or-nothing over the ranks of the node: the supervisor that
+    sees its child fail (or hang) inside the communicator window publishes a verdict file -- "abort" (strict, the default)
+    or "fallback" -- that every supervisor polls; on "abort" all kill their children and exit non-zero, on "fallback" all
+    kill their children and start the torch.distributed attempt on a rendezvous rank 0 publishes.  The files carry the
+    launcher's pid and port in their names, and rank 0 clears stale ones before the first attempt."""
+    import signal
     import socket
     import subprocess
     import tempfile
+    strict = strict_rccl(args)
+    if not one_node_launch(world):
+        strict = True                      # the file rendezvous below is one node's: no fall-back across nodes
+    t_start = time.time()
+    base = os.path.join(tempfile.gettempdir(), "fxbench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+    port_file, verdict_file = base + ".port", base + ".verdict"
+    if rank == 0:
+        for stale in (port_file, verdict_file):
+            try:
+                os.unlink(stale)
+            except OSError:
+                pass
     status = tempfile.NamedTemporaryFile(prefix="fxbench_status_r%d_" % rank, suffix=".txt", delete=False)
     status.close()
     argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]      # (the child knows it is one: CHILD_ENV)
+    live = [None]
 
     def start(extra_args, extra_env):
         env = dict(os.environ, **{CHILD_ENV: "1", STATUS_ENV: status.name})
         env.update(extra_env)
         open(status.name, "w").close()
-        return subprocess.Popen(argv + extra_args, env=env)
+        live[0] = subprocess.Popen(argv + extra_args, env=env)
+        return live[0]
+
+    def on_term(signum, _frame):           # the launcher ends its ranks with SIGTERM: the measuring child goes with us
+        if live[0] is not None and live[0].poll() is None:
+            live[0].kill()
+        raise SystemExit(128 + signum)
+    signal.signal(signal.SIGTERM, on_term)
 
     def state():
         with open(status.name) as fh:
@@ -489,25 +618,56 @@ def supervise(args, rank, world):
         begun = [ln for ln in text.splitlines() if ln.startswith("comm:start")]
         return (float(begun[-1].split()[1]) if begun else None), "comm:done" in text
 
+    def verdict():
+        """(kind, why) another supervisor (or this one) published during THIS launch, else None."""
+        try:
+            if os.path.getmtime(verdict_file) < t_start - 5.0:
+                return None
+            with open(verdict_file) as fh:
+                kind, _, why = fh.read().partition(": ")
+            return (kind, why) if kind in ("abort", "fallback") else None
+        except OSError:
+            return None
+
+    def publish(kind, why):
+        try:
+            fd = os.open(verdict_file, os.O_WRONLY | os.O_CREAT | os.O_EXCL)     # the first verdict stands
+            with os.fdopen(fd, "w") as fh:
+                fh.write("%s: %s" % (kind, why))
+        except FileExistsError:
+            pass
+        return verdict() or (kind, why)
+
     proc = start([], {})
-    why = None
-    while True:
+    decided = None
+    while decided is None:
         rc = proc.poll()
         begun, done = state()
-        if rc is not None:
+        seen = verdict()
+        if seen is not None:                                   # another rank's supervisor decided for everyone
+            decided = seen
+        elif rc is not None:
             if rc != 0 and begun is not None and not done:
-                why = "the measuring process of rank %d exited %s while the RCCL communicator was being made" % (rank, rc)
-                break
-            os.unlink(status.name)
-            return rc
-        if begun is not None and not done and time.time() - begun > args.comm_timeout:
-            proc.kill()                      # exactly the child this supervisor started
-            proc.wait()
-            why = "no RCCL communicator on rank %d within %.0f s (measuring process killed)" % (rank, args.comm_timeout)
-            break
-        time.sleep(0.2)
+                decided = publish("abort" if strict else "fallback", "the measuring process of rank %d exited %s while the "
+                                  "RCCL communicator was being made" % (rank, rc))
+            else:
+                os.unlink(status.name)
+                return rc
+        elif begun is not None and not done and time.time() - begun > args.comm_timeout:
+            decided = publish("abort" if strict else "fallback", "no RCCL communicator on rank %d within %.0f s"
+                              % (rank, args.comm_timeout))
+        else:
+            time.sleep(0.2)
+    kind, why = decided
+    if proc.poll() is None:
+        proc.kill()                          # exactly the child this supervisor started
+    proc.wait()
+    if kind == "abort":
+        os.unlink(status.name)
+        sys.stderr.write("bench.py rank %d: %s -- fxc_reduce is required (pass --allow-torch-fallback to take the "
+                         "torch.distributed transport instead)\n" % (rank, why))
+        return 3
     # fall back: a fresh child on the torch.distributed transport, with a rendezvous the first attempt never touched
-    port_file = os.path.join(tempfile.gettempdir(), "fxbench_fallback_port_%s" % os.environ.get("MASTER_PORT", "0"))
     if rank == 0:
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
@@ -526,9 +686,31 @@ def supervise(args, rank, world):
     proc = start(["--reduce", "torch"], {NOTE_ENV: why, "MASTER_PORT": str(port), "TORCHELASTIC_USE_AGENT_STORE": "False"})
     rc = proc.wait()
     os.unlink(status.name)
-    if rank == 0 and os.path.exists(port_file):
-        os.unlink(port_file)
+    if rank == 0:
+        for used in (port_file, verdict_file):
+            if os.path.exists(used):
+                os.unlink(used)
     return rc
+
+
+def rccl_evidence(comm, comm_note, strict, world, backend):
+    """This rank's part of the line's "rccl" object: what the communicator fxc_comm_create made says about itself
+    (fxc_comm_info: ncclCommCount / ncclCommUserRank / ncclCommCuDevice asked of the live ncclComm_t) and the count RCCL
+    itself added up in one all-reduce of ones (fxc_comm_probe, collective).  Without a communicator: nulls and the reason."""
+    from effex_amd.plan import RcclComm
+    ev = {"transport": "fxc_reduce" if comm is not None else ("torch.distributed" if world > 1 else "none"),
+          "ranks_seen": None, "rank": None, "device_seen": None, "ranks_summed": None, "version": None, "library": None,
+          "async_error": None, "fallback_reason": comm_note, "strict": bool(strict), "torch_backend": backend if world > 1 else None}
+    try:
+        ev["version"], ev["library"] = RcclComm.library()
+    except Exception as exc:
+        ev["library"] = "not bound: %s" % exc
+    if comm is not None:
+        info = comm.info()
+        ev.update(ranks_seen=info["ranks_seen"], rank=info["rank_seen"], device_seen=info["device_seen"],
+                  version=info["rccl_version"] or ev["version"], async_error=info["async_error"])
+        ev["ranks_summed"] = comm.probe()
+    return ev
 
 
 def gather_rank_stats(stats, world):
@@ -654,7 +836,11 @@ def main():
                     help="N > 1: the cross-rank reduce.  rccl: fxc_reduce (libfxcorr calls RCCL on the plan's stream); torch: "
                          "torch.distributed (backend nccl = RCCL); auto: rccl if its preflight passes on every rank, else torch")
     ap.add_argument("--strict-rccl", action="store_true",
-                    help="exit non-zero instead of falling back to torch.distributed when fxc_reduce cannot be used")
+                    help="exit non-zero instead of falling back to torch.distributed when fxc_reduce cannot be used: the "
+                         "default with --dist-backend nccl (one GPU per rank)")
+    ap.add_argument("--allow-torch-fallback", action="store_true",
+                    help="N > 1: if fxc_reduce cannot be used (preflight fails, no communicator within --comm-timeout) take the "
+                         "torch.distributed transport instead of exiting non-zero; the line says so in rccl.fallback_reason")
     ap.add_argument("--rccl-timeout", type=float, default=120.0, help="seconds the RCCL preflight child of a rank may take")
     ap.add_argument("--comm-timeout", type=float, default=180.0,
                     help="N > 1: seconds the measuring process may spend making the real RCCL communicator before its supervisor "
@@ -756,11 +942,16 @@ def main():
                 milestone("comm:done")
             if comm is None:
                 comm_note = "no RCCL communicator (%s)" % (why or "another rank failed")
-        if comm is None and args.strict_rccl:
-            raise SystemExit("bench.py --strict-rccl: fxc_reduce is not usable: %s" % comm_note)
+        if comm is None and strict_rccl(args):
+            raise SystemExit("bench.py: fxc_reduce is not usable: %s (--allow-torch-fallback takes the torch.distributed "
+                             "transport instead)" % comm_note)
     if os.environ.get(NOTE_ENV):
         comm_note = "fell back from fxc_reduce: " + os.environ[NOTE_ENV]
     integ = sharding.ShardedIntegrator(plan, rank, world, comm=comm)
+    rccl = None
+    if world > 1:
+        why_not = comm_note or ("the torch.distributed transport was asked for (--reduce torch)" if comm is None else None)
+        rccl = rccl_evidence(comm, why_not, strict_rccl(args), world, args.dist_backend)
 
     def issue():
         """Queue one integration: the F+X launch(es) over this rank's frames, then reduce + finalize + reset (one
@@ -859,6 +1050,9 @@ def main():
           "ms_per_step_this_rank": round(elapsed_rank / max(args.steps, 1) * 1e3, 4),
           "sclk_mhz": power["sclk_mhz"] if power else None, "package_w": power["package_w"] if power else None,
           "reduce_us": reduce_us}
+    if rccl is not None:
+        my["rccl"] = {k: rccl[k] for k in ("ranks_seen", "rank", "device_seen", "ranks_summed", "async_error")}
+        my["rccl"]["reduces_queued"] = comm.info()["reduces"] if comm is not None else 0
     ranks = gather_rank_stats(my, world)
 
     if rank == 0:
@@ -910,6 +1104,13 @@ def main():
             "power": power,
         }
         if world > 1:
+            # the proof of the ranks RCCL saw, from the communicator itself (rank 0's answers; every rank's are in
+            # ranks.per_rank[*].rccl): ranks_seen = ncclCommCount, ranks_summed = an all-reduce of ones
+            per = [r.get("rccl") or {} for r in ranks]
+            rccl["reduces_queued"] = per[0].get("reduces_queued")
+            rccl["all_ranks_agree"] = (comm is not None and all(q.get("ranks_seen") == world and q.get("ranks_summed") == world
+                                                                and q.get("rank") == k for k, q in enumerate(per)))
+            line["rccl"] = rccl
             # what an efficiency below 1 is made of: the slowest rank's kernel (clock under the power cap differs from
             # GPU to GPU), the reduce, and what is left of the step outside the kernel
             line["ranks"] = {"per_rank": ranks,

@@ -49,6 +49,12 @@ class FxcInfo(ctypes.Structure):
                 ("workspace_bytes", ctypes.c_int64)]
 
 
+class FxcCommDesc(ctypes.Structure):
+    _fields_ = [("ranks_seen", ctypes.c_int32), ("rank_seen", ctypes.c_int32), ("device_seen", ctypes.c_int32),
+                ("world_given", ctypes.c_int32), ("rank_given", ctypes.c_int32), ("device_given", ctypes.c_int32),
+                ("rccl_version", ctypes.c_int32), ("async_error", ctypes.c_int32), ("reduces", ctypes.c_int64)]
+
+
 _c = ctypes
 _vp = ctypes.c_void_p
 # name -> (restype, argtypes); every symbol include/fxcorr.h declares
@@ -79,6 +85,9 @@ SIGNATURES = {
     "fxc_comm_create": (_c.c_int, [_c.POINTER(_vp), _c.c_int, _c.c_int, _c.c_int, _vp]),
     "fxc_comm_destroy": (_c.c_int, [_vp]),
     "fxc_reduce": (_c.c_int, [_vp, _vp, _c.c_int]),
+    "fxc_comm_info": (_c.c_int, [_vp, _c.POINTER(FxcCommDesc)]),
+    "fxc_comm_probe": (_c.c_int, [_vp, _c.POINTER(_c.c_int64)]),
+    "fxc_rccl_version": (_c.c_int, [_c.POINTER(_c.c_int), _c.c_char_p, _c.c_int]),
     "fxc_sync": (_c.c_int, [_vp]),
     "fxc_remove_dc": (_c.c_int, [_vp, _vp, _vp, _c.c_int64]),
     "fxc_convert_u8": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int]),

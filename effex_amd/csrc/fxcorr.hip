@@ -45,6 +45,11 @@ ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, nccl
                         ncclComm_t comm, hipStream_t stream);
 ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
                            ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank);
+ncclResult_t ncclCommCuDevice(const ncclComm_t comm, int* device);
+ncclResult_t ncclGetVersion(int* version);
+ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError);
 }
 #endif
 
@@ -796,6 +801,87 @@ int fxc_comm_destroy(void* rccl_comm) {
     return FXC_OK;
 }
 
+int fxc_rccl_version(int* version, char* path_out, int path_bytes) {
+    if (!version) return fail(nullptr, FXC_ERR_ARG, "version is NULL");
+    *version = 0;
+    if (path_out && path_bytes > 0) path_out[0] = 0;
+    RcclApi* api = rccl_api();
+    if (!api->handle) return fail(nullptr, FXC_ERR_COMM, "%s", api->error.c_str());
+    if (api->get_version) {
+        const ncclResult_t r = api->get_version(version);
+        if (r != ncclSuccess) return rccl_fail(nullptr, api, "ncclGetVersion", r);
+    }
+    if (path_out && path_bytes > 0) std::snprintf(path_out, (size_t)path_bytes, "%s", api->path.c_str());
+    return FXC_OK;
+}
+
+int fxc_comm_info(void* rccl_comm, fxc_comm_desc* info) {
+    if (!rccl_comm || !info) return fail(nullptr, FXC_ERR_ARG, "NULL argument");
+    fxc_comm* c = static_cast<fxc_comm*>(rccl_comm);
+    if (c->magic != fxc_comm::kMagic) return fail(nullptr, FXC_ERR_ARG, "not a communicator made by fxc_comm_create");
+    RcclApi* api = rccl_api();
+    if (!api->handle) return fail(nullptr, FXC_ERR_COMM, "%s", api->error.c_str());
+    std::memset(info, 0, sizeof *info);
+    info->ranks_seen = info->rank_seen = info->device_seen = info->async_error = -1;   // -1: this RCCL has no such query
+    info->world_given = c->world_size;
+    info->rank_given = c->rank;
+    info->device_given = c->device;
+    info->reduces = c->reduces;
+    // asked of the live ncclComm_t, not echoed from the arguments of fxc_comm_create
+    ncclResult_t r = ncclSuccess;
+    int v = 0;
+    if (api->comm_count) {
+        if ((r = api->comm_count(c->comm, &v)) != ncclSuccess) return rccl_fail(nullptr, api, "ncclCommCount", r);
+        info->ranks_seen = v;
+    }
+    if (api->comm_user_rank) {
+        if ((r = api->comm_user_rank(c->comm, &v)) != ncclSuccess) return rccl_fail(nullptr, api, "ncclCommUserRank", r);
+        info->rank_seen = v;
+    }
+    if (api->comm_cu_device) {
+        if ((r = api->comm_cu_device(c->comm, &v)) != ncclSuccess) return rccl_fail(nullptr, api, "ncclCommCuDevice", r);
+        info->device_seen = v;
+    }
+    if (api->get_version && api->get_version(&v) == ncclSuccess) info->rccl_version = v;
+    if (api->comm_async_error) {
+        ncclResult_t async = ncclSuccess;
+        if (api->comm_async_error(c->comm, &async) == ncclSuccess) info->async_error = (int)async;
+    }
+    return FXC_OK;
+}
+
+int fxc_comm_probe(void* rccl_comm, int64_t* ranks_summed) {
+    if (!rccl_comm || !ranks_summed) return fail(nullptr, FXC_ERR_ARG, "NULL argument");
+    *ranks_summed = 0;
+    fxc_comm* c = static_cast<fxc_comm*>(rccl_comm);
+    if (c->magic != fxc_comm::kMagic) return fail(nullptr, FXC_ERR_ARG, "not a communicator made by fxc_comm_create");
+    RcclApi* api = rccl_api();
+    if (!api->handle) return fail(nullptr, FXC_ERR_COMM, "%s", api->error.c_str());
+    FXC_DEVICE(nullptr, c->device);
+    // every rank puts in 1.0 (and its rank + 1 in a second slot): what comes back was added up by RCCL itself
+    double* d = nullptr;
+    hipStream_t s = nullptr;
+    FXC_HIP(nullptr, hipMalloc(reinterpret_cast<void**>(&d), 2 * sizeof(double)));
+    int rc = FXC_OK;
+    double h[2] = {1.0, (double)(c->rank + 1)};
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        const ncclResult_t r = api->all_reduce(d, d, 2, ncclFloat64, ncclSum, c->comm, s);
+        if (r != ncclSuccess) rc = rccl_fail(nullptr, api, "ncclAllReduce", r);
+    }
+    if (e == hipSuccess && rc == FXC_OK) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && rc == FXC_OK) e = hipStreamSynchronize(s);
+    if (s) (void)hipStreamDestroy(s);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(nullptr, FXC_ERR_HIP, "fxc_comm_probe: %s", hipGetErrorString(e));
+    const double n = h[0];
+    if (h[1] != n * (n + 1) / 2) return fail(nullptr, FXC_ERR_COMM, "fxc_comm_probe: %g ranks answered but their ranks sum to %g", n, h[1]);
+    *ranks_summed = (int64_t)n;
+    return FXC_OK;
+}
+
 int fxc_reduce(fxc_plan* p, void* rccl_comm, int root) {
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     fxc_comm* c = static_cast<fxc_comm*>(rccl_comm);
@@ -819,6 +905,7 @@ int fxc_reduce(fxc_plan* p, void* rccl_comm, int root) {
     const ncclResult_t r = root < 0 ? api->all_reduce(p->d_sums, p->d_sums, count, ncclFloat64, ncclSum, c->comm, p->stream)
                                     : api->reduce(p->d_sums, p->d_sums, count, ncclFloat64, ncclSum, root, c->comm, p->stream);
     if (r != ncclSuccess) return rccl_fail(p, api, root < 0 ? "ncclAllReduce" : "ncclReduce", r);
+    ++c->reduces;
     return FXC_OK;
 }
 

@@ -12,6 +12,7 @@ struct fxc_comm {
     unsigned magic = kMagic;
     ncclComm_t comm = nullptr;
     int device = -1, rank = 0, world_size = 1;
+    long long reduces = 0;          // collectives fxc_reduce has queued on it
 };
 
 namespace {
@@ -24,7 +25,13 @@ struct RcclApi {
     decltype(&ncclReduce) reduce = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
-    std::string error;
+    // what the communicator says about itself (fxc_comm_info); optional: an RCCL without them still reduces
+    decltype(&ncclCommCount) comm_count = nullptr;
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
+    decltype(&ncclCommCuDevice) comm_cu_device = nullptr;
+    decltype(&ncclGetVersion) get_version = nullptr;
+    decltype(&ncclCommGetAsyncError) comm_async_error = nullptr;
+    std::string error, path;
 };
 
 void rccl_bind(RcclApi& api) {
@@ -52,7 +59,17 @@ void rccl_bind(RcclApi& api) {
     api.reduce = reinterpret_cast<decltype(api.reduce)>(bind("ncclReduce"));
     api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(bind("ncclAllReduce"));
     api.error_string = reinterpret_cast<decltype(api.error_string)>(bind("ncclGetErrorString"));
-    if (!ok) api.handle = nullptr;
+    if (!ok) {
+        api.handle = nullptr;
+        return;
+    }
+    api.comm_count = reinterpret_cast<decltype(api.comm_count)>(dlsym(api.handle, "ncclCommCount"));
+    api.comm_user_rank = reinterpret_cast<decltype(api.comm_user_rank)>(dlsym(api.handle, "ncclCommUserRank"));
+    api.comm_cu_device = reinterpret_cast<decltype(api.comm_cu_device)>(dlsym(api.handle, "ncclCommCuDevice"));
+    api.get_version = reinterpret_cast<decltype(api.get_version)>(dlsym(api.handle, "ncclGetVersion"));
+    api.comm_async_error = reinterpret_cast<decltype(api.comm_async_error)>(dlsym(api.handle, "ncclCommGetAsyncError"));
+    Dl_info where;                           // which copy was bound: the line of an N > 1 run names it
+    if (api.reduce && dladdr(reinterpret_cast<void*>(api.reduce), &where) && where.dli_fname) api.path = where.dli_fname;
 }
 
 // bound once per process, on first use (a function-local static: initialised exactly once even with several caller threads)

@@ -547,6 +547,33 @@ class RcclComm(object):
         _lib.check(lib.fxc_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), None)
         return bytes(buf.raw)
 
+    def info(self):
+        """What the live communicator says about itself (``fxc_comm_info``): ``ranks_seen`` / ``rank_seen`` /
+        ``device_seen`` are asked of the ncclComm_t (None where the bound RCCL lacks the query), ``*_given`` are what this
+        object was made with; ``rccl_version``, ``async_error`` (0 = ncclSuccess), ``reduces`` queued through it."""
+        d = _lib.FxcCommDesc()
+        _lib.check(self._lib.fxc_comm_info(self.handle, ctypes.byref(d)), None)
+        out = {name: int(getattr(d, name)) for name, _ in d._fields_}
+        for key in ("ranks_seen", "rank_seen", "device_seen", "async_error"):
+            if out[key] < 0:
+                out[key] = None
+        return out
+
+    def probe(self):
+        """Collective, blocking: every rank contributes 1.0 to one ncclAllReduce; returns the count RCCL added up."""
+        n = ctypes.c_int64(0)
+        _lib.check(self._lib.fxc_comm_probe(self.handle, ctypes.byref(n)), None)
+        return int(n.value)
+
+    @staticmethod
+    def library():
+        """(version, path) of the librccl bound at run time; raises FxcError(FXC_ERR_COMM) if none could be."""
+        lib = _lib.load()
+        v = ctypes.c_int(0)
+        buf = ctypes.create_string_buffer(1024)
+        _lib.check(lib.fxc_rccl_version(ctypes.byref(v), buf, len(buf)), None)
+        return int(v.value), buf.value.decode("utf-8", "replace")
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.fxc_comm_destroy(self.handle)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FXC_VERSION 104 /* 0.1.0 */
+#define FXC_VERSION 105 /* 0.1.0 */
 
 typedef struct fxc_plan fxc_plan; /* opaque; one per (device, configuration) */
 typedef struct fxc_pipe fxc_pipe; /* opaque; host-fed double-buffered front end on a plan */
@@ -141,6 +141,24 @@ int fxc_comm_unique_id(void* id_out);
 int fxc_comm_create(void** rccl_comm_out, int device, int rank, int world_size, const void* id);
 int fxc_comm_destroy(void* rccl_comm);
 int fxc_reduce(fxc_plan* plan, void* rccl_comm, int root);
+
+/* What a communicator says about itself, so that a multi-GPU result can carry the proof of the ranks RCCL saw (the
+ * reference has no counterpart: its chunks are merely independent, effex.py:391-410).  *_seen are asked of the live
+ * ncclComm_t (ncclCommCount / ncclCommUserRank / ncclCommCuDevice; -1 where the bound RCCL lacks the query), *_given are
+ * the arguments fxc_comm_create was called with; rccl_version = ncclGetVersion (e.g. 22105); async_error =
+ * ncclCommGetAsyncError (0 = ncclSuccess); reduces = collectives fxc_reduce has queued on this communicator.
+ * fxc_comm_probe (collective, blocking): one ncclAllReduce in which every rank contributes 1.0 -- *ranks_summed is the
+ * number of ranks RCCL itself added up; FXC_ERR_COMM if their rank numbers do not add up to 1 + ... + n.
+ * fxc_rccl_version: the version and (path_out, may be NULL) the file name of the librccl that was bound at run time. */
+typedef struct fxc_comm_desc {
+    int32_t ranks_seen, rank_seen, device_seen;
+    int32_t world_given, rank_given, device_given;
+    int32_t rccl_version, async_error;
+    int64_t reduces;
+} fxc_comm_desc;
+int fxc_comm_info(void* rccl_comm, fxc_comm_desc* info);
+int fxc_comm_probe(void* rccl_comm, int64_t* ranks_summed);
+int fxc_rccl_version(int* version, char* path_out, int path_bytes);
 
 /* Single-GPU finalize: mean over everything accumulated, times conj(rot), fftshift; D2H.
  *   SPECTRUM : out_host = [n_baselines][nchan] complex128;  CONTINUUM: [n_baselines] complex128.

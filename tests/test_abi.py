@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.fxc_version() == 104
+    assert lib.fxc_version() == 105
     assert lib.fxc_status_string(0) == b"ok"
     assert b"unsupported" in lib.fxc_status_string(_lib.FXC_ERR_UNSUPPORTED)
 
@@ -59,6 +59,8 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.fxc_comm_unique_id(None) == _lib.FXC_ERR_ARG
     assert lib.fxc_comm_create(None, 0, 0, 1, None) == _lib.FXC_ERR_ARG
     assert lib.fxc_comm_destroy(None) == _lib.FXC_OK
+    assert lib.fxc_comm_info(None, None) == _lib.FXC_ERR_ARG and lib.fxc_comm_probe(None, None) == _lib.FXC_ERR_ARG
+    assert lib.fxc_rccl_version(None, None, 0) == _lib.FXC_ERR_ARG
     assert b"RCCL" in lib.fxc_status_string(_lib.FXC_ERR_COMM)
     assert lib.fxc_plan_destroy(None) == _lib.FXC_OK
     assert lib.fxc_fx_rows_iq(None, None, None, 1, 0, 0, 1.0, _lib.FXC_IQ_C128, 1) == _lib.FXC_ERR_ARG

@@ -324,12 +324,15 @@ def test_shared_row_file_shows_nothing_before_the_count_is_published(tmp_path):
     assert rows.shape == (6, 4) and (rows[2:5] == 3).all() and not rows[:2].any() and not rows[5:].any()
 
 
-def _dry_run(n_ranks, *extra, env=None):
+def _dry_run(n_ranks, *extra, env=None, expect_failure=False):
     import json
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--steps", "3",
            "--warmup", "1", "--dry-run-dist"] + list(extra)
     proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    if expect_failure:
+        assert proc.returncode != 0 and not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")], proc.stdout[-2000:]
+        return proc.stderr
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                       # rank 0 alone prints the line
@@ -342,12 +345,29 @@ def test_bench_supervisor_falls_back_when_the_communicator_hangs():
     killed after --comm-timeout and a fresh child takes the torch.distributed transport on a rendezvous of its own.  The
     run completes, exits 0, and says what happened."""
     env = dict(os.environ, FXC_BENCH_TEST_COMM_HANG="1")
-    line = _dry_run(3, "--supervise", "--comm-timeout", "3", env=env)
+    line = _dry_run(3, "--supervise", "--comm-timeout", "3", "--allow-torch-fallback", env=env)
     assert line["n_gpus"] == 3 and line["frames_total"] == 300 and line["mean_chunk_index"] == 149.5
-    assert "no RCCL communicator on rank 0 within 3 s" in line["fallback"]
+    assert "no RCCL communicator on rank" in line["fallback"] and "within 3 s" in line["fallback"]
+    assert line["rccl"]["ranks_seen"] is None and line["rccl"]["fallback_reason"] == line["fallback"]
     # without the hang: the same supervised launch finishes on the first attempt
     line = _dry_run(2, "--supervise", "--comm-timeout", "30")
     assert line["fallback"] is None and line["frames_total"] == 200
+
+
+def test_bench_supervisor_decides_for_all_ranks():
+    """One rank of three never gets its communicator; the other two are past theirs and wait for it in a collective.  The
+    verdict of the supervisor that times out is everybody's (a file all supervisors poll): with --allow-torch-fallback all
+    three start the torch.distributed attempt together and the run completes; without it (the default: fxc_reduce or
+    nothing) all three kill their children and the launch exits non-zero within seconds, printing no line."""
+    import time
+    env = dict(os.environ, FXC_BENCH_TEST_COMM_HANG="rank:1")
+    line = _dry_run(3, "--supervise", "--comm-timeout", "3", "--allow-torch-fallback", env=env)
+    assert line["frames_total"] == 300 and line["mean_chunk_index"] == 149.5
+    assert "no RCCL communicator on rank 1 within 3 s" in line["fallback"]
+    t0 = time.time()
+    err = _dry_run(3, "--supervise", "--comm-timeout", "3", env=env, expect_failure=True)
+    assert "no RCCL communicator on rank 1 within 3 s" in err and "fxc_reduce is required" in err
+    assert time.time() - t0 < 120
 
 
 def test_bench_dry_run_dist_two_ranks():
@@ -358,6 +378,7 @@ def test_bench_dry_run_dist_two_ranks():
     assert line["dry_run"] and line["n_gpus"] == 2 and line["steps"] == 3 and line["frames_per_rank"] == [100, 100]
     assert line["scaling"] == "weak" and line["frames_total"] == 200
     assert line["first_chunk_last_rank"] == 100 and line["transport"] == "torch.distributed"
+    assert line["rccl"]["ranks_seen"] is None and "gloo" in line["rccl"]["fallback_reason"]      # says why RCCL saw no ranks
     assert line["mean_chunk_index"] == 99.5      # mean over both ranks' chunk ranges: the reduce reached the root
     assert [r["rank"] for r in line["ranks"]["per_rank"]] == [0, 1]
     assert line["ranks"]["ms_per_step_this_rank"]["max"] <= line["ms_per_step"] * 1.5 + 1.0

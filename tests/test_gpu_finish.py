@@ -186,6 +186,14 @@ def test_one_communicator_serves_several_plans(plan_mod, torch):
         with pytest.raises(ValueError):
             pa.reduce(comm, 1)
         np.testing.assert_array_equal(pa.finalize("SPECTRUM"), ref_a)     # the refused call queued nothing
+        # the communicator's own account of itself (fxc_comm_info / fxc_comm_probe): asked of the live ncclComm_t
+        info = comm.info()
+        assert info["ranks_seen"] == 1 and info["rank_seen"] == 0 and info["device_seen"] == 0, info
+        assert (info["world_given"], info["rank_given"], info["device_given"]) == (1, 0, 0)
+        assert info["reduces"] == 4 and info["async_error"] == 0 and info["rccl_version"] >= 20000, info
+        assert comm.probe() == 1
+        version, path = plan_mod.RcclComm.library()
+        assert version == info["rccl_version"] and "rccl" in path
 
 
 def test_headline_config_at_full_size(plan_mod, torch):
@@ -306,3 +314,7 @@ def test_reduce_between_two_gpus():
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+    import json
+    for r, out in enumerate(outs):          # each rank's communicator saw two ranks, and RCCL added up two ones
+        seen = json.loads(out[out.index("ok {") + 3:].splitlines()[0])
+        assert seen["ranks_seen"] == 2 and seen["rank"] == r and seen["ranks_summed"] == 2 and seen["reduces"] == 3, seen

@@ -1713,6 +1713,12 @@ def test_bench_two_ranks_share_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["frames_per_gpu"] == 600 and line["config"]["path"] == "fused"
     assert line["config"]["reduce_transport"].startswith("torch.distributed; ranks share GPUs")
+    # the line says which ranks RCCL saw: none here (gloo, shared GPU), with the reason, and not under the strict default
+    rccl = line["rccl"]
+    assert rccl["transport"] == "torch.distributed" and rccl["ranks_seen"] is None and rccl["ranks_summed"] is None
+    assert "ranks share GPUs" in rccl["fallback_reason"] and rccl["strict"] is False and rccl["all_ranks_agree"] is False
+    assert rccl["torch_backend"] == "gloo" and rccl["version"] >= 20000 and "rccl" in rccl["library"]
+    assert all(r["rccl"]["ranks_seen"] is None and r["rccl"]["reduces_queued"] == 0 for r in ranks)
     assert line["verify"]["frames"] == 1200 and line["verify"]["integration_vs_float64_mean_of_rows"] < 1e-6
     assert line["value"] > 0 and line["roofline"]["launches"] == 2 and line["scaling"] == "weak"
     ranks = line["ranks"]
@@ -1756,6 +1762,12 @@ def test_bench_eight_ranks_share_one_gpu(scaling, frames):
     assert max(r["frames"] for r in ranks) - min(r["frames"] for r in ranks) <= (0 if scaling == "weak" else 1)
     assert all(r["avg_kernel_ms"] > 0 and r["launches"] == 2 for r in ranks) and line["ranks"]["reduce_us"]["max"] > 0
     assert line["config"]["reduce_transport"].startswith("torch.distributed; ranks share GPUs")
+    # the line says which ranks RCCL saw: none here (gloo, shared GPU), with the reason, and not under the strict default
+    rccl = line["rccl"]
+    assert rccl["transport"] == "torch.distributed" and rccl["ranks_seen"] is None and rccl["ranks_summed"] is None
+    assert "ranks share GPUs" in rccl["fallback_reason"] and rccl["strict"] is False and rccl["all_ranks_agree"] is False
+    assert rccl["torch_backend"] == "gloo" and rccl["version"] >= 20000 and "rccl" in rccl["library"]
+    assert all(r["rccl"]["ranks_seen"] is None and r["rccl"]["reduces_queued"] == 0 for r in ranks)
     assert line["value"] > 0 and line["roofline"]["launches"] == 2
 
 
