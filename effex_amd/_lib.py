@@ -46,7 +46,7 @@ class FxcInfo(ctypes.Structure):
                 ("ntaps", ctypes.c_int32), ("num_samp", ctypes.c_int64), ("n_pts", ctypes.c_int64),
                 ("path", ctypes.c_int32), ("grid", ctypes.c_int32), ("block", ctypes.c_int32),
                 ("lds_bytes", ctypes.c_int32), ("device", ctypes.c_int32), ("cu_count", ctypes.c_int32),
-                ("workspace_bytes", ctypes.c_int64)]
+                ("workspace_bytes", ctypes.c_int64), ("specialised", ctypes.c_int32), ("spec_vgprs", ctypes.c_int32)]
 
 
 class FxcCommDesc(ctypes.Structure):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "fxc_plan_destroy": (_c.c_int, [_vp]),
     "fxc_set_stream": (_c.c_int, [_vp, _vp]),
     "fxc_plan_get_info": (_c.c_int, [_vp, _c.POINTER(FxcInfo)]),
+    "fxc_spec_probe": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_char_p, _c.c_char_p, _c.c_int]),
     "fxc_last_error": (_c.c_char_p, [_vp]),
     "fxc_set_rot": (_c.c_int, [_vp, _vp]),
     "fxc_channelize": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int]),

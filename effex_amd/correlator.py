@@ -320,6 +320,7 @@ class Correlator(object):
         self._fx_plan = None
         self._f_plans = {}
         self._rot_key = None
+        self._filler_grace_s = 10.0     # _run_batched's error path: how long a closed source's read may take to return
 
         self.run_time = run_time
         self.bandwidth = bandwidth
@@ -338,7 +339,7 @@ class Correlator(object):
         self._alloc_staging(int(self.num_samp))
 
         self.ntaps = 4                                           # effex.py:115
-        n_int = len(self.gpu_iq_0) // self.ntaps // self.nbins   # effex.py:118-124
+        n_int = len(self._gpu_iq[0]) // self.ntaps // self.nbins   # effex.py:118-124
         assert (n_int >= 1), ('Assertion failed: there must be at least 1 window of length n_branches*ntaps '
                               'in each input timeseries.\ntimeseries len: {}\nn_branches: {}\nntaps: {}\n'
                               'n_branches*ntaps: {}').format(len(self.gpu_iq_0), self.nbins, self.ntaps,
@@ -364,7 +365,7 @@ class Correlator(object):
         self._pair_buf[...] = 0
         self._gpu_iq = [self._pair_buf[0, 0], self._pair_buf[0, 1]]
         self._row_bufs = {}
-        self._staged_dc = False     # the staged pair still carries its mean: the device removes it (set by _stage)
+        self._dc_pending = False    # the pair _stage left in the pinned buffers still carries its mean (see _settle_dc)
 
     def _row_buf(self, shape, dtype):
         key = (shape, np.dtype(dtype).str)
@@ -373,33 +374,47 @@ class Correlator(object):
             buf = self._row_bufs[key] = _staging_empty(shape, dtype)[0]
         return buf
 
+    def _settle_dc(self):
+        """The RUN loop's _stage leaves the raw chunk pair in the pinned buffers and lets the device take the mean off on
+        the way in (``_dc_pending``; effex.py:394-395 without a host pass).  The reference's ``gpu_iq_0/1`` hold de-meaned
+        samples at that point, and its ``_pfb_xcorr`` never removes anything: so the moment anybody looks at the buffers
+        through the public names -- to read them, to write into them in place (``cor.gpu_iq_0[:] = data``, effex.py:391) or
+        to rebind them -- the mean comes off here, on the host, in place, and the device is no longer asked to.  What
+        ``_run_task`` then computes is exactly what the buffers hold."""
+        if self._dc_pending:
+            self._dc_pending = False
+            for a in range(2):
+                view = self._pair_buf[0, a]
+                view -= np.complex64(complex(view.real.mean(dtype=np.float64), view.imag.mean(dtype=np.float64)))
+
     @property
     def gpu_iq_0(self):
+        self._settle_dc()
         return self._gpu_iq[0]
 
     @gpu_iq_0.setter
     def gpu_iq_0(self, value):
+        self._settle_dc()
         self._gpu_iq[0] = value
-        self._staged_dc = False
 
     @property
     def gpu_iq_1(self):
+        self._settle_dc()
         return self._gpu_iq[1]
 
     @gpu_iq_1.setter
     def gpu_iq_1(self, value):
+        self._settle_dc()
         self._gpu_iq[1] = value
-        self._staged_dc = False
 
     def _staged_pair(self):
         """The pinned chunk pair [1, 2, n] complex64 holding gpu_iq_0 / gpu_iq_1: as it is when they still are its two
         halves, else filled from whatever they were rebound to (one narrowing pass per stream)."""
         n = len(self._gpu_iq[0])
         if self._pair_buf.shape[2] != n:
-            held = list(self._gpu_iq)
-            dc = self._staged_dc
+            held = list(self._gpu_iq)       # (never with _dc_pending: _stage sizes the pair itself)
             self._alloc_staging(n)
-            self._gpu_iq, self._staged_dc = held, dc
+            self._gpu_iq = held
         for a in range(2):
             view = self._pair_buf[0, a]
             if self._gpu_iq[a] is not view:
@@ -560,13 +575,14 @@ class Correlator(object):
             out = self._row_buf((1, 1, int(self.nbins)), np.complex64)
             return plan.fx_rows_u8(u8, 'SPECTRUM', remove_dc=self.remove_dc, out=out)[0, 0].astype(np.complex128)
         # the pinned pair goes over PCIe by DMA, the row comes back written by the device into a pinned row buffer; a pair
-        # staged by _stage is de-meaned on the device on the way (effex.py:394-395)
+        # _stage left there and nobody has looked at since is de-meaned on the device on the way (effex.py:394-395)
+        dc = self._dc_pending
         pair = self._staged_pair()
         if self.mode in ('CONTINUUM', 'TEST'):
             out = self._row_buf((1, 1), np.complex128)
-            return plan.fx_rows(pair, 'CONTINUUM', self.bandwidth, remove_dc=self._staged_dc, out=out)[0, 0]
+            return plan.fx_rows(pair, 'CONTINUUM', self.bandwidth, remove_dc=dc, out=out)[0, 0]
         out = self._row_buf((1, 1, int(self.nbins)), np.complex64)
-        return plan.fx_rows(pair, 'SPECTRUM', remove_dc=self._staged_dc, out=out)[0, 0].astype(np.complex128)
+        return plan.fx_rows(pair, 'SPECTRUM', remove_dc=dc, out=out)[0, 0].astype(np.complex128)
 
     def _run_task(self):
         """effex.py:490-494."""
@@ -654,7 +670,7 @@ class Correlator(object):
         for a, iq in enumerate((iq_0, iq_1)):
             np.copyto(self._pair_buf[0, a], np.asarray(iq).reshape(n), casting='same_kind')
         self._gpu_iq = [self._pair_buf[0, 0], self._pair_buf[0, 1]]
-        self._staged_dc = bool(self.remove_dc)
+        self._dc_pending = bool(self.remove_dc)
 
     def _run_batched(self, first_pair, sink, fh):
         """The RUN state for ``batch`` > 1: chunk pairs go ``batch`` at a time through a three-slot ``FxPipeline`` -- the
@@ -698,6 +714,7 @@ class Correlator(object):
             # meanwhile collects the oldest batch in flight; every fxc_* call stays on the main thread
             import concurrent.futures
             filler = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            job = None
             try:
                 pending, k = first_pair, 0
                 while True:
@@ -711,10 +728,19 @@ class Correlator(object):
                         break
                     pipe.submit()
             except BaseException:
-                # the filler may sit in a blocking read (a socket source): closing the source ends that read, and the
-                # exit below does not wait for it
+                # the filler may sit in a blocking read (a socket source) that writes into a pinned slot of the pipe:
+                # closing the source ends that read; the pipe (and its slots) may only be freed once the read has
+                # returned.  A read that does not come back within the bound keeps its memory: the pipe is abandoned
+                # (leaked, with its plan) rather than freed under a live writer.
                 self.source.close()
                 filler.shutdown(wait=False, cancel_futures=True)
+                if job is not None and not job.cancelled():
+                    done, _ = concurrent.futures.wait([job], timeout=self._filler_grace_s)
+                    if not done:
+                        self.logger.error('the source did not return from its read within {} s of being closed: '
+                                          'leaking the staging slots it writes into'.format(self._filler_grace_s))
+                        pipe.abandon()
+                        self._fx_plan = None      # (the plan object keeps the abandoned handle alive; close() skips it)
                 raise
             filler.shutdown(wait=True)
             while pipe.in_flight:

@@ -4,7 +4,9 @@
 #pragma once
 
 #if defined(__HIPCC__)
+#if !defined(__HIPCC_RTC__)      // (hiprtc brings the runtime's declarations itself: fx_spec.h is compiled through it)
 #include <hip/hip_runtime.h>
+#endif
 #define FXC_HD __host__ __device__ __forceinline__
 #define FXC_D __device__ __forceinline__
 #else

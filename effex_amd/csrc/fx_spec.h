@@ -1,0 +1,401 @@
+// fx_spec.h -- the F+X kernel for two antennas at a channel count that is not a power of two (`--resolution` is a free
+// integer in the reference, effex/effex.py:733-739), SPECIALISED for one channel count at run time: libfxcorr hands
+// this file to hiprtc with the shape as -D options (h_rtc.h), the way FFT libraries build their kernels.  Same
+// arithmetic as the any-shape kernel of k_generic.h (polyphase FIR of SURVEY.md 2.3, the Stockham autosort stages of
+// fx_mixed.h on the same float64-rounded twiddle table, s0 conj(s1) summed over the run of frames), but with every
+// stride, stage and trip count a compile-time constant:
+//
+//   * every sample is fetched ONCE: a thread keeps the last T - 1 frames' samples of its own points in registers (the
+//     ring), frame f + 1 is in flight while frame f goes through its stages; the window taps of those points and the
+//     inter-stage twiddles of the thread's butterflies are loaded once per launch and live in registers too;
+//   * the FIR feeds the first butterfly straight from registers (a thread's points ARE the inputs of its stage-0
+//     butterflies: m = b + r N/R0), and the last butterfly feeds the X stage straight from registers (both antennas'
+//     outputs for the same bins are in the same thread): S - 1 trips through LDS instead of S + 1, S - 1 barriers;
+//   * LDS addresses are one base register plus immediates; the only index arithmetic left inside the frame loop is the
+//     frame pointer's increment.
+//
+// Options (all required): FXM_N channels, FXM_T taps (1..4), FXM_TPR threads per slot (a slot = the threads that carry
+// one frame pair), FXM_SLOTS slots per workgroup (each with its own contiguous run of frames), FXM_NST stages,
+// FXM_RADICES their radices (comma list; product = N; 2, 3, 4, 5, 7, 11, 13), FXM_U8 (1: samples are the receivers'
+// interleaved unsigned bytes, converted as pyrtlsdr does behind effex.py:652 with the per-stream offset of k_conditioning.h).
+//
+// Compiles as device code under hiprtc / hipcc and as plain C++ under g++: tests/emul/emul_spec.cpp runs the same body
+// with one host thread per GPU thread and a real barrier (test infrastructure only).
+#pragma once
+
+#include "fx_mixed.h"
+
+#if !defined(FXM_N) || !defined(FXM_T) || !defined(FXM_TPR) || !defined(FXM_SLOTS) || !defined(FXM_NST) || !defined(FXM_RADICES) || !defined(FXM_U8)
+#error "fx_spec.h is compiled per shape: -DFXM_N= -DFXM_T= -DFXM_TPR= -DFXM_SLOTS= -DFXM_NST= -DFXM_RADICES= -DFXM_U8="
+#endif
+
+namespace fxm {
+
+using fxc::cf;
+using fxc::pk;
+using fxc::pk2;
+using fxc::pk_cmul;
+using fxc::pk_fma;
+using fxc::pk_splat;
+using fxc::unpk;
+
+constexpr int N = FXM_N;
+constexpr int T = FXM_T;
+constexpr int TPR = FXM_TPR;
+constexpr int SLOTS = FXM_SLOTS;
+constexpr int S = FXM_NST;
+constexpr int kRadix[S] = {FXM_RADICES};
+constexpr bool U8 = FXM_U8 != 0;
+constexpr int THREADS = TPR * SLOTS;
+
+constexpr int ns_of(int s) {
+    int v = 1;
+    for (int i = 0; i < s; ++i) v *= kRadix[i];
+    return v;
+}
+constexpr int nb_of(int s) { return N / kRadix[s]; }
+constexpr int j_of(int s) { return (nb_of(s) + TPR - 1) / TPR; }        // butterflies of stage s per thread
+constexpr bool full_of(int s) { return j_of(s) * TPR == nb_of(s); }     // ... and every thread has all of them
+constexpr int tw_base(int s) {                                          // first twiddle register of stage s (s >= 1)
+    int c = 0;
+    for (int i = 1; i < s; ++i) c += j_of(i) * (kRadix[i] - 1);
+    return c;
+}
+constexpr int ob_base(int s) {                                          // first output-offset register of stage s (1 <= s <= S-2)
+    int c = 0;
+    for (int i = 1; i < s; ++i) c += j_of(i);
+    return c;
+}
+constexpr int R0 = kRadix[0], J0 = j_of(0), PTS = R0 * J0;              // a thread's points: m = lt + j TPR + r N/R0
+constexpr int RL = kRadix[S - 1], JL = j_of(S - 1);
+constexpr int TWC = tw_base(S), OBC = ob_base(S > 1 ? S - 1 : 1);
+constexpr bool SWAP = S >= 2 && S % 2 == 0;      // the last stage reads the buffer the next frame's first stage writes: alternate them
+constexpr int ROW = N;                           // one antenna's row; a slot's LDS: [buffer X | Y][antenna][N]
+constexpr int LDS_PER_SLOT = S >= 2 ? 4 * N : 0; // complex64 elements
+
+static_assert(ns_of(S) == N, "the radices multiply to N");
+static_assert(T >= 1 && T <= 4, "one to four taps (the ring lives in registers)");
+static_assert(SLOTS >= 1 && (SLOTS == 1 || TPR % 64 == 0 || 64 % TPR == 0), "slots do not straddle waves");
+
+// per-thread state, all of it registers once the loops below are unrolled
+struct Thread {
+    pk2 ring[2][PTS][T];             // frame f's samples of the thread's points in slot f mod T
+    float hw[T][PTS];                // the window taps of those points
+    pk2 tw[TWC > 0 ? TWC : 1];       // twiddles of the thread's butterflies in stages 1 .. S-1
+    int ob[OBC > 0 ? OBC : 1];       // where the butterflies of stages 1 .. S-2 put their outputs
+    pk2 xacc[JL * RL];               // sum over the run of s0 conj(s1) at the bins the thread's last butterflies produce
+};
+
+template <int R>
+FXC_HD void dft_regs(pk2 (&v)[R], const fxc::Roots<R>& rt, pk2 (&o)[R]) {
+    cf tmp[R];
+    fxc::dft_store<R>(v, rt, tmp, 1);
+#pragma unroll
+    for (int q = 0; q < R; ++q) o[q] = pk(tmp[q]);
+}
+
+// a conj(b) added to acc:  b.x (a.x, a.y) + b.y (a.y, -a.x)
+FXC_HD pk2 x_acc(pk2 acc, pk2 a, pk2 b) {
+    const pk2 ar = {a[1], -a[0]};
+    return pk_fma(pk_splat(b[1]), ar, pk_fma(pk_splat(b[0]), a, acc));
+}
+
+// what the launch hands every thread
+struct Args {
+    const void* x;            // [chunk][2][num_samp] complex64, or interleaved unsigned bytes (U8)
+    const float* h;           // [T][N]
+    cf* out;                  // raw[split][chunk][N], split = workgroup split * SLOTS + slot
+    const cf* tw;             // [N] exp(+2 pi i n / N)
+    const cf* dc_u8;          // U8: conversion offsets [chunk][2]
+    long long num_samp, n_pts, n_chunks;
+    int wg_splits;
+};
+
+// The body of one GPU thread.  Ctx: tid(), bid(), lds() (the workgroup's LDS as cf*), sync() (all threads of the
+// workgroup -- or, for slots inside one wave, just program order).
+template <class Ctx>
+struct Body {
+    Ctx& cx;
+    const Args& ar;
+    Thread th;
+    int lt, slot;
+    cf *bx, *by;              // this slot's two buffers (S >= 2)
+    const cf* xs[2];          // this chunk's two streams (complex64)
+    const unsigned short* xb[2];
+    pk2 off8[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rsrc[2];
+#endif
+
+    FXC_HD Body(Ctx& c, const Args& a) : cx(c), ar(a) {}
+
+    FXC_HD static bool has_bfly(int s, int j, int lt_) { return full_of(s) || j + 1 < j_of(s) || lt_ + j * TPR < nb_of(s); }
+
+    // ---- once per launch: taps, twiddles, output offsets
+    FXC_HD void init() {
+        lt = cx.tid() % TPR;
+        slot = cx.tid() / TPR;
+        bx = cx.lds() + slot * LDS_PER_SLOT;
+        by = bx + 2 * N;
+#pragma unroll
+        for (int j = 0; j < J0; ++j)
+#pragma unroll
+            for (int r = 0; r < R0; ++r) {
+                const int m = lt + j * TPR + r * nb_of(0);
+#pragma unroll
+                for (int t = 0; t < T; ++t) th.hw[t][j * R0 + r] = has_bfly(0, j, lt) ? ar.h[t * N + m] : 0.f;
+            }
+        init_stage<1>();
+#pragma unroll
+        for (int i = 0; i < JL * RL; ++i) th.xacc[i] = pk_splat(0.f);
+    }
+    template <int s>
+    FXC_HD void init_stage() {
+        if constexpr (s < S) {
+            constexpr int R = kRadix[s], nb = nb_of(s), ns = ns_of(s), tmul = nb / ns;
+#pragma unroll
+            for (int j = 0; j < j_of(s); ++j) {
+                int b = lt + j * TPR;
+                if (b >= nb) b = 0;                       // (a thread without this butterfly: any valid index)
+                const int k = b % ns;
+#pragma unroll
+                for (int r = 1; r < R; ++r) th.tw[tw_base(s) + j * (R - 1) + r - 1] = pk(ar.tw[r * k * tmul]);
+                if constexpr (s < S - 1) th.ob[ob_base(s) + j] = (b - k) * R + k;
+            }
+            init_stage<s + 1>();
+        }
+    }
+
+    // ---- samples of frame f (relative to the chunk) into ring slot P.  Device: buffer loads -- one VGPR byte offset per
+    // thread (it carries the frame: slots inside one wave are at different frames), the point's place in the frame is an
+    // immediate, the antenna a buffer descriptor of its own.
+    static constexpr int kElem = U8 ? 2 : 8;                  // bytes per sample
+    template <int P>
+    FXC_HD void load_frame(long long f, bool valid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+        // butterfly j's points sit at N-1-m, m = lt + j TPR + r N/R0: one VGPR offset per j, counted from the lowest address of
+        // its points (r = R0 - 1), so that it is non-negative for every thread that has the butterfly and the rest is an immediate
+        unsigned voff[J0];
+#pragma unroll
+        for (int j = 0; j < J0; ++j)
+            voff[j] = (unsigned)((int)(f * N) + (N - 1 - lt - j * TPR - (R0 - 1) * nb_of(0))) * (unsigned)kElem;      // a chunk is below 2 GiB
+#endif
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < J0; ++j)
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    const int m = lt + j * TPR + r * nb_of(0);
+                    const bool ok = valid && has_bfly(0, j, lt);
+                    pk2 v = pk_splat(0.f);
+                    if (ok) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                        const unsigned cst = (unsigned)((R0 - 1 - r) * nb_of(0)) * (unsigned)kElem;
+                        if constexpr (U8) {
+                            const unsigned raw = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc[a], voff[j], cst, 0);
+                            const pk2 bytes = {(float)(raw & 0xFFu), (float)(raw >> 8)};
+                            v = pk_fma(bytes, pk_splat(1.0f / 127.5f), off8[a]);
+                        } else {
+                            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc[a], voff[j], cst, 0);
+                            v = pk2{__uint_as_float(d[0]), __uint_as_float(d[1])};
+                        }
+#else
+                        const long long at = f * N + (N - 1 - m);
+                        if constexpr (U8) {
+                            const unsigned raw = xb[a][at];
+                            const pk2 bytes = {(float)(raw & 0xFFu), (float)(raw >> 8)};
+                            v = pk_fma(bytes, pk_splat(1.0f / 127.5f), off8[a]);
+                        } else {
+                            v = pk(xs[a][at]);
+                        }
+#endif
+                    }
+                    th.ring[a][j * R0 + r][P] = v;
+                }
+    }
+
+    // ---- one middle stage: LDS -> LDS
+    template <int s>
+    FXC_HD void mid_stage(const cf* src, cf* dst) {
+        constexpr int R = kRadix[s], nb = nb_of(s), ns = ns_of(s);
+        const fxc::Roots<R> rt = fxc::load_roots<R>(ar.tw, nb);
+#pragma unroll
+        for (int j = 0; j < j_of(s); ++j) {
+            const int b = lt + j * TPR;
+            if (has_bfly(s, j, lt)) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    pk2 v[R];
+                    v[0] = pk(src[a * ROW + b]);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[r] = pk_cmul(pk(src[a * ROW + b + r * nb]), th.tw[tw_base(s) + j * (R - 1) + r - 1]);
+                    fxc::dft_store<R>(v, rt, dst + a * ROW + th.ob[ob_base(s) + j], ns);
+                }
+            }
+        }
+    }
+
+    // ---- the last stage (s = S - 1 >= 1): LDS -> registers -> X
+    FXC_HD void last_stage(const cf* src, bool live) {
+        constexpr int s = S - 1, R = RL, nb = nb_of(s);
+        const fxc::Roots<R> rt = fxc::load_roots<R>(ar.tw, nb);
+#pragma unroll
+        for (int j = 0; j < JL; ++j) {
+            const int b = lt + j * TPR;
+            if (live && has_bfly(s, j, lt)) {
+                pk2 o[2][R];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    pk2 v[R];
+                    v[0] = pk(src[a * ROW + b]);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[r] = pk_cmul(pk(src[a * ROW + b + r * nb]), th.tw[tw_base(s) + j * (R - 1) + r - 1]);
+                    dft_regs<R>(v, rt, o[a]);
+                }
+#pragma unroll
+                for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc(th.xacc[j * R + q], o[0][q], o[1][q]);
+            }
+        }
+    }
+
+    template <int s>
+    FXC_HD void mid_stages(cf* rd, cf* wr) {       // stage s reads rd, writes wr; a barrier behind each
+        if constexpr (s < S - 1) {
+            mid_stage<s>(rd, wr);
+            cx.sync();
+            mid_stages<s + 1>(wr, rd);
+        }
+    }
+
+    // ---- one frame: FIR out of the ring, first butterfly, the stages, X.  P = the ring slot of this frame.
+    // `live`: the frame exists for this slot (slots of a workgroup take the same number of steps)
+    template <int P>
+    FXC_HD void step(long long f, bool live, bool next_live) {
+        pk2 acc[2][PTS];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int p = 0; p < PTS; ++p) {
+                pk2 v = pk_splat(th.hw[0][p]) * th.ring[a][p][P];
+#pragma unroll
+                for (int t = 1; t < T; ++t) v = pk_fma(pk_splat(th.hw[t][p]), th.ring[a][p][(P - t + T) % T], v);
+                acc[a][p] = v;
+            }
+        // the oldest slot is free now: the next frame's samples go there, in flight through the stages below
+        load_frame<(P + 1) % T>(f + 1, next_live);
+        const fxc::Roots<R0> rt = fxc::load_roots<R0>(ar.tw, nb_of(0));
+        if constexpr (S == 1) {
+#pragma unroll
+            for (int j = 0; j < J0; ++j)
+                if (live && has_bfly(0, j, lt)) {
+                    pk2 o[2][R0];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        pk2 v[R0];
+#pragma unroll
+                        for (int r = 0; r < R0; ++r) v[r] = acc[a][j * R0 + r];
+                        dft_regs<R0>(v, rt, o[a]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc(th.xacc[j * R0 + q], o[0][q], o[1][q]);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < J0; ++j)
+                if (has_bfly(0, j, lt)) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        pk2 v[R0];
+#pragma unroll
+                        for (int r = 0; r < R0; ++r) v[r] = acc[a][j * R0 + r];
+                        fxc::dft_store<R0>(v, rt, bx + a * ROW + (lt + j * TPR) * R0, 1);      // ns = 1: o = b R0
+                    }
+                }
+            cx.sync();
+            mid_stages<1>(bx, by);
+            last_stage((S % 2 == 0) ? bx : by, live);      // stage S-2 wrote X when S is even
+            if constexpr (SWAP) {
+                cf* t = bx;
+                bx = by;
+                by = t;
+            }
+        }
+    }
+
+    template <int P>
+    FXC_HD void steps(long long f, long long f1, long long i, long long n_steps) {      // T frames per trip, slots rotate
+        if constexpr (P < T) {
+            if (i + P < n_steps) {          // uniform over the workgroup
+                step<P>(f + P, f + P < f1, f + P + 1 < f1);
+                steps<P + 1>(f, f1, i, n_steps);
+            }
+        }
+    }
+
+    template <int P>
+    FXC_HD void preload(long long f0) {     // frames f0 - (T-1) .. f0 into slots so that frame f0 sits in slot 0
+        if constexpr (P < T) {
+            const long long f = f0 - P;
+            load_frame<(T - P) % T>(f, f >= 0);
+            preload<P + 1>(f0);
+        }
+    }
+
+    FXC_HD void run() {
+        const long long chunk = cx.bid() / ar.wg_splits;
+        const int sp = (int)(cx.bid() % ar.wg_splits);
+        init();
+        const int e = sp * SLOTS + slot, E = ar.wg_splits * SLOTS;
+        const long long f0 = (long long)e * ar.n_pts / E, f1 = ((long long)e + 1) * ar.n_pts / E;
+        const long long n_steps = (ar.n_pts + E - 1) / E;       // the longest run of any slot: uniform
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            xs[a] = reinterpret_cast<const cf*>(ar.x) + (2 * chunk + a) * ar.num_samp;
+            xb[a] = reinterpret_cast<const unsigned short*>(ar.x) + (2 * chunk + a) * ar.num_samp;
+            off8[a] = U8 ? pk(ar.dc_u8[2 * chunk + a]) : pk_splat(0.f);
+#if defined(__HIP_DEVICE_COMPILE__)
+            rsrc[a] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(ar.x)) + (2 * chunk + a) * ar.num_samp * kElem, 0,
+                                                        (int)(ar.num_samp * kElem), 0x00020000);
+#endif
+        }
+        // zero history in front of the chunk; a run that starts inside it re-reads T - 1 frames
+        preload<0>(f0 < f1 ? f0 : -(long long)T);
+        for (long long i = 0; i < n_steps; i += T) steps<0>(f0 + i, f1, i, n_steps);
+        // the thread's bins: the last stage's butterfly b puts output q at b + q N/RL (k = b there: ns = N/RL)
+        cf* o = ar.out + ((long long)e * ar.n_chunks + chunk) * N;
+#pragma unroll
+        for (int j = 0; j < JL; ++j)
+            if (has_bfly(S - 1, j, lt))
+#pragma unroll
+                for (int q = 0; q < RL; ++q) o[lt + j * TPR + q * nb_of(S - 1)] = unpk(th.xacc[j * RL + q]);
+    }
+};
+
+}  // namespace fxm
+
+#if defined(__HIPCC__)
+namespace fxm {
+struct DeviceCtx {
+    cf* lds_;
+    __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ long long bid() const { return (long long)blockIdx.x; }
+    __device__ __forceinline__ cf* lds() const { return lds_; }
+    __device__ __forceinline__ void sync() const {
+        if constexpr (TPR <= 64)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // a slot is (part of) one wave: LDS operations of a wave complete in order
+        else
+            __syncthreads();
+    }
+};
+}  // namespace fxm
+
+extern "C" __global__ __launch_bounds__(FXM_TPR * FXM_SLOTS) void fxm_fx2_kernel(const fxm::Args args) {
+    // static: the size is a compile-time constant here, and a module function needs no attribute to go past 64 KiB this way
+    __shared__ __attribute__((aligned(16))) fxm::cf fxm_smem[fxm::SLOTS * fxm::LDS_PER_SLOT > 0 ? fxm::SLOTS * fxm::LDS_PER_SLOT : 1];
+    fxm::DeviceCtx cx{fxm_smem};
+    fxm::Body<fxm::DeviceCtx> body(cx, args);
+    body.run();
+}
+#endif

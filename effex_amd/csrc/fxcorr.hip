@@ -58,6 +58,7 @@ ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError);
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -111,6 +112,7 @@ int64_t ws_target() {
 #include "k_delay.h"
 #include "k_synth.h"
 #include "h_plan.h"
+#include "h_rtc.h"
 #include "h_launch.h"
 #include "h_run.h"
 #include "h_rccl.h"
@@ -333,6 +335,19 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             // (without the table in LDS that kernel has no register butterflies for 11 / 13: such channel counts go through the
             // F-only kernel, which has, and xmul_kernel)
             if (!p->mixed_xf_twl && fxc::mixed_rows_per_slot_cap(p->mixed_plan) == 1) p->mixed_xf = false;
+            // the kernel built for exactly this channel count (fx_spec.h through hiprtc, h_rtc.h): every sample fetched once,
+            // strides and trip counts compile-time constants.  FXC_RTC=0 keeps the any-shape kernel (developer knob, and what
+            // a box without hiprtc runs)
+            if (p->mixed_xf && env_int("FXC_RTC", 1) && p->num_samp < (1ll << 28)) {       // (32-bit byte offsets inside a chunk)
+                const SpecShape sh = spec_shape(N, T);
+                if (sh.ok) {
+                    const SpecKernel* k = spec_kernel(p->device, sh, false);
+                    if (k->fn)
+                        p->spec = k;
+                    else if (env_int("FXC_RTC_VERBOSE", 0))
+                        std::fprintf(stderr, "libfxcorr: no specialised kernel for %d channels: %s\n", N, k->error.c_str());
+                }
+            }
         }
     }
     // generic FFT twiddles exp(+2 pi i j / N): [N/2] for the radix-2 kernel, [N] for the mixed-radix kernel and the direct DFT
@@ -716,9 +731,40 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
         info->block = 256;
         info->lds_bytes = p->nchan > 1 ? p->nchan * (int)sizeof(cf) : 0;
     }
+    if (p->spec) {
+        info->specialised = 1;
+        info->spec_vgprs = p->spec->vgprs;
+        info->grid = p->cu_count * p->spec->wgs_per_cu;
+        info->block = p->spec->shape.threads();
+        info->lds_bytes = (int)p->spec->shape.lds_bytes();
+    }
     info->device = p->device;
     info->cu_count = p->cu_count;
     info->workspace_bytes = p->ws_bytes;
+    return FXC_OK;
+}
+
+int fxc_spec_probe(int nchan, int ntaps, int u8, const char* arch, char* report, int report_bytes) {
+    if (report && report_bytes > 0) report[0] = 0;
+    const SpecShape sh = spec_shape(nchan, ntaps);
+    if (!sh.ok) return fail(nullptr, FXC_ERR_UNSUPPORTED, "no specialised kernel for %d channels, %d taps", nchan, ntaps);
+    std::string target = arch ? arch : "";
+    if (target.empty()) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device to take the architecture from");
+        target = prop.gcnArchName;
+    }
+    std::vector<char> image;
+    std::string error;
+    if (!spec_compile(sh, u8 != 0, target.c_str(), image, error)) return fail(nullptr, FXC_ERR_HIP, "%s", error.c_str());
+    if (report && report_bytes > 0) {
+        std::string radices;
+        for (int i = 0; i < sh.n_stages; ++i) radices += (i ? "," : "") + std::to_string(sh.radix[i]);
+        std::snprintf(report, (size_t)report_bytes, "nchan=%d ntaps=%d tpr=%d slots=%d stages=%s lds_bytes=%zu code_bytes=%zu", sh.n, sh.taps,
+                      sh.tpr, sh.slots, radices.c_str(), sh.lds_bytes(), image.size());
+    }
     return FXC_OK;
 }
 

@@ -11,12 +11,6 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a = 0);
 
-// developer knobs: an integer from the environment, read once
-int env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? std::atoi(e) : dflt;
-}
-
 // Slots of one wave (tpr <= 64) go without the workgroup barrier between their steps: measured on one box, two antennas
 // 7 - 16 % faster at 8 ... 250 channels, F only 5 - 7 % faster at 96 ... 250 but 17 % slower at 12 (slots of 4 threads) -- so F
 // only from 16 threads per slot.  Developer knob: FXC_MIXED_WAVELOCAL=0 keeps the barrier everywhere.
@@ -114,6 +108,27 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
 // two antennas on the mixed-radix kernel: F and X in one pass, raw[split][chunk][nchan] out (xmul_kernel's layout)
 // (dc_u8 != nullptr: x is the uint8 I,Q stream of these chunks and dc_u8 its conversion offsets per stream)
 int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
+    if (p->spec) {
+        // the build of fx_spec.h made for this channel count (h_rtc.h); its byte-ingest twin is compiled on first use
+        const SpecKernel* k = p->spec;
+        if (dc_u8) {
+            if (!p->spec_u8_tried) {
+                p->spec_u8_tried = true;
+                const SpecKernel* k8 = spec_kernel(p->device, p->spec->shape, true);
+                p->spec_u8 = k8->fn ? k8 : nullptr;
+            }
+            k = p->spec_u8;
+        }
+        if (k && n_splits % k->shape.slots == 0) {
+            const int wg_splits = n_splits / k->shape.slots;
+            const int64_t grid = n_chunks * wg_splits;
+            if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
+            SpecArgs a = {x, p->d_win, raw, p->d_tw, dc_u8, (long long)p->num_samp, (long long)p->n_pts, (long long)n_chunks, wg_splits};
+            void* params[] = {&a};
+            FXC_HIP(p, hipModuleLaunchKernel(k->fn, (unsigned)grid, 1, 1, (unsigned)k->shape.threads(), 1, 1, 0, p->stream, params, nullptr));
+            return FXC_OK;
+        }
+    }
     const int threads = std::max(256, p->mixed_tpr);
     const int rpw = threads / p->mixed_tpr;
     const size_t lds = ((size_t)rpw * 4 + (p->mixed_xf_twl ? 1 : 0)) * p->nchan * sizeof(cf);
@@ -140,12 +155,42 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
     return FXC_OK;
 }
 
+// float32 sums of up to kRowSpectra spectra per raw row (the rows themselves are summed in float64).  Measured on 10 000
+// frames against the float64 mean of the per-frame rows (profiles/r02/round2_experiments.md): 256 spectra per row 5.6e-9 of
+// max|vis|, 1 024: 2.5e-8, 4 096: 6.3e-8 -- against a tolerance of 1e-5; 1 024 leaves a quarter of the rows to fold (34 MB
+// instead of 92 MB per 10 000 frames)
+constexpr int64_t kRowSpectra = 1024;
+
 struct XGeom {
     int kx, n_splits;
 };
 
 XGeom x_geometry(const fxc_plan* p, int64_t n_chunks) {
     XGeom g;
+    if (p->mixed_xf && p->spec) {
+        // workgroups = chunks x splits, every slot of a workgroup with a run of its own (a raw row each).  A run re-reads
+        // ntaps - 1 frames of history and should be 16 frames at least; float32 sums of at most kRowSpectra spectra; among the
+        // splits that allow, the one that fills the device's resident workgroups in whole rounds best
+        const SpecShape& sh = p->spec->shape;
+        const int64_t cap = (int64_t)p->cu_count * p->spec->wgs_per_cu;
+        const int64_t ws_lo = std::max<int64_t>(1, (p->n_pts + sh.slots * kRowSpectra - 1) / (sh.slots * kRowSpectra));
+        const int64_t ws_hi = std::max<int64_t>(ws_lo, std::min<int64_t>(64, p->n_pts / (16 * (int64_t)sh.slots)));
+        int64_t best = ws_lo;
+        double best_cost = 1e300;
+        for (int64_t ws = ws_lo; ws <= ws_hi; ++ws) {
+            const int64_t wgs = n_chunks * ws;
+            const double rounds = (double)((wgs + cap - 1) / cap) * (double)cap / (double)wgs;      // >= 1: idle share of the last round
+            const double run = std::max(1.0, (double)p->n_pts / (double)(ws * sh.slots));
+            const double cost = rounds * (1.0 + (double)(p->ntaps - 1) / run);
+            if (cost < best_cost - 1e-9) {
+                best_cost = cost;
+                best = ws;
+            }
+        }
+        g.kx = 1;
+        g.n_splits = (int)(best * sh.slots);
+        return g;
+    }
     if (p->mixed_xf) {
         // workgroups = chunks x splits: eight per CU when the frames allow it, runs of four frame groups at least
         const int rpw = std::max(256, p->mixed_tpr) / p->mixed_tpr;
@@ -153,6 +198,10 @@ XGeom x_geometry(const fxc_plan* p, int64_t n_chunks) {
         const int64_t want = ((int64_t)p->cu_count * 8 + n_chunks - 1) / std::max<int64_t>(n_chunks, 1);
         g.kx = 1;
         g.n_splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 256), gps / 4));
+        // a slot sums its run of frame groups -- one spectrum per group -- in float32 registers: no run longer than the
+        // kRowSpectra spectra every other path limits a float32 row to (few channels with long chunks: nchan 12,
+        // num_samp 2^22 would otherwise put 5 400 terms into one float32 sum)
+        g.n_splits = (int)std::min<int64_t>(std::max<int64_t>(g.n_splits, (gps + kRowSpectra - 1) / kRowSpectra), 1 << 16);
         return g;
     }
     g.kx = 1;
@@ -247,11 +296,7 @@ int fused_grid(const fxc_plan* p, int64_t n_pairs) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(frames / 4, p->fused_grid_max));
 }
 
-// chunks per raw row when only the integration is wanted: float32 sums of up to kRowSpectra spectra (the rows
-// themselves are summed in float64).  Measured on 10 000 frames against the float64 mean of the per-frame rows
-// (profiles/r02/round2_experiments.md): 256 spectra per row 5.6e-9 of max|vis|, 1 024: 2.5e-8, 4 096: 6.3e-8 -- against
-// a tolerance of 1e-5; 1 024 leaves a quarter of the rows to fold (34 MB instead of 92 MB per 10 000 frames)
-constexpr int64_t kRowSpectra = 1024;
+// chunks per raw row when only the integration is wanted: float32 sums of up to kRowSpectra spectra
 int64_t fused_unit(const fxc_plan* p) { return std::max<int64_t>(1, std::min<int64_t>(kRowSpectra / std::max<int64_t>(1, p->n_pts), 64)); }
 
 // raw rows a 2-antenna fused launch over nc chunks writes (leading-part rows included)

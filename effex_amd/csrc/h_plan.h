@@ -8,6 +8,12 @@ namespace {
 
 thread_local std::string g_lib_error;
 
+// developer knobs: an integer from the environment
+int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+
 // Pinned host allocations handed out by fxc_host_alloc (process-wide).  with_host_staging looks a caller's pointer up
 // here: an output buffer inside one of them is written by the finishing kernel through `dev` (no copy back).
 struct PinnedBlock {
@@ -44,6 +50,10 @@ struct fxc_pipe_slot {
     bool busy = false;
 };
 
+namespace {
+struct SpecKernel;      // h_rtc.h
+}
+
 struct fxc_plan {
     int device = 0, cu_count = 0;
     int n_ant = 0, n_base = 0, nchan = 0, ntaps = 0;
@@ -61,6 +71,11 @@ struct fxc_plan {
     bool mixed_xeng = false;       // 3 .. 64 antennas: F-only mixed kernel (antenna-interleaved spectra) + the X-engines
     bool mixed_xf_twl = true;      // ... with the twiddle table in LDS (up to 4096 channels; from L2 up to 5120)
     bool mixed_xf = false;         // two antennas: the same kernel multiplies and integrates too (no spectra in HBM)
+    // ... and, where the shape allows, in the build of fx_spec.h made for exactly this channel count (h_rtc.h); spec_u8: its
+    // byte-ingest twin, compiled when bytes first arrive
+    const SpecKernel* spec = nullptr;
+    const SpecKernel* spec_u8 = nullptr;
+    bool spec_u8_tried = false;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev_order = nullptr;   // orders the old stream's work before the new one's (fxc_set_stream)

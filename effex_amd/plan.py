@@ -100,6 +100,9 @@ class FxPlan(object):
         _lib.check(rc, self._h)
 
     def close(self):
+        if getattr(self, "_abandoned", False):      # a pipe of this plan was abandoned with a thread still writing into its
+            self._h = ctypes.c_void_p()             # slots (FxPipeline.abandon): the plan stays, for the process's life
+            return
         if getattr(self, "_h", None) is not None and self._h:
             for ref in list(getattr(self, "_pipes", ())):     # pipes hold a pointer to the plan: they go first
                 pipe = ref()
@@ -510,6 +513,13 @@ class FxPipeline(object):
         if self._h:
             self.plan._lib.fxc_pipe_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+    def abandon(self):
+        """Give the pipe up WITHOUT freeing it: for the error path of a caller whose producer thread may still be writing
+        into a pinned slot (a read that did not notice its source being closed).  The slots, and the plan they belong to,
+        stay allocated for the life of the process -- a leak instead of a write into freed memory."""
+        self._h = ctypes.c_void_p()
+        self.plan._abandoned = True
 
     def __del__(self):
         try:

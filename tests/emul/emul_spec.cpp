@@ -1,0 +1,55 @@
+// Test infrastructure only: the specialised F+X kernel of effex_amd/csrc/fx_spec.h on the host -- the same Body<> the
+// device runs, one host thread per GPU thread of a workgroup, a real barrier for its sync() -- so that its index logic
+// (thread -> points, ring slots, stage buffers, slots' frame runs, output bins) is checked against the oracle here, without a
+// GPU and under ASan / UBSan.  Built per shape by tests/test_emul.py with the same -DFXM_* options hiprtc gets.
+#include <pthread.h>
+
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../effex_amd/csrc/fx_spec.h"
+
+namespace {
+
+struct HostCtx {
+    int tid_;
+    long long bid_;
+    fxm::cf* lds_;
+    pthread_barrier_t* bar_;
+    int tid() const { return tid_; }
+    long long bid() const { return bid_; }
+    fxm::cf* lds() const { return lds_; }
+    void sync() const { pthread_barrier_wait(bar_); }      // (the device needs less inside one wave; more is always safe)
+};
+
+}  // namespace
+
+extern "C" {
+
+int emul_spec_threads() { return fxm::THREADS; }
+int emul_spec_slots() { return fxm::SLOTS; }
+
+// raw[split][chunk][N] for n_chunks chunks, split = workgroup split * SLOTS + slot
+int emul_spec_run(const void* x, const float* h, void* out, const void* tw, const void* dc_u8, long long num_samp, long long n_pts,
+                  long long n_chunks, int wg_splits) {
+    const fxm::Args args = {x, h, static_cast<fxm::cf*>(out), static_cast<const fxm::cf*>(tw), static_cast<const fxm::cf*>(dc_u8),
+                            num_samp, n_pts, n_chunks, wg_splits};
+    for (long long bid = 0; bid < n_chunks * wg_splits; ++bid) {
+        std::vector<fxm::cf> lds((size_t)fxm::SLOTS * fxm::LDS_PER_SLOT + 1);
+        std::memset(lds.data(), 0xFF, lds.size() * sizeof(fxm::cf));          // NaNs: nothing may be read before it is written
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, nullptr, fxm::THREADS);
+        std::vector<std::thread> threads;
+        for (int t = 0; t < fxm::THREADS; ++t)
+            threads.emplace_back([&, t] {
+                HostCtx cx{t, bid, lds.data(), &bar};
+                fxm::Body<HostCtx> body(cx, args);
+                body.run();
+            });
+        for (std::thread& th : threads) th.join();
+        pthread_barrier_destroy(&bar);
+    }
+    return 0;
+}
+}

@@ -242,3 +242,86 @@ print("sanitized emulation ok")
     assert proc.returncode == 0, proc.stderr[-3000:]
     assert "sanitized emulation ok" in proc.stdout
     assert "AddressSanitizer" not in proc.stderr and "runtime error" not in proc.stderr, proc.stderr[-3000:]
+
+
+def _spec_shape(nchan, ntaps, u8=False):
+    """The library's own cut of fx_spec.h for this shape (fxc_spec_probe compiles it through hiprtc -- no GPU needed -- and
+    reports threads per slot, slots and stage order), as the -D options the host emulation is built with."""
+    import re
+    from effex_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(512)
+    rc = lib.fxc_spec_probe(nchan, ntaps, int(u8), b"gfx950", buf, len(buf))
+    if rc != 0:
+        return rc, None
+    rep = dict(kv.split("=") for kv in buf.value.decode().split())
+    stages = rep["stages"]
+    flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=%d" % ntaps, "-DFXM_TPR=%s" % rep["tpr"], "-DFXM_SLOTS=%s" % rep["slots"],
+             "-DFXM_NST=%d" % len(stages.split(",")), "-DFXM_RADICES=%s" % stages, "-DFXM_U8=%d" % int(u8)]
+    assert re.fullmatch(r"[0-9,]+", stages) and int(rep["code_bytes"]) > 1000
+    return 0, (flags, int(rep["tpr"]), int(rep["slots"]))
+
+
+def test_specialised_kernel_shapes():
+    """Which channel counts get a kernel of their own (h_rtc.h::spec_shape): every prime factor a register butterfly, up to
+    four taps, the first stage's points within the ring; the others keep the any-shape kernel (FXC_ERR_UNSUPPORTED here)."""
+    from effex_amd import _lib
+    for nchan, ntaps in ((997, 4), (143, 4), (1000, 5), (2 * 17, 4), (16384, 4)):
+        assert _spec_shape(nchan, ntaps)[0] == _lib.FXC_ERR_UNSUPPORTED, (nchan, ntaps)
+    rc, (flags, tpr, slots) = _spec_shape(1000, 4)
+    assert rc == 0 and (tpr, slots) == (256, 1) and "-DFXM_RADICES=4,2,5,5,5" in flags
+    rc, (flags, tpr, slots) = _spec_shape(96, 4)
+    assert (tpr, slots) == (32, 8)
+
+
+@pytest.mark.parametrize("nchan,ntaps,n_pts,wg_splits,u8", [
+    (1000, 4, 11, 2, False), (1000, 4, 5, 1, True), (96, 4, 37, 1, False), (12, 4, 150, 2, False), (6, 2, 9, 1, False),
+    (7, 1, 5, 1, False), (250, 4, 13, 2, False), (720, 3, 7, 2, False), (1001, 4, 6, 1, False), (1536, 4, 6, 1, False),
+    (20, 4, 33, 1, True), (4, 4, 40, 1, False)])
+def test_specialised_kernel_matches_oracle(tmp_path, nchan, ntaps, n_pts, wg_splits, u8):
+    """fx_spec.h -- the two-antenna F+X kernel compiled per channel count -- run on the host (tests/emul/emul_spec.cpp: one
+    thread per GPU thread, a real barrier) with the options the library would hand hiprtc: the sums over each slot's run of
+    frames, added up over the slots, are the oracle's sum_i spec0[i] conj(spec1[i]) of the chunk (effex.py:508-521 before the
+    mean).  Covers odd and even stage counts (buffer swap), one-stage shapes (no LDS), several slots per workgroup with runs of
+    different lengths and empty runs, partial lanes in every stage, three taps, and the byte ingest."""
+    rc, shape = _spec_shape(nchan, ntaps, u8)
+    assert rc == 0
+    flags, tpr, slots = shape
+    lib_path = str(tmp_path / "libemul_spec.so")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-pthread"] + flags +
+                   ["-o", lib_path, os.path.join(HERE, "emul", "emul_spec.cpp")], check=True)
+    lib = ctypes.CDLL(lib_path)
+    assert lib.emul_spec_threads() == tpr * slots and lib.emul_spec_slots() == slots
+    n_chunks, num_samp = 2, nchan * n_pts + min(3, nchan - 1)
+    rng = np.random.default_rng(nchan * 7 + n_pts)
+    window = rng.standard_normal(ntaps * nchan) if nchan < 16 else design_window(ntaps, nchan)
+    if u8:
+        xb = rng.integers(0, 256, size=(n_chunks, 2, num_samp, 2), dtype=np.uint8)
+        xb[:, 1, 2:] = xb[:, 0, :-2] // 2 + xb[:, 1, 2:] // 2
+        dc = (rng.standard_normal((n_chunks, 2, 2)) * 0.1).astype(np.float32)            # conversion offsets [chunk][antenna] (re, im)
+        x = (xb.astype(np.float32) / np.float32(127.5) + dc[:, :, None, :]).view(np.complex64)[..., 0]
+        x_in, dc_in = xb, dc
+    else:
+        x = synth.synth_iq(nchan, n_chunks, 2, num_samp)
+        x_in, dc_in = x, None
+    tw = np.exp(2j * np.pi * np.arange(nchan) / nchan).astype(np.complex64)
+    h32 = np.ascontiguousarray(window, dtype=np.float32)
+    E = wg_splits * slots
+    out = np.full((E, n_chunks, nchan), np.nan + 0j, dtype=np.complex64)
+    lib.emul_spec_run.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_longlong] * 3 + [ctypes.c_int]
+    assert lib.emul_spec_run(x_in.ctypes.data, h32.ctypes.data, out.ctypes.data, tw.ctypes.data,
+                             dc_in.ctypes.data if u8 else None, num_samp, n_pts, n_chunks, wg_splits) == 0
+    assert np.isfinite(out).all()
+    got = out.astype(np.complex128).sum(axis=0)
+    for c in range(n_chunks):
+        s0 = fx_oracle.spectrometer_poly(x[c, 0], ntaps, nchan, window)
+        s1 = fx_oracle.spectrometer_poly(x[c, 1], ntaps, nchan, window)
+        ref = (s0 * np.conj(s1)).sum(axis=0)
+        assert np.abs(got[c] - ref).max() <= 1e-5 * np.abs(ref).max(), (nchan, c)
+    # a slot's row is the sum over ITS run of frames: slot e of E takes frames [e n_pts / E, (e + 1) n_pts / E)
+    e = E - 1
+    lo, hi = e * n_pts // E, (e + 1) * n_pts // E
+    s0 = fx_oracle.spectrometer_poly(x[0, 0], ntaps, nchan, window)[lo:hi]
+    s1 = fx_oracle.spectrometer_poly(x[0, 1], ntaps, nchan, window)[lo:hi]
+    ref = (s0 * np.conj(s1)).sum(axis=0)
+    assert np.abs(out[e, 0] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30)

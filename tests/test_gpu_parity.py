@@ -1590,12 +1590,27 @@ def test_drop_in_stage_then_run_task(torch, mode):
         cor._state = 'RUN'
         for c in range(3):
             cor._stage((x[c, 0], x[c, 1]))
-            assert cor.gpu_iq_0.dtype == np.complex64 and np.shares_memory(cor.gpu_iq_0, cor._pair_buf)
-            vis = cor._run_task()
+            assert cor._dc_pending and cor._gpu_iq[0].dtype == np.complex64 and np.shares_memory(cor._gpu_iq[0], cor._pair_buf)
+            vis = cor._run_task()                       # nobody looked at the buffers: the device takes the mean off
             ref = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(x[c, 0]), fx_oracle.remove_dc(x[c, 1]), 4, 4096, cor.window,
                                       cor.bandwidth, cor.frequency, 0.0, mode)
             assert rel_err(vis, ref) < TOL_VIS
             np.testing.assert_array_equal(cor._run_task(), vis)
+            # looking at them through the public names shows what the reference holds there (effex.py:394-395: de-meaned
+            # samples), and from then on _run_task computes exactly what they hold -- the same visibility
+            held = np.array(cor.gpu_iq_0)
+            assert not cor._dc_pending and np.shares_memory(cor.gpu_iq_0, cor._pair_buf)
+            assert abs(held.mean()) < 1e-6 and rel_err(held, fx_oracle.remove_dc(x[c, 0])) < 1e-6
+            assert rel_err(cor._run_task(), ref) < TOL_VIS
+        # effex.py:391's idiom right after a staged pair: an in-place write is handed over as written, mean and all
+        cor._stage((x[0, 0], x[0, 1]))
+        cor.gpu_iq_0[:] = x[1, 0]
+        cor.gpu_iq_1[:] = x[1, 1]
+        ref = fx_oracle.pfb_xcorr(x[1, 0].astype(np.complex64), x[1, 1].astype(np.complex64), 4, 4096, cor.window,
+                                  cor.bandwidth, cor.frequency, 0.0, mode)
+        assert rel_err(cor._run_task(), ref) < TOL_VIS
+        plain = cor._plan().fx_rows(np.stack([x[1, 0], x[1, 1]]).astype(np.complex64)[None], mode, cor.bandwidth)[0, 0]
+        assert rel_err(cor._run_task(), plain) < 1e-6
         # rebinding (effex.py:394-395 style) hands over exactly what was bound: no DC removal behind the caller's back
         cor.gpu_iq_0, cor.gpu_iq_1 = x[0, 0], x[0, 1]
         ref = fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], 4, 4096, cor.window, cor.bandwidth, cor.frequency, 0.0, mode)

@@ -337,6 +337,71 @@ def test_batched_run_control_flow(tmp_path, monkeypatch, mode, fmt, n_chunks, ba
     assert fake.tail_calls == (1 if n_chunks % batch else 0)
 
 
+@pytest.mark.parametrize("stuck", [False, True])
+def test_batched_run_error_path_never_frees_slots_under_a_live_reader(tmp_path, monkeypatch, stuck):
+    """Correlator._run_batched when the device side fails while the filler thread sits in the source's read: the source is
+    closed, and the pipe (whose pinned slot the read writes into) is closed only once the read has returned; a read that
+    does not come back within the grace period keeps its memory -- the pipe is abandoned, not freed."""
+    import threading
+    import effex_amd.plan as plan_module
+    num_samp, nbins, batch = 256, 16, 4
+    events = []
+    release = threading.Event()
+
+    class Source(object):
+        rs = fc = gain = None
+        closed = False
+
+        def read(self, n):
+            return np.zeros((n, 2), np.uint8), np.zeros((n, 2), np.uint8)
+
+        def read_many_into(self, n, view):
+            if getattr(self, "calls", 0) == 0:       # first batch fills at once, the second read blocks
+                self.calls = 1
+                return len(view)
+            release.wait(timeout=30 if stuck else None)
+            events.append("read returned")
+            view[...] = 7                              # the write a freed slot must never see
+            return len(view)
+
+        def close(self):
+            self.closed = True
+            if not stuck:                              # a source that notices being closed ends its read
+                release.set()
+
+    class Pipe(_FakePipe):
+        def close(self):
+            events.append("pipe closed")            # (FxPipeline.close after abandon() frees nothing: its handle is gone)
+
+        def abandon(self):
+            events.append("pipe abandoned")
+
+    fake = _FakePlan(num_samp, nbins)
+    monkeypatch.setattr(plan_module, "FxPipeline", Pipe)
+    monkeypatch.setattr(Correlator, "_plan", lambda self: fake)
+    cor = Correlator(num_samp=num_samp, nbins=nbins, source=Source(), output_file=str(tmp_path / "rows.fxb"), output_format="bin",
+                     batch=batch, calibrate=False)
+    cor._filler_grace_s = 0.5
+    # the second batch's read blocks; the main thread, waiting for it, fails (stands in for a failing device call)
+    import concurrent.futures
+    real_result = concurrent.futures.Future.result
+
+    def result(self, timeout=None):
+        try:
+            return real_result(self, timeout=0.3)
+        except concurrent.futures.TimeoutError:
+            raise RuntimeError("device call failed")
+    monkeypatch.setattr(concurrent.futures.Future, "result", result)
+    with pytest.raises(RuntimeError, match="device call failed"):
+        cor.run_state_machine()
+    assert cor.source.closed
+    if stuck:
+        assert events == ["pipe abandoned", "pipe closed"], events       # given up before anything could be freed under the read
+    else:
+        assert events[0] == "read returned" and "pipe abandoned" not in events and events[-1] == "pipe closed", events
+    release.set()
+
+
 def test_socket_source_reads_chunk_pairs_from_two_streams():
     """SocketSource (a network stream in place of effex.py:630-664's live dongles): two TCP streams of
     rtl_tcp-style bytes -- a 12-byte greeting, then interleaved uint8 I,Q -- read chunk pair by chunk pair whatever the
