@@ -80,7 +80,6 @@ static_assert(SLOTS >= 1 && (SLOTS == 1 || TPR % 64 == 0 || 64 % TPR == 0), "slo
 // per-thread state, all of it registers once the loops below are unrolled
 struct Thread {
     pk2 ring[2][PTS][T];             // frame f's samples of the thread's points in slot f mod T
-    float hw[T][PTS];                // the window taps of those points
     pk2 tw[TWC > 0 ? TWC : 1];       // twiddles of the thread's butterflies in stages 1 .. S-1
     int ob[OBC > 0 ? OBC : 1];       // where the butterflies of stages 1 .. S-2 put their outputs
     pk2 xacc[JL * RL];               // sum over the run of s0 conj(s1) at the bins the thread's last butterflies produce
@@ -116,8 +115,10 @@ struct Args {
 template <class Ctx>
 struct Body {
     Ctx& cx;
-    const Args& ar;
+    const Args ar;            // (a copy: a reference would pin the kernel argument block to the stack)
     Thread th;
+    pk2 hw2[(T * PTS + 1) / 2];   // the window taps of the thread's points, [t][p], two to a register pair (an array of
+                              // plain floats stayed on the stack under clang 20)
     int lt, slot;
     cf *bx, *by;              // this slot's two buffers (S >= 2)
     const cf* xs[2];          // this chunk's two streams (complex64)
@@ -141,9 +142,13 @@ struct Body {
         for (int j = 0; j < J0; ++j)
 #pragma unroll
             for (int r = 0; r < R0; ++r) {
-                const int m = lt + j * TPR + r * nb_of(0);
+                const bool ok = has_bfly(0, j, lt);
+                const int m = ok ? lt + j * TPR + r * nb_of(0) : 0;      // (an unconditional load and a select: a branch here kept the taps on the stack)
 #pragma unroll
-                for (int t = 0; t < T; ++t) th.hw[t][j * R0 + r] = has_bfly(0, j, lt) ? ar.h[t * N + m] : 0.f;
+                for (int t = 0; t < T; ++t) {
+                    const float w = ar.h[t * N + m];
+                    hw2[(t * PTS + j * R0 + r) / 2][(t * PTS + j * R0 + r) % 2] = ok ? w : 0.f;
+                }
             }
         init_stage<1>();
 #pragma unroll
@@ -278,9 +283,9 @@ struct Body {
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int p = 0; p < PTS; ++p) {
-                pk2 v = pk_splat(th.hw[0][p]) * th.ring[a][p][P];
+                pk2 v = pk_splat(hw2[p / 2][p % 2]) * th.ring[a][p][P];
 #pragma unroll
-                for (int t = 1; t < T; ++t) v = pk_fma(pk_splat(th.hw[t][p]), th.ring[a][p][(P - t + T) % T], v);
+                for (int t = 1; t < T; ++t) v = pk_fma(pk_splat(hw2[(t * PTS + p) / 2][(t * PTS + p) % 2]), th.ring[a][p][(P - t + T) % T], v);
                 acc[a][p] = v;
             }
         // the oldest slot is free now: the next frame's samples go there, in flight through the stages below

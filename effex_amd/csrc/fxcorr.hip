@@ -762,8 +762,9 @@ int fxc_spec_probe(int nchan, int ntaps, int u8, const char* arch, char* report,
     if (report && report_bytes > 0) {
         std::string radices;
         for (int i = 0; i < sh.n_stages; ++i) radices += (i ? "," : "") + std::to_string(sh.radix[i]);
-        std::snprintf(report, (size_t)report_bytes, "nchan=%d ntaps=%d tpr=%d slots=%d stages=%s lds_bytes=%zu code_bytes=%zu", sh.n, sh.taps,
-                      sh.tpr, sh.slots, radices.c_str(), sh.lds_bytes(), image.size());
+        std::snprintf(report, (size_t)report_bytes, "nchan=%d ntaps=%d tpr=%d slots=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld",
+                      sh.n, sh.taps, sh.tpr, sh.slots, radices.c_str(), sh.lds_bytes(), image.size(), code_object_int(image, ".vgpr_count"),
+                      code_object_int(image, ".private_segment_fixed_size"));
     }
     return FXC_OK;
 }

@@ -139,6 +139,23 @@ struct SpecArgs {
 std::mutex g_spec_mutex;
 std::map<std::string, SpecKernel*> g_spec_cache;     // (device, shape) -> kernel; entries live as long as the process
 
+// An integer of the kernel's metadata note in a code object (msgpack: the key as a string, then the value): -1 if absent.
+// (hipFuncGetAttribute's LOCAL_SIZE_BYTES does not report the scratch of a module function here: it read 80 for a kernel
+// whose .private_segment_fixed_size is 0.)
+long long code_object_int(const std::vector<char>& image, const char* key) {
+    const size_t klen = std::strlen(key);
+    for (size_t i = 0; i + klen + 1 < image.size(); ++i) {
+        if (std::memcmp(image.data() + i, key, klen) != 0) continue;
+        const unsigned char* v = reinterpret_cast<const unsigned char*>(image.data()) + i + klen;
+        const size_t left = image.size() - i - klen;
+        if (v[0] <= 0x7f) return v[0];
+        if (v[0] == 0xcc && left >= 2) return v[1];
+        if (v[0] == 0xcd && left >= 3) return ((long long)v[1] << 8) | v[2];
+        if (v[0] == 0xce && left >= 5) return ((long long)v[1] << 24) | ((long long)v[2] << 16) | ((long long)v[3] << 8) | v[4];
+    }
+    return -1;
+}
+
 // fx_spec.h for one shape -> a code object for `arch` (e.g. "gfx950:sramecc+:xnack-"); needs no device
 bool spec_compile(const SpecShape& shape, bool u8, const char* arch, std::vector<char>& image, std::string& error) {
     RtcApi* api = rtc_api();
@@ -210,11 +227,10 @@ const SpecKernel* spec_kernel(int device, const SpecShape& shape, bool u8) {
         k->fn = nullptr;
         return k;
     }
-    int scratch = 0, regs = 0, blocks = 0;
-    (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->fn);
-    (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn);
-    k->vgprs = regs;
-    if (scratch > 0 && !env_int("FXC_RTC_ALLOW_SPILLS", 0)) {      // a shape whose registers spill: the any-shape kernel is the better one
+    int blocks = 0;
+    const long long scratch = code_object_int(image, ".private_segment_fixed_size");
+    k->vgprs = (int)code_object_int(image, ".vgpr_count");
+    if (scratch != 0 && !env_int("FXC_RTC_ALLOW_SPILLS", 0)) {      // a shape whose registers spill: the any-shape kernel is the better one
         k->error = "the specialised kernel spills (" + std::to_string(scratch) + " B of scratch per lane)";
         k->fn = nullptr;
         return k;
