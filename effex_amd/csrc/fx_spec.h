@@ -29,6 +29,12 @@
 #error "fx_spec.h is compiled per shape: -DFXM_N= -DFXM_T= -DFXM_TPR= -DFXM_SLOTS= -DFXM_NST= -DFXM_RADICES= -DFXM_U8="
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FXM_SEQ) && FXM_SEQ
+#define FXM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FXM_SCHED_BARRIER() ((void)0)
+#endif
+
 namespace fxm {
 
 using fxc::cf;
@@ -85,18 +91,124 @@ struct Thread {
     pk2 xacc[JL * RL];               // sum over the run of s0 conj(s1) at the bins the thread's last butterflies produce
 };
 
-template <int R>
-FXC_HD void dft_regs(pk2 (&v)[R], const fxc::Roots<R>& rt, pk2 (&o)[R]) {
-    cf tmp[R];
-    fxc::dft_store<R>(v, rt, tmp, 1);
-#pragma unroll
-    for (int q = 0; q < R; ++q) o[q] = pk(tmp[q]);
+// Complex arithmetic on register pairs with the operand modifiers of the packed instructions (op_sel picks the half of a
+// 64-bit operand each lane reads, neg_lo / neg_hi negate it): a complex multiply is two instructions, a +- i d one, with no
+// swizzle moves or sign flips in between (the compiler emits a v_mov / v_xor pair for each of those -- a sixth of this
+// kernel's vector instructions).  Host build: the same values in plain C.
+// a w in two halves: callers run the first halves of several products, then the second halves (a packed instruction that
+// reads the result of the one just before it costs a wait state)
+FXC_HD pk2 cmul_lo(pk2 a, pk2 w) {           // a.x (w.x, w.y)
+#if defined(__HIP_DEVICE_COMPILE__)
+    pk2 t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    return t;
+#else
+    return pk_splat(a[0]) * w;
+#endif
+}
+FXC_HD pk2 cmul_hi(pk2 a, pk2 w, pk2 t) {    // t + a.y (-w.y, w.x)
+#if defined(__HIP_DEVICE_COMPILE__)
+    pk2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+#else
+    return pk_fma(pk_splat(a[1]), fxc::pk_muli(w), t);
+#endif
+}
+FXC_HD pk2 add_i(pk2 a, pk2 d) {             // a + i d
+#if defined(__HIP_DEVICE_COMPILE__)
+    pk2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+#else
+    return pk2{a[0] - d[1], a[1] + d[0]};
+#endif
+}
+FXC_HD pk2 sub_i(pk2 a, pk2 d) {             // a - i d
+#if defined(__HIP_DEVICE_COMPILE__)
+    pk2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+#else
+    return pk2{a[0] + d[1], a[1] - d[0]};
+#endif
+}
+// acc + a conj(b), likewise in two halves
+FXC_HD pk2 x_acc_lo(pk2 acc, pk2 a, pk2 b) { // acc + b.x (a.x, a.y)
+#if defined(__HIP_DEVICE_COMPILE__)
+    pk2 t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "v"(b), "v"(acc));
+    return t;
+#else
+    return pk_fma(pk_splat(b[0]), a, acc);
+#endif
+}
+FXC_HD pk2 x_acc_hi(pk2 t, pk2 a, pk2 b) {   // t + b.y (a.y, -a.x)
+#if defined(__HIP_DEVICE_COMPILE__)
+    pk2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+#else
+    const pk2 ar = {a[1], -a[0]};
+    return pk_fma(pk_splat(b[1]), ar, t);
+#endif
 }
 
-// a conj(b) added to acc:  b.x (a.x, a.y) + b.y (a.y, -a.x)
-FXC_HD pk2 x_acc(pk2 acc, pk2 a, pk2 b) {
-    const pk2 ar = {a[1], -a[0]};
-    return pk_fma(pk_splat(b[1]), ar, pk_fma(pk_splat(b[0]), a, acc));
+// R-point DFT, kernel exp(+2 pi i q r / R), of v[0..R) into o[0..R) (registers): fx_mixed.h's dft_store with the +- i
+// rotations folded into the additions.  Odd R: outputs q and R - q are P +- i Q, P = v0 + sum a_r cos, Q = sum d_r sin with
+// a_r = v_r + v_{R-r}, d_r = v_r - v_{R-r}.
+template <int R>
+FXC_HD void dft_regs(pk2 (&v)[R], const fxc::Roots<R>& rt, pk2 (&o)[R]) {
+    if constexpr (R == 2) {
+        o[0] = v[0] + v[1];
+        o[1] = v[0] - v[1];
+    } else if constexpr (R == 4) {
+        const pk2 t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], t3 = v[1] - v[3];
+        o[0] = t0 + t2;
+        o[1] = add_i(t1, t3);
+        o[2] = t0 - t2;
+        o[3] = sub_i(t1, t3);
+    } else {
+        static_assert(R % 2 == 1, "odd radix");
+        constexpr int H = (R - 1) / 2;
+        pk2 sum = v[0];
+#pragma unroll
+        for (int r = 1; r <= H; ++r) {
+            const pk2 a = v[r] + v[R - r], d = v[r] - v[R - r];
+            v[r] = a;
+            v[R - r] = d;
+            sum = sum + a;
+        }
+        o[0] = sum;
+        pk2 pacc[H + 1], qacc[H + 1];
+#pragma unroll
+        for (int r = 1; r <= H; ++r)                           // (r outside: consecutive instructions belong to different outputs)
+#pragma unroll
+            for (int q = 1; q <= H; ++q) {
+                const int m = (q * r) % R;                     // cos(2 pi m / R), sin(2 pi m / R) from the half table
+                const pk2 ww = rt.w[m <= H ? m : R - m];
+                const float sn = m <= H ? ww[1] : -ww[1];
+                if (r == 1) {
+                    pacc[q] = pk_fma(pk_splat(ww[0]), v[r], v[0]);
+                    qacc[q] = pk_splat(sn) * v[R - r];
+                } else {
+                    pacc[q] = pk_fma(pk_splat(ww[0]), v[r], pacc[q]);
+                    qacc[q] = pk_fma(pk_splat(sn), v[R - r], qacc[q]);
+                }
+            }
+#pragma unroll
+        for (int q = 1; q <= H; ++q) {
+            o[q] = add_i(pacc[q], qacc[q]);
+            o[R - q] = sub_i(pacc[q], qacc[q]);
+        }
+    }
+}
+template <int R>
+FXC_HD void dft_to(pk2 (&v)[R], const fxc::Roots<R>& rt, cf* d, int ds) {      // ... into d[q * ds]
+    pk2 o[R];
+    dft_regs<R>(v, rt, o);
+#pragma unroll
+    for (int q = 0; q < R; ++q) d[q * ds] = unpk(o[q]);
 }
 
 // what the launch hands every thread
@@ -232,11 +344,15 @@ struct Body {
             if (has_bfly(s, j, lt)) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    pk2 v[R];
-                    v[0] = pk(src[a * ROW + b]);
+                    pk2 v[R], t[R];
 #pragma unroll
-                    for (int r = 1; r < R; ++r) v[r] = pk_cmul(pk(src[a * ROW + b + r * nb]), th.tw[tw_base(s) + j * (R - 1) + r - 1]);
-                    fxc::dft_store<R>(v, rt, dst + a * ROW + th.ob[ob_base(s) + j], ns);
+                    for (int r = 0; r < R; ++r) v[r] = pk(src[a * ROW + b + r * nb]);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1]);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1], t[r]);
+                    dft_to<R>(v, rt, dst + a * ROW + th.ob[ob_base(s) + j], ns);
+                    FXM_SCHED_BARRIER();
                 }
             }
         }
@@ -253,14 +369,20 @@ struct Body {
                 pk2 o[2][R];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    pk2 v[R];
-                    v[0] = pk(src[a * ROW + b]);
+                    pk2 v[R], t[R];
 #pragma unroll
-                    for (int r = 1; r < R; ++r) v[r] = pk_cmul(pk(src[a * ROW + b + r * nb]), th.tw[tw_base(s) + j * (R - 1) + r - 1]);
+                    for (int r = 0; r < R; ++r) v[r] = pk(src[a * ROW + b + r * nb]);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1]);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1], t[r]);
                     dft_regs<R>(v, rt, o[a]);
+                    FXM_SCHED_BARRIER();
                 }
 #pragma unroll
-                for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc(th.xacc[j * R + q], o[0][q], o[1][q]);
+                for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_lo(th.xacc[j * R + q], o[0][q], o[1][q]);
+#pragma unroll
+                for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_hi(th.xacc[j * R + q], o[0][q], o[1][q]);
             }
         }
     }
@@ -280,14 +402,14 @@ struct Body {
     FXC_HD void step(long long f, bool live, bool next_live) {
         pk2 acc[2][PTS];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int t = 0; t < T; ++t)                     // (tap outside: consecutive instructions belong to different points)
 #pragma unroll
-            for (int p = 0; p < PTS; ++p) {
-                pk2 v = pk_splat(hw2[p / 2][p % 2]) * th.ring[a][p][P];
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int t = 1; t < T; ++t) v = pk_fma(pk_splat(hw2[(t * PTS + p) / 2][(t * PTS + p) % 2]), th.ring[a][p][(P - t + T) % T], v);
-                acc[a][p] = v;
-            }
+                for (int p = 0; p < PTS; ++p) {
+                    const pk2 w = pk_splat(hw2[(t * PTS + p) / 2][(t * PTS + p) % 2]);
+                    acc[a][p] = t == 0 ? w * th.ring[a][p][P] : pk_fma(w, th.ring[a][p][(P - t + T) % T], acc[a][p]);
+                }
         // the oldest slot is free now: the next frame's samples go there, in flight through the stages below
         load_frame<(P + 1) % T>(f + 1, next_live);
         const fxc::Roots<R0> rt = fxc::load_roots<R0>(ar.tw, nb_of(0));
@@ -304,7 +426,9 @@ struct Body {
                         dft_regs<R0>(v, rt, o[a]);
                     }
 #pragma unroll
-                    for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc(th.xacc[j * R0 + q], o[0][q], o[1][q]);
+                    for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc_lo(th.xacc[j * R0 + q], o[0][q], o[1][q]);
+#pragma unroll
+                    for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc_hi(th.xacc[j * R0 + q], o[0][q], o[1][q]);
                 }
         } else {
 #pragma unroll
@@ -315,7 +439,7 @@ struct Body {
                         pk2 v[R0];
 #pragma unroll
                         for (int r = 0; r < R0; ++r) v[r] = acc[a][j * R0 + r];
-                        fxc::dft_store<R0>(v, rt, bx + a * ROW + (lt + j * TPR) * R0, 1);      // ns = 1: o = b R0
+                        dft_to<R0>(v, rt, bx + a * ROW + (lt + j * TPR) * R0, 1);      // ns = 1: o = b R0
                     }
                 }
             cx.sync();
@@ -396,7 +520,10 @@ struct DeviceCtx {
 };
 }  // namespace fxm
 
-extern "C" __global__ __launch_bounds__(FXM_TPR * FXM_SLOTS) void fxm_fx2_kernel(const fxm::Args args) {
+#ifndef FXM_WAVES
+#define FXM_WAVES 1      // waves per SIMD the register allocation is held to (h_rtc.h tries the higher occupancy first)
+#endif
+extern "C" __global__ __launch_bounds__(FXM_TPR * FXM_SLOTS, FXM_WAVES) void fxm_fx2_kernel(const fxm::Args args) {
     // static: the size is a compile-time constant here, and a module function needs no attribute to go past 64 KiB this way
     __shared__ __attribute__((aligned(16))) fxm::cf fxm_smem[fxm::SLOTS * fxm::LDS_PER_SLOT > 0 ? fxm::SLOTS * fxm::LDS_PER_SLOT : 1];
     fxm::DeviceCtx cx{fxm_smem};

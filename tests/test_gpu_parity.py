@@ -773,11 +773,56 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
             ref = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(x[0, 0] + (0.25 - 0.5j)), fx_oracle.remove_dc(x[0, 1] + (0.25 - 0.5j)),
                                       ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, -2e-7, "SPECTRUM")
             assert rel_err(dc[0, 0], ref) < TOL_VIS
+        specialised = p.info["specialised"]
+    if specialised:          # the kernel compiled for this channel count ran above: the any-shape kernel must agree with it and the oracle
+        monkeypatch.setenv("FXC_RTC", "0")
+        with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as a:
+            assert a.info["specialised"] == 0
+            a.set_rot(rot)
+            rows_any = a.fx_rows(xd, "SPECTRUM").cpu().numpy()
+            assert rel_err(rows_any, rows) < 2e-6
+            assert rel_err(rows_any[0, 0], fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, -2e-7,
+                                                               "SPECTRUM")) < TOL_VIS
+        monkeypatch.delenv("FXC_RTC")
+    assert bool(specialised) == ((n_ant, nchan, ntaps) in {(2, 1000, 4), (2, 96, 4), (2, 100, 3), (2, 6, 4), (2, 12, 1),
+                                                            (2, 3, 4), (2, 1001, 4), (2, 250, 4)})
     monkeypatch.setenv("FXC_GENERIC_FFT", "radix2")            # the direct DFT (developer knob, read when the plan is built)
     with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as d:
         d.set_rot(rot)
         # (the direct DFT's own float32 sums of nchan terms are the larger share of the difference at the top sizes)
         assert rel_err(rows, d.fx_rows(xd, "SPECTRUM").cpu().numpy()) < (4e-6 if nchan <= 8192 else 1e-5)
+
+
+@pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [
+    (1000, 4, 700, 40, 3), (1000, 4, 3, 262, 144), (96, 4, 2100, 25, 0), (1536, 4, 5, 170, 1), (720, 3, 64, 33, 2), (250, 2, 9, 1000, 0),
+    (12, 4, 3, 20000, 5), (2000, 4, 1, 131, 0), (1001, 4, 2, 11, 0), (600, 1, 40, 50, 7), (20, 4, 1, 1, 0), (7, 1, 300, 90, 0)])
+def test_specialised_kernel_on_the_device(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
+    """The F+X kernel compiled for one channel count when the plan is made (fx_spec.h through hiprtc, h_rtc.h) -- every shape
+    class the host emulation covers (tests/test_emul.py), here on the device and at launch sizes that take several rounds of
+    workgroups, several splits of a chunk's frames, runs of one frame and runs longer than the float32 row limit: rows against
+    the oracle (effex.py:490-527), the integration against the float64 mean of the rows, the byte ingest against the conversion
+    pass, and bit-identical results from two calls (no atomics, no order left to chance)."""
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(4242 + nchan, n_chunks, 2, num_samp)
+    window = design_window(ntaps, nchan)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as p:
+        assert p.path == "generic" and p.info["specialised"] == 1 and p.info["spec_vgprs"] > 0, p.info
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 3e-7)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        for c in sorted({0, n_chunks // 2, n_chunks - 1}):
+            ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 3e-7, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        np.testing.assert_array_equal(p.fx_rows(xd, "SPECTRUM").cpu().numpy(), rows)
+        p.fx_accumulate(xd)
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ, rows.astype(np.complex128).mean(axis=0)) < 2e-6
+        cont = p.fx_rows(xd[:2], "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
+        ref = fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 3e-7, "CONTINUUM")
+        assert abs(cont[0, 0] - ref) < 1e-5 * abs(ref) + 1e-9 * np.abs(rows[0]).max() / gi.BANDWIDTH
+        u8 = torch.from_numpy(np.random.default_rng(nchan).integers(0, 256, size=(min(n_chunks, 4), 2, num_samp, 2), dtype=np.uint8)).cuda()
+        by = p.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()
+        assert rel_err(by, p.fx_rows(p.convert_u8(u8, remove_dc=True)).cpu().numpy()) < TOL_VIS
 
 
 @pytest.mark.parametrize("nchan", [8, 64, 1024, 4096, 8192])
