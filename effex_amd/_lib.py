@@ -12,6 +12,9 @@ IN_TREE_LIB = os.path.join(_HERE, "csrc", "libfxcorr.so")
 # FXCORR_LIB: developer override to A/B kernel variants built elsewhere (tools/kbench.py); the default is the in-tree
 # build, and bench.py / the tests refuse anything else (``is_in_tree()``)
 LIB_PATH = os.environ.get("FXCORR_LIB") or IN_TREE_LIB
+# the developer build (-DFXC_DEV_KERNELS=1): the shipped kernels plus the reference / A-B kernels the tests and tools/soak.py
+# compare them with -- never what a caller gets by default
+DEV_LIB = os.path.join(_HERE, "csrc", "libfxcorr_dev.so")
 
 
 def is_in_tree():
@@ -60,6 +63,7 @@ _vp = ctypes.c_void_p
 # name -> (restype, argtypes); every symbol include/fxcorr.h declares
 SIGNATURES = {
     "fxc_version": (_c.c_int, []),
+    "fxc_dev_kernels": (_c.c_int, []),
     "fxc_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
     "fxc_status_string": (_c.c_char_p, [_c.c_int]),
     "fxc_plan_create": (_c.c_int, [_c.POINTER(_vp), _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _vp, _vp,
@@ -118,6 +122,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_dev_lib = None
 
 
 class FxcError(RuntimeError):
@@ -129,9 +134,27 @@ class FxcError(RuntimeError):
         self.message = message
 
 
-def load():
-    """Load libfxcorr.so and bind every declared symbol.  Raises if anything is missing."""
-    global _lib
+def _bind(path, mode=ctypes.RTLD_GLOBAL):
+    lib = ctypes.CDLL(path, mode=mode)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+def load(dev=False):
+    """Load libfxcorr.so and bind every declared symbol.  Raises if anything is missing.  ``dev``: the developer build
+    (tests and tools only)."""
+    global _lib, _dev_lib
+    if dev:
+        if _dev_lib is None:
+            if not os.path.isfile(DEV_LIB):
+                raise ImportError("libfxcorr_dev.so not found at {} -- `python -m effex_amd.build --dev` builds it".format(DEV_LIB))
+            load()                       # (the shipped library first: one HIP runtime in the process)
+            _dev_lib = _bind(DEV_LIB, ctypes.RTLD_LOCAL)
+            assert _dev_lib.fxc_dev_kernels() == 1
+        return _dev_lib
     if _lib is not None:
         return _lib
     if not os.path.isfile(LIB_PATH):
@@ -143,20 +166,16 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-    for name, (restype, argtypes) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
-        fn.restype = restype
-        fn.argtypes = argtypes
+    lib = _bind(LIB_PATH)
     _lib = lib
     return lib
 
 
-def check(status, plan_handle=None):
+def check(status, plan_handle=None, lib=None):
     """Map a non-zero status to the reference's exception types (SURVEY.md §8b 'Errors')."""
     if status == FXC_OK:
         return
-    lib = load()
+    lib = lib or load()
     msg = lib.fxc_last_error(plan_handle)
     msg = msg.decode("utf-8", "replace") if msg else lib.fxc_status_string(status).decode()
     if status == FXC_ERR_UNSUPPORTED:

@@ -7,6 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libfxcorr.so")
+LIB_DEV = os.path.join(CSRC, "libfxcorr_dev.so")      # -DFXC_DEV_KERNELS=1: tests and tools only (effex_amd/_lib.py::load(dev=True))
 # one translation unit: fxcorr.hip (the C ABI) includes the kernel (k_*.h), phase (fx_*.h) and host (h_*.h) parts
 
 
@@ -18,7 +19,9 @@ def sources():
 
 # -fno-slp-vectorize: packed f32 VALU runs at the scalar-f32 rate on gfx950 and the v_pk_* forms cost
 # operand-shuffling moves, so SLP packing of the butterflies is a net loss (MI355X_MICROARCH.md).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
+# -Bsymbolic-functions: calls between the library's own exported functions stay inside it (the developer build is loaded
+# beside the shipped one in the test process: the first-loaded copy must not answer for the other)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions"]
 
 
 def hipcc_path():
@@ -28,23 +31,25 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
-def up_to_date():
-    if not os.path.isfile(LIB):
+def up_to_date(lib=LIB):
+    if not os.path.isfile(lib):
         return False
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return all(os.path.getmtime(os.path.join(CSRC, s)) <= t for s in sources())
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
-        return LIB
-    cmd = [hipcc_path()] + FLAGS + ["-o", LIB, "fxcorr.hip"]
+def build(force=False, verbose=False, dev=False):
+    lib = LIB_DEV if dev else LIB
+    if not force and up_to_date(lib):
+        return lib
+    cmd = [hipcc_path()] + FLAGS + (["-DFXC_DEV_KERNELS=1"] if dev else []) + ["-o", lib, "fxcorr.hip"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, cwd=CSRC, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    print(build(force="--force" in sys.argv, verbose=True))
+    if "--dev" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, dev=True))

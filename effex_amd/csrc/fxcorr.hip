@@ -64,6 +64,13 @@ ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError);
 #include <vector>
 
 #include "../../include/fxcorr.h"
+
+// FXC_DEV_KERNELS=1 (libfxcorr_dev.so, built by effex_amd/build.py for the tests and tools only): also the kernels and knobs
+// that exist to check or time the shipped ones against -- the direct O(N^2) DFT for channel counts that are not a power of two
+// (FXC_GENERIC_FFT=radix2) and the vector X-engine where the matrix-core one serves (FXC_XENGINE=block)
+#ifndef FXC_DEV_KERNELS
+#define FXC_DEV_KERNELS 0
+#endif
 #include "fx_fused4096.h"
 #include "fx_tiled.h"
 #include "fx_small.h"
@@ -124,6 +131,7 @@ int64_t ws_target() {
 extern "C" {
 
 int fxc_version(void) { return FXC_VERSION; }
+int fxc_dev_kernels(void) { return FXC_DEV_KERNELS; }
 
 const char* fxc_status_string(int status) {
     switch (status) {
@@ -276,7 +284,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     // FXC_GENERIC_FFT=mixed|radix2 moves the powers of two onto it / everything off it (developer knob)
     {
         const char* gf = std::getenv("FXC_GENERIC_FFT");
-        const bool force_mixed = gf && !std::strcmp(gf, "mixed"), force_old = gf && !std::strcmp(gf, "radix2");
+        const bool force_mixed = gf && !std::strcmp(gf, "mixed");
+        // (off the powers of two "radix2" means the direct DFT, a kernel only the developer build has)
+        const bool force_old = gf && !std::strcmp(gf, "radix2") && (p->pow2 || FXC_DEV_KERNELS);
         // powers of two on the automatic path that no tuned kernel takes -- 4, 8 and 16384 channels -- ride along; a forced
         // generic path keeps the radix-2 kernels (the tests' independent reference)
         const bool auto_pow2 = force_path == -1 && (N == 4 || N == 8 || N == 16384);
@@ -605,7 +615,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         // more than 8 antennas: the matrix-core X-engine (k_xmfma.h) unless FXC_XENGINE=block (developer knob: the vector
         // kernel over blocks of 8 antennas it replaced)
         const char* xe = std::getenv("FXC_XENGINE");
-        p->x_mfma = p->n_ant > kXB && !(xe && std::string(xe) == "block");
+        p->x_mfma = p->n_ant > kXB && !(FXC_DEV_KERNELS && xe && std::string(xe) == "block");
         if (p->x_mfma) {
             int per_cu = 0, threads = 0, lds = 0;
             FXC_XMFMA_DISPATCH(p, {
@@ -646,9 +656,11 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         if (p->pow2)
             FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_pow2_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#if FXC_DEV_KERNELS
         else
             FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&dft_any_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#endif
     }
     return FXC_OK;
 }

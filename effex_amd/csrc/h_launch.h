@@ -99,7 +99,11 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
             hipLaunchKernelGGL(fft_pow2_kernel, dim3(grid), dim3(256), lds, p->stream, spec, p->d_tw, p->nchan,
                                p->lg2n, rows);
         else
+#if FXC_DEV_KERNELS
             hipLaunchKernelGGL(dft_any_kernel, dim3(grid), dim3(256), lds, p->stream, spec, p->d_tw, p->nchan, rows);
+#else
+            return fail(p, FXC_ERR_UNSUPPORTED, "no FFT kernel for %d channels in this build", p->nchan);      // (every such count takes the mixed-radix kernel)
+#endif
     }
     FXC_HIP(p, hipGetLastError());
     return FXC_OK;

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void fft_pow2_kernel(cf* __restrict__ data, co
     }
 }
 
-// same transform for any nchan <= 16384 (O(N^2) per row); tw = [N] table, exact index arithmetic
+#if FXC_DEV_KERNELS
+// same transform for any nchan <= 16384 (O(N^2) per row); tw = [N] table, exact index arithmetic.  Not in the shipped library:
+// the tests' and the soak's independent reference for channel counts that are not a power of two (libfxcorr_dev.so)
 __global__ __launch_bounds__(256) void dft_any_kernel(cf* __restrict__ data, const cf* __restrict__ tw, int nchan,
                                                      int64_t n_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(256) void dft_any_kernel(cf* __restrict__ data, con
         __syncthreads();
     }
 }
+#endif
 
 // FIR + FFT for any nchan whose two LDS rows fit (kMixedMaxN): the polyphase FIR runs on the way into LDS, the mixed-radix
 // Stockham stages of fx_mixed.h ping-pong between the two rows, and the natural-order spectrum goes out once.

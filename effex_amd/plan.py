@@ -64,8 +64,8 @@ def rot_table(nbins, bandwidth, frequency, calibrated_delay):
 
 
 class FxPlan(object):
-    def __init__(self, n_ant, nchan, ntaps, num_samp, window=None, device=0, stream=None, path=None):
-        self._lib = _lib.load()
+    def __init__(self, n_ant, nchan, ntaps, num_samp, window=None, device=0, stream=None, path=None, dev=False):
+        self._lib = _lib.load(dev=dev)          # dev: the developer build with the reference kernels (tests, tools/soak.py)
         self._h = ctypes.c_void_p()
         if window is None:
             window = design_window(ntaps, nchan)
@@ -87,7 +87,7 @@ class FxPlan(object):
         stream_ptr = ctypes.c_void_p(int(stream) & 0xFFFFFFFFFFFFFFFF) if stream else None
         rc = self._lib.fxc_plan_create(ctypes.byref(self._h), int(device), int(n_ant), int(nchan), int(ntaps),
                                        int(num_samp), window.ctypes.data, stream_ptr, PATHS[path])
-        _lib.check(rc, None)
+        _lib.check(rc, None, self._lib)
         info = _lib.FxcInfo()
         self._check(self._lib.fxc_plan_get_info(self._h, ctypes.byref(info)))
         self.n_ant, self.n_baselines, self.nchan, self.ntaps = info.n_ant, info.n_baselines, info.nchan, info.ntaps
@@ -97,7 +97,7 @@ class FxPlan(object):
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, rc):
-        _lib.check(rc, self._h)
+        _lib.check(rc, self._h, self._lib)
 
     def close(self):
         if getattr(self, "_abandoned", False):      # a pipe of this plan was abandoned with a thread still writing into its

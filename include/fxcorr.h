@@ -77,6 +77,7 @@ typedef struct fxc_info {
 } fxc_info;
 
 int         fxc_version(void);
+int         fxc_dev_kernels(void); /* 0: the shipped library; 1: the developer build with the reference / A-B kernels as well */
 int         fxc_device_count(int* count);
 const char* fxc_status_string(int status);
 

@@ -786,8 +786,9 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
         monkeypatch.delenv("FXC_RTC")
     assert bool(specialised) == ((n_ant, nchan, ntaps) in {(2, 1000, 4), (2, 96, 4), (2, 100, 3), (2, 6, 4), (2, 12, 1),
                                                             (2, 3, 4), (2, 1001, 4), (2, 250, 4)})
-    monkeypatch.setenv("FXC_GENERIC_FFT", "radix2")            # the direct DFT (developer knob, read when the plan is built)
-    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as d:
+    # the direct DFT: a kernel of the developer build only (libfxcorr_dev.so), chosen by a knob read when the plan is built
+    monkeypatch.setenv("FXC_GENERIC_FFT", "radix2")
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window, dev=True) as d:
         d.set_rot(rot)
         # (the direct DFT's own float32 sums of nchan terms are the larger share of the difference at the top sizes)
         assert rel_err(rows, d.fx_rows(xd, "SPECTRUM").cpu().numpy()) < (4e-6 if nchan <= 8192 else 1e-5)

@@ -65,7 +65,7 @@ def main():
             if any_n:
                 os.environ["FXC_GENERIC_FFT"] = "radix2"
             try:
-                g_plan = FxPlan(n_ant, nchan, ntaps, num_samp, window=window, path="generic")
+                g_plan = FxPlan(n_ant, nchan, ntaps, num_samp, window=window, path="generic", dev=any_n)      # (the direct DFT: developer build)
             finally:
                 os.environ.pop("FXC_GENERIC_FFT", None)
             with FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as f, g_plan as g:
