@@ -33,6 +33,7 @@ FXC_COMM_ID_BYTES = 128
 
 FXC_MEM_HOST = 0
 FXC_MEM_DEVICE = 1
+FXC_MEM_DEVICE_TO_PINNED = 2
 FXC_MODE_SPECTRUM = 0
 FXC_MODE_CONTINUUM = 1
 FXC_IQ_C64 = 0

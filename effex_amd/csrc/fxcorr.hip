@@ -1007,7 +1007,26 @@ int fxc_fx_accumulate(fxc_plan* p, const void* x, int64_t n_chunks, int mem_kind
                              [&](const cf* dx, void*) { return fx_accumulate_dev(p, dx, n_chunks); });
 }
 
+namespace {
+// FXC_MEM_DEVICE_TO_PINNED: the rows of device-resident samples go straight into fxc_host_alloc memory -- the finishing
+// kernel writes them across PCIe through the device's mapping of the block, nothing is copied and nothing waits
+int pinned_rows_out(fxc_plan* p, void** out, int* mem_kind, int64_t n_chunks, int mode) {
+    if (*mem_kind != FXC_MEM_DEVICE_TO_PINNED) return FXC_OK;
+    if (!p || !*out || n_chunks <= 0) {
+        *mem_kind = FXC_MEM_DEVICE;         // (the entry's own argument checks answer)
+        return FXC_OK;
+    }
+    const size_t ob = mode == FXC_MODE_SPECTRUM ? (size_t)n_chunks * p->n_base * p->nchan * sizeof(cf) : (size_t)n_chunks * p->n_base * sizeof(cd);
+    void* d = pinned_device_ptr(*out, ob);
+    if (!d) return fail(p, FXC_ERR_ARG, "FXC_MEM_DEVICE_TO_PINNED: `out` (%zu bytes) is not inside memory from fxc_host_alloc", ob);
+    *out = d;
+    *mem_kind = FXC_MEM_DEVICE;
+    return FXC_OK;
+}
+}  // namespace
+
 int fxc_fx_rows(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mem_kind, int mode, double bandwidth) {
+    if (const int rp = pinned_rows_out(p, &out, &mem_kind, n_chunks, mode)) return rp;
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     if (n_chunks < 0) return fail(p, FXC_ERR_ARG, "n_chunks < 0");
     if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
@@ -1312,6 +1331,8 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
 
 int fx_u8_entry(fxc_plan* p, const void* iq_u8, void* out, int64_t n_chunks, int mem_kind, int mode, double bandwidth,
                 int remove_dc, bool rows) {
+    if (rows)
+        if (const int rp = pinned_rows_out(p, &out, &mem_kind, n_chunks, mode)) return rp;
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
     if (n_chunks < 0) return fail(p, FXC_ERR_ARG, "n_chunks < 0");
@@ -1389,6 +1410,8 @@ int fx_iq_entry(fxc_plan* p, const void* x, void* out, int64_t n_chunks, int mem
     if (fmt != FXC_IQ_C64 && fmt != FXC_IQ_C128) return fail(p, FXC_ERR_ARG, "bad iq_format %d", fmt);
     if (fmt == FXC_IQ_C64 && !remove_dc)
         return rows ? fxc_fx_rows(p, x, out, n_chunks, mem_kind, mode, bandwidth) : fxc_fx_accumulate(p, x, n_chunks, mem_kind);
+    if (rows)
+        if (const int rp = pinned_rows_out(p, &out, &mem_kind, n_chunks, mode)) return rp;
     if (!p) return fail(p, FXC_ERR_ARG, "NULL plan");
     if (p->n_ant < 2) return fail(p, FXC_ERR_ARG, "cross-correlation needs n_ant >= 2");
     if (n_chunks < 0) return fail(p, FXC_ERR_ARG, "n_chunks < 0");

@@ -181,7 +181,15 @@ class FxPlan(object):
         return ptr, kind, shape[0], keep
 
     def _out(self, like, shape, dtype, out=None):
+        self._to_pinned = False
         if out is not None:
+            if _is_torch(like) and not _is_torch(out):
+                # device-resident samples, rows into pinned host memory (``pinned_empty``): the finishing kernel writes them
+                # there across PCIe, asynchronously -- the caller orders its reads with ``sync()`` or an event on the stream
+                if out.dtype != dtype or out.shape != tuple(shape) or not out.flags.c_contiguous or not out.flags.writeable:
+                    raise ValueError("out must be a writable C-contiguous {} array of shape {}".format(np.dtype(dtype).name, tuple(shape)))
+                self._to_pinned = True
+                return out, out.ctypes.data
             if _is_torch(like) != _is_torch(out):
                 raise ValueError("out must be of the same kind (host array / CUDA tensor) as the input")
             if _is_torch(out):
@@ -245,6 +253,8 @@ class FxPlan(object):
             out, optr = self._out(x, (n, self.n_baselines, self.nchan), np.complex64, out)
         else:
             out, optr = self._out(x, (n, self.n_baselines), np.complex128, out)
+        if self._to_pinned:
+            kind = _lib.FXC_MEM_DEVICE_TO_PINNED
         if remove_dc or self._fmt != _lib.FXC_IQ_C64:
             self._check(self._lib.fxc_fx_rows_iq(self._h, ptr, optr, n, kind, m, float(bandwidth), self._fmt,
                                                  int(bool(remove_dc))))
@@ -397,6 +407,8 @@ class FxPlan(object):
             out, optr = self._out(iq_u8, (n, self.n_baselines, self.nchan), np.complex64, out)
         else:
             out, optr = self._out(iq_u8, (n, self.n_baselines), np.complex128, out)
+        if self._to_pinned:
+            kind = _lib.FXC_MEM_DEVICE_TO_PINNED
         self._check(self._lib.fxc_fx_rows_u8(self._h, ptr, optr, n, kind, m, float(bandwidth), int(bool(remove_dc))))
         return out
 

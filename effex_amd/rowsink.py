@@ -214,7 +214,12 @@ class RowFile(object):
 def create_shared(path, header, freqs, row_len, row_dtype, n_rows):
     """One rank: the sidecar's head and room for ``n_rows`` rows, none of them committed yet."""
     sink = BinSink(path, header, freqs, row_len, row_dtype)
-    os.ftruncate(sink._fh.fileno(), sink.data_offset + int(n_rows) * sink.row_bytes)
+    size = sink.data_offset + int(n_rows) * sink.row_bytes
+    os.ftruncate(sink._fh.fileno(), size)
+    try:                                    # blocks allocated once, here, not one page fault (or extent) at a time under the writers
+        os.posix_fallocate(sink._fh.fileno(), 0, size)
+    except (AttributeError, OSError):
+        pass
     sink._fh.close()
     sink._fh = None
 
@@ -222,10 +227,13 @@ def create_shared(path, header, freqs, row_len, row_dtype, n_rows):
 class RowWindow(object):
     """Rows [lo, hi) of a sidecar made by ``create_shared``, mapped for writing: ``rows`` is [hi - lo, row_len]."""
 
-    def __init__(self, path, lo, hi):
+    def __init__(self, path, lo, hi, mapped=True):
         lo, hi = int(lo), int(hi)
         self._fh = open(path, 'r+b')
-        _, itemsize, row_len, data_offset, _, _, _ = _read_preamble(self._fh)
+        _, itemsize, row_len, data_offset, _, committed, _ = _read_preamble(self._fh)
+        if committed is None:
+            self._fh.close()
+            raise ValueError("{}: an FXB1 sidecar has no row count to publish: shared writing needs the FXB2 layout".format(path))
         self.row_dtype = np.dtype(np.complex64 if itemsize == 8 else np.complex128)
         self.row_len = int(row_len)
         need = data_offset + hi * self.row_len * itemsize
@@ -233,8 +241,21 @@ class RowWindow(object):
             self._fh.close()
             raise ValueError("{}: rows [{}, {}) are outside the file".format(path, lo, hi))
         self.lo, self.hi = lo, hi
-        self.rows = (np.memmap(self._fh, dtype=self.row_dtype, mode='r+', offset=data_offset + lo * self.row_len * itemsize,
-                               shape=(hi - lo, self.row_len)) if hi > lo else np.zeros((0, self.row_len), self.row_dtype))
+        self._base = data_offset + lo * self.row_len * itemsize
+        self._row_bytes = self.row_len * itemsize
+        # mapped=False: rows go in through write() (pwrite from the caller's -- pinned -- buffer; several threads may call it)
+        self.rows = (np.memmap(self._fh, dtype=self.row_dtype, mode='r+', offset=self._base, shape=(hi - lo, self.row_len))
+                     if (mapped and hi > lo) else np.zeros((0, self.row_len), self.row_dtype))
+
+    def write(self, first, rows):
+        """rows [n, row_len] -> rows [first, first + n) of the window (relative to its first row); thread-safe."""
+        rows = np.ascontiguousarray(rows, dtype=self.row_dtype).reshape(-1, self.row_len)
+        if first < 0 or first + rows.shape[0] > self.hi - self.lo:
+            raise ValueError("rows [{}, {}) are outside the window".format(first, first + rows.shape[0]))
+        buf = memoryview(rows).cast('B')
+        at, done = self._base + first * self._row_bytes, 0
+        while done < len(buf):
+            done += os.pwrite(self._fh.fileno(), buf[done:], at + done)
 
     def close(self):
         if self._fh is not None:
@@ -254,8 +275,10 @@ class RowWindow(object):
 def commit_shared(path, n_rows):
     """One rank, after every writer has closed its window: publish the count."""
     with open(path, 'r+b') as fh:
-        count_at = _read_preamble(fh)[6]
-        os.pwrite(fh.fileno(), struct.pack("<Q", int(n_rows)), count_at)
+        pre = _read_preamble(fh)
+        if pre[5] is None:          # FXB1: those eight bytes are the frequency row's (or padding), not a count
+            raise ValueError("{}: an FXB1 sidecar has no row count to publish".format(path))
+        os.pwrite(fh.fileno(), struct.pack("<Q", int(n_rows)), pre[6])
 
 
 def to_csv(path_in, path_out):

@@ -192,35 +192,98 @@ class ShardedRows(object):
             import torch.distributed as dist
             dist.barrier(group=self.group)
 
-    def run(self, path, header, freqs, read_chunks, n_chunks, mode="SPECTRUM", bandwidth=1.0, remove_dc=False):
+    def run(self, path, header, freqs, read_chunks, n_chunks, mode="SPECTRUM", bandwidth=1.0, remove_dc=False, consumer=None):
         """``read_chunks(lo, hi)`` -> the samples of global chunks [lo, hi): a host array or CUDA tensor
-        [hi - lo, n_ant, num_samp] complex64 (or uint8 [..., 2]: the receivers' bytes).  Returns (lo, hi) of this rank."""
+        [hi - lo, n_ant, num_samp] complex64 (or uint8 [..., 2]: the receivers' bytes).  Returns (lo, hi) of this rank.
+
+        Device-resident samples: the rows of batch k + 1 are queued before those of batch k are taken off the device's hands --
+        the finishing kernel writes them into one of two pinned host slots across PCIe (``FXC_MEM_DEVICE_TO_PINNED``: no copy,
+        no wait), and a small pool of threads moves a finished slot into the file (``pwrite``) while the device is two batches on.
+        ``consumer(first_chunk, rows)``: called instead of the file writer with each batch in its pinned slot (valid until the
+        call returns); then ``path`` may be None and no file is made."""
         import numpy as np
         from . import rowsink
         spectrum = mode.upper() == "SPECTRUM"
         row_len = self.plan.n_baselines * (self.plan.nchan if spectrum else 1)
         dtype = np.complex64 if spectrum else np.complex128
         lo, hi = self.my_range(n_chunks)
-        if self.rank == 0:
+        to_file = consumer is None
+        if self.rank == 0 and to_file:
             rowsink.create_shared(path, header, freqs if spectrum else None, row_len, dtype, n_chunks)
         self._barrier()
         shape_tail = (self.plan.n_baselines, self.plan.nchan) if spectrum else (self.plan.n_baselines,)
-        with rowsink.RowWindow(path, lo, hi) as win:
+        probe = read_chunks(lo, min(hi, lo + 1)) if hi > lo else None
+        if probe is not None and type(probe).__module__.startswith("torch"):
+            self._rows_from_device(path, lo, hi, read_chunks, mode, bandwidth, remove_dc, shape_tail, dtype, consumer)
+        elif to_file:
+            with rowsink.RowWindow(path, lo, hi) as win:
+                for b_lo in range(lo, hi, self.batch):
+                    b_hi = min(hi, b_lo + self.batch)
+                    x = read_chunks(b_lo, b_hi)
+                    dst = win.rows[b_lo - lo:b_hi - lo].reshape((b_hi - b_lo,) + shape_tail)
+                    if str(getattr(x, "dtype", "")).endswith("uint8"):
+                        self.plan.fx_rows_u8(x, mode, bandwidth, remove_dc=remove_dc, out=dst)
+                    else:
+                        self.plan.fx_rows(x, mode, bandwidth, remove_dc=remove_dc, out=dst)
+        else:
             for b_lo in range(lo, hi, self.batch):
                 b_hi = min(hi, b_lo + self.batch)
                 x = read_chunks(b_lo, b_hi)
-                dst = win.rows[b_lo - lo:b_hi - lo].reshape((b_hi - b_lo,) + shape_tail)
                 u8 = str(getattr(x, "dtype", "")).endswith("uint8")
-                on_device = type(x).__module__.startswith("torch")
-                kwargs = dict(out=None if on_device else dst)
-                if u8:
-                    out = self.plan.fx_rows_u8(x, mode, bandwidth, remove_dc=remove_dc, **kwargs)
-                else:
-                    out = self.plan.fx_rows(x, mode, bandwidth, remove_dc=remove_dc, **kwargs)
-                if on_device:
-                    dst[...] = out.cpu().numpy()
+                consumer(b_lo, (self.plan.fx_rows_u8 if u8 else self.plan.fx_rows)(x, mode, bandwidth, remove_dc=remove_dc))
         self._barrier()
-        if self.rank == 0:
+        if self.rank == 0 and to_file:
             rowsink.commit_shared(path, n_chunks)
         self._barrier()                      # nobody returns (and reads the file) before the count is there
         return lo, hi
+
+    def _rows_from_device(self, path, lo, hi, read_chunks, mode, bandwidth, remove_dc, shape_tail, dtype, consumer):
+        import concurrent.futures
+        import torch
+        from . import rowsink
+        from .plan import pinned_empty
+        slots = getattr(self, "_slots", None)
+        if slots is None or slots[0].shape != (self.batch,) + shape_tail or slots[0].dtype != dtype:
+            slots = self._slots = [pinned_empty((self.batch,) + shape_tail, dtype) for _ in range(2)]
+        writers = 4
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=writers) if consumer is None else None
+        win = rowsink.RowWindow(path, lo, hi, mapped=False) if consumer is None else None
+        busy = [[], []]                     # file writes still reading slot s
+
+        def deliver(first, rows, s):
+            if consumer is not None:
+                consumer(first, rows)
+                return
+            n = rows.shape[0]
+            flat = rows.reshape(n, -1)
+            step = (n + writers - 1) // writers
+            busy[s] = [pool.submit(win.write, first - lo + r0, flat[r0:min(n, r0 + step)]) for r0 in range(0, n, step)]
+
+        try:
+            pending = None
+            for k, b_lo in enumerate(range(lo, hi, self.batch)):
+                b_hi, s = min(hi, b_lo + self.batch), k & 1
+                for job in busy[s]:
+                    job.result()            # the file has this slot's previous rows
+                busy[s] = []
+                x = read_chunks(b_lo, b_hi)
+                view = slots[s][:b_hi - b_lo]
+                u8 = str(x.dtype).endswith("uint8")
+                (self.plan.fx_rows_u8 if u8 else self.plan.fx_rows)(x, mode, bandwidth, remove_dc=remove_dc, out=view)
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(x.device))
+                if pending is not None:     # batch k - 1, while batch k is on the device
+                    pending[2].synchronize()
+                    deliver(pending[0], pending[1], pending[3])
+                pending = (b_lo, view, done, s)
+            if pending is not None:
+                pending[2].synchronize()
+                deliver(pending[0], pending[1], pending[3])
+            for s in (0, 1):
+                for job in busy[s]:
+                    job.result()
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
+            if win is not None:
+                win.close()

@@ -44,7 +44,11 @@ enum fxc_status {
     FXC_ERR_COMM = -7         /* librccl could not be bound, or an RCCL call failed              */
 };
 
-enum fxc_mem_kind { FXC_MEM_HOST = 0, FXC_MEM_DEVICE = 1 };
+/* FXC_MEM_DEVICE_TO_PINNED (fxc_fx_rows, _u8, _iq only): x is device memory, `out` lies in memory from fxc_host_alloc -- the
+ * finishing kernel writes the rows there across PCIe (no copy, no wait: the call is asynchronous on the plan's stream like any
+ * device call; the rows are complete when the stream reaches that point, fxc_sync or an event of the caller's).  For the
+ * time-series product of device-resident samples (one row per chunk pair, effex.py:402-410, 687-696). */
+enum fxc_mem_kind { FXC_MEM_HOST = 0, FXC_MEM_DEVICE = 1, FXC_MEM_DEVICE_TO_PINNED = 2 };
 enum fxc_mode { FXC_MODE_SPECTRUM = 0, FXC_MODE_CONTINUUM = 1 }; /* TEST == CONTINUUM arithmetic */
 /* sample formats of the fxc_*_iq entry points: complex64 (what the path computes in), the receivers' interleaved
  * unsigned 8-bit I,Q (pyrtlsdr's packed bytes, effex.py:652), and complex128 (the reference's own sample type,
@@ -124,7 +128,7 @@ int fxc_fx_accumulate(fxc_plan* plan, const void* x, int64_t n_chunks, int mem_k
 /* F+X, one visibility row per chunk — the reference's literal _run_task() output (effex.py:490-527):
  *   SPECTRUM : out = [n_chunks][n_baselines][nchan] complex64 = fftshift(mean_i(f_a*conj(f_b*rot)))
  *   CONTINUUM: out = [n_chunks][n_baselines] complex128      = mean_k(that) / bandwidth  (:523-524)
- * `out` has the same mem_kind as `x`. */
+ * `out` has the same mem_kind as `x` (or is pinned host memory: FXC_MEM_DEVICE_TO_PINNED). */
 int fxc_fx_rows(fxc_plan* plan, const void* x, void* out, int64_t n_chunks, int mem_kind, int mode,
                 double bandwidth);
 

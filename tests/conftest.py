@@ -4,7 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -28,6 +28,26 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _name_the_running_test(request):
+    """tests/tolerances.py looks the bound of a comparison up by the test function that makes it."""
+    import tolerances
+    tolerances._current[0] = request.node.originalname or request.node.name
+    yield
+    tolerances._current[0] = None
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Every comparison that went through a tests/tolerances.py bound, with the bound it met: gpurun_out/observed_errors.json
+    (what tools/make_tolerances.py turns into tests/golden/tolerances.json and the table of DESIGN.md)."""
+    try:
+        import tolerances
+        if tolerances.observed and _has_gpu():
+            tolerances.dump(os.path.join(ROOT, "gpurun_out", "observed_errors.json"))
+    except Exception as exc:        # a reporting aid must never fail a run
+        sys.stderr.write("observed_errors.json not written: %s\n" % exc)
 
 
 @pytest.fixture(scope="session")

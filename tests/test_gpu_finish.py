@@ -16,7 +16,7 @@ from effex_amd.window import design_window
 
 pytestmark = pytest.mark.gpu
 
-TOL_VIS = 1e-5
+from tolerances import TOL_VIS
 
 
 @pytest.fixture(scope="module")

@@ -17,8 +17,7 @@ from effex_amd.window import design_window
 
 pytestmark = pytest.mark.gpu
 
-TOL_SPEC = 2e-6
-TOL_VIS = 1e-5
+from tolerances import TOL_CONT, TOL_SPEC, TOL_SPEC_ANY, TOL_TONE, TOL_VIS      # bounds from measurement, never above 2e-6 / 1e-5
 
 
 @pytest.fixture(scope="module")
@@ -69,7 +68,7 @@ def test_reference_tone_cases(plan_mod, torch, golden):
             rows, cols = gi.spec_sample_indices(spec.shape)
             ref = arrays["tone_samples"][idx]
             scale = np.abs(fx_oracle.spectrometer_poly(iq.astype(np.complex64), taps, branches, window)).max()
-            assert np.abs(spec[rows, cols] - ref).max() < 5e-6 * scale, (idx, g["case"])
+            assert np.abs(spec[rows, cols] - ref).max() < TOL_TONE * scale, (idx, g["case"])
     finally:
         cor.close()
 
@@ -88,7 +87,7 @@ def test_channelize_matches_oracle(plan_mod, torch, nchan, ntaps, num_samp):
     for s in range(2):
         ref = fx_oracle.spectrometer_poly(x[s], ntaps, nchan, h)
         assert host[s].shape == ref.shape
-        assert rel_err(host[s], ref) < (2e-5 if (nchan & (nchan - 1)) else TOL_SPEC)
+        assert rel_err(host[s], ref) < (TOL_SPEC_ANY if (nchan & (nchan - 1)) else TOL_SPEC)
 
 
 @pytest.mark.parametrize("n_streams", [1, 2, 5])
@@ -136,11 +135,11 @@ def test_pfb_xcorr_against_reference_goldens(plan_mod, torch, golden, path):
                 assert rel_err(p.finalize("SPECTRUM")[0], ref) < TOL_VIS
             else:
                 vis = p.fx_rows(xd, item["mode"], gi.BANDWIDTH).cpu().numpy()[0, 0]
-                assert abs(vis - ref) < TOL_VIS * abs(ref) + 1e-3 * TOL_VIS * np.abs(arrays["xcorr_SPECTRUM_0"]).max() / gi.BANDWIDTH
+                assert abs(vis - ref) < TOL_CONT * abs(ref) + 1e-8 * np.abs(arrays["xcorr_SPECTRUM_0"]).max() / gi.BANDWIDTH
                 p.acc_reset()
                 p.fx_accumulate(xd)
                 integ = p.finalize(item["mode"], gi.BANDWIDTH)[0]
-                assert abs(integ - ref) < TOL_VIS * abs(ref) + 1e-3 * TOL_VIS * np.abs(arrays["xcorr_SPECTRUM_0"]).max() / gi.BANDWIDTH
+                assert abs(integ - ref) < TOL_CONT * abs(ref) + 1e-8 * np.abs(arrays["xcorr_SPECTRUM_0"]).max() / gi.BANDWIDTH
 
 
 def test_drop_in_run_task(torch, golden):
@@ -161,7 +160,7 @@ def test_drop_in_run_task(torch, golden):
                 assert rel_err(vis, ref) < TOL_VIS
             else:
                 assert np.ndim(vis) == 0
-                assert abs(vis - ref) < 1e-4 * abs(ref)
+                assert abs(vis - ref) < TOL_CONT * abs(ref)
     finally:
         cor.close()
 
@@ -213,7 +212,7 @@ def test_drop_in_any_resolution(torch, nbins):
             if mode == "SPECTRUM":
                 assert vis.shape == (nbins,) and rel_err(vis, ref) < TOL_VIS
             else:
-                assert abs(vis - ref) < 1e-4 * abs(ref) + 1e-9 * np.abs(x).max() ** 2
+                assert abs(vis - ref) < TOL_CONT * abs(ref) + 1e-9 * np.abs(x).max() ** 2
     finally:
         cor.close()
 
@@ -585,8 +584,8 @@ def test_continuum_reference_semantics_full_size(plan_mod, torch):
         p.fx_accumulate(xd)
         integ = p.finalize("CONTINUUM", gi.BANDWIDTH)
     ref = fx_oracle.pfb_xcorr(x[1, 0], x[1, 1], 4, 4096, window, gi.BANDWIDTH, gi.FREQUENCY, 1e-6, "CONTINUUM")
-    assert abs(cont[1, 0] - ref) < TOL_VIS * abs(ref)
-    assert abs(cont_a[1, 0] - ref) < TOL_VIS * abs(ref)
+    assert abs(cont[1, 0] - ref) < TOL_CONT * abs(ref)
+    assert abs(cont_a[1, 0] - ref) < TOL_CONT * abs(ref)
     np.testing.assert_allclose(cont[:, 0], spec[:, 0].astype(np.complex128).mean(axis=1) / gi.BANDWIDTH, rtol=2e-5)
     np.testing.assert_allclose(integ[0], cont[:, 0].mean(), rtol=2e-5)
 
@@ -820,7 +819,7 @@ def test_specialised_kernel_on_the_device(plan_mod, torch, nchan, ntaps, n_chunk
         assert rel_err(integ, rows.astype(np.complex128).mean(axis=0)) < 2e-6
         cont = p.fx_rows(xd[:2], "CONTINUUM", gi.BANDWIDTH).cpu().numpy()
         ref = fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 3e-7, "CONTINUUM")
-        assert abs(cont[0, 0] - ref) < 1e-5 * abs(ref) + 1e-9 * np.abs(rows[0]).max() / gi.BANDWIDTH
+        assert abs(cont[0, 0] - ref) < TOL_CONT * abs(ref) + 1e-9 * np.abs(rows[0]).max() / gi.BANDWIDTH
         u8 = torch.from_numpy(np.random.default_rng(nchan).integers(0, 256, size=(min(n_chunks, 4), 2, num_samp, 2), dtype=np.uint8)).cuda()
         by = p.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()
         assert rel_err(by, p.fx_rows(p.convert_u8(u8, remove_dc=True)).cpu().numpy()) < TOL_VIS
@@ -1086,10 +1085,10 @@ def test_continuum_streaming_limit_nchan1(plan_mod, torch, ntaps, num_samp):
     refs = [fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], ntaps, 1, h, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "CONTINUUM")
             for c in range(3)]
     for c in range(3):
-        assert abs(cont[c, 0] - refs[c]) < 1e-5 * abs(refs[c])
-        assert abs(cont_g[c, 0] - refs[c]) < 1e-5 * abs(refs[c])
-        assert abs(spec[c, 0, 0] / gi.BANDWIDTH - refs[c]) < 1e-5 * abs(refs[c])
-    assert abs(integ[0] - np.mean(refs)) < 1e-5 * abs(np.mean(refs))
+        assert abs(cont[c, 0] - refs[c]) < TOL_CONT * abs(refs[c])
+        assert abs(cont_g[c, 0] - refs[c]) < TOL_CONT * abs(refs[c])
+        assert abs(spec[c, 0, 0] / gi.BANDWIDTH - refs[c]) < TOL_CONT * abs(refs[c])
+    assert abs(integ[0] - np.mean(refs)) < TOL_CONT * abs(np.mean(refs))
 
 
 def test_empty_batches_and_errors(plan_mod, torch):
