@@ -1778,7 +1778,7 @@ def test_bench_two_ranks_share_one_gpu():
     assert rccl["transport"] == "torch.distributed" and rccl["ranks_seen"] is None and rccl["ranks_summed"] is None
     assert "ranks share GPUs" in rccl["fallback_reason"] and rccl["strict"] is False and rccl["all_ranks_agree"] is False
     assert rccl["torch_backend"] == "gloo" and rccl["version"] >= 20000 and "rccl" in rccl["library"]
-    assert all(r["rccl"]["ranks_seen"] is None and r["rccl"]["reduces_queued"] == 0 for r in ranks)
+    assert all(r["rccl"]["ranks_seen"] is None and r["rccl"]["reduces_queued"] == 0 for r in line["ranks"]["per_rank"])
     assert line["verify"]["frames"] == 1200 and line["verify"]["integration_vs_float64_mean_of_rows"] < 1e-6
     assert line["value"] > 0 and line["roofline"]["launches"] == 2 and line["scaling"] == "weak"
     ranks = line["ranks"]
