@@ -25,6 +25,9 @@
 
 #include "fx_mixed.h"
 
+#ifndef FXM_U
+#define FXM_U 1          // frames a slot carries through every step together (2: half the barriers per frame, twice the work in flight)
+#endif
 #if !defined(FXM_N) || !defined(FXM_T) || !defined(FXM_TPR) || !defined(FXM_SLOTS) || !defined(FXM_NST) || !defined(FXM_RADICES) || !defined(FXM_U8)
 #error "fx_spec.h is compiled per shape: -DFXM_N= -DFXM_T= -DFXM_TPR= -DFXM_SLOTS= -DFXM_NST= -DFXM_RADICES= -DFXM_U8="
 #endif
@@ -33,6 +36,13 @@
 #define FXM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #else
 #define FXM_SCHED_BARRIER() ((void)0)
+#endif
+
+// FXM_ABL: developer-only timing ablations (WRONG RESULTS by design; plans are built with 0 unless FXC_RTC_ABL says otherwise):
+//   1 no barriers   2 stage outputs not stored to LDS   4 butterflies skipped (inputs passed through)   8 samples not loaded
+//   16 every load reads the chunk's first frames (cache hits: the memory system out of the picture, same instruction stream)
+#ifndef FXM_ABL
+#define FXM_ABL 0
 #endif
 
 namespace fxm {
@@ -52,7 +62,14 @@ constexpr int SLOTS = FXM_SLOTS;
 constexpr int S = FXM_NST;
 constexpr int kRadix[S] = {FXM_RADICES};
 constexpr bool U8 = FXM_U8 != 0;
+constexpr int U = FXM_U;
 constexpr int THREADS = TPR * SLOTS;
+// The ring: the frames a step needs -- its own U and the T - 1 before them -- in NS = T + U - 1 slots, frame g of a run in
+// slot g mod NS; the next step's U frames land in the U slots the FIR has just finished with.  The slot pattern repeats after
+// UNR steps, and the step loop is unrolled that far so that every slot index is a constant.
+constexpr int NS = T + U - 1;
+constexpr int gcd_of(int a, int b) { return b == 0 ? a : gcd_of(b, a % b); }
+constexpr int UNR = NS / gcd_of(NS, U);
 
 constexpr int ns_of(int s) {
     int v = 1;
@@ -76,16 +93,18 @@ constexpr int R0 = kRadix[0], J0 = j_of(0), PTS = R0 * J0;              // a thr
 constexpr int RL = kRadix[S - 1], JL = j_of(S - 1);
 constexpr int TWC = tw_base(S), OBC = ob_base(S > 1 ? S - 1 : 1);
 constexpr bool SWAP = S >= 2 && S % 2 == 0;      // the last stage reads the buffer the next frame's first stage writes: alternate them
-constexpr int ROW = N;                           // one antenna's row; a slot's LDS: [buffer X | Y][antenna][N]
-constexpr int LDS_PER_SLOT = S >= 2 ? 4 * N : 0; // complex64 elements
+constexpr int ROW = N;                           // one antenna's row; a slot's LDS: [buffer X | Y][frame of the step][antenna][N]
+constexpr int ROWS = 2 * U;                      // rows a step carries: (frame u, antenna a) -> u * 2 + a
+constexpr int LDS_PER_SLOT = S >= 2 ? 2 * ROWS * N : 0; // complex64 elements
 
 static_assert(ns_of(S) == N, "the radices multiply to N");
 static_assert(T >= 1 && T <= 4, "one to four taps (the ring lives in registers)");
+static_assert(U == 1 || U == 2, "one or two frames per step");
 static_assert(SLOTS >= 1 && (SLOTS == 1 || TPR % 64 == 0 || 64 % TPR == 0), "slots do not straddle waves");
 
 // per-thread state, all of it registers once the loops below are unrolled
 struct Thread {
-    pk2 ring[2][PTS][T];             // frame f's samples of the thread's points in slot f mod T
+    pk2 ring[2][PTS][NS];            // frame g's samples of the thread's points in slot g mod NS (g counted from the run's first frame)
     pk2 tw[TWC > 0 ? TWC : 1];       // twiddles of the thread's butterflies in stages 1 .. S-1
     int ob[OBC > 0 ? OBC : 1];       // where the butterflies of stages 1 .. S-2 put their outputs
     pk2 xacc[JL * RL];               // sum over the run of s0 conj(s1) at the bins the thread's last butterflies produce
@@ -159,6 +178,11 @@ FXC_HD pk2 x_acc_hi(pk2 t, pk2 a, pk2 b) {   // t + b.y (a.y, -a.x)
 // a_r = v_r + v_{R-r}, d_r = v_r - v_{R-r}.
 template <int R>
 FXC_HD void dft_regs(pk2 (&v)[R], const fxc::Roots<R>& rt, pk2 (&o)[R]) {
+#if (FXM_ABL & 4)
+#pragma unroll
+    for (int q = 0; q < R; ++q) o[q] = v[q];
+    return;
+#endif
     if constexpr (R == 2) {
         o[0] = v[0] + v[1];
         o[1] = v[0] - v[1];
@@ -207,6 +231,9 @@ template <int R>
 FXC_HD void dft_to(pk2 (&v)[R], const fxc::Roots<R>& rt, cf* d, int ds) {      // ... into d[q * ds]
     pk2 o[R];
     dft_regs<R>(v, rt, o);
+#if (FXM_ABL & 2)
+    if (ds >= 0) return;          // (never true at run time as far as the compiler knows: ds is data)
+#endif
 #pragma unroll
     for (int q = 0; q < R; ++q) d[q * ds] = unpk(o[q]);
 }
@@ -249,7 +276,7 @@ struct Body {
         lt = cx.tid() % TPR;
         slot = cx.tid() / TPR;
         bx = cx.lds() + slot * LDS_PER_SLOT;
-        by = bx + 2 * N;
+        by = bx + ROWS * N;
 #pragma unroll
         for (int j = 0; j < J0; ++j)
 #pragma unroll
@@ -289,6 +316,9 @@ struct Body {
     static constexpr int kElem = U8 ? 2 : 8;                  // bytes per sample
     template <int P>
     FXC_HD void load_frame(long long f, bool valid) {
+#if (FXM_ABL & 16)
+        f &= 3;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
         // butterfly j's points sit at N-1-m, m = lt + j TPR + r N/R0: one VGPR offset per j, counted from the lowest address of
@@ -305,7 +335,7 @@ struct Body {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
                     const int m = lt + j * TPR + r * nb_of(0);
-                    const bool ok = valid && has_bfly(0, j, lt);
+                    const bool ok = valid && has_bfly(0, j, lt) && !(FXM_ABL & 8);
                     pk2 v = pk_splat(0.f);
                     if (ok) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -343,7 +373,7 @@ struct Body {
             const int b = lt + j * TPR;
             if (has_bfly(s, j, lt)) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
+                for (int a = 0; a < ROWS; ++a) {       // (every row of the step: the same indices, twiddles and barrier serve them all)
                     pk2 v[R], t[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) v[r] = pk(src[a * ROW + b + r * nb]);
@@ -358,32 +388,34 @@ struct Body {
         }
     }
 
-    // ---- the last stage (s = S - 1 >= 1): LDS -> registers -> X
-    FXC_HD void last_stage(const cf* src, bool live) {
+    // ---- the last stage (s = S - 1 >= 1): LDS -> registers -> X.  live[u]: frame u of the step exists for this slot
+    FXC_HD void last_stage(const cf* src, const bool (&live)[U]) {
         constexpr int s = S - 1, R = RL, nb = nb_of(s);
         const fxc::Roots<R> rt = fxc::load_roots<R>(ar.tw, nb);
 #pragma unroll
         for (int j = 0; j < JL; ++j) {
             const int b = lt + j * TPR;
-            if (live && has_bfly(s, j, lt)) {
-                pk2 o[2][R];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    pk2 v[R], t[R];
+            for (int u = 0; u < U; ++u)
+                if (live[u] && has_bfly(s, j, lt)) {
+                    pk2 o[2][R];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) v[r] = pk(src[a * ROW + b + r * nb]);
+                    for (int a = 0; a < 2; ++a) {
+                        pk2 v[R], t[R];
 #pragma unroll
-                    for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1]);
+                        for (int r = 0; r < R; ++r) v[r] = pk(src[(u * 2 + a) * ROW + b + r * nb]);
 #pragma unroll
-                    for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1], t[r]);
-                    dft_regs<R>(v, rt, o[a]);
-                    FXM_SCHED_BARRIER();
+                        for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1]);
+#pragma unroll
+                        for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1], t[r]);
+                        dft_regs<R>(v, rt, o[a]);
+                        FXM_SCHED_BARRIER();
+                    }
+#pragma unroll
+                    for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_lo(th.xacc[j * R + q], o[0][q], o[1][q]);
+#pragma unroll
+                    for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_hi(th.xacc[j * R + q], o[0][q], o[1][q]);
                 }
-#pragma unroll
-                for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_lo(th.xacc[j * R + q], o[0][q], o[1][q]);
-#pragma unroll
-                for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_hi(th.xacc[j * R + q], o[0][q], o[1][q]);
-            }
         }
     }
 
@@ -396,51 +428,63 @@ struct Body {
         }
     }
 
-    // ---- one frame: FIR out of the ring, first butterfly, the stages, X.  P = the ring slot of this frame.
-    // `live`: the frame exists for this slot (slots of a workgroup take the same number of steps)
+    // ---- one step: the FIR of its U frames out of the ring, the first butterfly, the stages, X.  P = the ring slot of the
+    // step's first frame f.  live[u]: frame f + u exists for this slot (the slots of a workgroup take the same number of
+    // steps); f_end: the end of the slot's run (frames from there on are not loaded)
     template <int P>
-    FXC_HD void step(long long f, bool live, bool next_live) {
-        pk2 acc[2][PTS];
+    FXC_HD void step(long long f, long long f_end) {
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) live[u] = f + u < f_end;
+        pk2 acc[U][2][PTS];
 #pragma unroll
         for (int t = 0; t < T; ++t)                     // (tap outside: consecutive instructions belong to different points)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int p = 0; p < PTS; ++p) {
-                    const pk2 w = pk_splat(hw2[(t * PTS + p) / 2][(t * PTS + p) % 2]);
-                    acc[a][p] = t == 0 ? w * th.ring[a][p][P] : pk_fma(w, th.ring[a][p][(P - t + T) % T], acc[a][p]);
-                }
-        // the oldest slot is free now: the next frame's samples go there, in flight through the stages below
-        load_frame<(P + 1) % T>(f + 1, next_live);
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int p = 0; p < PTS; ++p) {
+                        const pk2 w = pk_splat(hw2[(t * PTS + p) / 2][(t * PTS + p) % 2]);
+                        const pk2 x = th.ring[a][p][(P + u - t + NS) % NS];
+                        acc[u][a][p] = t == 0 ? w * x : pk_fma(w, x, acc[u][a][p]);
+                    }
+        // the U oldest slots are free now: the next step's frames go there, in flight through the stages below
+        load_frame<(P + U) % NS>(f + U, f + U < f_end);
+        if constexpr (U == 2) load_frame<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end);
         const fxc::Roots<R0> rt = fxc::load_roots<R0>(ar.tw, nb_of(0));
         if constexpr (S == 1) {
 #pragma unroll
             for (int j = 0; j < J0; ++j)
-                if (live && has_bfly(0, j, lt)) {
-                    pk2 o[2][R0];
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        pk2 v[R0];
+                for (int u = 0; u < U; ++u)
+                    if (live[u] && has_bfly(0, j, lt)) {
+                        pk2 o[2][R0];
 #pragma unroll
-                        for (int r = 0; r < R0; ++r) v[r] = acc[a][j * R0 + r];
-                        dft_regs<R0>(v, rt, o[a]);
+                        for (int a = 0; a < 2; ++a) {
+                            pk2 v[R0];
+#pragma unroll
+                            for (int r = 0; r < R0; ++r) v[r] = acc[u][a][j * R0 + r];
+                            dft_regs<R0>(v, rt, o[a]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc_lo(th.xacc[j * R0 + q], o[0][q], o[1][q]);
+#pragma unroll
+                        for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc_hi(th.xacc[j * R0 + q], o[0][q], o[1][q]);
                     }
-#pragma unroll
-                    for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc_lo(th.xacc[j * R0 + q], o[0][q], o[1][q]);
-#pragma unroll
-                    for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc_hi(th.xacc[j * R0 + q], o[0][q], o[1][q]);
-                }
         } else {
 #pragma unroll
             for (int j = 0; j < J0; ++j)
                 if (has_bfly(0, j, lt)) {
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        pk2 v[R0];
+                    for (int u = 0; u < U; ++u)
 #pragma unroll
-                        for (int r = 0; r < R0; ++r) v[r] = acc[a][j * R0 + r];
-                        dft_to<R0>(v, rt, bx + a * ROW + (lt + j * TPR) * R0, 1);      // ns = 1: o = b R0
-                    }
+                        for (int a = 0; a < 2; ++a) {
+                            pk2 v[R0];
+#pragma unroll
+                            for (int r = 0; r < R0; ++r) v[r] = acc[u][a][j * R0 + r];
+                            dft_to<R0>(v, rt, bx + (u * 2 + a) * ROW + (lt + j * TPR) * R0, 1);      // ns = 1: o = b R0
+                        }
                 }
             cx.sync();
             mid_stages<1>(bx, by);
@@ -453,22 +497,24 @@ struct Body {
         }
     }
 
-    template <int P>
-    FXC_HD void steps(long long f, long long f1, long long i, long long n_steps) {      // T frames per trip, slots rotate
-        if constexpr (P < T) {
-            if (i + P < n_steps) {          // uniform over the workgroup
-                step<P>(f + P, f + P < f1, f + P + 1 < f1);
-                steps<P + 1>(f, f1, i, n_steps);
+    // UNR steps per trip: step k of a trip starts at ring slot (k U) mod NS
+    template <int K>
+    FXC_HD void steps(long long f, long long f_end, long long i, long long n_steps) {
+        if constexpr (K < UNR) {
+            if (i + K < n_steps) {          // uniform over the workgroup
+                step<(K * U) % NS>(f + K * U, f_end);
+                steps<K + 1>(f, f_end, i, n_steps);
             }
         }
     }
 
-    template <int P>
-    FXC_HD void preload(long long f0) {     // frames f0 - (T-1) .. f0 into slots so that frame f0 sits in slot 0
-        if constexpr (P < T) {
-            const long long f = f0 - P;
-            load_frame<(T - P) % T>(f, f >= 0);
-            preload<P + 1>(f0);
+    // frames f0 - (T - 1) .. f0 + U - 1 into their slots: frame g in slot (g - f0) mod NS
+    template <int K>
+    FXC_HD void preload(long long f0, long long f_end) {
+        if constexpr (K < NS) {
+            const long long g = f0 - (T - 1) + K;
+            load_frame<(K - (T - 1) + NS) % NS>(g, g >= 0 && g < f_end);
+            preload<K + 1>(f0, f_end);
         }
     }
 
@@ -478,7 +524,7 @@ struct Body {
         init();
         const int e = sp * SLOTS + slot, E = ar.wg_splits * SLOTS;
         const long long f0 = (long long)e * ar.n_pts / E, f1 = ((long long)e + 1) * ar.n_pts / E;
-        const long long n_steps = (ar.n_pts + E - 1) / E;       // the longest run of any slot: uniform
+        const long long n_steps = ((ar.n_pts + E - 1) / E + U - 1) / U;       // steps of the longest run of any slot: uniform
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             xs[a] = reinterpret_cast<const cf*>(ar.x) + (2 * chunk + a) * ar.num_samp;
@@ -490,8 +536,8 @@ struct Body {
 #endif
         }
         // zero history in front of the chunk; a run that starts inside it re-reads T - 1 frames
-        preload<0>(f0 < f1 ? f0 : -(long long)T);
-        for (long long i = 0; i < n_steps; i += T) steps<0>(f0 + i, f1, i, n_steps);
+        preload<0>(f0, f1);
+        for (long long i = 0; i < n_steps; i += UNR) steps<0>(f0 + i * U, f1, i, n_steps);
         // the thread's bins: the last stage's butterfly b puts output q at b + q N/RL (k = b there: ns = N/RL)
         cf* o = ar.out + ((long long)e * ar.n_chunks + chunk) * N;
 #pragma unroll
@@ -512,6 +558,9 @@ struct DeviceCtx {
     __device__ __forceinline__ long long bid() const { return (long long)blockIdx.x; }
     __device__ __forceinline__ cf* lds() const { return lds_; }
     __device__ __forceinline__ void sync() const {
+#if (FXM_ABL & 1)
+        return;
+#endif
         if constexpr (TPR <= 64)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // a slot is (part of) one wave: LDS operations of a wave complete in order
         else

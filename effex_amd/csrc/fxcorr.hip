@@ -349,9 +349,8 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             // strides and trip counts compile-time constants.  FXC_RTC=0 keeps the any-shape kernel (developer knob, and what
             // a box without hiprtc runs)
             if (p->mixed_xf && env_int("FXC_RTC", 1) && p->num_samp < (1ll << 28)) {       // (32-bit byte offsets inside a chunk)
-                const SpecShape sh = spec_shape(N, T);
-                if (sh.ok) {
-                    const SpecKernel* k = spec_kernel(p->device, sh, false);
+                if (!spec_first_radices(N, T).empty()) {
+                    const SpecKernel* k = spec_kernel(p->device, N, T, false);
                     if (k->fn)
                         p->spec = k;
                     else if (env_int("FXC_RTC_VERBOSE", 0))
@@ -758,8 +757,8 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
 
 int fxc_spec_probe(int nchan, int ntaps, int u8, const char* arch, char* report, int report_bytes) {
     if (report && report_bytes > 0) report[0] = 0;
-    const SpecShape sh = spec_shape(nchan, ntaps);
-    if (!sh.ok) return fail(nullptr, FXC_ERR_UNSUPPORTED, "no specialised kernel for %d channels, %d taps", nchan, ntaps);
+    if (spec_first_radices(nchan, ntaps).empty())
+        return fail(nullptr, FXC_ERR_UNSUPPORTED, "no specialised kernel for %d channels, %d taps", nchan, ntaps);
     std::string target = arch ? arch : "";
     if (target.empty()) {
         int dev = 0;
@@ -768,15 +767,15 @@ int fxc_spec_probe(int nchan, int ntaps, int u8, const char* arch, char* report,
             return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device to take the architecture from");
         target = prop.gcnArchName;
     }
-    std::vector<char> image;
-    std::string error;
-    if (!spec_compile(sh, u8 != 0, target.c_str(), image, error)) return fail(nullptr, FXC_ERR_HIP, "%s", error.c_str());
+    const SpecBuild b = spec_search(nchan, ntaps, u8 != 0, target.c_str());
+    if (b.image.empty()) return fail(nullptr, b.scratch ? FXC_ERR_UNSUPPORTED : FXC_ERR_HIP, "%s", b.error.c_str());
     if (report && report_bytes > 0) {
+        const SpecShape& sh = b.shape;
         std::string radices;
         for (int i = 0; i < sh.n_stages; ++i) radices += (i ? "," : "") + std::to_string(sh.radix[i]);
-        std::snprintf(report, (size_t)report_bytes, "nchan=%d ntaps=%d tpr=%d slots=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld",
-                      sh.n, sh.taps, sh.tpr, sh.slots, radices.c_str(), sh.lds_bytes(), image.size(), code_object_int(image, ".vgpr_count"),
-                      code_object_int(image, ".private_segment_fixed_size"));
+        std::snprintf(report, (size_t)report_bytes,
+                      "nchan=%d ntaps=%d tpr=%d slots=%d frames_per_step=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld resident=%d",
+                      sh.n, sh.taps, sh.tpr, sh.slots, sh.u, radices.c_str(), sh.lds_bytes(), b.image.size(), b.vgprs, b.scratch, b.resident);
     }
     return FXC_OK;
 }

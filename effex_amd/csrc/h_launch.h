@@ -118,12 +118,12 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
         if (dc_u8) {
             if (!p->spec_u8_tried) {
                 p->spec_u8_tried = true;
-                const SpecKernel* k8 = spec_kernel(p->device, p->spec->shape, true);
+                const SpecKernel* k8 = spec_kernel(p->device, p->nchan, p->ntaps, true);
                 p->spec_u8 = k8->fn ? k8 : nullptr;
             }
             k = p->spec_u8;
         }
-        if (k && n_splits % k->shape.slots == 0) {
+        if (k && n_splits % k->shape.slots == 0 && n_splits / k->shape.slots >= 1) {
             const int wg_splits = n_splits / k->shape.slots;
             const int64_t grid = n_chunks * wg_splits;
             if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");

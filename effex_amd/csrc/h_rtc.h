@@ -80,14 +80,17 @@ RtcApi* rtc_api() {
 struct SpecShape {
     bool ok = false;
     int n = 0, taps = 0, n_stages = 0, radix[fxc::kMixedMaxStages] = {0}, tpr = 0, slots = 0;
+    int u = 1;                   // frames a slot carries through a step together
     int threads() const { return tpr * slots; }
-    size_t lds_bytes() const { return n_stages >= 2 ? (size_t)slots * 4 * n * sizeof(cf) : 0; }
+    size_t lds_bytes() const { return n_stages >= 2 ? (size_t)slots * 4 * u * n * sizeof(cf) : 0; }
 };
 
 // Eligible: two antennas, up to four taps (the frame ring lives in registers), every prime factor has a register butterfly
 // (2, 3, 4, 5, 7, 11, 13), a thread's points (first radix x its first-stage butterflies) fit the ring (<= 8), the slots'
-// rows fit the LDS.  Stage order as fx_mixed.h's: fours, a two, the odd primes ascending.
-SpecShape spec_shape(int n, int taps) {
+// rows fit the LDS.  `first`: the radix of the first stage (0: fx_mixed.h's order -- fours, a two, the odd primes ascending);
+// it sets the threads per slot (N / first butterflies), the points a thread keeps in its ring (first of them) and the LDS
+// bank pattern of the first stage's stores (an odd stride is conflict-free).  `u`: frames per step.
+SpecShape spec_shape(int n, int taps, int first = 0, int u = 1) {
     SpecShape s;
     if (n < 2 || n > 8192 || taps < 1 || taps > 4) return s;
     const fxc::MixedPlan mp = fxc::mixed_factor(n);
@@ -100,6 +103,14 @@ SpecShape spec_shape(int n, int taps) {
     s.n = n;
     s.taps = taps;
     s.n_stages = mp.n_stages;
+    if (first) {
+        int at = -1;
+        for (int i = 0; i < s.n_stages && at < 0; ++i)
+            if (s.radix[i] == first) at = i;
+        if (at < 0) return s;
+        for (int i = at; i > 0; --i) s.radix[i] = s.radix[i - 1];      // (the others keep their order)
+        s.radix[0] = first;
+    }
     const int nb0 = n / s.radix[0];
     int j0 = 1;
     if (nb0 <= 64) {
@@ -111,9 +122,41 @@ SpecShape spec_shape(int n, int taps) {
     }
     s.slots = std::max(1, 256 / s.tpr);
     if (s.radix[0] * j0 > 8) return s;
+    s.u = u;
+    if (u != 1 && (u != 2 || s.n_stages < 2 || 2 * s.lds_bytes() > (size_t)(160 * 1024))) return s;
     if (s.lds_bytes() > (size_t)(160 * 1024)) return s;
     s.ok = true;
     return s;
+}
+
+// The first-stage radices worth building for n channels, best guess first.  Measured (tools/sweep_spec_r0.sh, 14 channel counts,
+// profiles/r05/experiments.md): workgroups of whole multiples of 256 threads -- a wave on every SIMD -- win (720 channels: 3 first,
+// 240 butterflies on 256 threads, 1.72 ms; 4 first, 180 on 192 threads, 2.11 ms), 2 first loses wherever there is a choice
+// (N / 2 threads per frame leave the later stages a few butterflies each: 600 channels 3.4 ms against 1.75), then the fuller
+// first stage, then the smaller radix (fewer ring registers).
+std::vector<int> spec_first_radices(int n, int taps) {
+    struct Cand {
+        int r, unbalanced, is_two, waste;
+    };
+    std::vector<Cand> c;
+    const SpecShape base = spec_shape(n, taps);
+    if (!base.n) return {};
+    for (int r : {3, 4, 5, 7, 2, 11, 13}) {
+        const SpecShape s = spec_shape(n, taps, r);
+        if (!s.ok || s.threads() > 512) continue;      // (more than 512 threads leave under 256 registers a thread: the ring does not fit)
+        const int nb0 = n / r, j0 = (nb0 + s.tpr - 1) / s.tpr;
+        const int waste = 20 - 20 * nb0 / (s.tpr * j0);                 // idle lanes of the first stage, in twentieths
+        c.push_back({r, s.threads() % 256 != 0, r == 2, waste});
+    }
+    std::stable_sort(c.begin(), c.end(), [](const Cand& a, const Cand& b) {
+        if (a.unbalanced != b.unbalanced) return a.unbalanced < b.unbalanced;
+        if (a.is_two != b.is_two) return a.is_two < b.is_two;
+        if (a.waste != b.waste) return a.waste < b.waste;
+        return a.r < b.r;
+    });
+    std::vector<int> out;
+    for (const Cand& k : c) out.push_back(k.r);
+    return out;
 }
 
 struct SpecKernel {
@@ -169,7 +212,8 @@ bool spec_compile(const SpecShape& shape, bool u8, const char* arch, std::vector
                                      "-DFXM_N=" + std::to_string(shape.n), "-DFXM_T=" + std::to_string(shape.taps),
                                      "-DFXM_TPR=" + std::to_string(shape.tpr), "-DFXM_SLOTS=" + std::to_string(shape.slots),
                                      "-DFXM_NST=" + std::to_string(shape.n_stages), "-DFXM_RADICES=" + radices,
-                                     "-DFXM_U8=" + std::to_string((int)u8)};
+                                     "-DFXM_U8=" + std::to_string((int)u8), "-DFXM_U=" + std::to_string(shape.u),
+                                     "-DFXM_ABL=" + std::to_string(env_int("FXC_RTC_ABL", 0))};      // (timing ablations: wrong results, developer runs only)
     std::vector<const char*> optv;
     for (const std::string& o : opts) optv.push_back(o.c_str());
     const char* headers[] = {fxc_src_fx_spec_h, fxc_src_fx_mixed_h, fxc_src_fx_math_h};
@@ -200,27 +244,94 @@ bool spec_compile(const SpecShape& shape, bool u8, const char* arch, std::vector
     return true;
 }
 
-// compile (or find) the kernel for `shape` on `device`; never nullptr -- a failed build is cached with its reason
-const SpecKernel* spec_kernel(int device, const SpecShape& shape, bool u8) {
+// workgroups of this build a CU holds: registers (512 per lane and SIMD, granule 8), LDS (160 KiB), 32 waves
+int spec_resident(const SpecShape& sh, long long vgprs) {
+    const int alloc = (int)((vgprs + 7) / 8 * 8);
+    const int waves_simd = std::min(8, 512 / std::max(alloc, 8));
+    const int wg_waves_simd = (sh.threads() / 64 + 3) / 4;                    // waves of one workgroup on its fullest SIMD
+    int wgs = waves_simd / std::max(wg_waves_simd, 1);
+    if (sh.lds_bytes() > 0) wgs = std::min<long long>(wgs, (long long)(160 * 1024) / (long long)sh.lds_bytes());
+    return std::min(wgs, 32 * 64 / std::max(sh.threads(), 64));
+}
+
+// one build: compile `shape`, read its registers / scratch from the code object.  image empty: the compile failed (error says why)
+struct SpecBuild {
+    SpecShape shape;
+    std::vector<char> image;
+    long long vgprs = 0, scratch = 0;
+    int resident = 0;
+    std::string error;
+};
+SpecBuild spec_build(const SpecShape& shape, bool u8, const char* arch) {
+    SpecBuild b;
+    b.shape = shape;
+    if (!spec_compile(shape, u8, arch, b.image, b.error)) {
+        b.image.clear();
+        return b;
+    }
+    b.vgprs = code_object_int(b.image, ".vgpr_count");
+    b.scratch = code_object_int(b.image, ".private_segment_fixed_size");
+    b.resident = b.scratch == 0 ? spec_resident(shape, b.vgprs) : 0;
+    return b;
+}
+
+// The build for (n, taps): the first candidate order that keeps two workgroups on a CU (else the best seen), with two frames per
+// step when that costs no resident workgroup (4 - 10 % where it fits: 1000 channels 206 -> 256 registers, 1.87 -> 1.73 ms; 96
+// channels with 3 first 150 -> 192 registers, three workgroups -> two, 1.25 -> 1.33 ms: one frame there).  Developer knobs:
+// FXC_RTC_R0 / FXC_RTC_U force the first radix / the frames per step.
+SpecBuild spec_search(int n, int taps, bool u8, const char* arch) {
+    SpecBuild best;
+    best.error = "no specialised kernel for this channel count";
+    std::vector<int> firsts = spec_first_radices(n, taps);
+    if (const int want = env_int("FXC_RTC_R0", 0)) firsts.assign(1, want);
+    const int force_u = env_int("FXC_RTC_U", 0);
+    int tried = 0;
+    for (int r : firsts) {
+        if (tried == 2) break;                       // (a compile is about a second: two orders at most)
+        const SpecShape one = spec_shape(n, taps, r, 1);
+        if (!one.ok) continue;
+        ++tried;
+        const SpecShape two = spec_shape(n, taps, r, 2);
+        SpecBuild b = (force_u == 2 && two.ok) ? SpecBuild() : spec_build(one, u8, arch);
+        if (two.ok && force_u != 1) {
+            SpecBuild b2 = spec_build(two, u8, arch);
+            if (b2.resident >= 1 && (b2.resident >= b.resident || force_u == 2)) b = std::move(b2);
+        }
+        if (b.image.empty() || b.resident < 1) {
+            if (best.image.empty() && !b.error.empty()) best.error = b.error;
+            else if (best.image.empty() && b.scratch) best.error = "the specialised kernel spills (" + std::to_string(b.scratch) + " B of scratch per lane)";
+            continue;
+        }
+        if (best.image.empty() || b.resident * b.shape.threads() > best.resident * best.shape.threads()) best = std::move(b);
+        if (best.resident * best.shape.threads() >= 512) break;       // two workgroups of 256 (or one of 512 and more): good enough
+    }
+    return best;
+}
+
+// compile (or find) the kernel for n channels on `device`; never nullptr -- a failed build is cached with its reason
+const SpecKernel* spec_kernel(int device, int n, int taps, bool u8) {
     char key[256];
-    std::string radices;
-    for (int i = 0; i < shape.n_stages; ++i) radices += (i ? "," : "") + std::to_string(shape.radix[i]);
-    std::snprintf(key, sizeof key, "d%d n%d t%d tpr%d s%d r%s u%d", device, shape.n, shape.taps, shape.tpr, shape.slots, radices.c_str(), (int)u8);
+    std::snprintf(key, sizeof key, "d%d n%d t%d u%d a%d r%d f%d", device, n, taps, (int)u8, env_int("FXC_RTC_ABL", 0), env_int("FXC_RTC_R0", 0),
+                  env_int("FXC_RTC_U", 0));
     std::lock_guard<std::mutex> lock(g_spec_mutex);
     auto it = g_spec_cache.find(key);
     if (it != g_spec_cache.end()) return it->second;
     SpecKernel* k = new SpecKernel;
-    k->shape = shape;
     g_spec_cache[key] = k;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
         k->error = "hipGetDeviceProperties failed";
         return k;
     }
-    std::vector<char> image;
-    if (!spec_compile(shape, u8, prop.gcnArchName, image, k->error)) return k;
+    SpecBuild b = spec_search(n, taps, u8, prop.gcnArchName);
+    if (b.image.empty()) {
+        k->error = b.error;
+        return k;
+    }
+    k->shape = b.shape;
+    k->vgprs = (int)b.vgprs;
     DeviceGuard guard(device);
-    hipError_t e = hipModuleLoadData(&k->module, image.data());
+    hipError_t e = hipModuleLoadData(&k->module, b.image.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, "fxm_fx2_kernel");
     if (e != hipSuccess) {
         k->error = std::string("loading the compiled kernel: ") + hipGetErrorString(e);
@@ -228,14 +339,8 @@ const SpecKernel* spec_kernel(int device, const SpecShape& shape, bool u8) {
         return k;
     }
     int blocks = 0;
-    const long long scratch = code_object_int(image, ".private_segment_fixed_size");
-    k->vgprs = (int)code_object_int(image, ".vgpr_count");
-    if (scratch != 0 && !env_int("FXC_RTC_ALLOW_SPILLS", 0)) {      // a shape whose registers spill: the any-shape kernel is the better one
-        k->error = "the specialised kernel spills (" + std::to_string(scratch) + " B of scratch per lane)";
-        k->fn = nullptr;
-        return k;
-    }
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k->fn, shape.threads(), 0) == hipSuccess && blocks > 0)
+    k->wgs_per_cu = std::max(1, b.resident);
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k->fn, k->shape.threads(), 0) == hipSuccess && blocks > 0)
         k->wgs_per_cu = blocks;
     return k;
 }

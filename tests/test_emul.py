@@ -257,7 +257,8 @@ def _spec_shape(nchan, ntaps, u8=False):
     rep = dict(kv.split("=") for kv in buf.value.decode().split())
     stages = rep["stages"]
     flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=%d" % ntaps, "-DFXM_TPR=%s" % rep["tpr"], "-DFXM_SLOTS=%s" % rep["slots"],
-             "-DFXM_NST=%d" % len(stages.split(",")), "-DFXM_RADICES=%s" % stages, "-DFXM_U8=%d" % int(u8)]
+             "-DFXM_NST=%d" % len(stages.split(",")), "-DFXM_RADICES=%s" % stages, "-DFXM_U8=%d" % int(u8),
+             "-DFXM_U=%s" % rep["frames_per_step"]]
     assert re.fullmatch(r"[0-9,]+", stages) and int(rep["code_bytes"]) > 1000
     return 0, (flags, int(rep["tpr"]), int(rep["slots"]))
 
@@ -278,15 +279,19 @@ def test_specialised_kernel_shapes():
     (1000, 4, 11, 2, False), (1000, 4, 5, 1, True), (96, 4, 37, 1, False), (12, 4, 150, 2, False), (6, 2, 9, 1, False),
     (7, 1, 5, 1, False), (250, 4, 13, 2, False), (720, 3, 7, 2, False), (1001, 4, 6, 1, False), (1536, 4, 6, 1, False),
     (20, 4, 33, 1, True), (4, 4, 40, 1, False)])
-def test_specialised_kernel_matches_oracle(tmp_path, nchan, ntaps, n_pts, wg_splits, u8):
+@pytest.mark.parametrize("frames_per_step", [1, 2])
+def test_specialised_kernel_matches_oracle(tmp_path, monkeypatch, nchan, ntaps, n_pts, wg_splits, u8, frames_per_step):
     """fx_spec.h -- the two-antenna F+X kernel compiled per channel count -- run on the host (tests/emul/emul_spec.cpp: one
     thread per GPU thread, a real barrier) with the options the library would hand hiprtc: the sums over each slot's run of
     frames, added up over the slots, are the oracle's sum_i spec0[i] conj(spec1[i]) of the chunk (effex.py:508-521 before the
     mean).  Covers odd and even stage counts (buffer swap), one-stage shapes (no LDS), several slots per workgroup with runs of
     different lengths and empty runs, partial lanes in every stage, three taps, and the byte ingest."""
+    monkeypatch.setenv("FXC_RTC_U", str(frames_per_step))      # (developer knob: one or two frames per step where the LDS allows)
     rc, shape = _spec_shape(nchan, ntaps, u8)
     assert rc == 0
     flags, tpr, slots = shape
+    if frames_per_step == 2 and "-DFXM_U=2" not in flags:
+        pytest.skip("one frame per step for this shape (one stage only)")
     lib_path = str(tmp_path / "libemul_spec.so")
     subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-pthread"] + flags +
                    ["-o", lib_path, os.path.join(HERE, "emul", "emul_spec.cpp")], check=True)
