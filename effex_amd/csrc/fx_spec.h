@@ -25,6 +25,10 @@
 
 #include "fx_mixed.h"
 
+#ifndef FXM_FONLY
+#define FXM_FONLY 0      // 1: the F stage alone -- a slot's two rows are two STREAMS (2 pair, 2 pair + 1) and the last butterfly's outputs are
+                         // the spectra, stored in natural order; replaces cusignal's channelize_poly + .T (effex.py:553) at any channel count
+#endif
 #ifndef FXM_U
 #define FXM_U 1          // frames a slot carries through every step together (2: half the barriers per frame, twice the work in flight)
 #endif
@@ -63,6 +67,7 @@ constexpr int S = FXM_NST;
 constexpr int kRadix[S] = {FXM_RADICES};
 constexpr bool U8 = FXM_U8 != 0;
 constexpr int U = FXM_U;
+constexpr bool FONLY = FXM_FONLY != 0;
 constexpr int THREADS = TPR * SLOTS;
 // The ring: the frames a step needs -- its own U and the T - 1 before them -- in NS = T + U - 1 slots, frame g of a run in
 // slot g mod NS; the next step's U frames land in the U slots the FIR has just finished with.  The slot pattern repeats after
@@ -100,6 +105,7 @@ constexpr int LDS_PER_SLOT = S >= 2 ? 2 * ROWS * N : 0; // complex64 elements
 static_assert(ns_of(S) == N, "the radices multiply to N");
 static_assert(T >= 1 && T <= 4, "one to four taps (the ring lives in registers)");
 static_assert(U == 1 || U == 2, "one or two frames per step");
+static_assert(!(FONLY && U8), "the byte ingest is the two-antenna kernel's");
 static_assert(SLOTS >= 1 && (SLOTS == 1 || TPR % 64 == 0 || 64 % TPR == 0), "slots do not straddle waves");
 
 // per-thread state, all of it registers once the loops below are unrolled
@@ -245,8 +251,9 @@ struct Args {
     cf* out;                  // raw[split][chunk][N], split = workgroup split * SLOTS + slot
     const cf* tw;             // [N] exp(+2 pi i n / N)
     const cf* dc_u8;          // U8: conversion offsets [chunk][2]
-    long long num_samp, n_pts, n_chunks;
+    long long num_samp, n_pts, n_chunks;   // F only: n_chunks = the number of STREAMS (a workgroup takes a pair of them)
     int wg_splits;
+    int ant;                  // F only: spectra as out[stream / ant][frame][stream % ant][N] (1: [stream][frame][N])
 };
 
 // The body of one GPU thread.  Ctx: tid(), bid(), lds() (the workgroup's LDS as cf*), sync() (all threads of the
@@ -263,6 +270,8 @@ struct Body {
     const cf* xs[2];          // this chunk's two streams (complex64)
     const unsigned short* xb[2];
     pk2 off8[2];
+    bool row_ok[2];           // F only: the row's stream exists (the last pair of an odd number of streams has one)
+    cf* row_out[2];           // F only: where the row's stream puts its first frame's spectrum
 #if defined(__HIP_DEVICE_COMPILE__)
     __amdgpu_buffer_rsrc_t rsrc[2];
 #endif
@@ -335,7 +344,7 @@ struct Body {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
                     const int m = lt + j * TPR + r * nb_of(0);
-                    const bool ok = valid && has_bfly(0, j, lt) && !(FXM_ABL & 8);
+                    const bool ok = valid && has_bfly(0, j, lt) && !(FXM_ABL & 8) && (!FONLY || row_ok[a]);
                     pk2 v = pk_splat(0.f);
                     if (ok) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -389,7 +398,7 @@ struct Body {
     }
 
     // ---- the last stage (s = S - 1 >= 1): LDS -> registers -> X.  live[u]: frame u of the step exists for this slot
-    FXC_HD void last_stage(const cf* src, const bool (&live)[U]) {
+    FXC_HD void last_stage(const cf* src, const bool (&live)[U], long long f) {
         constexpr int s = S - 1, R = RL, nb = nb_of(s);
         const fxc::Roots<R> rt = fxc::load_roots<R>(ar.tw, nb);
 #pragma unroll
@@ -411,11 +420,28 @@ struct Body {
                         dft_regs<R>(v, rt, o[a]);
                         FXM_SCHED_BARRIER();
                     }
-#pragma unroll
-                    for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_lo(th.xacc[j * R + q], o[0][q], o[1][q]);
-#pragma unroll
-                    for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_hi(th.xacc[j * R + q], o[0][q], o[1][q]);
+                    emit<R>(o, j, f + u);
                 }
+        }
+    }
+
+    // the two rows' spectra of one butterfly of the last stage: X-multiplied into the thread's sums, or (F only) stored -- output q of
+    // butterfly b is bin b + q N/R there, so the lanes of a wave write R runs of consecutive bins
+    template <int R>
+    FXC_HD void emit(pk2 (&o)[2][R], int j, long long frame) {
+        if constexpr (FONLY) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                if (row_ok[a]) {
+                    cf* d = row_out[a] + frame * (long long)ar.ant * N + lt + j * TPR;
+#pragma unroll
+                    for (int q = 0; q < R; ++q) d[q * (N / R)] = unpk(o[a][q]);
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_lo(th.xacc[j * R + q], o[0][q], o[1][q]);
+#pragma unroll
+            for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_hi(th.xacc[j * R + q], o[0][q], o[1][q]);
         }
     }
 
@@ -467,10 +493,7 @@ struct Body {
                             for (int r = 0; r < R0; ++r) v[r] = acc[u][a][j * R0 + r];
                             dft_regs<R0>(v, rt, o[a]);
                         }
-#pragma unroll
-                        for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc_lo(th.xacc[j * R0 + q], o[0][q], o[1][q]);
-#pragma unroll
-                        for (int q = 0; q < R0; ++q) th.xacc[j * R0 + q] = x_acc_hi(th.xacc[j * R0 + q], o[0][q], o[1][q]);
+                        emit<R0>(o, j, f + u);
                     }
         } else {
 #pragma unroll
@@ -488,7 +511,7 @@ struct Body {
                 }
             cx.sync();
             mid_stages<1>(bx, by);
-            last_stage((S % 2 == 0) ? bx : by, live);      // stage S-2 wrote X when S is even
+            last_stage((S % 2 == 0) ? bx : by, live, f);      // stage S-2 wrote X when S is even
             if constexpr (SWAP) {
                 cf* t = bx;
                 bx = by;
@@ -527,17 +550,22 @@ struct Body {
         const long long n_steps = ((ar.n_pts + E - 1) / E + U - 1) / U;       // steps of the longest run of any slot: uniform
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
+            const long long st = 2 * chunk + a;                     // F only: the row's stream; `chunk` counts pairs of streams
+            row_ok[a] = !FONLY || st < ar.n_chunks;
+            const long long oc = FONLY && row_ok[a] ? st / ar.ant : 0;
+            row_out[a] = FONLY && row_ok[a] ? ar.out + ((oc * ar.n_pts) * ar.ant + (st - oc * ar.ant)) * N : nullptr;
             xs[a] = reinterpret_cast<const cf*>(ar.x) + (2 * chunk + a) * ar.num_samp;
             xb[a] = reinterpret_cast<const unsigned short*>(ar.x) + (2 * chunk + a) * ar.num_samp;
             off8[a] = U8 ? pk(ar.dc_u8[2 * chunk + a]) : pk_splat(0.f);
 #if defined(__HIP_DEVICE_COMPILE__)
-            rsrc[a] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(ar.x)) + (2 * chunk + a) * ar.num_samp * kElem, 0,
+            rsrc[a] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(ar.x)) + (row_ok[a] ? st : 0) * ar.num_samp * kElem, 0,
                                                         (int)(ar.num_samp * kElem), 0x00020000);
 #endif
         }
         // zero history in front of the chunk; a run that starts inside it re-reads T - 1 frames
         preload<0>(f0, f1);
         for (long long i = 0; i < n_steps; i += UNR) steps<0>(f0 + i * U, f1, i, n_steps);
+        if constexpr (FONLY) return;
         // the thread's bins: the last stage's butterfly b puts output q at b + q N/RL (k = b there: ns = N/RL)
         cf* o = ar.out + ((long long)e * ar.n_chunks + chunk) * N;
 #pragma unroll

@@ -350,7 +350,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             // a box without hiprtc runs)
             if (p->mixed_xf && env_int("FXC_RTC", 1) && p->num_samp < (1ll << 28)) {       // (32-bit byte offsets inside a chunk)
                 if (!spec_first_radices(N, T).empty()) {
-                    const SpecKernel* k = spec_kernel(p->device, N, T, false);
+                    const SpecKernel* k = spec_kernel(p->device, N, T, kSpecC64);
                     if (k->fn)
                         p->spec = k;
                     else if (env_int("FXC_RTC_VERBOSE", 0))
@@ -755,7 +755,8 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
     return FXC_OK;
 }
 
-int fxc_spec_probe(int nchan, int ntaps, int u8, const char* arch, char* report, int report_bytes) {
+int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* report, int report_bytes) {
+    if (variant < 0 || variant > 2) return fail(nullptr, FXC_ERR_ARG, "variant %d: 0 complex64 F+X, 1 bytes F+X, 2 F only", variant);
     if (report && report_bytes > 0) report[0] = 0;
     if (spec_first_radices(nchan, ntaps).empty())
         return fail(nullptr, FXC_ERR_UNSUPPORTED, "no specialised kernel for %d channels, %d taps", nchan, ntaps);
@@ -767,7 +768,7 @@ int fxc_spec_probe(int nchan, int ntaps, int u8, const char* arch, char* report,
             return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device to take the architecture from");
         target = prop.gcnArchName;
     }
-    const SpecBuild b = spec_search(nchan, ntaps, u8 != 0, target.c_str());
+    const SpecBuild b = spec_search(nchan, ntaps, variant, target.c_str());
     if (b.image.empty()) return fail(nullptr, b.scratch ? FXC_ERR_UNSUPPORTED : FXC_ERR_HIP, "%s", b.error.c_str());
     if (report && report_bytes > 0) {
         const SpecShape& sh = b.shape;

@@ -10,6 +10,7 @@ int launch_fused(fxc_plan* p, const cf* x, int64_t n_pairs, cf* out, bool spec_o
 
 // F-stage of `n_streams` streams: x -> spec (both device, natural bin order)
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a = 0);
+int64_t spec_wg_splits(const fxc_plan* p, const SpecKernel* k, int64_t n_groups, bool sums);
 
 // Slots of one wave (tpr <= 64) go without the workgroup barrier between their steps: measured on one box, two antennas
 // 7 - 16 % faster at 8 ... 250 channels, F only 5 - 7 % faster at 96 ... 250 but 17 % slower at 12 (slots of 4 threads) -- so F
@@ -41,6 +42,26 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
                                spec, p->d_tw, p->mixed_plan, p->num_samp, p->nchan, p->ntaps, p->n_pts, n_streams, p->mixed_tpr, 1, blu);
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
+    }
+    if (p->mixed && p->ntaps <= 4 && p->num_samp < (1ll << 28) && env_int("FXC_RTC", 1)) {
+        // the F stage built for exactly this channel count (fx_spec.h, FXM_FONLY: a workgroup carries two streams through the
+        // stages, the last butterfly stores the spectra); compiled on first use
+        if (!p->spec_f_tried) {
+            p->spec_f_tried = true;
+            if (!spec_first_radices(p->nchan, p->ntaps).empty()) {
+                const SpecKernel* k = spec_kernel(p->device, p->nchan, p->ntaps, kSpecFOnly);
+                p->spec_f = k->fn ? k : nullptr;
+            }
+        }
+        if (const SpecKernel* k = p->spec_f) {
+            const int64_t pairs = (n_streams + 1) / 2;
+            const int64_t ws = spec_wg_splits(p, k, pairs, false);
+            if (pairs * ws > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many streams for one launch");
+            SpecArgs a = {x, p->d_win, spec, p->d_tw, nullptr, (long long)p->num_samp, (long long)p->n_pts, (long long)n_streams, (int)ws, ant};
+            void* params[] = {&a};
+            FXC_HIP(p, hipModuleLaunchKernel(k->fn, (unsigned)(pairs * ws), 1, 1, (unsigned)k->shape.threads(), 1, 1, 0, p->stream, params, nullptr));
+            return FXC_OK;
+        }
     }
     if (p->mixed && p->nchan > kMixedMaxN) {
         // one LDS row, the other in the output (pfb_fft_mixed_kernel, BIG): one frame per workgroup pass, 1024 threads
@@ -118,7 +139,7 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
         if (dc_u8) {
             if (!p->spec_u8_tried) {
                 p->spec_u8_tried = true;
-                const SpecKernel* k8 = spec_kernel(p->device, p->nchan, p->ntaps, true);
+                const SpecKernel* k8 = spec_kernel(p->device, p->nchan, p->ntaps, kSpecU8);
                 p->spec_u8 = k8->fn ? k8 : nullptr;
             }
             k = p->spec_u8;
@@ -127,7 +148,7 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
             const int wg_splits = n_splits / k->shape.slots;
             const int64_t grid = n_chunks * wg_splits;
             if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
-            SpecArgs a = {x, p->d_win, raw, p->d_tw, dc_u8, (long long)p->num_samp, (long long)p->n_pts, (long long)n_chunks, wg_splits};
+            SpecArgs a = {x, p->d_win, raw, p->d_tw, dc_u8, (long long)p->num_samp, (long long)p->n_pts, (long long)n_chunks, wg_splits, 1};
             void* params[] = {&a};
             FXC_HIP(p, hipModuleLaunchKernel(k->fn, (unsigned)grid, 1, 1, (unsigned)k->shape.threads(), 1, 1, 0, p->stream, params, nullptr));
             return FXC_OK;
@@ -169,30 +190,35 @@ struct XGeom {
     int kx, n_splits;
 };
 
+// Workgroup splits of a chunk's (or stream pair's) frames for a specialised kernel: workgroups = groups x splits, every slot of a
+// workgroup with a run of its own.  A run re-reads ntaps - 1 frames of history and should be 16 frames at least; with the X stage
+// in the kernel a run is a float32 sum of at most kRowSpectra spectra; among the splits that allow, the one that fills the device's
+// resident workgroups in whole rounds best
+int64_t spec_wg_splits(const fxc_plan* p, const SpecKernel* k, int64_t n_groups, bool sums) {
+    const SpecShape& sh = k->shape;
+    const int64_t cap = (int64_t)p->cu_count * k->wgs_per_cu;
+    const int64_t ws_lo = sums ? std::max<int64_t>(1, (p->n_pts + sh.slots * kRowSpectra - 1) / (sh.slots * kRowSpectra)) : 1;
+    const int64_t ws_hi = std::max<int64_t>(ws_lo, std::min<int64_t>(64, p->n_pts / (16 * (int64_t)sh.slots)));
+    int64_t best = ws_lo;
+    double best_cost = 1e300;
+    for (int64_t ws = ws_lo; ws <= ws_hi; ++ws) {
+        const int64_t wgs = std::max<int64_t>(n_groups, 1) * ws;
+        const double rounds = (double)((wgs + cap - 1) / cap) * (double)cap / (double)wgs;      // >= 1: idle share of the last round
+        const double run = std::max(1.0, (double)p->n_pts / (double)(ws * sh.slots));
+        const double cost = rounds * (1.0 + (double)(p->ntaps - 1) / run);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = ws;
+        }
+    }
+    return best;
+}
+
 XGeom x_geometry(const fxc_plan* p, int64_t n_chunks) {
     XGeom g;
     if (p->mixed_xf && p->spec) {
-        // workgroups = chunks x splits, every slot of a workgroup with a run of its own (a raw row each).  A run re-reads
-        // ntaps - 1 frames of history and should be 16 frames at least; float32 sums of at most kRowSpectra spectra; among the
-        // splits that allow, the one that fills the device's resident workgroups in whole rounds best
-        const SpecShape& sh = p->spec->shape;
-        const int64_t cap = (int64_t)p->cu_count * p->spec->wgs_per_cu;
-        const int64_t ws_lo = std::max<int64_t>(1, (p->n_pts + sh.slots * kRowSpectra - 1) / (sh.slots * kRowSpectra));
-        const int64_t ws_hi = std::max<int64_t>(ws_lo, std::min<int64_t>(64, p->n_pts / (16 * (int64_t)sh.slots)));
-        int64_t best = ws_lo;
-        double best_cost = 1e300;
-        for (int64_t ws = ws_lo; ws <= ws_hi; ++ws) {
-            const int64_t wgs = n_chunks * ws;
-            const double rounds = (double)((wgs + cap - 1) / cap) * (double)cap / (double)wgs;      // >= 1: idle share of the last round
-            const double run = std::max(1.0, (double)p->n_pts / (double)(ws * sh.slots));
-            const double cost = rounds * (1.0 + (double)(p->ntaps - 1) / run);
-            if (cost < best_cost - 1e-9) {
-                best_cost = cost;
-                best = ws;
-            }
-        }
         g.kx = 1;
-        g.n_splits = (int)(best * sh.slots);
+        g.n_splits = (int)(spec_wg_splits(p, p->spec, n_chunks, true) * p->spec->shape.slots);
         return g;
     }
     if (p->mixed_xf) {

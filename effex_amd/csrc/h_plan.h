@@ -76,6 +76,8 @@ struct fxc_plan {
     const SpecKernel* spec = nullptr;
     const SpecKernel* spec_u8 = nullptr;
     bool spec_u8_tried = false;
+    const SpecKernel* spec_f = nullptr;      // the F stage alone (fxc_channelize, 3 + antennas), built on first use
+    bool spec_f_tried = false;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev_order = nullptr;   // orders the old stream's work before the new one's (fxc_set_stream)

@@ -177,6 +177,7 @@ struct SpecArgs {
     const cf* dc_u8;
     long long num_samp, n_pts, n_chunks;
     int wg_splits;
+    int ant;
 };
 
 std::mutex g_spec_mutex;
@@ -199,8 +200,11 @@ long long code_object_int(const std::vector<char>& image, const char* key) {
     return -1;
 }
 
+// the builds of fx_spec.h: F+X from complex64 samples, F+X from the receivers' bytes, the F stage alone
+enum SpecVariant { kSpecC64 = 0, kSpecU8 = 1, kSpecFOnly = 2 };
+
 // fx_spec.h for one shape -> a code object for `arch` (e.g. "gfx950:sramecc+:xnack-"); needs no device
-bool spec_compile(const SpecShape& shape, bool u8, const char* arch, std::vector<char>& image, std::string& error) {
+bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::vector<char>& image, std::string& error) {
     RtcApi* api = rtc_api();
     if (!api->handle) {
         error = api->error;
@@ -212,7 +216,8 @@ bool spec_compile(const SpecShape& shape, bool u8, const char* arch, std::vector
                                      "-DFXM_N=" + std::to_string(shape.n), "-DFXM_T=" + std::to_string(shape.taps),
                                      "-DFXM_TPR=" + std::to_string(shape.tpr), "-DFXM_SLOTS=" + std::to_string(shape.slots),
                                      "-DFXM_NST=" + std::to_string(shape.n_stages), "-DFXM_RADICES=" + radices,
-                                     "-DFXM_U8=" + std::to_string((int)u8), "-DFXM_U=" + std::to_string(shape.u),
+                                     "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)), "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly)),
+                                     "-DFXM_U=" + std::to_string(shape.u),
                                      "-DFXM_ABL=" + std::to_string(env_int("FXC_RTC_ABL", 0))};      // (timing ablations: wrong results, developer runs only)
     std::vector<const char*> optv;
     for (const std::string& o : opts) optv.push_back(o.c_str());
@@ -262,10 +267,10 @@ struct SpecBuild {
     int resident = 0;
     std::string error;
 };
-SpecBuild spec_build(const SpecShape& shape, bool u8, const char* arch) {
+SpecBuild spec_build(const SpecShape& shape, int variant, const char* arch) {
     SpecBuild b;
     b.shape = shape;
-    if (!spec_compile(shape, u8, arch, b.image, b.error)) {
+    if (!spec_compile(shape, variant, arch, b.image, b.error)) {
         b.image.clear();
         return b;
     }
@@ -279,7 +284,7 @@ SpecBuild spec_build(const SpecShape& shape, bool u8, const char* arch) {
 // step when that costs no resident workgroup (4 - 10 % where it fits: 1000 channels 206 -> 256 registers, 1.87 -> 1.73 ms; 96
 // channels with 3 first 150 -> 192 registers, three workgroups -> two, 1.25 -> 1.33 ms: one frame there).  Developer knobs:
 // FXC_RTC_R0 / FXC_RTC_U force the first radix / the frames per step.
-SpecBuild spec_search(int n, int taps, bool u8, const char* arch) {
+SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
     SpecBuild best;
     best.error = "no specialised kernel for this channel count";
     std::vector<int> firsts = spec_first_radices(n, taps);
@@ -292,10 +297,11 @@ SpecBuild spec_search(int n, int taps, bool u8, const char* arch) {
         if (!one.ok) continue;
         ++tried;
         const SpecShape two = spec_shape(n, taps, r, 2);
-        SpecBuild b = (force_u == 2 && two.ok) ? SpecBuild() : spec_build(one, u8, arch);
+        SpecBuild b = (force_u == 2 && two.ok) ? SpecBuild() : spec_build(one, variant, arch);
         if (two.ok && force_u != 1) {
-            SpecBuild b2 = spec_build(two, u8, arch);
+            SpecBuild b2 = spec_build(two, variant, arch);
             if (b2.resident >= 1 && (b2.resident >= b.resident || force_u == 2)) b = std::move(b2);
+            else if (b.image.empty()) b = spec_build(one, variant, arch);      // (two frames were asked for and do not fit)
         }
         if (b.image.empty() || b.resident < 1) {
             if (best.image.empty() && !b.error.empty()) best.error = b.error;
@@ -309,9 +315,9 @@ SpecBuild spec_search(int n, int taps, bool u8, const char* arch) {
 }
 
 // compile (or find) the kernel for n channels on `device`; never nullptr -- a failed build is cached with its reason
-const SpecKernel* spec_kernel(int device, int n, int taps, bool u8) {
+const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
     char key[256];
-    std::snprintf(key, sizeof key, "d%d n%d t%d u%d a%d r%d f%d", device, n, taps, (int)u8, env_int("FXC_RTC_ABL", 0), env_int("FXC_RTC_R0", 0),
+    std::snprintf(key, sizeof key, "d%d n%d t%d v%d a%d r%d f%d", device, n, taps, variant, env_int("FXC_RTC_ABL", 0), env_int("FXC_RTC_R0", 0),
                   env_int("FXC_RTC_U", 0));
     std::lock_guard<std::mutex> lock(g_spec_mutex);
     auto it = g_spec_cache.find(key);
@@ -323,7 +329,7 @@ const SpecKernel* spec_kernel(int device, int n, int taps, bool u8) {
         k->error = "hipGetDeviceProperties failed";
         return k;
     }
-    SpecBuild b = spec_search(n, taps, u8, prop.gcnArchName);
+    SpecBuild b = spec_search(n, taps, variant, prop.gcnArchName);
     if (b.image.empty()) {
         k->error = b.error;
         return k;

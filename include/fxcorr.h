@@ -100,13 +100,14 @@ int fxc_plan_destroy(fxc_plan* plan); /* FXC_ERR_STATE while an fxc_pipe still u
  * wait.  Not for plans that own their stream. */
 int fxc_set_stream(fxc_plan* plan, void* stream);
 int fxc_plan_get_info(const fxc_plan* plan, fxc_info* info);
-/* Diagnostic: build the specialised F+X kernel (fxc_info.specialised) for `nchan` channels and `ntaps` taps -- complex64
- * samples, or the receivers' bytes with u8 != 0 -- for the device architecture `arch` ("gfx950"; NULL: the current
+/* Diagnostic: build the specialised kernel (fxc_info.specialised) for `nchan` channels and `ntaps` taps -- variant 0: F+X from
+ * complex64 samples, 1: F+X from the receivers' bytes, 2: the F stage alone (fxc_channelize; the F pass of 3 and more
+ * antennas) -- for the device architecture `arch` ("gfx950"; NULL: the current
  * device's), without a device and without a plan: the library's embedded kernel source through hiprtc.  FXC_OK and a one-line
  * description in `report` (may be NULL); FXC_ERR_UNSUPPORTED when the shape has no such kernel (plans of that shape run the
  * any-shape kernel); FXC_ERR_HIP with the compiler's log in fxc_last_error(NULL) when the build fails.
  * (The reference takes any integer --resolution, effex.py:733-739; this is where the build meets that freedom.) */
-int fxc_spec_probe(int nchan, int ntaps, int u8, const char* arch, char* report, int report_bytes);
+int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* report, int report_bytes);
 const char* fxc_last_error(const fxc_plan* plan);
 
 /* rot[k] = exp(+2*pi*i*f_k*tau), natural bin order — effex.py:516,519.  Formed by the caller in

@@ -31,11 +31,15 @@ int emul_spec_threads() { return fxm::THREADS; }
 int emul_spec_slots() { return fxm::SLOTS; }
 
 // raw[split][chunk][N] for n_chunks chunks, split = workgroup split * SLOTS + slot
+int emul_spec_fonly() { return fxm::FONLY ? 1 : 0; }
+
+// F only (FXM_FONLY): n_chunks = the number of streams, `out` = spec[stream / ant][frame][stream % ant][N]
 int emul_spec_run(const void* x, const float* h, void* out, const void* tw, const void* dc_u8, long long num_samp, long long n_pts,
-                  long long n_chunks, int wg_splits) {
+                  long long n_chunks, int wg_splits, int ant) {
     const fxm::Args args = {x, h, static_cast<fxm::cf*>(out), static_cast<const fxm::cf*>(tw), static_cast<const fxm::cf*>(dc_u8),
-                            num_samp, n_pts, n_chunks, wg_splits};
-    for (long long bid = 0; bid < n_chunks * wg_splits; ++bid) {
+                            num_samp, n_pts, n_chunks, wg_splits, ant};
+    const long long groups = fxm::FONLY ? (n_chunks + 1) / 2 : n_chunks;      // workgroups per split: chunk pairs, or pairs of streams
+    for (long long bid = 0; bid < groups * wg_splits; ++bid) {
         std::vector<fxm::cf> lds((size_t)fxm::SLOTS * fxm::LDS_PER_SLOT + 1);
         std::memset(lds.data(), 0xFF, lds.size() * sizeof(fxm::cf));          // NaNs: nothing may be read before it is written
         pthread_barrier_t bar;

@@ -244,21 +244,21 @@ print("sanitized emulation ok")
     assert "AddressSanitizer" not in proc.stderr and "runtime error" not in proc.stderr, proc.stderr[-3000:]
 
 
-def _spec_shape(nchan, ntaps, u8=False):
+def _spec_shape(nchan, ntaps, u8=False, fonly=False):
     """The library's own cut of fx_spec.h for this shape (fxc_spec_probe compiles it through hiprtc -- no GPU needed -- and
     reports threads per slot, slots and stage order), as the -D options the host emulation is built with."""
     import re
     from effex_amd import _lib
     lib = _lib.load()
     buf = ctypes.create_string_buffer(512)
-    rc = lib.fxc_spec_probe(nchan, ntaps, int(u8), b"gfx950", buf, len(buf))
+    rc = lib.fxc_spec_probe(nchan, ntaps, 2 if fonly else int(u8), b"gfx950", buf, len(buf))
     if rc != 0:
         return rc, None
     rep = dict(kv.split("=") for kv in buf.value.decode().split())
     stages = rep["stages"]
     flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=%d" % ntaps, "-DFXM_TPR=%s" % rep["tpr"], "-DFXM_SLOTS=%s" % rep["slots"],
              "-DFXM_NST=%d" % len(stages.split(",")), "-DFXM_RADICES=%s" % stages, "-DFXM_U8=%d" % int(u8),
-             "-DFXM_U=%s" % rep["frames_per_step"]]
+             "-DFXM_U=%s" % rep["frames_per_step"], "-DFXM_FONLY=%d" % int(fonly)]
     assert re.fullmatch(r"[0-9,]+", stages) and int(rep["code_bytes"]) > 1000
     return 0, (flags, int(rep["tpr"]), int(rep["slots"]))
 
@@ -313,9 +313,9 @@ def test_specialised_kernel_matches_oracle(tmp_path, monkeypatch, nchan, ntaps, 
     h32 = np.ascontiguousarray(window, dtype=np.float32)
     E = wg_splits * slots
     out = np.full((E, n_chunks, nchan), np.nan + 0j, dtype=np.complex64)
-    lib.emul_spec_run.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_longlong] * 3 + [ctypes.c_int]
+    lib.emul_spec_run.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_longlong] * 3 + [ctypes.c_int] * 2
     assert lib.emul_spec_run(x_in.ctypes.data, h32.ctypes.data, out.ctypes.data, tw.ctypes.data,
-                             dc_in.ctypes.data if u8 else None, num_samp, n_pts, n_chunks, wg_splits) == 0
+                             dc_in.ctypes.data if u8 else None, num_samp, n_pts, n_chunks, wg_splits, 1) == 0
     assert np.isfinite(out).all()
     got = out.astype(np.complex128).sum(axis=0)
     for c in range(n_chunks):
@@ -330,3 +330,36 @@ def test_specialised_kernel_matches_oracle(tmp_path, monkeypatch, nchan, ntaps, 
     s1 = fx_oracle.spectrometer_poly(x[0, 1], ntaps, nchan, window)[lo:hi]
     ref = (s0 * np.conj(s1)).sum(axis=0)
     assert np.abs(out[e, 0] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.mark.parametrize("nchan,ntaps,n_pts,wg_splits,n_streams,ant", [
+    (1000, 4, 9, 2, 3, 1), (96, 4, 21, 1, 6, 3), (250, 2, 7, 1, 1, 1), (7, 1, 5, 1, 4, 2), (720, 3, 6, 1, 5, 5), (12, 4, 70, 2, 2, 1)])
+def test_specialised_f_stage_matches_oracle(tmp_path, nchan, ntaps, n_pts, wg_splits, n_streams, ant):
+    """fx_spec.h built as the F stage alone (FXM_FONLY: what fxc_channelize and the F pass of 3 and more antennas run off the
+    powers of two): a workgroup carries a pair of streams, the last butterfly's outputs are the spectra -- against the oracle's
+    _spectrometer_poly (effex.py:530-555), natural bin order, for an odd number of streams (the last pair has one) and for the
+    antenna-interleaved layout the X-engines read ([chunk][frame][antenna][nchan])."""
+    rc, shape = _spec_shape(nchan, ntaps, fonly=True)
+    assert rc == 0
+    flags, tpr, slots = shape
+    lib_path = str(tmp_path / "libemul_spec_f.so")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-pthread"] + flags +
+                   ["-o", lib_path, os.path.join(HERE, "emul", "emul_spec.cpp")], check=True)
+    lib = ctypes.CDLL(lib_path)
+    assert lib.emul_spec_fonly() == 1
+    num_samp = nchan * n_pts + min(2, nchan - 1)
+    rng = np.random.default_rng(nchan + n_streams)
+    window = rng.standard_normal(ntaps * nchan) if nchan < 16 else design_window(ntaps, nchan)
+    x = synth.synth_iq(31 + nchan, n_streams, 1, num_samp)[:, 0]
+    tw = np.exp(2j * np.pi * np.arange(nchan) / nchan).astype(np.complex64)
+    h32 = np.ascontiguousarray(window, dtype=np.float32)
+    assert n_streams % ant == 0
+    out = np.full((n_streams // ant, n_pts, ant, nchan), np.nan + 0j, dtype=np.complex64)
+    lib.emul_spec_run.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_longlong] * 3 + [ctypes.c_int] * 2
+    assert lib.emul_spec_run(x.ctypes.data, h32.ctypes.data, out.ctypes.data, tw.ctypes.data, None, num_samp, n_pts, n_streams,
+                             wg_splits, ant) == 0
+    assert np.isfinite(out).all()
+    for s_ in range(n_streams):
+        ref = fx_oracle.spectrometer_poly(x[s_], ntaps, nchan, window)
+        got = out[s_ // ant, :, s_ % ant, :]
+        assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max(), (nchan, s_)

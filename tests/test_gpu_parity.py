@@ -783,14 +783,50 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
             assert rel_err(rows_any[0, 0], fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, -2e-7,
                                                                "SPECTRUM")) < TOL_VIS
         monkeypatch.delenv("FXC_RTC")
-    assert bool(specialised) == ((n_ant, nchan, ntaps) in {(2, 1000, 4), (2, 96, 4), (2, 100, 3), (2, 6, 4), (2, 12, 1),
-                                                            (2, 3, 4), (2, 1001, 4), (2, 250, 4)})
+    # a plan is specialised exactly when the library can build the kernel for its shape (fxc_spec_probe: the same search,
+    # no plan) -- two antennas only; shapes without one (a large prime factor, more than four taps, rows too long for the
+    # registers of a workgroup) keep the any-shape kernel
+    from effex_amd import _lib
+    can = n_ant == 2 and _lib.load().fxc_spec_probe(nchan, ntaps, 0, None, None, 0) == 0
+    assert bool(specialised) == can, (specialised, can)
+    if (n_ant, nchan, ntaps) in {(2, 1000, 4), (2, 96, 4), (2, 100, 3), (2, 6, 4), (2, 12, 1), (2, 3, 4), (2, 250, 4)}:
+        assert specialised
+    if (n_ant, nchan, ntaps) in {(2, 997, 4), (2, 1536, 8), (3, 48, 5), (2, 6561, 4), (2, 12000, 4), (2, 7, 32)}:
+        assert not specialised
     # the direct DFT: a kernel of the developer build only (libfxcorr_dev.so), chosen by a knob read when the plan is built
     monkeypatch.setenv("FXC_GENERIC_FFT", "radix2")
     with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window, dev=True) as d:
         d.set_rot(rot)
         # (the direct DFT's own float32 sums of nchan terms are the larger share of the difference at the top sizes)
         assert rel_err(rows, d.fx_rows(xd, "SPECTRUM").cpu().numpy()) < (4e-6 if nchan <= 8192 else 1e-5)
+
+
+@pytest.mark.parametrize("n_ant,nchan,ntaps,n_streams,frames,extra", [
+    (1, 1000, 4, 5, 60, 3), (1, 96, 4, 333, 40, 0), (1, 720, 3, 2, 17, 1), (1, 250, 1, 1, 1, 0), (1, 2000, 4, 3, 9, 0),
+    (3, 1000, 4, 4, 30, 5), (5, 96, 2, 3, 100, 0)])
+def test_specialised_f_stage_on_the_device(plan_mod, torch, monkeypatch, n_ant, nchan, ntaps, n_streams, frames, extra):
+    """fxc_channelize (the drop-in's _spectrometer_poly, effex.py:530-555) at channel counts that are not a power of two runs
+    fx_spec.h built as the F stage alone -- a pair of streams per workgroup, odd stream counts included; 3 and more antennas
+    take it for their F pass (spectra antenna-interleaved for the X-engines).  Against the oracle, and the any-shape kernel
+    (FXC_RTC=0) must agree."""
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(99 + nchan, n_streams, n_ant, num_samp, delays=np.arange(n_ant) % 5)
+    window = design_window(ntaps, nchan)
+    xd = torch.from_numpy(x).cuda()
+    flat = xd.reshape(-1, num_samp)
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as p:
+        spec = p.channelize(flat).cpu().numpy()
+        for s_ in sorted({0, flat.shape[0] // 2, flat.shape[0] - 1}):
+            ref = fx_oracle.spectrometer_poly(x.reshape(-1, num_samp)[s_], ntaps, nchan, window)
+            assert rel_err(spec[s_], ref) < TOL_SPEC_ANY, s_
+        rows = p.fx_rows(xd).cpu().numpy() if n_ant > 1 else None
+        if n_ant > 1:
+            assert rel_err(rows[0], fx_oracle.fx_integrate(x[:1], nchan, window)) < TOL_VIS
+    monkeypatch.setenv("FXC_RTC", "0")
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as a:
+        assert rel_err(a.channelize(flat).cpu().numpy(), spec) < 2e-6
+        if n_ant > 1:
+            assert rel_err(a.fx_rows(xd).cpu().numpy(), rows) < 2e-6
 
 
 @pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [

@@ -77,6 +77,7 @@ def main():
                 cf_, cg_ = f.fx_rows(x, "CONTINUUM", 2.4e6).cpu().numpy(), g.fx_rows(x, "CONTINUUM", 2.4e6).cpu().numpy()
                 e_cont = rel_err(cf_, cg_)
                 path = f.path
+                spec = int(f.info["specialised"])
         except Exception as exc:
             print(json.dumps({"FAILED": str(exc), **tag}), flush=True)
             raise
@@ -117,7 +118,7 @@ def main():
             tol = 1.5e-5
         key = (path, nchan if nchan in (1, 4096, 8192) else (256 if nchan <= 256 else 0), ntaps > 4)
         if any_n:
-            key = ("mixed-radix", int(n_ant == 2), ntaps > 4)
+            key = ("specialised per channel count" if spec else "mixed-radix", int(n_ant == 2), ntaps > 4)
         worst[key] = max(worst.get(key, 0.0), e_rows, e_int)
         if not (e_rows < tol and e_int < tol and e_cont < 5e-5):
             print(json.dumps({"MISMATCH": [e_rows, e_int, e_cont], "path": path, **tag}), flush=True)
