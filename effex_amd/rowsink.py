@@ -27,6 +27,7 @@ Rows can be written one at a time, a batch at a time, or by filling a memory-map
 produced for the same rows, so ``post_process.py``-style readers keep working.
 """
 import os
+import time
 import struct
 
 import numpy as np
@@ -103,6 +104,7 @@ class BinSink(object):
         self._fh.write(b'\0' * (self.data_offset - unaligned))
         self._fh.flush()
         self.rows = 0                 # rows committed
+        self._published_at = 0.0
         self._map = None
         self._map_rows = 0            # rows the file is currently sized for beyond `rows`
         self.row_bytes = self.row_len * self.row_dtype.itemsize
@@ -116,12 +118,17 @@ class BinSink(object):
         self._fh.seek(self.data_offset + self.rows * self.row_bytes)
         self._fh.write(rows.view(np.uint8).data)
         self.rows += len(rows)
-        self._publish()
+        # the per-row writer path (one visibility per call, effex.py:689-693) publishes the count at most every 0.1 s -- the
+        # reference's own writer wakes that often -- instead of two system calls per row; batches and close() always publish
+        now = time.monotonic()
+        if len(rows) > 1 or now - self._published_at >= 0.1:
+            self._publish()
 
     def _publish(self):
         """The committed-row count goes into the preamble behind the rows it counts (same file object: ordered)."""
         self._fh.flush()
         os.pwrite(self._fh.fileno(), struct.pack("<Q", self.rows), self._count_at)
+        self._published_at = time.monotonic()
 
     def reserve(self, n_rows):
         """A writable [n_rows, row_len] view of the file just behind the committed rows (the file grows to hold it);

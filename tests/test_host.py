@@ -523,8 +523,8 @@ def test_binary_sidecar_shows_committed_rows_only(tmp_path):
     view[3:5] = 2                                            # (a writer killed here leaves six rows' worth of file)
     assert len(rowsink.RowFile(path).rows) == 3
     sink.commit(2)
-    sink.write(np.full(4, 5, np.complex64))
-    assert len(rowsink.RowFile(path).rows) == 6
+    sink.write(np.full(4, 5, np.complex64))                  # single rows publish the count at most every 0.1 s (and on close)
+    assert len(rowsink.RowFile(path).rows) in (5, 6)
     sink.close()
     rows = np.asarray(rowsink.RowFile(path).rows)
     assert rows.shape == (6, 4) and (rows[:3] == 1).all() and (rows[3:5] == 2).all() and (rows[5] == 5).all()
