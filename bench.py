@@ -26,6 +26,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("FXC_RTC_CACHE", os.path.join(ROOT, "build", "rtc_cache"))      # run-time compiled kernels (other_configs), kept in the tree
 
 NUM_SAMP = 262144
 NCHAN = 4096

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 // RCCL: types and prototypes only -- the library itself is bound at run time (rccl_api), so a ROCm install without the
 // rccl headers still builds libfxcorr (single-GPU users need no RCCL at all)
 #if __has_include(<rccl/rccl.h>)

@@ -38,6 +38,7 @@ struct RtcApi {
     int (*code)(rtc_program, char*) = nullptr;
     int (*destroy)(rtc_program*) = nullptr;
     const char* (*error_string)(int) = nullptr;
+    int (*version)(int*, int*) = nullptr;      // optional
     std::string error;
 };
 
@@ -70,6 +71,7 @@ RtcApi* rtc_api() {
         a->code = reinterpret_cast<decltype(a->code)>(bind("hiprtcGetCode"));
         a->destroy = reinterpret_cast<decltype(a->destroy)>(bind("hiprtcDestroyProgram"));
         a->error_string = reinterpret_cast<decltype(a->error_string)>(bind("hiprtcGetErrorString"));
+        if (ok) a->version = reinterpret_cast<decltype(a->version)>(dlsym(a->handle, "hiprtcVersion"));
         if (!ok) a->handle = nullptr;
         return a;
     }();
@@ -203,6 +205,72 @@ long long code_object_int(const std::vector<char>& image, const char* key) {
 // the builds of fx_spec.h: F+X from complex64 samples, F+X from the receivers' bytes, the F stage alone
 enum SpecVariant { kSpecC64 = 0, kSpecU8 = 1, kSpecFOnly = 2 };
 
+// Code objects on disk: a build is keyed by everything that goes into it -- the three sources as embedded, the options, the
+// architecture, the compiler's version -- and kept under $FXC_RTC_CACHE (default $XDG_CACHE_HOME/fxcorr or ~/.cache/fxcorr; "0"
+// turns it off), so that only the first process on a machine pays the second or so a shape costs.  Written to a temporary name
+// and renamed: concurrent ranks may race for the same key and all end up with a whole file.
+std::string spec_cache_dir() {
+    const char* e = std::getenv("FXC_RTC_CACHE");
+    if (e) return (e[0] == 0 || std::strcmp(e, "0") == 0) ? std::string() : std::string(e);
+    const char* x = std::getenv("XDG_CACHE_HOME");
+    if (x && x[0]) return std::string(x) + "/fxcorr";
+    const char* h = std::getenv("HOME");
+    return (h && h[0]) ? std::string(h) + "/.cache/fxcorr" : std::string();
+}
+
+std::string spec_cache_key(const std::vector<std::string>& opts, RtcApi* api) {
+    unsigned long long a = 1469598103934665603ull, b = 0x9E3779B97F4A7C15ull;      // two FNV-1a style sums over the same bytes
+    auto eat = [&](const char* p, size_t n) {
+        for (size_t i = 0; i < n; ++i) {
+            a = (a ^ (unsigned char)p[i]) * 1099511628211ull;
+            b = (b + (unsigned char)p[i] + 1) * 0xD6E8FEB86659FD93ull;
+            b ^= b >> 29;
+        }
+    };
+    for (const char* src : {fxc_src_fx_spec_h, fxc_src_fx_mixed_h, fxc_src_fx_math_h}) eat(src, std::strlen(src) + 1);
+    for (const std::string& o : opts) eat(o.c_str(), o.size() + 1);
+    int major = 0, minor = 0;
+    if (api->version) (void)api->version(&major, &minor);
+    const std::string v = "hiprtc " + std::to_string(major) + "." + std::to_string(minor);
+    eat(v.c_str(), v.size());
+    Dl_info where;                           // (two hiprtc builds of one version number: PyTorch's and ROCm's differ in path)
+    if (api->compile && dladdr(reinterpret_cast<void*>(api->compile), &where) && where.dli_fname) eat(where.dli_fname, std::strlen(where.dli_fname));
+    char hex[40];
+    std::snprintf(hex, sizeof hex, "%016llx%016llx", a, b);
+    return hex;
+}
+
+bool spec_cache_load(const std::string& path, std::vector<char>& image) {
+    FILE* fh = std::fopen(path.c_str(), "rb");
+    if (!fh) return false;
+    std::fseek(fh, 0, SEEK_END);
+    const long n = std::ftell(fh);
+    std::fseek(fh, 0, SEEK_SET);
+    bool ok = n > 64;
+    if (ok) {
+        image.resize((size_t)n);
+        ok = std::fread(image.data(), 1, (size_t)n, fh) == (size_t)n && std::memcmp(image.data(), "\177ELF", 4) == 0;
+    }
+    std::fclose(fh);
+    if (!ok) image.clear();
+    return ok;
+}
+
+void spec_cache_store(const std::string& dir, const std::string& path, const std::vector<char>& image) {
+    std::string made;
+    for (size_t i = 1; i <= dir.size(); ++i)        // mkdir -p
+        if (i == dir.size() || dir[i] == '/') {
+            made = dir.substr(0, i);
+            (void)mkdir(made.c_str(), 0755);
+        }
+    const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+    FILE* fh = std::fopen(tmp.c_str(), "wb");
+    if (!fh) return;
+    const bool ok = std::fwrite(image.data(), 1, image.size(), fh) == image.size();
+    std::fclose(fh);
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+
 // fx_spec.h for one shape -> a code object for `arch` (e.g. "gfx950:sramecc+:xnack-"); needs no device
 bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::vector<char>& image, std::string& error) {
     RtcApi* api = rtc_api();
@@ -219,6 +287,9 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)), "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly)),
                                      "-DFXM_U=" + std::to_string(shape.u),
                                      "-DFXM_ABL=" + std::to_string(env_int("FXC_RTC_ABL", 0))};      // (timing ablations: wrong results, developer runs only)
+    const std::string dir = spec_cache_dir();
+    const std::string cached = dir.empty() ? std::string() : dir + "/" + spec_cache_key(opts, api) + ".co";
+    if (!cached.empty() && spec_cache_load(cached, image)) return true;
     std::vector<const char*> optv;
     for (const std::string& o : opts) optv.push_back(o.c_str());
     const char* headers[] = {fxc_src_fx_spec_h, fxc_src_fx_mixed_h, fxc_src_fx_math_h};
@@ -246,6 +317,7 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
     image.resize(bytes);
     api->code(prog, image.data());
     api->destroy(&prog);
+    if (!cached.empty()) spec_cache_store(dir, cached, image);
     return true;
 }
 

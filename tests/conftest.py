@@ -9,6 +9,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# kernels compiled at run time (fx_spec.h through hiprtc) are kept on disk between processes: inside the repository for the tests
+os.environ.setdefault("FXC_RTC_CACHE", os.path.join(ROOT, "build", "rtc_cache"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

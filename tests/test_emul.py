@@ -363,3 +363,31 @@ def test_specialised_f_stage_matches_oracle(tmp_path, nchan, ntaps, n_pts, wg_sp
         ref = fx_oracle.spectrometer_poly(x[s_], ntaps, nchan, window)
         got = out[s_ // ant, :, s_ % ant, :]
         assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max(), (nchan, s_)
+
+
+def test_specialised_kernels_are_cached_on_disk(tmp_path, monkeypatch):
+    """A build of fx_spec.h is kept as a code object under FXC_RTC_CACHE, keyed by sources, options, architecture and compiler: the
+    second process (here: the second search, with the in-process cache out of the picture -- fxc_spec_probe has none) loads it
+    instead of compiling; a damaged file is ignored and replaced; FXC_RTC_CACHE=0 writes nothing."""
+    import time
+    from effex_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(512)
+    cache = tmp_path / "rtc"
+    monkeypatch.setenv("FXC_RTC_CACHE", str(cache))
+    t0 = time.time()
+    assert lib.fxc_spec_probe(360, 4, 0, b"gfx950", buf, len(buf)) == 0
+    cold, first = time.time() - t0, buf.value
+    files = sorted(cache.glob("*.co"))
+    assert files and all(f.read_bytes()[:4] == b"\x7fELF" for f in files)
+    t0 = time.time()
+    assert lib.fxc_spec_probe(360, 4, 0, b"gfx950", buf, len(buf)) == 0 and buf.value == first
+    warm = time.time() - t0
+    assert warm < 0.5 * cold, (cold, warm)
+    files[0].write_bytes(b"not a code object")
+    assert lib.fxc_spec_probe(360, 4, 0, b"gfx950", buf, len(buf)) == 0 and buf.value == first
+    assert files[0].read_bytes()[:4] == b"\x7fELF"
+    off = tmp_path / "off"
+    monkeypatch.setenv("FXC_RTC_CACHE", "0")
+    assert lib.fxc_spec_probe(360, 4, 2, b"gfx950", buf, len(buf)) == 0
+    assert not off.exists() and len(sorted(cache.glob("*.co"))) == len(files)
