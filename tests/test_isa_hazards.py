@@ -104,3 +104,37 @@ def test_no_flat_memory_instructions(asm_listing):
     23 flat loads per frame in the 8192-channel kernel, 35 in the first matrix-core X-engine)."""
     flat = [ln.strip() for ln in asm_listing.split("\n") if re.match(r"\s+flat_(load|store|atomic)", ln)]
     assert not flat, flat[:8]
+
+
+@needs_hipcc
+@pytest.mark.parametrize("nchan,variant", [(1000, 0), (96, 0), (720, 0), (1000, 1), (1000, 2), (1536, 0)])
+def test_specialised_kernels_keep_their_registers(tmp_path, nchan, variant):
+    """fx_spec.h as the library builds it for one channel count (the options fxc_spec_probe reports; variant 0 / 1 / 2 = complex64,
+    bytes, F only), compiled here with hipcc and -- by the probe itself -- with the hiprtc the process has: no scratch under
+    either compiler (the ring, the taps and the twiddles are registers or nothing), at most 256 registers where the build means to
+    keep two workgroups of 256 threads on a CU, no flat or scratch memory instruction, the samples through buffer loads, and one
+    barrier per LDS round trip (S - 1 per step)."""
+    import ctypes
+    from effex_amd import _lib
+    buf = ctypes.create_string_buffer(512)
+    assert _lib.load().fxc_spec_probe(nchan, 4, variant, b"gfx950", buf, len(buf)) == 0
+    rep = dict(kv.split("=") for kv in buf.value.decode().split())
+    assert int(rep["scratch"]) == 0 and 0 < int(rep["vgprs"]) <= 512 // max(1, (int(rep["tpr"]) * int(rep["slots"]) // 64 + 3) // 4 * int(rep["resident"]))
+    stages = rep["stages"].split(",")
+    flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=4", "-DFXM_TPR=" + rep["tpr"], "-DFXM_SLOTS=" + rep["slots"], "-DFXM_NST=%d" % len(stages),
+             "-DFXM_RADICES=" + rep["stages"], "-DFXM_U8=%d" % int(variant == 1), "-DFXM_FONLY=%d" % int(variant == 2), "-DFXM_U=" + rep["frames_per_step"]]
+    src = tmp_path / "spec.hip"
+    src.write_text('#include "fx_spec.h"\n')
+    asm = tmp_path / "spec.s"
+    subprocess.run([fx_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I", CSRC] + flags +
+                   ["-S", "--cuda-device-only", "-o", str(asm), str(src)], check=True, stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    assert re.search(r"\.private_segment_fixed_size:\s*0\b", text) and re.search(r"\.vgpr_spill_count:\s*0\b", text)
+    body = [ln.split(";")[0].strip() for ln in text.split("\n")]
+    ops = [ln.split()[0] for ln in body if ln and not ln.startswith((".", ";")) and not ln.endswith(":")]
+    assert not [o for o in ops if o.startswith(("flat_", "scratch_"))]
+    assert any(o.startswith("buffer_load_") for o in ops)
+    if int(rep["tpr"]) > 64 and len(stages) >= 2:
+        unrolled = (4 + int(rep["frames_per_step"]) - 1)
+        unrolled //= __import__("math").gcd(unrolled, int(rep["frames_per_step"]))
+        assert ops.count("s_barrier") == unrolled * (len(stages) - 1), (ops.count("s_barrier"), unrolled, stages)
