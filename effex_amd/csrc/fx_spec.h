@@ -36,12 +36,6 @@
 #error "fx_spec.h is compiled per shape: -DFXM_N= -DFXM_T= -DFXM_TPR= -DFXM_SLOTS= -DFXM_NST= -DFXM_RADICES= -DFXM_U8="
 #endif
 
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FXM_SEQ) && FXM_SEQ
-#define FXM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#else
-#define FXM_SCHED_BARRIER() ((void)0)
-#endif
-
 // FXM_ABL: developer-only timing ablations (WRONG RESULTS by design; plans are built with 0 unless FXC_RTC_ABL says otherwise):
 //   1 no barriers   2 stage outputs not stored to LDS   4 butterflies skipped (inputs passed through)   8 samples not loaded
 //   16 every load reads the chunk's first frames (cache hits: the memory system out of the picture, same instruction stream)
@@ -391,7 +385,6 @@ struct Body {
 #pragma unroll
                     for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1], t[r]);
                     dft_to<R>(v, rt, dst + a * ROW + th.ob[ob_base(s) + j], ns);
-                    FXM_SCHED_BARRIER();
                 }
             }
         }
@@ -418,8 +411,7 @@ struct Body {
 #pragma unroll
                         for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1], t[r]);
                         dft_regs<R>(v, rt, o[a]);
-                        FXM_SCHED_BARRIER();
-                    }
+                        }
                     emit<R>(o, j, f + u);
                 }
         }
