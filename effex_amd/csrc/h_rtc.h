@@ -26,6 +26,9 @@ extern const char fxc_src_fx_math_h[];
 
 namespace {
 
+// timing ablations of fx_spec.h (FXM_ABL: wrong results by design) exist in the developer library only
+int spec_ablation() { return FXC_DEV_KERNELS ? env_int("FXC_RTC_ABL", 0) : 0; }
+
 // hiprtc's C API, the handful of calls used here (its header is not needed: plain C types)
 typedef struct _hiprtcProgram* rtc_program;
 struct RtcApi {
@@ -286,7 +289,7 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXM_NST=" + std::to_string(shape.n_stages), "-DFXM_RADICES=" + radices,
                                      "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)), "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly)),
                                      "-DFXM_U=" + std::to_string(shape.u),
-                                     "-DFXM_ABL=" + std::to_string(env_int("FXC_RTC_ABL", 0))};      // (timing ablations: wrong results, developer runs only)
+                                     "-DFXM_ABL=" + std::to_string(spec_ablation())};      // (timing ablations: wrong results, developer library only)
     const std::string dir = spec_cache_dir();
     const std::string cached = dir.empty() ? std::string() : dir + "/" + spec_cache_key(opts, api) + ".co";
     if (!cached.empty() && spec_cache_load(cached, image)) return true;
@@ -389,7 +392,7 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
 // compile (or find) the kernel for n channels on `device`; never nullptr -- a failed build is cached with its reason
 const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
     char key[256];
-    std::snprintf(key, sizeof key, "d%d n%d t%d v%d a%d r%d f%d", device, n, taps, variant, env_int("FXC_RTC_ABL", 0), env_int("FXC_RTC_R0", 0),
+    std::snprintf(key, sizeof key, "d%d n%d t%d v%d a%d r%d f%d", device, n, taps, variant, spec_ablation(), env_int("FXC_RTC_R0", 0),
                   env_int("FXC_RTC_U", 0));
     std::lock_guard<std::mutex> lock(g_spec_mutex);
     auto it = g_spec_cache.find(key);

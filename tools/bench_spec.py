@@ -28,7 +28,7 @@ def run_cases(args):
     xb = torch.randint(0, 256, (n_chunks, 2, num_samp, 2), dtype=torch.uint8, device="cuda") if args.u8 else None
     for nchan in (int(v) for v in args.cases.split(",")):
         out = {"tag": "rtc" if os.environ.get("FXC_RTC", "1") != "0" else "any-shape", "nchan": nchan, "ntaps": args.taps}
-        with FxPlan(2, nchan, args.taps, num_samp) as plan:
+        with FxPlan(2, nchan, args.taps, num_samp, dev=args.dev) as plan:
             info = plan.info
             out.update(path=plan.path, specialised=info["specialised"], vgprs=info["spec_vgprs"], block=info["block"], lds=info["lds_bytes"])
             if args.check:
@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--u8", action="store_true")
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--dev", action="store_true", help="the developer library (libfxcorr_dev.so): FXC_RTC_ABL timing ablations live there")
     args = ap.parse_args()
     if args.child:
         return run_cases(args)
