@@ -128,7 +128,7 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1) {
     s.slots = std::max(1, 256 / s.tpr);
     if (s.radix[0] * j0 > 8) return s;
     s.u = u;
-    if (u != 1 && (u != 2 || s.n_stages < 2 || 2 * s.lds_bytes() > (size_t)(160 * 1024))) return s;
+    if (u != 1 && (u != 2 || s.n_stages < 2)) return s;      // (whether two frames' rows cost a resident workgroup: spec_search)
     if (s.lds_bytes() > (size_t)(160 * 1024)) return s;
     s.ok = true;
     return s;
