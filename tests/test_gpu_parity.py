@@ -801,6 +801,26 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
         assert rel_err(rows, d.fx_rows(xd, "SPECTRUM").cpu().numpy()) < (4e-6 if nchan <= 8192 else 1e-5)
 
 
+@pytest.mark.parametrize("rtc", ["1", "0"])
+def test_long_chunks_of_few_channels_keep_float32_runs_short(plan_mod, torch, monkeypatch, rtc):
+    """Few channels with long chunks (12 channels, 2^19 samples: 43 690 spectra per chunk): every kernel that sums s0 conj(s1) in
+    float32 registers over a run of frames cuts the chunk into runs of at most 1 024 spectra (h_launch.h::kRowSpectra; the
+    any-shape mixed-radix kernel had no such cap: ADVICE r04) -- rows against the oracle, and the integration against the float64
+    mean of the rows, with the kernel compiled for the channel count and with the any-shape one."""
+    monkeypatch.setenv("FXC_RTC", rtc)
+    nchan, ntaps, num_samp, n_chunks = 12, 4, 2 ** 19 + 7, 3
+    x = synth.synth_iq(2024, n_chunks, 2, num_samp)
+    window = np.random.default_rng(12).standard_normal(ntaps * nchan)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as p:
+        assert p.info["specialised"] == int(rtc)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        ref = fx_oracle.pfb_xcorr(x[1, 0], x[1, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+        assert rel_err(rows[1, 0], ref) < TOL_VIS
+        p.fx_accumulate(xd)
+        assert rel_err(p.finalize("SPECTRUM"), rows.astype(np.complex128).mean(axis=0)) < 2e-6
+
+
 @pytest.mark.parametrize("n_ant,nchan,ntaps,n_streams,frames,extra", [
     (1, 1000, 4, 5, 60, 3), (1, 96, 4, 333, 40, 0), (1, 720, 3, 2, 17, 1), (1, 250, 1, 1, 1, 0), (1, 2000, 4, 3, 9, 0),
     (3, 1000, 4, 4, 30, 5), (5, 96, 2, 3, 100, 0)])
