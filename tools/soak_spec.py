@@ -37,6 +37,8 @@ def main():
     while time.time() < t_end:
         nchan = int(rng.integers(2, args.max_nchan))
         ntaps = int(rng.choice([1, 2, 3, 4, 4, 4]))
+        if nchan & (nchan - 1) == 0 and nchan >= 16:      # the powers of two from 16 on have tuned kernels of their own
+            continue
         if lib.fxc_spec_probe(nchan, ntaps, 0, None, None, 0) != 0:
             continue
         frames = int(rng.integers(1, 400 if nchan <= 256 else (60 if nchan <= 1024 else 24)))
@@ -49,7 +51,7 @@ def main():
             g = FxPlan(2, nchan, ntaps, num_samp)
             os.environ["FXC_RTC"] = "1"
             with FxPlan(2, nchan, ntaps, num_samp) as f, g:
-                assert f.info["specialised"] == 1 and g.info["specialised"] == 0
+                assert f.info["specialised"] == 1 and g.info["specialised"] == 0, (tag, f.path, f.info, g.info)
                 shapes.add((nchan, f.info["block"], f.info["lds_bytes"]))
                 rf, rg = f.fx_rows(x).cpu().numpy(), g.fx_rows(x).cpu().numpy()
                 e = {"rows": rel_err(rf, rg)}
