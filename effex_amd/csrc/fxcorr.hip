@@ -337,6 +337,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                 p->mixed_tpr = fxc::mixed_threads_per_row(m, 1024);
             }
         }
+        p->rtc = env_int("FXC_RTC", 1) != 0;      // (read once, when the plan is made)
         p->mixed_xeng = p->mixed && p->n_ant >= 3 && env_int("FXC_MIXED_XENGINE", 1);
         if (p->mixed && !p->mixed_blu && p->n_ant == 2 && env_int("FXC_MIXED_XF", 1)) {
             const size_t rpw = (size_t)(std::max(256, p->mixed_tpr) / p->mixed_tpr);
@@ -350,7 +351,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             // the kernel built for exactly this channel count (fx_spec.h through hiprtc, h_rtc.h): every sample fetched once,
             // strides and trip counts compile-time constants.  FXC_RTC=0 keeps the any-shape kernel (developer knob, and what
             // a box without hiprtc runs)
-            if (p->mixed_xf && env_int("FXC_RTC", 1) && p->num_samp < (1ll << 28)) {       // (32-bit byte offsets inside a chunk)
+            if (p->mixed_xf && p->rtc && p->num_samp < (1ll << 28)) {       // (32-bit byte offsets inside a chunk)
                 if (!spec_first_radices(N, T).empty()) {
                     const SpecKernel* k = spec_kernel(p->device, N, T, kSpecC64);
                     if (k->fn)

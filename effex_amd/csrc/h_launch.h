@@ -43,7 +43,7 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
     }
-    if (p->mixed && p->ntaps <= 4 && p->num_samp < (1ll << 28) && env_int("FXC_RTC", 1)) {
+    if (p->mixed && p->ntaps <= 4 && p->num_samp < (1ll << 28) && p->rtc) {
         // the F stage built for exactly this channel count (fx_spec.h, FXM_FONLY: a workgroup carries two streams through the
         // stages, the last butterfly stores the spectra); compiled on first use
         if (!p->spec_f_tried) {

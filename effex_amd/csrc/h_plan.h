@@ -78,6 +78,7 @@ struct fxc_plan {
     bool spec_u8_tried = false;
     const SpecKernel* spec_f = nullptr;      // the F stage alone (fxc_channelize, 3 + antennas), built on first use
     bool spec_f_tried = false;
+    bool rtc = true;                         // FXC_RTC as it stood when the plan was made (developer knob: 0 keeps the any-shape kernels)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev_order = nullptr;   // orders the old stream's work before the new one's (fxc_set_stream)

@@ -70,7 +70,7 @@ def main():
             os.environ.pop("FXC_RTC", None)
         for k, v in e.items():
             worst[k] = max(worst.get(k, 0.0), v)
-        if not all(v < 6e-6 for v in e.values()):
+        if not all(v < 6e-6 for v in e.values()) or e["spectra"] == 0.0 and nchan > 4:      # (identical spectra: both plans ran one kernel)
             print(json.dumps({"MISMATCH": e, **tag}), flush=True)
             raise SystemExit(1)
         cases += 1
