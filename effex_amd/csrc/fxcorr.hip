@@ -745,8 +745,9 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
         info->block = 256;
         info->lds_bytes = p->nchan > 1 ? p->nchan * (int)sizeof(cf) : 0;
     }
+    if (p->spec_f) info->specialised |= 2;
     if (p->spec) {
-        info->specialised = 1;
+        info->specialised |= 1;
         info->spec_vgprs = p->spec->vgprs;
         info->grid = p->cu_count * p->spec->wgs_per_cu;
         info->block = p->spec->shape.threads();

@@ -75,8 +75,9 @@ typedef struct fxc_info {
     int32_t lds_bytes;         /* dynamic LDS of the dominant kernel                             */
     int32_t device, cu_count;
     int64_t workspace_bytes;
-    int32_t specialised;       /* 1: the F+X kernel was compiled for exactly this channel count when the plan was made
-                                  (two antennas, a channel count that is not a power of two, up to four taps)           */
+    int32_t specialised;       /* bit 0: the F+X kernel was compiled for exactly this channel count when the plan was made
+                                  (two antennas, a channel count that is not a power of two, up to four taps); bit 1: so was
+                                  the F stage alone (built at the first fxc_channelize / multi-antenna call)            */
     int32_t spec_vgprs;        /* its vector registers per lane                                                          */
 } fxc_info;
 

@@ -51,7 +51,7 @@ def main():
             g = FxPlan(2, nchan, ntaps, num_samp)
             os.environ["FXC_RTC"] = "1"
             with FxPlan(2, nchan, ntaps, num_samp) as f, g:
-                assert f.info["specialised"] == 1 and g.info["specialised"] == 0, (tag, f.path, f.info, g.info)
+                assert f.info["specialised"] & 1 and g.info["specialised"] == 0, (tag, f.path, f.info, g.info)
                 shapes.add((nchan, f.info["block"], f.info["lds_bytes"]))
                 rf, rg = f.fx_rows(x).cpu().numpy(), g.fx_rows(x).cpu().numpy()
                 e = {"rows": rel_err(rf, rg)}
@@ -59,6 +59,8 @@ def main():
                 e["integ"] = rel_err(f.finalize("SPECTRUM"), rg.astype(np.complex128).mean(axis=0))
                 xs = x.reshape(-1, num_samp)[: max(1, min(2 * n_chunks, 5))]
                 e["spectra"] = rel_err(f.channelize(xs).cpu().numpy(), g.channelize(xs).cpu().numpy())
+                # (bit 1 of fxc_info.specialised: the F stage alone ran the build for this channel count, where there is one)
+                assert bool(f.info["specialised"] & 2) == (lib.fxc_spec_probe(nchan, ntaps, 2, None, None, 0) == 0) and g.info["specialised"] == 0, tag
                 if rng.random() < 0.3:
                     nb = min(n_chunks, 3)
                     u8 = torch.randint(0, 256, (nb, 2, num_samp, 2), dtype=torch.uint8, device="cuda")
@@ -70,8 +72,7 @@ def main():
             os.environ.pop("FXC_RTC", None)
         for k, v in e.items():
             worst[k] = max(worst.get(k, 0.0), v)
-        same_f = e["spectra"] == 0.0 and nchan > 4 and lib.fxc_spec_probe(nchan, ntaps, 2, None, None, 0) == 0      # identical spectra although an F-only build exists: both plans ran one kernel
-        if not all(v < 6e-6 for v in e.values()) or same_f:
+        if not all(v < 6e-6 for v in e.values()):
             print(json.dumps({"MISMATCH": e, **tag}), flush=True)
             raise SystemExit(1)
         cases += 1
