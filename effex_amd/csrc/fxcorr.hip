@@ -580,7 +580,10 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, fxc::fused::kLdsBytes));
         }
         p->tiled_ring = ((T <= 4 || p->prefilter) && N <= 4096);
-        if (p->tiled_ring && (!p->d_win4 || p->prefilter)) {
+        // 8192 channels, up to four taps: the F stage alone has a ring kernel of its own (k_tiled.h::f8192_ring_kernel), fed with the
+        // same window quads from L2.  FXC_F8192=0: the pair kernel (developer knob)
+        p->f8192 = N == 8192 && T <= 4 && !p->prefilter && env_int("FXC_F8192", 1);
+        if ((p->tiled_ring || p->f8192) && (!p->d_win4 || p->prefilter)) {
             std::vector<f4> w4((size_t)N);
             for (int r = 0; r < 16; ++r)
                 for (int u = 0; u < P; ++u) {

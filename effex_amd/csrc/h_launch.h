@@ -729,6 +729,20 @@ int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, 
 // F-stage only: n_streams consecutive streams -> spec[stream][i][k], pairs of streams per work item
 int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a) {
     if (p->small_f) return small_channelize(p, x, spec, n_streams, spec_a);
+    if (p->f8192 && p->num_samp < (1ll << 28)) {
+        // one stream per workgroup; runs of at least eight frames (a run re-reads three frames of history), enough workgroups
+        // for two rounds of the CUs when the streams are few
+        KernelTimer kt8(p);
+        const int64_t want = (2 * (int64_t)p->cu_count + n_streams - 1) / n_streams;
+        const int n_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / 8));
+        const int64_t wgs = n_streams * n_splits;
+        const int grid = (int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8);
+        hipLaunchKernelGGL(f8192_ring_kernel, dim3(grid), dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, n_streams, n_splits,
+                           p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, spec, spec_a, (int64_t)0);
+        kt8.stop();
+        FXC_HIP(p, hipGetLastError());
+        return FXC_OK;
+    }
     KernelTimer kt(p);
     const int64_t per_pass = prefilter_streams_per_pass(p);
     for (int64_t s0 = 0; s0 < n_streams; s0 += per_pass) {

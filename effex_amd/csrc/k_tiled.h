@@ -422,4 +422,146 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// nchan 8192, ntaps <= 4, F only (fxc_channelize, the drop-in's _spectrometer_poly at 8192 branches -- effex.py:530-555):
+// ONE stream per workgroup of 512 threads (16 branches each), so that the four frames the FIR needs fit a VGPR ring (128
+// registers; the pair kernel above has 1024 threads of 128 registers and re-reads 2.5 frames per frame) and every sample is
+// fetched once.  The pre-stage and stage-A twiddles sit in LDS beside the exchange rows (137 KiB in all); the window quads (another
+// 128 KiB) come from L2 every frame.  Phases and exchange layout: fx_tiled.h, geometry Geo<2, true> with u = the thread.
+// ------------------------------------------------------------------------------------------
+using G8192 = fxc::tiled::Geo<2, true>;
+constexpr int kF8192Threads = G8192::P;                                          // 512
+// exchange rows of one stream + w256 table + the eight pre-stage twiddle rows in use + the stage-A table (137 KiB: the window
+// quads, another 128 KiB, stay in L2)
+constexpr int kF8192LdsCf = G8192::kRegion + 256 + 8 * G8192::P + 16 * 256;
+
+template <int PH>
+__device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict__ win_g, const cf* tw0_l,
+                                           const cf* twA_l, cf* reg, const cf* tw16, int u, const cf* stream_base,
+                                           unsigned stream_bytes, unsigned xoff, int64_t i, int64_t i1, cf* out_row, int64_t out_step) {
+    using G = G8192;
+    cf v[16];
+    {   // FIR out of the ring, window quads [r P + u] = taps 0 .. 3 of branch u + P r straight from their table (L2), four at a time
+        const cf (&x0)[16] = h[PH];
+        const cf (&x1)[16] = h[(PH + 3) & 3];
+        const cf (&x2)[16] = h[(PH + 2) & 3];
+        const cf (&x3)[16] = h[(PH + 1) & 3];
+        __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4*>(win_g), 0, (int)(G::N * sizeof(f4)), 0x00020000);
+        const unsigned woff = (unsigned)(u * (int)sizeof(f4));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            FXC_SCHED_FENCE();
+            v4u32 w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff, (unsigned)((4 * g + q) * G::P * (int)sizeof(f4)), 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * g + q;
+                cf a = fxc::cscale(x0[r], __uint_as_float(w[q][0]));
+                a = fxc::cfma(__uint_as_float(w[q][1]), x1[r], a);
+                a = fxc::cfma(__uint_as_float(w[q][2]), x2[r], a);
+                v[r] = fxc::cfma(__uint_as_float(w[q][3]), x3[r], a);
+            }
+        }
+    }
+    // the oldest slot is dead: the next frame of the run goes there, in flight through the stages below (the current one again
+    // at the end of the run: never used, and no branch guards a definition of ring registers)
+    FXC_SCHED_FENCE();
+    tiled_load_part<G, 0, 16>(h[(PH + 1) & 3], stream_base, stream_bytes, xoff, (i + 1 < i1) ? i + 1 : i);
+    FXC_SCHED_FENCE();
+    {   // pre-stage (R0 = 2): slots g and g + 8, twiddle wN^((u + P g) k) on the second -- the eight rows in use sit in LDS
+        cf w[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) w[g] = fxc::fused::lds_load(tw0_l + g * G::P + u);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            fxc::tiled::dft2(v[g], v[g + 8]);
+            v[g + 8] = fxc::cmul(v[g + 8], w[g]);
+        }
+        FXC_SCHED_FENCE();
+    }
+    __syncthreads();   // every wave has finished reading the previous spectrum's exchange rows
+    G::store0(v, reg, u);
+    __syncthreads();
+    G::loadA(reg, u, v);
+    fxc::dft16(v);
+    __syncthreads();
+    {   // = G::twiddleA_store with the stage-A twiddles w4096^(n' k) read from their LDS copy five at a time
+        cf* b = reg + (u >> 8) * 4352 + (u & 255);
+        b[0] = v[0];
+#pragma unroll
+        for (int k0 = 1; k0 < 16; k0 += 5) {
+            FXC_SCHED_FENCE();
+            cf w[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) w[k] = fxc::fused::lds_load(twA_l + (k0 + k) * 256 + (u & 255));
+#pragma unroll
+            for (int k = 0; k < 5; ++k) b[272 * (k0 + k)] = fxc::cmul(v[k0 + k], w[k]);
+            FXC_SCHED_FENCE();
+        }
+    }
+    __syncthreads();
+    G::loadB(reg, u, v);
+    fxc::dft16(v);
+    G::twiddleB(v, tw16, u);
+    wave_sync();       // the 16x16 transpose stays inside each 16-lane group: no s_barrier
+    G::storeT(v, reg, u);
+    wave_sync();
+    G::loadC(reg, u, v);
+    fxc::dft16(v);
+    tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, true);
+}
+
+__global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
+                                                                   int64_t n_streams, int n_splits, const f4* __restrict__ win_g,
+                                                                   const cf* __restrict__ tw0_g, const cf* __restrict__ twA_g,
+                                                                   const cf* __restrict__ tw16_g, cf* __restrict__ spec, int spec_a,
+                                                                   int64_t s_base) {
+    using G = G8192;
+    __shared__ __attribute__((aligned(16))) cf smem[kF8192LdsCf];
+    cf* reg = smem;
+    cf* tw16 = smem + G::kRegion;
+    cf* tw0_l = tw16 + 256;                       // rows 8 .. 15 of the [16][P] pre-stage table
+    cf* twA_l = tw0_l + 8 * G::P;                 // [16][256]
+    const int u = threadIdx.x;
+    for (int idx = u; idx < 256; idx += kF8192Threads) tw16[idx] = tw16_g[idx];
+    for (int idx = u; idx < 8 * G::P; idx += kF8192Threads) tw0_l[idx] = tw0_g[8 * G::P + idx];
+    for (int idx = u; idx < 16 * 256; idx += kF8192Threads) twA_l[idx] = twA_g[idx];
+    __syncthreads();
+    const int64_t per = (n_pts + n_splits - 1) / n_splits;
+    const unsigned stream_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf));
+    const unsigned xoff = (unsigned)((G::P - 1 - u) * (int)sizeof(cf));
+    for (int64_t w = blockIdx.x; w < n_streams * n_splits; w += gridDim.x) {
+        const int64_t s = w % n_streams, split = w / n_streams;
+        const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
+        const cf* stream_base = x + s * num_samp;
+        cf* out_row = spec + spec_row(s_base + s, 0, n_pts, spec_a) * G::N;
+        const int64_t out_step = (int64_t)(spec_a > 0 ? spec_a : 1) * G::N;
+        cf h[4][16];
+        // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the stream's start)
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+            if (i0 - d >= 0 && i0 < i1) {
+                tiled_load_part<G, 0, 16>(h[4 - d], stream_base, stream_bytes, xoff, i0 - d);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[4 - d][r] = fxc::mk(0.f, 0.f);
+            }
+        }
+        if (i0 < i1) {
+            tiled_load_part<G, 0, 16>(h[0], stream_base, stream_bytes, xoff, i0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[0][r] = fxc::mk(0.f, 0.f);
+        }
+        for (int64_t i = i0; i < i1; i += 4) {
+            f8192_step<0>(h, win_g, tw0_l, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i, i1, out_row, out_step);
+            if (i + 1 < i1) f8192_step<1>(h, win_g, tw0_l, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 1, i1, out_row, out_step);
+            if (i + 2 < i1) f8192_step<2>(h, win_g, tw0_l, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 2, i1, out_row, out_step);
+            if (i + 3 < i1) f8192_step<3>(h, win_g, tw0_l, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 3, i1, out_row, out_step);
+        }
+    }
+}
+
 }  // namespace

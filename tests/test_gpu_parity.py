@@ -801,6 +801,34 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
         assert rel_err(rows, d.fx_rows(xd, "SPECTRUM").cpu().numpy()) < (4e-6 if nchan <= 8192 else 1e-5)
 
 
+@pytest.mark.parametrize("n_ant,ntaps,n_streams,frames,extra", [(1, 4, 3, 7, 5), (1, 4, 600, 9, 0), (1, 3, 1, 40, 8191), (1, 1, 2, 1, 0),
+                                                           (3, 4, 2, 11, 3), (1, 4, 1, 300, 1)])
+def test_channelize_at_8192_channels(plan_mod, torch, monkeypatch, n_ant, ntaps, n_streams, frames, extra):
+    """fxc_channelize (the drop-in's _spectrometer_poly, effex.py:530-555) at 8192 branches and up to four taps: one stream per
+    workgroup with the four frames of the FIR in a register ring (k_tiled.h::f8192_ring_kernel; the pair kernel it replaces
+    re-read 2.5 frames per frame) -- spectra against the oracle for odd stream counts, runs of one frame, runs cut into several
+    splits, and the antenna-interleaved layout of the 3-antenna route; the pair kernel (FXC_F8192=0) agrees."""
+    nchan = 8192
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(8192 + n_streams, n_streams, n_ant, num_samp, delays=np.arange(n_ant) % 5)
+    window = design_window(ntaps, nchan)
+    xd = torch.from_numpy(x).cuda()
+    flat = xd.reshape(-1, num_samp)
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as p:
+        spec = p.channelize(flat).cpu().numpy()
+        for s_ in sorted({0, flat.shape[0] // 2, flat.shape[0] - 1}):
+            ref = fx_oracle.spectrometer_poly(x.reshape(-1, num_samp)[s_], ntaps, nchan, window)
+            assert rel_err(spec[s_], ref) < TOL_SPEC, s_
+        if n_ant > 1:
+            rows = p.fx_rows(xd).cpu().numpy()
+            assert rel_err(rows[0], fx_oracle.fx_integrate(x[:1], nchan, window)) < TOL_VIS
+    monkeypatch.setenv("FXC_F8192", "0")
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as a:
+        assert rel_err(a.channelize(flat).cpu().numpy(), spec) < 2e-6
+        if n_ant > 1:
+            assert rel_err(a.fx_rows(xd).cpu().numpy(), rows) < 2e-6
+
+
 @pytest.mark.parametrize("rtc", ["1", "0"])
 def test_long_chunks_of_few_channels_keep_float32_runs_short(plan_mod, torch, monkeypatch, rtc):
     """Few channels with long chunks (12 channels, 2^19 samples: 43 690 spectra per chunk): every kernel that sums s0 conj(s1) in
