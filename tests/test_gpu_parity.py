@@ -829,6 +829,36 @@ def test_channelize_at_8192_channels(plan_mod, torch, monkeypatch, n_ant, ntaps,
             assert rel_err(a.fx_rows(xd).cpu().numpy(), rows) < 2e-6
 
 
+@pytest.mark.parametrize("nchan,mode", [(4096, "SPECTRUM"), (4096, "CONTINUUM"), (1000, "SPECTRUM"), (256, "SPECTRUM")])
+def test_rows_straight_into_pinned_host_memory(plan_mod, torch, nchan, mode):
+    """FXC_MEM_DEVICE_TO_PINNED: samples resident in device memory, rows delivered into fxc_host_alloc memory by the finishing
+    kernel itself (what the time-series sink double-buffers, effex.py:402-410, 687-696 at the device's pace): the call returns
+    with the work queued, after plan.sync() the pinned array holds exactly the rows of the ordinary device call -- for complex64
+    and byte samples and with the DC removal; an `out` that is not pinned memory is refused before anything is queued."""
+    num_samp, n_chunks = nchan * 21 + 3, 37
+    x = torch.from_numpy(synth.synth_iq(606, n_chunks, 2, num_samp)).cuda()
+    u8 = torch.randint(0, 256, (n_chunks, 2, num_samp, 2), dtype=torch.uint8, device="cuda")
+    with plan_mod.FxPlan(2, nchan, 4, num_samp) as p:
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-7)
+        ref = p.fx_rows(x, mode, gi.BANDWIDTH).cpu().numpy()
+        out = plan_mod.pinned_empty(ref.shape, ref.dtype)
+        out[...] = 0
+        assert p.fx_rows(x, mode, gi.BANDWIDTH, out=out) is out
+        p.sync()
+        np.testing.assert_array_equal(out, ref)
+        ref_dc = p.fx_rows(x, mode, gi.BANDWIDTH, remove_dc=True).cpu().numpy()
+        p.fx_rows(x, mode, gi.BANDWIDTH, remove_dc=True, out=out)
+        p.sync()
+        np.testing.assert_array_equal(out, ref_dc)
+        ref_u8 = p.fx_rows_u8(u8, mode, gi.BANDWIDTH).cpu().numpy()
+        p.fx_rows_u8(u8, mode, gi.BANDWIDTH, out=out)
+        p.sync()
+        np.testing.assert_array_equal(out, ref_u8)
+        with pytest.raises(ValueError):
+            p.fx_rows(x, mode, gi.BANDWIDTH, out=np.empty(ref.shape, ref.dtype))       # pageable memory: not a device-writable target
+        p.sync()
+
+
 @pytest.mark.parametrize("rtc", ["1", "0"])
 def test_long_chunks_of_few_channels_keep_float32_runs_short(plan_mod, torch, monkeypatch, rtc):
     """Few channels with long chunks (12 channels, 2^19 samples: 43 690 spectra per chunk): every kernel that sums s0 conj(s1) in
