@@ -427,22 +427,24 @@ __global__ __launch_bounds__(G::kThreads, 2) void fx_tiled_ring_kernel(const cf*
 // nchan 8192, ntaps <= 4, F only (fxc_channelize, the drop-in's _spectrometer_poly at 8192 branches -- effex.py:530-555):
 // ONE stream per workgroup of 512 threads (16 branches each), so that the four frames the FIR needs fit a VGPR ring (128
 // registers; the pair kernel above has 1024 threads of 128 registers and re-reads 2.5 frames per frame) and every sample is
-// fetched once.  The pre-stage and stage-A twiddles sit in LDS beside the exchange rows (137 KiB in all); the window quads (another
-// 128 KiB) come from L2 every frame.  Phases and exchange layout: fx_tiled.h, geometry Geo<2, true> with u = the thread.
+// fetched once.  Beside the exchange rows the LDS holds the stage-A twiddles and 7 / 16 of the window quads (158 KiB in all);
+// the other window quads come from L2 every frame, the pre-stage twiddle is a register pair times a constant.  Phases and exchange layout: fx_tiled.h, geometry Geo<2, true> with u = the thread.
 // ------------------------------------------------------------------------------------------
 using G8192 = fxc::tiled::Geo<2, true>;
 constexpr int kF8192Threads = G8192::P;                                          // 512
-// exchange rows of one stream + w256 table + the eight pre-stage twiddle rows in use + the stage-A table (137 KiB: the window
-// quads, another 128 KiB, stay in L2)
-constexpr int kF8192LdsCf = G8192::kRegion + 256 + 8 * G8192::P + 16 * 256;
+// exchange rows of one stream + w256 table + the stage-A table + the window quads of the first kF8192WinLds branch groups (the
+// other 16 - kF8192WinLds groups -- the window is 128 KiB -- come from L2 every frame): 158 KiB
+constexpr int kF8192WinLds = 7;
+constexpr int kF8192LdsCf = G8192::kRegion + 256 + 16 * 256 + kF8192WinLds * G8192::P * 2;
 
 template <int PH>
-__device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict__ win_g, const cf* tw0_l,
+__device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict__ win_g, const f4* win_l, cf wu,
                                            const cf* twA_l, cf* reg, const cf* tw16, int u, const cf* stream_base,
                                            unsigned stream_bytes, unsigned xoff, int64_t i, int64_t i1, cf* out_row, int64_t out_step) {
     using G = G8192;
     cf v[16];
-    {   // FIR out of the ring, window quads [r P + u] = taps 0 .. 3 of branch u + P r straight from their table (L2), four at a time
+    {   // FIR out of the ring, window quads [r P + u] = taps 0 .. 3 of branch u + P r: the first kF8192WinLds groups from LDS, the
+        // rest straight from their table (L2), four at a time
         const cf (&x0)[16] = h[PH];
         const cf (&x1)[16] = h[(PH + 3) & 3];
         const cf (&x2)[16] = h[(PH + 2) & 3];
@@ -452,16 +454,27 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             FXC_SCHED_FENCE();
-            v4u32 w[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff, (unsigned)((4 * g + q) * G::P * (int)sizeof(f4)), 0);
+            f4 w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = 4 * g + q;
-                cf a = fxc::cscale(x0[r], __uint_as_float(w[q][0]));
-                a = fxc::cfma(__uint_as_float(w[q][1]), x1[r], a);
-                a = fxc::cfma(__uint_as_float(w[q][2]), x2[r], a);
-                v[r] = fxc::cfma(__uint_as_float(w[q][3]), x3[r], a);
+                if (r < kF8192WinLds) {
+                    w[q] = win_l[r * G::P + u];
+                } else {
+                    const v4u32 d = __builtin_amdgcn_raw_buffer_load_b128(rw, woff, (unsigned)(r * G::P * (int)sizeof(f4)), 0);
+                    w[q].x = __uint_as_float(d[0]);
+                    w[q].y = __uint_as_float(d[1]);
+                    w[q].z = __uint_as_float(d[2]);
+                    w[q].w = __uint_as_float(d[3]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * g + q;
+                cf a = fxc::cscale(x0[r], w[q].x);
+                a = fxc::cfma(w[q].y, x1[r], a);
+                a = fxc::cfma(w[q].z, x2[r], a);
+                v[r] = fxc::cfma(w[q].w, x3[r], a);
             }
         }
     }
@@ -470,14 +483,16 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
     FXC_SCHED_FENCE();
     tiled_load_part<G, 0, 16>(h[(PH + 1) & 3], stream_base, stream_bytes, xoff, (i + 1 < i1) ? i + 1 : i);
     FXC_SCHED_FENCE();
-    {   // pre-stage (R0 = 2): slots g and g + 8, twiddle wN^((u + P g) k) on the second -- the eight rows in use sit in LDS
-        cf w[8];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) w[g] = fxc::fused::lds_load(tw0_l + g * G::P + u);
+    {   // pre-stage (R0 = 2): slots g and g + 8, twiddle w8192^(u + 512 g) = w8192^u w16^g on the second: the thread's own factor
+        // (a register pair) times a constant
+        constexpr float kC[8] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                                 0.f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+        constexpr float kS[8] = {0.f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
+                                 1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             fxc::tiled::dft2(v[g], v[g + 8]);
-            v[g + 8] = fxc::cmul(v[g + 8], w[g]);
+            v[g + 8] = fxc::cmul(fxc::cmul(v[g + 8], wu), fxc::mk(kC[g], kS[g]));
         }
         FXC_SCHED_FENCE();
     }
@@ -522,12 +537,13 @@ __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __r
     __shared__ __attribute__((aligned(16))) cf smem[kF8192LdsCf];
     cf* reg = smem;
     cf* tw16 = smem + G::kRegion;
-    cf* tw0_l = tw16 + 256;                       // rows 8 .. 15 of the [16][P] pre-stage table
-    cf* twA_l = tw0_l + 8 * G::P;                 // [16][256]
+    cf* twA_l = tw16 + 256;                       // [16][256]
+    f4* win_l = reinterpret_cast<f4*>(twA_l + 16 * 256);      // window quads of branch groups 0 .. kF8192WinLds - 1
     const int u = threadIdx.x;
     for (int idx = u; idx < 256; idx += kF8192Threads) tw16[idx] = tw16_g[idx];
-    for (int idx = u; idx < 8 * G::P; idx += kF8192Threads) tw0_l[idx] = tw0_g[8 * G::P + idx];
     for (int idx = u; idx < 16 * 256; idx += kF8192Threads) twA_l[idx] = twA_g[idx];
+    for (int idx = u; idx < kF8192WinLds * G::P; idx += kF8192Threads) win_l[idx] = win_g[idx];
+    const cf wu = tw0_g[8 * G::P + u];            // w8192^u (row g = 0 of the second half of the [16][P] pre-stage table)
     __syncthreads();
     const int64_t per = (n_pts + n_splits - 1) / n_splits;
     const unsigned stream_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf));
@@ -556,10 +572,10 @@ __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __r
             for (int r = 0; r < 16; ++r) h[0][r] = fxc::mk(0.f, 0.f);
         }
         for (int64_t i = i0; i < i1; i += 4) {
-            f8192_step<0>(h, win_g, tw0_l, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i, i1, out_row, out_step);
-            if (i + 1 < i1) f8192_step<1>(h, win_g, tw0_l, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 1, i1, out_row, out_step);
-            if (i + 2 < i1) f8192_step<2>(h, win_g, tw0_l, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 2, i1, out_row, out_step);
-            if (i + 3 < i1) f8192_step<3>(h, win_g, tw0_l, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 3, i1, out_row, out_step);
+            f8192_step<0>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i, i1, out_row, out_step);
+            if (i + 1 < i1) f8192_step<1>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 1, i1, out_row, out_step);
+            if (i + 2 < i1) f8192_step<2>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 2, i1, out_row, out_step);
+            if (i + 3 < i1) f8192_step<3>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 3, i1, out_row, out_step);
         }
     }
 }
