@@ -42,6 +42,15 @@
 #ifndef FXM_ABL
 #define FXM_ABL 0
 #endif
+// FXM_LEAN 1: the build for frames of more than 2048 channels (a thread carries up to eight points of each antenna: 128
+// registers of ring) -- nothing but the ring and the sums stays in registers from step to step.  The window taps come from L2
+// every step (Args::h4: the four taps of a point in one 16-byte load); of a butterfly's twiddles only the first is fetched
+// (Args::tw1, a table by stage, butterfly and thread -- consecutive lanes read consecutive entries -- requested one stage ahead
+// of its use), the others are its powers (a few complex multiplies a stage, shared by the rows of the step); the output offsets
+// are recomputed.
+#ifndef FXM_LEAN
+#define FXM_LEAN 0
+#endif
 
 namespace fxm {
 
@@ -62,6 +71,7 @@ constexpr int kRadix[S] = {FXM_RADICES};
 constexpr bool U8 = FXM_U8 != 0;
 constexpr int U = FXM_U;
 constexpr bool FONLY = FXM_FONLY != 0;
+constexpr bool LEAN = FXM_LEAN != 0;
 constexpr int THREADS = TPR * SLOTS;
 // The ring: the frames a step needs -- its own U and the T - 1 before them -- in NS = T + U - 1 slots, frame g of a run in
 // slot g mod NS; the next step's U frames land in the U slots the FIR has just finished with.  The slot pattern repeats after
@@ -78,9 +88,10 @@ constexpr int ns_of(int s) {
 constexpr int nb_of(int s) { return N / kRadix[s]; }
 constexpr int j_of(int s) { return (nb_of(s) + TPR - 1) / TPR; }        // butterflies of stage s per thread
 constexpr bool full_of(int s) { return j_of(s) * TPR == nb_of(s); }     // ... and every thread has all of them
+constexpr int tw_per(int s) { return LEAN ? 1 : kRadix[s] - 1; }         // twiddle registers of one butterfly of stage s
 constexpr int tw_base(int s) {                                          // first twiddle register of stage s (s >= 1)
     int c = 0;
-    for (int i = 1; i < s; ++i) c += j_of(i) * (kRadix[i] - 1);
+    for (int i = 1; i < s; ++i) c += j_of(i) * tw_per(i);
     return c;
 }
 constexpr int ob_base(int s) {                                          // first output-offset register of stage s (1 <= s <= S-2)
@@ -90,7 +101,8 @@ constexpr int ob_base(int s) {                                          // first
 }
 constexpr int R0 = kRadix[0], J0 = j_of(0), PTS = R0 * J0;              // a thread's points: m = lt + j TPR + r N/R0
 constexpr int RL = kRadix[S - 1], JL = j_of(S - 1);
-constexpr int TWC = tw_base(S), OBC = ob_base(S > 1 ? S - 1 : 1);
+constexpr int TWC = LEAN ? 0 : tw_base(S), OBC = LEAN ? 0 : ob_base(S > 1 ? S - 1 : 1);
+constexpr int TW1C = tw_base(S);                 // LEAN: rows of Args::tw1, [TW1C][TPR]
 constexpr bool SWAP = S >= 2 && S % 2 == 0;      // the last stage reads the buffer the next frame's first stage writes: alternate them
 constexpr int ROW = N;                           // one antenna's row; a slot's LDS: [buffer X | Y][frame of the step][antenna][N]
 constexpr int ROWS = 2 * U;                      // rows a step carries: (frame u, antenna a) -> u * 2 + a
@@ -248,6 +260,9 @@ struct Args {
     long long num_samp, n_pts, n_chunks;   // F only: n_chunks = the number of STREAMS (a workgroup takes a pair of them)
     int wg_splits;
     int ant;                  // F only: spectra as out[stream / ant][frame][stream % ant][N] (1: [stream][frame][N])
+    const float* h4;          // LEAN: the taps by point, [N][4] (zeros beyond T)
+    const cf* tw1;            // LEAN: the first twiddle of butterfly j of stage s at thread lt: [tw_base(s) + j][TPR] = tw[(b mod ns) nb / ns],
+                              // b = lt + j TPR (0 where the thread has no such butterfly)
 };
 
 // The body of one GPU thread.  Ctx: tid(), bid(), lds() (the workgroup's LDS as cf*), sync() (all threads of the
@@ -257,7 +272,7 @@ struct Body {
     Ctx& cx;
     const Args ar;            // (a copy: a reference would pin the kernel argument block to the stack)
     Thread th;
-    pk2 hw2[(T * PTS + 1) / 2];   // the window taps of the thread's points, [t][p], two to a register pair (an array of
+    pk2 hw2[LEAN ? 1 : (T * PTS + 1) / 2];   // the window taps of the thread's points, [t][p], two to a register pair (an array of
                               // plain floats stayed on the stack under clang 20)
     int lt, slot;
     cf *bx, *by;              // this slot's two buffers (S >= 2)
@@ -267,7 +282,7 @@ struct Body {
     bool row_ok[2];           // F only: the row's stream exists (the last pair of an odd number of streams has one)
     cf* row_out[2];           // F only: where the row's stream puts its first frame's spectrum
 #if defined(__HIP_DEVICE_COMPILE__)
-    __amdgpu_buffer_rsrc_t rsrc[2];
+    __amdgpu_buffer_rsrc_t rsrc[2], rsrc_h, rsrc_t;
 #endif
 
     FXC_HD Body(Ctx& c, const Args& a) : cx(c), ar(a) {}
@@ -280,19 +295,21 @@ struct Body {
         slot = cx.tid() / TPR;
         bx = cx.lds() + slot * LDS_PER_SLOT;
         by = bx + ROWS * N;
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int j = 0; j < J0; ++j)
+            for (int j = 0; j < J0; ++j)
 #pragma unroll
-            for (int r = 0; r < R0; ++r) {
-                const bool ok = has_bfly(0, j, lt);
-                const int m = ok ? lt + j * TPR + r * nb_of(0) : 0;      // (an unconditional load and a select: a branch here kept the taps on the stack)
+                for (int r = 0; r < R0; ++r) {
+                    const bool ok = has_bfly(0, j, lt);
+                    const int m = ok ? lt + j * TPR + r * nb_of(0) : 0;      // (an unconditional load and a select: a branch here kept the taps on the stack)
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const float w = ar.h[t * N + m];
-                    hw2[(t * PTS + j * R0 + r) / 2][(t * PTS + j * R0 + r) % 2] = ok ? w : 0.f;
+                    for (int t = 0; t < T; ++t) {
+                        const float w = ar.h[t * N + m];
+                        hw2[(t * PTS + j * R0 + r) / 2][(t * PTS + j * R0 + r) % 2] = ok ? w : 0.f;
+                    }
                 }
-            }
-        init_stage<1>();
+        }
+        if constexpr (!LEAN) init_stage<1>();
 #pragma unroll
         for (int i = 0; i < JL * RL; ++i) th.xacc[i] = pk_splat(0.f);
     }
@@ -306,8 +323,8 @@ struct Body {
                 if (b >= nb) b = 0;                       // (a thread without this butterfly: any valid index)
                 const int k = b % ns;
 #pragma unroll
-                for (int r = 1; r < R; ++r) th.tw[tw_base(s) + j * (R - 1) + r - 1] = pk(ar.tw[r * k * tmul]);
-                if constexpr (s < S - 1) th.ob[ob_base(s) + j] = (b - k) * R + k;
+                for (int r = 1; r <= tw_per(s); ++r) th.tw[tw_base(s) + j * tw_per(s) + r - 1] = pk(ar.tw[r * k * tmul]);
+                if constexpr (s < S - 1 && !LEAN) th.ob[ob_base(s) + j] = (b - k) * R + k;
             }
             init_stage<s + 1>();
         }
@@ -319,6 +336,11 @@ struct Body {
     static constexpr int kElem = U8 ? 2 : 8;                  // bytes per sample
     template <int P>
     FXC_HD void load_frame(long long f, bool valid) {
+#pragma unroll
+        for (int j = 0; j < J0; ++j) load_points<P>(f, valid, j);
+    }
+    template <int P>
+    FXC_HD void load_points(long long f, bool valid, int j) {       // ... the points of first-stage butterfly j
 #if (FXM_ABL & 16)
         f &= 3;
 #endif
@@ -326,15 +348,11 @@ struct Body {
         typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
         // butterfly j's points sit at N-1-m, m = lt + j TPR + r N/R0: one VGPR offset per j, counted from the lowest address of
         // its points (r = R0 - 1), so that it is non-negative for every thread that has the butterfly and the rest is an immediate
-        unsigned voff[J0];
-#pragma unroll
-        for (int j = 0; j < J0; ++j)
-            voff[j] = (unsigned)((int)(f * N) + (N - 1 - lt - j * TPR - (R0 - 1) * nb_of(0))) * (unsigned)kElem;      // a chunk is below 2 GiB
+        const unsigned voff = (unsigned)((int)(f * N) + (N - 1 - lt - j * TPR - (R0 - 1) * nb_of(0))) * (unsigned)kElem;      // a chunk is below 2 GiB
 #endif
 #pragma unroll
         for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int j = 0; j < J0; ++j)
+            {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
                     const int m = lt + j * TPR + r * nb_of(0);
@@ -344,11 +362,11 @@ struct Body {
 #if defined(__HIP_DEVICE_COMPILE__)
                         const unsigned cst = (unsigned)((R0 - 1 - r) * nb_of(0)) * (unsigned)kElem;
                         if constexpr (U8) {
-                            const unsigned raw = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc[a], voff[j], cst, 0);
+                            const unsigned raw = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc[a], voff, cst, 0);
                             const pk2 bytes = {(float)(raw & 0xFFu), (float)(raw >> 8)};
                             v = pk_fma(bytes, pk_splat(1.0f / 127.5f), off8[a]);
                         } else {
-                            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc[a], voff[j], cst, 0);
+                            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc[a], voff, cst, 0);
                             v = pk2{__uint_as_float(d[0]), __uint_as_float(d[1])};
                         }
 #else
@@ -364,39 +382,85 @@ struct Body {
                     }
                     th.ring[a][j * R0 + r][P] = v;
                 }
+            }
+    }
+
+    // LEAN: the first twiddles of the thread's butterflies of stage s, from the table
+    template <int s>
+    FXC_HD void load_tw1(pk2 (&w1)[j_of(s)]) {
+#pragma unroll
+        for (int j = 0; j < j_of(s); ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc_t, (unsigned)lt * 8u, (unsigned)((tw_base(s) + j) * TPR) * 8u, 0);
+            w1[j] = pk2{__uint_as_float(d[0]), __uint_as_float(d[1])};
+#else
+            w1[j] = pk(ar.tw1[(tw_base(s) + j) * TPR + lt]);
+#endif
+        }
+    }
+    // the twiddles w^1 .. w^(R-1) of butterfly j of stage s: registers, or (LEAN) powers of the first
+    template <int s>
+    FXC_HD void stage_tw(int j, pk2 (&w)[kRadix[s]], const pk2* w1) {
+        constexpr int R = kRadix[s];
+        if constexpr (!LEAN) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) w[r] = th.tw[tw_base(s) + j * (R - 1) + r - 1];
+        } else {
+            w[1] = w1[j];
+#pragma unroll
+            for (int r = 2; r < R; ++r) {      // w^r = w^(r/2) w^(r - r/2): the shortest chains
+                const pk2 a = w[r / 2], b = w[r - r / 2];
+                w[r] = cmul_hi(a, b, cmul_lo(a, b));
+            }
+        }
     }
 
     // ---- one middle stage: LDS -> LDS
     template <int s>
-    FXC_HD void mid_stage(const cf* src, cf* dst) {
+    FXC_HD void mid_stage(const cf* src, cf* dst, const pk2* w1 = nullptr) {
         constexpr int R = kRadix[s], nb = nb_of(s), ns = ns_of(s);
         const fxc::Roots<R> rt = fxc::load_roots<R>(ar.tw, nb);
 #pragma unroll
         for (int j = 0; j < j_of(s); ++j) {
             const int b = lt + j * TPR;
             if (has_bfly(s, j, lt)) {
+                pk2 w[R];
+                stage_tw<s>(j, w, w1);
+                int ob;
+                if constexpr (LEAN) {
+                    int bb = b;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" : "+v"(bb));      // (recomputed every step: hoisted out of the step loop these offsets are registers again)
+#endif
+                    ob = (bb - bb % ns) * R + bb % ns;
+                } else {
+                    ob = th.ob[LEAN ? 0 : ob_base(s) + j];
+                }
 #pragma unroll
                 for (int a = 0; a < ROWS; ++a) {       // (every row of the step: the same indices, twiddles and barrier serve them all)
                     pk2 v[R], t[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) v[r] = pk(src[a * ROW + b + r * nb]);
 #pragma unroll
-                    for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1]);
+                    for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], w[r]);
 #pragma unroll
-                    for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1], t[r]);
-                    dft_to<R>(v, rt, dst + a * ROW + th.ob[ob_base(s) + j], ns);
+                    for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], w[r], t[r]);
+                    dft_to<R>(v, rt, dst + a * ROW + ob, ns);
                 }
             }
         }
     }
 
     // ---- the last stage (s = S - 1 >= 1): LDS -> registers -> X.  live[u]: frame u of the step exists for this slot
-    FXC_HD void last_stage(const cf* src, const bool (&live)[U], long long f) {
+    FXC_HD void last_stage(const cf* src, const bool (&live)[U], long long f, const pk2* w1 = nullptr) {
         constexpr int s = S - 1, R = RL, nb = nb_of(s);
         const fxc::Roots<R> rt = fxc::load_roots<R>(ar.tw, nb);
 #pragma unroll
         for (int j = 0; j < JL; ++j) {
             const int b = lt + j * TPR;
+            pk2 w[R];
+            stage_tw<s>(j, w, w1);
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (live[u] && has_bfly(s, j, lt)) {
@@ -407,9 +471,9 @@ struct Body {
 #pragma unroll
                         for (int r = 0; r < R; ++r) v[r] = pk(src[(u * 2 + a) * ROW + b + r * nb]);
 #pragma unroll
-                        for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1]);
+                        for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], w[r]);
 #pragma unroll
-                        for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], th.tw[tw_base(s) + j * (R - 1) + r - 1], t[r]);
+                        for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], w[r], t[r]);
                         dft_regs<R>(v, rt, o[a]);
                         }
                     emit<R>(o, j, f + u);
@@ -454,6 +518,10 @@ struct Body {
         bool live[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) live[u] = f + u < f_end;
+        if constexpr (LEAN) {
+            step_lean<P>(f, f_end, live);
+            return;
+        }
         pk2 acc[U][2][PTS];
 #pragma unroll
         for (int t = 0; t < T; ++t)                     // (tap outside: consecutive instructions belong to different points)
@@ -463,7 +531,7 @@ struct Body {
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int p = 0; p < PTS; ++p) {
-                        const pk2 w = pk_splat(hw2[(t * PTS + p) / 2][(t * PTS + p) % 2]);
+                        const pk2 w = pk_splat(hw2[LEAN ? 0 : (t * PTS + p) / 2][(t * PTS + p) % 2]);
                         const pk2 x = th.ring[a][p][(P + u - t + NS) % NS];
                         acc[u][a][p] = t == 0 ? w * x : pk_fma(w, x, acc[u][a][p]);
                     }
@@ -512,6 +580,74 @@ struct Body {
         }
     }
 
+    // LEAN: stage s reads rd and writes wr with the first twiddles w1; the next stage's are requested before, the last stage ends in X
+    template <int s>
+    FXC_HD void lean_stages(cf* rd, cf* wr, const pk2 (&w1)[j_of(s)], const bool (&live)[U], long long f) {
+        if constexpr (s < S - 1) {
+            pk2 nxt[j_of(s + 1)];
+            load_tw1<s + 1>(nxt);
+            mid_stage<s>(rd, wr, w1);
+            cx.sync();
+            lean_stages<s + 1>(wr, rd, nxt, live, f);
+        } else {
+            last_stage(rd, live, f, w1);
+        }
+    }
+
+    // LEAN (S >= 2): one first-stage butterfly at a time -- its points' taps from L2, their FIR, the next frames' samples into the
+    // ring slots those points have just left, the butterfly into LDS -- so that only R0 points' taps and sums are live at once
+    template <int P>
+    FXC_HD void step_lean(long long f, long long f_end, const bool (&live)[U]) {
+        static_assert(!LEAN || S >= 2, "the lean build is for frames of thousands of channels");
+        const fxc::Roots<R0> rt = fxc::load_roots<R0>(ar.tw, nb_of(0));
+        pk2 w1[j_of(1)];
+        load_tw1<1>(w1);
+#pragma unroll
+        for (int j = 0; j < J0; ++j) {
+            float hq[R0][4];
+#pragma unroll
+            for (int r = 0; r < R0; ++r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+                const v4u32 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (unsigned)(lt + j * TPR) * 16u, (unsigned)(r * nb_of(0)) * 16u, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hq[r][t] = __uint_as_float(q[t]);      // (past the table: zeros, and so are those lanes' samples)
+#else
+                const int m = has_bfly(0, j, lt) ? lt + j * TPR + r * nb_of(0) : 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hq[r][t] = ar.h4[4 * m + t];
+#endif
+            }
+            pk2 acc[U][2][R0];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int r = 0; r < R0; ++r) {
+                            const pk2 x = th.ring[a][j * R0 + r][(P + u - t + NS) % NS];
+                            acc[u][a][r] = t == 0 ? pk_splat(hq[r][t]) * x : pk_fma(pk_splat(hq[r][t]), x, acc[u][a][r]);
+                        }
+            load_points<(P + U) % NS>(f + U, f + U < f_end, j);
+            if constexpr (U == 2) load_points<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end, j);
+            if (has_bfly(0, j, lt)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) dft_to<R0>(acc[u][a], rt, bx + (u * 2 + a) * ROW + (lt + j * TPR) * R0, 1);
+            }
+        }
+        cx.sync();
+        lean_stages<1>(bx, by, w1, live, f);
+        if constexpr (SWAP) {
+            cf* t = bx;
+            bx = by;
+            by = t;
+        }
+    }
+
     // UNR steps per trip: step k of a trip starts at ring slot (k U) mod NS
     template <int K>
     FXC_HD void steps(long long f, long long f_end, long long i, long long n_steps) {
@@ -554,6 +690,12 @@ struct Body {
                                                         (int)(ar.num_samp * kElem), 0x00020000);
 #endif
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (LEAN) {
+            rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ar.h4), 0, N * 16, 0x00020000);
+            rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(ar.tw1), 0, TW1C * TPR * 8, 0x00020000);
+        }
+#endif
         // zero history in front of the chunk; a run that starts inside it re-reads T - 1 frames
         preload<0>(f0, f1);
         for (long long i = 0; i < n_steps; i += UNR) steps<0>(f0 + i * U, f1, i, n_steps);

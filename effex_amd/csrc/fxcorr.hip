@@ -338,6 +338,20 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             }
         }
         p->rtc = env_int("FXC_RTC", 1) != 0;      // (read once, when the plan is made)
+        if (p->mixed && p->rtc && N > kSpecLeanAbove && T <= 4 && !p->d_win4) {
+            // the lean builds of fx_spec.h (above 2048 channels) read a point's taps as one quad from L2: [N][4], zeros beyond T
+            std::vector<f4> w4((size_t)N);
+            for (int m = 0; m < N; ++m) {
+                f4 w;
+                w.x = wf[m];
+                w.y = T > 1 ? wf[(size_t)1 * N + m] : 0.f;
+                w.z = T > 2 ? wf[(size_t)2 * N + m] : 0.f;
+                w.w = T > 3 ? wf[(size_t)3 * N + m] : 0.f;
+                w4[(size_t)m] = w;
+            }
+            FXC_HIP(p, hipMalloc(&p->d_win4, w4.size() * sizeof(f4)));
+            FXC_HIP(p, hipMemcpy(p->d_win4, w4.data(), w4.size() * sizeof(f4), hipMemcpyHostToDevice));
+        }
         p->mixed_xeng = p->mixed && p->n_ant >= 3 && env_int("FXC_MIXED_XENGINE", 1);
         if (p->mixed && !p->mixed_blu && p->n_ant == 2 && env_int("FXC_MIXED_XF", 1)) {
             const size_t rpw = (size_t)(std::max(256, p->mixed_tpr) / p->mixed_tpr);
@@ -782,8 +796,9 @@ int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* re
         std::string radices;
         for (int i = 0; i < sh.n_stages; ++i) radices += (i ? "," : "") + std::to_string(sh.radix[i]);
         std::snprintf(report, (size_t)report_bytes,
-                      "nchan=%d ntaps=%d tpr=%d slots=%d frames_per_step=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld resident=%d",
-                      sh.n, sh.taps, sh.tpr, sh.slots, sh.u, radices.c_str(), sh.lds_bytes(), b.image.size(), b.vgprs, b.scratch, b.resident);
+                      "nchan=%d ntaps=%d tpr=%d slots=%d frames_per_step=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld resident=%d lean=%d",
+                      sh.n, sh.taps, sh.tpr, sh.slots, sh.u, radices.c_str(), sh.lds_bytes(), b.image.size(), b.vgprs, b.scratch, b.resident,
+                      (int)sh.lean);
     }
     return FXC_OK;
 }

@@ -57,7 +57,8 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
             const int64_t pairs = (n_streams + 1) / 2;
             const int64_t ws = spec_wg_splits(p, k, pairs, false);
             if (pairs * ws > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many streams for one launch");
-            SpecArgs a = {x, p->d_win, spec, p->d_tw, nullptr, (long long)p->num_samp, (long long)p->n_pts, (long long)n_streams, (int)ws, ant};
+            SpecArgs a = {x, p->d_win, spec, p->d_tw, nullptr, (long long)p->num_samp, (long long)p->n_pts, (long long)n_streams, (int)ws, ant,
+                          reinterpret_cast<const float*>(p->d_win4), k->d_tw1};
             void* params[] = {&a};
             FXC_HIP(p, hipModuleLaunchKernel(k->fn, (unsigned)(pairs * ws), 1, 1, (unsigned)k->shape.threads(), 1, 1, 0, p->stream, params, nullptr));
             return FXC_OK;
@@ -148,7 +149,8 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
             const int wg_splits = n_splits / k->shape.slots;
             const int64_t grid = n_chunks * wg_splits;
             if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
-            SpecArgs a = {x, p->d_win, raw, p->d_tw, dc_u8, (long long)p->num_samp, (long long)p->n_pts, (long long)n_chunks, wg_splits, 1};
+            SpecArgs a = {x, p->d_win, raw, p->d_tw, dc_u8, (long long)p->num_samp, (long long)p->n_pts, (long long)n_chunks, wg_splits, 1,
+                          reinterpret_cast<const float*>(p->d_win4), k->d_tw1};
             void* params[] = {&a};
             FXC_HIP(p, hipModuleLaunchKernel(k->fn, (unsigned)grid, 1, 1, (unsigned)k->shape.threads(), 1, 1, 0, p->stream, params, nullptr));
             return FXC_OK;

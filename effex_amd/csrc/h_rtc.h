@@ -82,10 +82,13 @@ RtcApi* rtc_api() {
 }
 
 // how fx_spec.h is cut for one channel count: stage order, threads per slot, slots per workgroup
+constexpr int kSpecLeanAbove = 2048;
+
 struct SpecShape {
     bool ok = false;
     int n = 0, taps = 0, n_stages = 0, radix[fxc::kMixedMaxStages] = {0}, tpr = 0, slots = 0;
     int u = 1;                   // frames a slot carries through a step together
+    bool lean = false;           // FXM_LEAN: taps and first twiddles from L2 tables, nothing but the ring and the sums kept in registers
     int threads() const { return tpr * slots; }
     size_t lds_bytes() const { return n_stages >= 2 ? (size_t)slots * 4 * u * n * sizeof(cf) : 0; }
 };
@@ -94,7 +97,8 @@ struct SpecShape {
 // (2, 3, 4, 5, 7, 11, 13), a thread's points (first radix x its first-stage butterflies) fit the ring (<= 8), the slots'
 // rows fit the LDS.  `first`: the radix of the first stage (0: fx_mixed.h's order -- fours, a two, the odd primes ascending);
 // it sets the threads per slot (N / first butterflies), the points a thread keeps in its ring (first of them) and the LDS
-// bank pattern of the first stage's stores (an odd stride is conflict-free).  `u`: frames per step.
+// bank pattern of the first stage's stores (an odd stride is conflict-free).  `u`: frames per step.  Above 2048 channels: the
+// lean build (fx_spec.h, FXM_LEAN), up to 512 threads a frame with up to two first-stage butterflies each.
 SpecShape spec_shape(int n, int taps, int first = 0, int u = 1) {
     SpecShape s;
     if (n < 2 || n > 8192 || taps < 1 || taps > 4) return s;
@@ -122,12 +126,14 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1) {
         s.tpr = 1;
         while (s.tpr < nb0) s.tpr <<= 1;
     } else {
-        j0 = (nb0 + 1023) / 1024;
+        j0 = n > kSpecLeanAbove ? (nb0 + 511) / 512 : (nb0 + 1023) / 1024;
         s.tpr = ((nb0 + j0 - 1) / j0 + 63) / 64 * 64;
     }
     s.slots = std::max(1, 256 / s.tpr);
     if (s.radix[0] * j0 > 8) return s;
     s.u = u;
+    s.lean = n > kSpecLeanAbove;
+    if (s.lean && s.n_stages < 2) return s;
     if (u != 1 && (u != 2 || s.n_stages < 2)) return s;      // (whether two frames' rows cost a resident workgroup: spec_search)
     if (s.lds_bytes() > (size_t)(160 * 1024)) return s;
     s.ok = true;
@@ -170,6 +176,7 @@ struct SpecKernel {
     SpecShape shape;
     int wgs_per_cu = 1;          // resident workgroups per CU (occupancy query)
     int vgprs = 0;
+    cf* d_tw1 = nullptr;         // lean builds: the first twiddles by stage, butterfly and thread (fx_spec.h, Args::tw1)
     std::string error;           // why there is none (fn == nullptr)
 };
 
@@ -183,7 +190,29 @@ struct SpecArgs {
     long long num_samp, n_pts, n_chunks;
     int wg_splits;
     int ant;
+    const float* h4;
+    const cf* tw1;
 };
+
+// Args::tw1 of a lean build: row tw_base(s) + j (stages 1 .. S-1, the thread's j-th butterfly) holds, at thread lt, the twiddle
+// exp(+2 pi i (b mod ns) (nb / ns) / N) of butterfly b = lt + j tpr (b = 0 where the thread has none) -- the values of the
+// plan's own table (fxcorr.hip: float32 of the float64 cosine and sine)
+std::vector<cf> spec_tw1_table(const SpecShape& sh) {
+    std::vector<cf> t;
+    int ns = sh.radix[0];
+    for (int s = 1; s < sh.n_stages; ++s) {
+        const int nb = sh.n / sh.radix[s], jn = (nb + sh.tpr - 1) / sh.tpr, tmul = nb / ns;
+        for (int j = 0; j < jn; ++j)
+            for (int lt = 0; lt < sh.tpr; ++lt) {
+                int b = lt + j * sh.tpr;
+                if (b >= nb) b = 0;
+                const double ph = 6.283185307179586476925286766559 * (double)((b % ns) * tmul) / (double)sh.n;
+                t.push_back(fxc::mk((float)std::cos(ph), (float)std::sin(ph)));
+            }
+        ns *= sh.radix[s];
+    }
+    return t;
+}
 
 std::mutex g_spec_mutex;
 std::map<std::string, SpecKernel*> g_spec_cache;     // (device, shape) -> kernel; entries live as long as the process
@@ -288,7 +317,7 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXM_TPR=" + std::to_string(shape.tpr), "-DFXM_SLOTS=" + std::to_string(shape.slots),
                                      "-DFXM_NST=" + std::to_string(shape.n_stages), "-DFXM_RADICES=" + radices,
                                      "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)), "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly)),
-                                     "-DFXM_U=" + std::to_string(shape.u),
+                                     "-DFXM_U=" + std::to_string(shape.u), "-DFXM_LEAN=" + std::to_string((int)shape.lean),
                                      "-DFXM_ABL=" + std::to_string(spec_ablation())};      // (timing ablations: wrong results, developer library only)
     const std::string dir = spec_cache_dir();
     const std::string cached = dir.empty() ? std::string() : dir + "/" + spec_cache_key(opts, api) + ".co";
@@ -418,6 +447,15 @@ const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
         k->error = std::string("loading the compiled kernel: ") + hipGetErrorString(e);
         k->fn = nullptr;
         return k;
+    }
+    if (k->shape.lean) {
+        const std::vector<cf> t = spec_tw1_table(k->shape);
+        if (hipMalloc(&k->d_tw1, t.size() * sizeof(cf)) != hipSuccess ||
+            hipMemcpy(k->d_tw1, t.data(), t.size() * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess) {
+            k->error = "the twiddle table of the lean build: out of device memory";
+            k->fn = nullptr;
+            return k;
+        }
     }
     int blocks = 0;
     k->wgs_per_cu = std::max(1, b.resident);

@@ -36,8 +36,25 @@ int emul_spec_fonly() { return fxm::FONLY ? 1 : 0; }
 // F only (FXM_FONLY): n_chunks = the number of streams, `out` = spec[stream / ant][frame][stream % ant][N]
 int emul_spec_run(const void* x, const float* h, void* out, const void* tw, const void* dc_u8, long long num_samp, long long n_pts,
                   long long n_chunks, int wg_splits, int ant) {
+    // the lean build's tables, from fx_spec.h's own definitions of them (the library builds them from the shape: h_rtc.h)
+    std::vector<float> h4((size_t)fxm::N * 4, 0.f);
+    for (int m = 0; m < fxm::N; ++m)
+        for (int t = 0; t < fxm::T; ++t) h4[(size_t)4 * m + t] = h[(size_t)t * fxm::N + m];
+    std::vector<fxm::cf> tw1((size_t)(fxm::TW1C > 0 ? fxm::TW1C : 1) * fxm::TPR);
+    {
+        const fxm::cf* twc = static_cast<const fxm::cf*>(tw);
+        int row = 0;
+        for (int s = 1; s < fxm::S; ++s) {
+            const int nb = fxm::nb_of(s), ns = fxm::ns_of(s);
+            for (int j = 0; j < fxm::j_of(s); ++j, ++row)
+                for (int lt = 0; lt < fxm::TPR; ++lt) {
+                    const int b = lt + j * fxm::TPR < nb ? lt + j * fxm::TPR : 0;
+                    if (fxm::LEAN) tw1[(size_t)row * fxm::TPR + lt] = twc[(b % ns) * (nb / ns)];
+                }
+        }
+    }
     const fxm::Args args = {x, h, static_cast<fxm::cf*>(out), static_cast<const fxm::cf*>(tw), static_cast<const fxm::cf*>(dc_u8),
-                            num_samp, n_pts, n_chunks, wg_splits, ant};
+                            num_samp, n_pts, n_chunks, wg_splits, ant, h4.data(), tw1.data()};
     const long long groups = fxm::FONLY ? (n_chunks + 1) / 2 : n_chunks;      // workgroups per split: chunk pairs, or pairs of streams
     for (long long bid = 0; bid < groups * wg_splits; ++bid) {
         std::vector<fxm::cf> lds((size_t)fxm::SLOTS * fxm::LDS_PER_SLOT + 1);

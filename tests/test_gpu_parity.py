@@ -881,7 +881,7 @@ def test_long_chunks_of_few_channels_keep_float32_runs_short(plan_mod, torch, mo
 
 @pytest.mark.parametrize("n_ant,nchan,ntaps,n_streams,frames,extra", [
     (1, 1000, 4, 5, 60, 3), (1, 96, 4, 333, 40, 0), (1, 720, 3, 2, 17, 1), (1, 250, 1, 1, 1, 0), (1, 2000, 4, 3, 9, 0),
-    (3, 1000, 4, 4, 30, 5), (5, 96, 2, 3, 100, 0)])
+    (3, 1000, 4, 4, 30, 5), (5, 96, 2, 3, 100, 0), (1, 3000, 4, 5, 12, 1), (3, 2400, 4, 2, 11, 0), (1, 4000, 4, 3, 8, 0)])
 def test_specialised_f_stage_on_the_device(plan_mod, torch, monkeypatch, n_ant, nchan, ntaps, n_streams, frames, extra):
     """fxc_channelize (the drop-in's _spectrometer_poly, effex.py:530-555) at channel counts that are not a power of two runs
     fx_spec.h built as the F stage alone -- a pair of streams per workgroup, odd stream counts included; 3 and more antennas
@@ -910,7 +910,9 @@ def test_specialised_f_stage_on_the_device(plan_mod, torch, monkeypatch, n_ant, 
 
 @pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [
     (1000, 4, 700, 40, 3), (1000, 4, 3, 262, 144), (96, 4, 2100, 25, 0), (1536, 4, 5, 170, 1), (720, 3, 64, 33, 2), (250, 2, 9, 1000, 0),
-    (12, 4, 3, 20000, 5), (2000, 4, 1, 131, 0), (1001, 4, 2, 11, 0), (600, 1, 40, 50, 7), (20, 4, 1, 1, 0), (7, 1, 300, 90, 0)])
+    (12, 4, 3, 20000, 5), (2000, 4, 1, 131, 0), (1001, 4, 2, 11, 0), (600, 1, 40, 50, 7), (20, 4, 1, 1, 0), (7, 1, 300, 90, 0),
+    # above 2048 channels: the lean build (taps and first twiddles from tables in L2)
+    (3000, 4, 300, 21, 7), (4000, 4, 2, 65, 0), (2560, 3, 5, 40, 1), (2400, 4, 700, 9, 0), (3072, 2, 3, 1, 0)])
 def test_specialised_kernel_on_the_device(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
     """The F+X kernel compiled for one channel count when the plan is made (fx_spec.h through hiprtc, h_rtc.h) -- every shape
     class the host emulation covers (tests/test_emul.py), here on the device and at launch sizes that take several rounds of

@@ -107,11 +107,11 @@ def test_no_flat_memory_instructions(asm_listing):
 
 
 @needs_hipcc
-@pytest.mark.parametrize("nchan,variant", [(1000, 0), (96, 0), (720, 0), (1000, 1), (1000, 2), (1536, 0)])
+@pytest.mark.parametrize("nchan,variant", [(1000, 0), (96, 0), (720, 0), (1000, 1), (1000, 2), (1536, 0), (3000, 0), (4000, 0), (4000, 2)])
 def test_specialised_kernels_keep_their_registers(tmp_path, nchan, variant):
     """fx_spec.h as the library builds it for one channel count (the options fxc_spec_probe reports; variant 0 / 1 / 2 = complex64,
     bytes, F only), compiled here with hipcc and -- by the probe itself -- with the hiprtc the process has: no scratch under
-    either compiler (the ring, the taps and the twiddles are registers or nothing), at most 256 registers where the build means to
+    either compiler (the ring, the taps and the twiddles are registers or -- the lean build above 2048 channels -- loads from tables, never the stack), at most 256 registers where the build means to
     keep two workgroups of 256 threads on a CU, no flat or scratch memory instruction, the samples through buffer loads, and one
     barrier per LDS round trip (S - 1 per step)."""
     import ctypes
@@ -122,7 +122,8 @@ def test_specialised_kernels_keep_their_registers(tmp_path, nchan, variant):
     assert int(rep["scratch"]) == 0 and 0 < int(rep["vgprs"]) <= 512 // max(1, (int(rep["tpr"]) * int(rep["slots"]) // 64 + 3) // 4 * int(rep["resident"]))
     stages = rep["stages"].split(",")
     flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=4", "-DFXM_TPR=" + rep["tpr"], "-DFXM_SLOTS=" + rep["slots"], "-DFXM_NST=%d" % len(stages),
-             "-DFXM_RADICES=" + rep["stages"], "-DFXM_U8=%d" % int(variant == 1), "-DFXM_FONLY=%d" % int(variant == 2), "-DFXM_U=" + rep["frames_per_step"]]
+             "-DFXM_RADICES=" + rep["stages"], "-DFXM_U8=%d" % int(variant == 1), "-DFXM_FONLY=%d" % int(variant == 2), "-DFXM_U=" + rep["frames_per_step"],
+             "-DFXM_LEAN=" + rep["lean"]]
     src = tmp_path / "spec.hip"
     src.write_text('#include "fx_spec.h"\n')
     asm = tmp_path / "spec.s"
