@@ -51,6 +51,11 @@
 #ifndef FXM_LEAN
 #define FXM_LEAN 0
 #endif
+// FXM_ROWS 1 (F only): a workgroup carries ONE stream instead of a pair -- a thread then has room for sixteen points of it (128
+// registers of ring): the F stage of 4097 ... 8192 channels.
+#ifndef FXM_ROWS
+#define FXM_ROWS 2
+#endif
 
 namespace fxm {
 
@@ -72,6 +77,7 @@ constexpr bool U8 = FXM_U8 != 0;
 constexpr int U = FXM_U;
 constexpr bool FONLY = FXM_FONLY != 0;
 constexpr bool LEAN = FXM_LEAN != 0;
+constexpr int NA = FXM_ROWS;                     // streams a workgroup carries through a step: the two antennas, or (F only) one or two streams
 constexpr int THREADS = TPR * SLOTS;
 // The ring: the frames a step needs -- its own U and the T - 1 before them -- in NS = T + U - 1 slots, frame g of a run in
 // slot g mod NS; the next step's U frames land in the U slots the FIR has just finished with.  The slot pattern repeats after
@@ -105,21 +111,22 @@ constexpr int TWC = LEAN ? 0 : tw_base(S), OBC = LEAN ? 0 : ob_base(S > 1 ? S - 
 constexpr int TW1C = tw_base(S);                 // LEAN: rows of Args::tw1, [TW1C][TPR]
 constexpr bool SWAP = S >= 2 && S % 2 == 0;      // the last stage reads the buffer the next frame's first stage writes: alternate them
 constexpr int ROW = N;                           // one antenna's row; a slot's LDS: [buffer X | Y][frame of the step][antenna][N]
-constexpr int ROWS = 2 * U;                      // rows a step carries: (frame u, antenna a) -> u * 2 + a
+constexpr int ROWS = NA * U;                     // rows a step carries: (frame u, antenna a) -> u * NA + a
 constexpr int LDS_PER_SLOT = S >= 2 ? 2 * ROWS * N : 0; // complex64 elements
 
 static_assert(ns_of(S) == N, "the radices multiply to N");
 static_assert(T >= 1 && T <= 4, "one to four taps (the ring lives in registers)");
 static_assert(U == 1 || U == 2, "one or two frames per step");
+static_assert(NA == 2 || (NA == 1 && FONLY), "one stream per workgroup: the F stage alone");
 static_assert(!(FONLY && U8), "the byte ingest is the two-antenna kernel's");
 static_assert(SLOTS >= 1 && (SLOTS == 1 || TPR % 64 == 0 || 64 % TPR == 0), "slots do not straddle waves");
 
 // per-thread state, all of it registers once the loops below are unrolled
 struct Thread {
-    pk2 ring[2][PTS][NS];            // frame g's samples of the thread's points in slot g mod NS (g counted from the run's first frame)
+    pk2 ring[NA][PTS][NS];            // frame g's samples of the thread's points in slot g mod NS (g counted from the run's first frame)
     pk2 tw[TWC > 0 ? TWC : 1];       // twiddles of the thread's butterflies in stages 1 .. S-1
     int ob[OBC > 0 ? OBC : 1];       // where the butterflies of stages 1 .. S-2 put their outputs
-    pk2 xacc[JL * RL];               // sum over the run of s0 conj(s1) at the bins the thread's last butterflies produce
+    pk2 xacc[FONLY ? 1 : JL * RL];               // sum over the run of s0 conj(s1) at the bins the thread's last butterflies produce
 };
 
 // Complex arithmetic on register pairs with the operand modifiers of the packed instructions (op_sel picks the half of a
@@ -311,7 +318,7 @@ struct Body {
         }
         if constexpr (!LEAN) init_stage<1>();
 #pragma unroll
-        for (int i = 0; i < JL * RL; ++i) th.xacc[i] = pk_splat(0.f);
+        for (int i = 0; i < (FONLY ? 1 : JL * RL); ++i) th.xacc[i] = pk_splat(0.f);
     }
     template <int s>
     FXC_HD void init_stage() {
@@ -351,7 +358,7 @@ struct Body {
         const unsigned voff = (unsigned)((int)(f * N) + (N - 1 - lt - j * TPR - (R0 - 1) * nb_of(0))) * (unsigned)kElem;      // a chunk is below 2 GiB
 #endif
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NA; ++a)
             {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
@@ -464,12 +471,12 @@ struct Body {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (live[u] && has_bfly(s, j, lt)) {
-                    pk2 o[2][R];
+                    pk2 o[NA][R];
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
+                    for (int a = 0; a < NA; ++a) {
                         pk2 v[R], t[R];
 #pragma unroll
-                        for (int r = 0; r < R; ++r) v[r] = pk(src[(u * 2 + a) * ROW + b + r * nb]);
+                        for (int r = 0; r < R; ++r) v[r] = pk(src[(u * NA + a) * ROW + b + r * nb]);
 #pragma unroll
                         for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], w[r]);
 #pragma unroll
@@ -484,10 +491,10 @@ struct Body {
     // the two rows' spectra of one butterfly of the last stage: X-multiplied into the thread's sums, or (F only) stored -- output q of
     // butterfly b is bin b + q N/R there, so the lanes of a wave write R runs of consecutive bins
     template <int R>
-    FXC_HD void emit(pk2 (&o)[2][R], int j, long long frame) {
+    FXC_HD void emit(pk2 (&o)[NA][R], int j, long long frame) {
         if constexpr (FONLY) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < NA; ++a)
                 if (row_ok[a]) {
                     cf* d = row_out[a] + frame * (long long)ar.ant * N + lt + j * TPR;
 #pragma unroll
@@ -495,9 +502,9 @@ struct Body {
                 }
         } else {
 #pragma unroll
-            for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_lo(th.xacc[j * R + q], o[0][q], o[1][q]);
+            for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_lo(th.xacc[j * R + q], o[0][q], o[NA - 1][q]);
 #pragma unroll
-            for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_hi(th.xacc[j * R + q], o[0][q], o[1][q]);
+            for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_hi(th.xacc[j * R + q], o[0][q], o[NA - 1][q]);
         }
     }
 
@@ -522,13 +529,13 @@ struct Body {
             step_lean<P>(f, f_end, live);
             return;
         }
-        pk2 acc[U][2][PTS];
+        pk2 acc[U][NA][PTS];
 #pragma unroll
         for (int t = 0; t < T; ++t)                     // (tap outside: consecutive instructions belong to different points)
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < NA; ++a)
 #pragma unroll
                     for (int p = 0; p < PTS; ++p) {
                         const pk2 w = pk_splat(hw2[LEAN ? 0 : (t * PTS + p) / 2][(t * PTS + p) % 2]);
@@ -545,9 +552,9 @@ struct Body {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     if (live[u] && has_bfly(0, j, lt)) {
-                        pk2 o[2][R0];
+                        pk2 o[NA][R0];
 #pragma unroll
-                        for (int a = 0; a < 2; ++a) {
+                        for (int a = 0; a < NA; ++a) {
                             pk2 v[R0];
 #pragma unroll
                             for (int r = 0; r < R0; ++r) v[r] = acc[u][a][j * R0 + r];
@@ -562,11 +569,11 @@ struct Body {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
 #pragma unroll
-                        for (int a = 0; a < 2; ++a) {
+                        for (int a = 0; a < NA; ++a) {
                             pk2 v[R0];
 #pragma unroll
                             for (int r = 0; r < R0; ++r) v[r] = acc[u][a][j * R0 + r];
-                            dft_to<R0>(v, rt, bx + (u * 2 + a) * ROW + (lt + j * TPR) * R0, 1);      // ns = 1: o = b R0
+                            dft_to<R0>(v, rt, bx + (u * NA + a) * ROW + (lt + j * TPR) * R0, 1);      // ns = 1: o = b R0
                         }
                 }
             cx.sync();
@@ -618,13 +625,13 @@ struct Body {
                 for (int t = 0; t < 4; ++t) hq[r][t] = ar.h4[4 * m + t];
 #endif
             }
-            pk2 acc[U][2][R0];
+            pk2 acc[U][NA][R0];
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
+                    for (int a = 0; a < NA; ++a)
 #pragma unroll
                         for (int r = 0; r < R0; ++r) {
                             const pk2 x = th.ring[a][j * R0 + r][(P + u - t + NS) % NS];
@@ -636,7 +643,7 @@ struct Body {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) dft_to<R0>(acc[u][a], rt, bx + (u * 2 + a) * ROW + (lt + j * TPR) * R0, 1);
+                    for (int a = 0; a < NA; ++a) dft_to<R0>(acc[u][a], rt, bx + (u * NA + a) * ROW + (lt + j * TPR) * R0, 1);
             }
         }
         cx.sync();
@@ -677,14 +684,14 @@ struct Body {
         const long long f0 = (long long)e * ar.n_pts / E, f1 = ((long long)e + 1) * ar.n_pts / E;
         const long long n_steps = ((ar.n_pts + E - 1) / E + U - 1) / U;       // steps of the longest run of any slot: uniform
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const long long st = 2 * chunk + a;                     // F only: the row's stream; `chunk` counts pairs of streams
+        for (int a = 0; a < NA; ++a) {
+            const long long st = NA * chunk + a;                    // F only: the row's stream; `chunk` counts groups of NA streams
             row_ok[a] = !FONLY || st < ar.n_chunks;
             const long long oc = FONLY && row_ok[a] ? st / ar.ant : 0;
             row_out[a] = FONLY && row_ok[a] ? ar.out + ((oc * ar.n_pts) * ar.ant + (st - oc * ar.ant)) * N : nullptr;
-            xs[a] = reinterpret_cast<const cf*>(ar.x) + (2 * chunk + a) * ar.num_samp;
-            xb[a] = reinterpret_cast<const unsigned short*>(ar.x) + (2 * chunk + a) * ar.num_samp;
-            off8[a] = U8 ? pk(ar.dc_u8[2 * chunk + a]) : pk_splat(0.f);
+            xs[a] = reinterpret_cast<const cf*>(ar.x) + st * ar.num_samp;
+            xb[a] = reinterpret_cast<const unsigned short*>(ar.x) + st * ar.num_samp;
+            off8[a] = U8 ? pk(ar.dc_u8[st]) : pk_splat(0.f);
 #if defined(__HIP_DEVICE_COMPILE__)
             rsrc[a] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(ar.x)) + (row_ok[a] ? st : 0) * ar.num_samp * kElem, 0,
                                                         (int)(ar.num_samp * kElem), 0x00020000);
@@ -699,14 +706,15 @@ struct Body {
         // zero history in front of the chunk; a run that starts inside it re-reads T - 1 frames
         preload<0>(f0, f1);
         for (long long i = 0; i < n_steps; i += UNR) steps<0>(f0 + i * U, f1, i, n_steps);
-        if constexpr (FONLY) return;
-        // the thread's bins: the last stage's butterfly b puts output q at b + q N/RL (k = b there: ns = N/RL)
-        cf* o = ar.out + ((long long)e * ar.n_chunks + chunk) * N;
+        if constexpr (!FONLY) {
+            // the thread's bins: the last stage's butterfly b puts output q at b + q N/RL (k = b there: ns = N/RL)
+            cf* o = ar.out + ((long long)e * ar.n_chunks + chunk) * N;
 #pragma unroll
-        for (int j = 0; j < JL; ++j)
-            if (has_bfly(S - 1, j, lt))
+            for (int j = 0; j < JL; ++j)
+                if (has_bfly(S - 1, j, lt))
 #pragma unroll
-                for (int q = 0; q < RL; ++q) o[lt + j * TPR + q * nb_of(S - 1)] = unpk(th.xacc[j * RL + q]);
+                    for (int q = 0; q < RL; ++q) o[lt + j * TPR + q * nb_of(S - 1)] = unpk(th.xacc[j * RL + q]);
+        }
     }
 };
 

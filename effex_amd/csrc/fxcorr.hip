@@ -338,7 +338,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             }
         }
         p->rtc = env_int("FXC_RTC", 1) != 0;      // (read once, when the plan is made)
-        if (p->mixed && p->rtc && N > kSpecLeanAbove && T <= 4 && !p->d_win4) {
+        if (p->mixed && p->rtc && N > spec_lean_above() && T <= 4 && !p->d_win4) {
             // the lean builds of fx_spec.h (above 2048 channels) read a point's taps as one quad from L2: [N][4], zeros beyond T
             std::vector<f4> w4((size_t)N);
             for (int m = 0; m < N; ++m) {
@@ -779,7 +779,7 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
 int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* report, int report_bytes) {
     if (variant < 0 || variant > 2) return fail(nullptr, FXC_ERR_ARG, "variant %d: 0 complex64 F+X, 1 bytes F+X, 2 F only", variant);
     if (report && report_bytes > 0) report[0] = 0;
-    if (spec_first_radices(nchan, ntaps).empty())
+    if (spec_first_radices(nchan, ntaps, spec_rows(nchan, variant)).empty())
         return fail(nullptr, FXC_ERR_UNSUPPORTED, "no specialised kernel for %d channels, %d taps", nchan, ntaps);
     std::string target = arch ? arch : "";
     if (target.empty()) {
@@ -796,9 +796,9 @@ int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* re
         std::string radices;
         for (int i = 0; i < sh.n_stages; ++i) radices += (i ? "," : "") + std::to_string(sh.radix[i]);
         std::snprintf(report, (size_t)report_bytes,
-                      "nchan=%d ntaps=%d tpr=%d slots=%d frames_per_step=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld resident=%d lean=%d",
+                      "nchan=%d ntaps=%d tpr=%d slots=%d frames_per_step=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld resident=%d lean=%d rows=%d",
                       sh.n, sh.taps, sh.tpr, sh.slots, sh.u, radices.c_str(), sh.lds_bytes(), b.image.size(), b.vgprs, b.scratch, b.resident,
-                      (int)sh.lean);
+                      (int)sh.lean, sh.rows);
     }
     return FXC_OK;
 }

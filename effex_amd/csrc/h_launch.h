@@ -48,13 +48,13 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
         // stages, the last butterfly stores the spectra); compiled on first use
         if (!p->spec_f_tried) {
             p->spec_f_tried = true;
-            if (!spec_first_radices(p->nchan, p->ntaps).empty()) {
+            if (!spec_first_radices(p->nchan, p->ntaps, spec_rows(p->nchan, kSpecFOnly)).empty()) {
                 const SpecKernel* k = spec_kernel(p->device, p->nchan, p->ntaps, kSpecFOnly);
                 p->spec_f = k->fn ? k : nullptr;
             }
         }
         if (const SpecKernel* k = p->spec_f) {
-            const int64_t pairs = (n_streams + 1) / 2;
+            const int64_t pairs = (n_streams + k->shape.rows - 1) / k->shape.rows;      // (groups of streams: a workgroup's rows)
             const int64_t ws = spec_wg_splits(p, k, pairs, false);
             if (pairs * ws > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many streams for one launch");
             SpecArgs a = {x, p->d_win, spec, p->d_tw, nullptr, (long long)p->num_samp, (long long)p->n_pts, (long long)n_streams, (int)ws, ant,

@@ -83,14 +83,16 @@ RtcApi* rtc_api() {
 
 // how fx_spec.h is cut for one channel count: stage order, threads per slot, slots per workgroup
 constexpr int kSpecLeanAbove = 2048;
+inline int spec_lean_above() { return env_int("FXC_RTC_LEAN_ABOVE", kSpecLeanAbove); }      // (developer knob)
 
 struct SpecShape {
     bool ok = false;
     int n = 0, taps = 0, n_stages = 0, radix[fxc::kMixedMaxStages] = {0}, tpr = 0, slots = 0;
     int u = 1;                   // frames a slot carries through a step together
+    int rows = 2;                // streams a workgroup carries: the two antennas / a pair of streams, or (F only, above 4096 channels) one
     bool lean = false;           // FXM_LEAN: taps and first twiddles from L2 tables, nothing but the ring and the sums kept in registers
     int threads() const { return tpr * slots; }
-    size_t lds_bytes() const { return n_stages >= 2 ? (size_t)slots * 4 * u * n * sizeof(cf) : 0; }
+    size_t lds_bytes() const { return n_stages >= 2 ? (size_t)slots * 2 * rows * u * n * sizeof(cf) : 0; }
 };
 
 // Eligible: two antennas, up to four taps (the frame ring lives in registers), every prime factor has a register butterfly
@@ -99,7 +101,7 @@ struct SpecShape {
 // it sets the threads per slot (N / first butterflies), the points a thread keeps in its ring (first of them) and the LDS
 // bank pattern of the first stage's stores (an odd stride is conflict-free).  `u`: frames per step.  Above 2048 channels: the
 // lean build (fx_spec.h, FXM_LEAN), up to 512 threads a frame with up to two first-stage butterflies each.
-SpecShape spec_shape(int n, int taps, int first = 0, int u = 1) {
+SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
     SpecShape s;
     if (n < 2 || n > 8192 || taps < 1 || taps > 4) return s;
     const fxc::MixedPlan mp = fxc::mixed_factor(n);
@@ -126,13 +128,14 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1) {
         s.tpr = 1;
         while (s.tpr < nb0) s.tpr <<= 1;
     } else {
-        j0 = n > kSpecLeanAbove ? (nb0 + 511) / 512 : (nb0 + 1023) / 1024;
+        j0 = n > spec_lean_above() ? (nb0 + 511) / 512 : (nb0 + 1023) / 1024;
         s.tpr = ((nb0 + j0 - 1) / j0 + 63) / 64 * 64;
     }
     s.slots = std::max(1, 256 / s.tpr);
-    if (s.radix[0] * j0 > 8) return s;
+    if (s.radix[0] * j0 > (rows == 1 ? 16 : 8)) return s;      // (the ring: 128 registers at most)
+    s.rows = rows;
     s.u = u;
-    s.lean = n > kSpecLeanAbove;
+    s.lean = n > spec_lean_above();
     if (s.lean && s.n_stages < 2) return s;
     if (u != 1 && (u != 2 || s.n_stages < 2)) return s;      // (whether two frames' rows cost a resident workgroup: spec_search)
     if (s.lds_bytes() > (size_t)(160 * 1024)) return s;
@@ -145,15 +148,18 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1) {
 // 240 butterflies on 256 threads, 1.72 ms; 4 first, 180 on 192 threads, 2.11 ms), 2 first loses wherever there is a choice
 // (N / 2 threads per frame leave the later stages a few butterflies each: 600 channels 3.4 ms against 1.75), then the fuller
 // first stage, then the smaller radix (fewer ring registers).
-std::vector<int> spec_first_radices(int n, int taps) {
+// streams per workgroup of the build for (n, variant): F only above 4096 channels carries one (sixteen points a thread)
+inline int spec_rows(int n, int variant) { return (variant == 2 && n > 4096) ? 1 : 2; }
+
+std::vector<int> spec_first_radices(int n, int taps, int rows = 2) {
     struct Cand {
         int r, unbalanced, is_two, waste;
     };
     std::vector<Cand> c;
-    const SpecShape base = spec_shape(n, taps);
+    const SpecShape base = spec_shape(n, taps, 0, 1, rows);
     if (!base.n) return {};
     for (int r : {3, 4, 5, 7, 2, 11, 13}) {
-        const SpecShape s = spec_shape(n, taps, r);
+        const SpecShape s = spec_shape(n, taps, r, 1, rows);
         if (!s.ok || s.threads() > 512) continue;      // (more than 512 threads leave under 256 registers a thread: the ring does not fit)
         const int nb0 = n / r, j0 = (nb0 + s.tpr - 1) / s.tpr;
         const int waste = 20 - 20 * nb0 / (s.tpr * j0);                 // idle lanes of the first stage, in twentieths
@@ -317,7 +323,7 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXM_TPR=" + std::to_string(shape.tpr), "-DFXM_SLOTS=" + std::to_string(shape.slots),
                                      "-DFXM_NST=" + std::to_string(shape.n_stages), "-DFXM_RADICES=" + radices,
                                      "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)), "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly)),
-                                     "-DFXM_U=" + std::to_string(shape.u), "-DFXM_LEAN=" + std::to_string((int)shape.lean),
+                                     "-DFXM_U=" + std::to_string(shape.u), "-DFXM_LEAN=" + std::to_string((int)shape.lean), "-DFXM_ROWS=" + std::to_string(shape.rows),
                                      "-DFXM_ABL=" + std::to_string(spec_ablation())};      // (timing ablations: wrong results, developer library only)
     const std::string dir = spec_cache_dir();
     const std::string cached = dir.empty() ? std::string() : dir + "/" + spec_cache_key(opts, api) + ".co";
@@ -391,16 +397,17 @@ SpecBuild spec_build(const SpecShape& shape, int variant, const char* arch) {
 SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
     SpecBuild best;
     best.error = "no specialised kernel for this channel count";
-    std::vector<int> firsts = spec_first_radices(n, taps);
+    const int rows = spec_rows(n, variant);
+    std::vector<int> firsts = spec_first_radices(n, taps, rows);
     if (const int want = env_int("FXC_RTC_R0", 0)) firsts.assign(1, want);
     const int force_u = env_int("FXC_RTC_U", 0);
     int tried = 0;
     for (int r : firsts) {
         if (tried == 2) break;                       // (a compile is about a second: two orders at most)
-        const SpecShape one = spec_shape(n, taps, r, 1);
+        const SpecShape one = spec_shape(n, taps, r, 1, rows);
         if (!one.ok) continue;
         ++tried;
-        const SpecShape two = spec_shape(n, taps, r, 2);
+        const SpecShape two = spec_shape(n, taps, r, 2, rows);
         SpecBuild b = (force_u == 2 && two.ok) ? SpecBuild() : spec_build(one, variant, arch);
         if (two.ok && force_u != 1) {
             SpecBuild b2 = spec_build(two, variant, arch);
@@ -421,8 +428,8 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
 // compile (or find) the kernel for n channels on `device`; never nullptr -- a failed build is cached with its reason
 const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
     char key[256];
-    std::snprintf(key, sizeof key, "d%d n%d t%d v%d a%d r%d f%d", device, n, taps, variant, spec_ablation(), env_int("FXC_RTC_R0", 0),
-                  env_int("FXC_RTC_U", 0));
+    std::snprintf(key, sizeof key, "d%d n%d t%d v%d a%d r%d f%d l%d", device, n, taps, variant, spec_ablation(), env_int("FXC_RTC_R0", 0),
+                  env_int("FXC_RTC_U", 0), spec_lean_above());
     std::lock_guard<std::mutex> lock(g_spec_mutex);
     auto it = g_spec_cache.find(key);
     if (it != g_spec_cache.end()) return it->second;

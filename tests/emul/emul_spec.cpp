@@ -55,7 +55,7 @@ int emul_spec_run(const void* x, const float* h, void* out, const void* tw, cons
     }
     const fxm::Args args = {x, h, static_cast<fxm::cf*>(out), static_cast<const fxm::cf*>(tw), static_cast<const fxm::cf*>(dc_u8),
                             num_samp, n_pts, n_chunks, wg_splits, ant, h4.data(), tw1.data()};
-    const long long groups = fxm::FONLY ? (n_chunks + 1) / 2 : n_chunks;      // workgroups per split: chunk pairs, or pairs of streams
+    const long long groups = fxm::FONLY ? (n_chunks + fxm::NA - 1) / fxm::NA : n_chunks;      // workgroups per split: chunk pairs, or groups of NA streams
     for (long long bid = 0; bid < groups * wg_splits; ++bid) {
         std::vector<fxm::cf> lds((size_t)fxm::SLOTS * fxm::LDS_PER_SLOT + 1);
         std::memset(lds.data(), 0xFF, lds.size() * sizeof(fxm::cf));          // NaNs: nothing may be read before it is written

@@ -258,7 +258,7 @@ def _spec_shape(nchan, ntaps, u8=False, fonly=False):
     stages = rep["stages"]
     flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=%d" % ntaps, "-DFXM_TPR=%s" % rep["tpr"], "-DFXM_SLOTS=%s" % rep["slots"],
              "-DFXM_NST=%d" % len(stages.split(",")), "-DFXM_RADICES=%s" % stages, "-DFXM_U8=%d" % int(u8),
-             "-DFXM_U=%s" % rep["frames_per_step"], "-DFXM_FONLY=%d" % int(fonly), "-DFXM_LEAN=%s" % rep["lean"]]
+             "-DFXM_U=%s" % rep["frames_per_step"], "-DFXM_FONLY=%d" % int(fonly), "-DFXM_LEAN=%s" % rep["lean"], "-DFXM_ROWS=%s" % rep["rows"]]
     assert re.fullmatch(r"[0-9,]+", stages) and int(rep["code_bytes"]) > 1000
     return 0, (flags, int(rep["tpr"]), int(rep["slots"]))
 
@@ -336,7 +336,9 @@ def test_specialised_kernel_matches_oracle(tmp_path, monkeypatch, nchan, ntaps, 
 
 @pytest.mark.parametrize("nchan,ntaps,n_pts,wg_splits,n_streams,ant", [
     (1000, 4, 9, 2, 3, 1), (96, 4, 21, 1, 6, 3), (250, 2, 7, 1, 1, 1), (7, 1, 5, 1, 4, 2), (720, 3, 6, 1, 5, 5), (12, 4, 70, 2, 2, 1),
-    (3000, 4, 5, 1, 3, 1), (3584, 2, 4, 1, 2, 2)])
+    (3000, 4, 5, 1, 3, 1), (3584, 2, 4, 1, 2, 2),
+    # above 4096 channels: one stream per workgroup, up to sixteen points a thread
+    (5000, 4, 5, 1, 3, 1), (6000, 2, 4, 2, 4, 2), (8000, 4, 3, 1, 1, 1)])
 def test_specialised_f_stage_matches_oracle(tmp_path, nchan, ntaps, n_pts, wg_splits, n_streams, ant):
     """fx_spec.h built as the F stage alone (FXM_FONLY: what fxc_channelize and the F pass of 3 and more antennas run off the
     powers of two): a workgroup carries a pair of streams, the last butterfly's outputs are the spectra -- against the oracle's

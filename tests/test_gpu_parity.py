@@ -791,8 +791,10 @@ def test_any_channel_count_matches_oracle(plan_mod, torch, monkeypatch, n_ant, n
     assert bool(specialised & 1) == can, (specialised, can)      # (bit 1: the F stage alone, also for 3 and more antennas)
     if (n_ant, nchan, ntaps) in {(2, 1000, 4), (2, 96, 4), (2, 100, 3), (2, 6, 4), (2, 12, 1), (2, 3, 4), (2, 250, 4)}:
         assert specialised & 1
-    if (n_ant, nchan, ntaps) in {(2, 997, 4), (2, 1536, 8), (3, 48, 5), (2, 6561, 4), (2, 12000, 4), (2, 7, 32)}:
+    if (n_ant, nchan, ntaps) in {(2, 997, 4), (2, 1536, 8), (3, 48, 5), (2, 12000, 4), (2, 7, 32)}:
         assert not specialised
+    if (n_ant, nchan, ntaps) == (2, 6561, 4):      # 4097 ... 8192 channels: the F stage alone (one stream per workgroup), X from spectra in HBM
+        assert specialised == 2
     # the direct DFT: a kernel of the developer build only (libfxcorr_dev.so), chosen by a knob read when the plan is built
     monkeypatch.setenv("FXC_GENERIC_FFT", "radix2")
     with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window, dev=True) as d:
@@ -881,7 +883,8 @@ def test_long_chunks_of_few_channels_keep_float32_runs_short(plan_mod, torch, mo
 
 @pytest.mark.parametrize("n_ant,nchan,ntaps,n_streams,frames,extra", [
     (1, 1000, 4, 5, 60, 3), (1, 96, 4, 333, 40, 0), (1, 720, 3, 2, 17, 1), (1, 250, 1, 1, 1, 0), (1, 2000, 4, 3, 9, 0),
-    (3, 1000, 4, 4, 30, 5), (5, 96, 2, 3, 100, 0), (1, 3000, 4, 5, 12, 1), (3, 2400, 4, 2, 11, 0), (1, 4000, 4, 3, 8, 0)])
+    (3, 1000, 4, 4, 30, 5), (5, 96, 2, 3, 100, 0), (1, 3000, 4, 5, 12, 1), (3, 2400, 4, 2, 11, 0), (1, 4000, 4, 3, 8, 0),
+    (1, 5000, 4, 5, 9, 2), (2, 6000, 3, 3, 7, 0), (3, 8000, 4, 2, 6, 1), (1, 7168, 4, 300, 5, 0)])
 def test_specialised_f_stage_on_the_device(plan_mod, torch, monkeypatch, n_ant, nchan, ntaps, n_streams, frames, extra):
     """fxc_channelize (the drop-in's _spectrometer_poly, effex.py:530-555) at channel counts that are not a power of two runs
     fx_spec.h built as the F stage alone -- a pair of streams per workgroup, odd stream counts included; 3 and more antennas

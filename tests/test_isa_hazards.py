@@ -123,7 +123,7 @@ def test_specialised_kernels_keep_their_registers(tmp_path, nchan, variant):
     stages = rep["stages"].split(",")
     flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=4", "-DFXM_TPR=" + rep["tpr"], "-DFXM_SLOTS=" + rep["slots"], "-DFXM_NST=%d" % len(stages),
              "-DFXM_RADICES=" + rep["stages"], "-DFXM_U8=%d" % int(variant == 1), "-DFXM_FONLY=%d" % int(variant == 2), "-DFXM_U=" + rep["frames_per_step"],
-             "-DFXM_LEAN=" + rep["lean"]]
+             "-DFXM_LEAN=" + rep["lean"], "-DFXM_ROWS=" + rep["rows"]]
     src = tmp_path / "spec.hip"
     src.write_text('#include "fx_spec.h"\n')
     asm = tmp_path / "spec.s"
