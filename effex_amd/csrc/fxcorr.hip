@@ -564,8 +564,11 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         }
         // nchan 8192, two antennas, up to 16 taps: the split into two 4096-channel problems (FXC_SPLIT8192=0: off)
         const char* split_env = std::getenv("FXC_SPLIT8192");
+        // ... up to four taps: two passes instead (f8192_ring_kernel and its XM form, h_launch.h::tiled_raw_sums; FXC_X8192=0: off)
+        const bool want_x8192 = N == 8192 && p->n_ant == 2 && T <= 4 && p->path == FXC_PATH_TILED && p->num_samp < (1ll << 28) &&
+                                env_int("FXC_X8192", 1) && env_int("FXC_F8192", 1);
         p->split8192 = (N == 8192 && p->n_ant == 2 && T <= 16 && p->path == FXC_PATH_TILED && p->num_samp <= (1ll << 27) &&
-                        !(split_env && std::atoi(split_env) == 0));
+                        !(split_env && std::atoi(split_env) == 0) && !want_x8192);
         if (p->split8192) {
             p->prefilter = false;
             p->pre_tp = T <= 4 ? 4 : (T <= 8 ? 8 : 16);
@@ -597,6 +600,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         // 8192 channels, up to four taps: the F stage alone has a ring kernel of its own (k_tiled.h::f8192_ring_kernel), fed with the
         // same window quads from L2.  FXC_F8192=0: the pair kernel (developer knob)
         p->f8192 = N == 8192 && T <= 4 && !p->prefilter && env_int("FXC_F8192", 1);
+        p->x8192 = want_x8192 && p->f8192;
         if ((p->tiled_ring || p->f8192) && (!p->d_win4 || p->prefilter)) {
             std::vector<f4> w4((size_t)N);
             for (int r = 0; r < 16; ++r)
@@ -761,6 +765,11 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
         info->grid = p->cu_count * 4;
         info->block = 256;
         info->lds_bytes = p->nchan > 1 ? p->nchan * (int)sizeof(cf) : 0;
+    }
+    if (p->x8192) {       // 8192 channels, two antennas, two passes: f8192_ring_kernel and its XM form
+        info->grid = p->cu_count * 8;
+        info->block = kF8192Threads;
+        info->lds_bytes = kF8192LdsCf * (int)sizeof(cf);
     }
     if (p->spec_f) info->specialised |= 2;
     if (p->spec) {

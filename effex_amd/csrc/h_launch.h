@@ -653,6 +653,10 @@ int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only) {
 
 // streams the pre-filter handles per pass (its output stays within the workspace target)
 int64_t prefilter_streams_per_pass(const fxc_plan* p) {
+    if (p->x8192) {       // 8192 channels in two passes: antenna 0's spectra of a pass stay within the workspace target
+        const int64_t chunks = std::max<int64_t>(1, ws_target() / (p->n_pts * (int64_t)p->nchan * (int64_t)sizeof(cf)));
+        return 2 * std::min<int64_t>(chunks, 1 << 20);
+    }
     if (!p->prefilter) return INT64_MAX;
     int64_t n = ws_target() / (p->num_samp * (int64_t)sizeof(cf));
     n = std::min<int64_t>(n, 65534) & ~(int64_t)1;      // grid.y carries the stream (or a row of them); whole pairs
@@ -718,6 +722,25 @@ int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, 
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
     }
+    if (p->x8192 && !dc_u8 && p->num_samp < (1ll << 28)) {
+        // 8192 channels, two antennas, up to four taps, in TWO passes (2 x the algorithmic bytes; the split into two 4096-channel
+        // problems and the pair kernel move 3 x): f8192_ring_kernel writes antenna 0's spectra, its XM form runs antenna 1 through
+        // the same stages and multiplies by them as it goes -- raw[split][chunk][N] like the tiled kernels'
+        int rc = grow(p, &p->d_pre, &p->pre_bytes, (size_t)nc * p->n_pts * p->nchan * sizeof(cf));
+        if (rc) return rc;
+        cf* s0 = static_cast<cf*>(p->d_pre);
+        const int64_t want = (2 * (int64_t)p->cu_count + nc - 1) / nc;
+        const int f_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / 8));
+        const dim3 grid_f((unsigned)std::min<int64_t>(nc, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / f_splits)), (unsigned)f_splits);
+        hipLaunchKernelGGL(f8192_ring_kernel<false>, grid_f, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, nc, f_splits,
+                           p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, s0, 0, (int64_t)0, 2 * p->num_samp, (const cf*)nullptr);
+        const dim3 grid_x((unsigned)std::min<int64_t>(nc, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / n_splits)), (unsigned)n_splits);
+        hipLaunchKernelGGL(f8192_ring_kernel<true>, grid_x, dim3(kF8192Threads), 0, p->stream, x + p->num_samp, p->num_samp, p->n_pts, nc,
+                           n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw, 0, (int64_t)0, 2 * p->num_samp, (const cf*)s0);
+        kt.stop();
+        FXC_HIP(p, hipGetLastError());
+        return FXC_OK;
+    }
     if (p->prefilter && !dc_u8) {
         const int rc = tiled_prefilter(p, x, 2 * nc, &x);
         if (rc) return rc;
@@ -737,10 +760,10 @@ int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int 
         KernelTimer kt8(p);
         const int64_t want = (2 * (int64_t)p->cu_count + n_streams - 1) / n_streams;
         const int n_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / 8));
-        const int64_t wgs = n_streams * n_splits;
-        const int grid = (int)std::min<int64_t>(wgs, (int64_t)p->cu_count * 8);
-        hipLaunchKernelGGL(f8192_ring_kernel, dim3(grid), dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, n_streams, n_splits,
-                           p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, spec, spec_a, (int64_t)0);
+        const int grid_x = (int)std::min<int64_t>(n_streams, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / n_splits));
+        const dim3 grid((unsigned)grid_x, (unsigned)n_splits);
+        hipLaunchKernelGGL(f8192_ring_kernel<false>, grid, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, n_streams, n_splits,
+                           p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, spec, spec_a, (int64_t)0, p->num_samp, (const cf*)nullptr);
         kt8.stop();
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;

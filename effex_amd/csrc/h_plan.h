@@ -106,6 +106,7 @@ struct fxc_plan {
     void* d_pre = nullptr;         // pre-filtered streams of one pass
     size_t pre_bytes = 0;
     bool f8192 = false;            // nchan 8192, ntaps <= 4: fxc_channelize on f8192_ring_kernel (one stream per workgroup, VGPR ring)
+    bool x8192 = false;            // nchan 8192, 2 antennas, ntaps <= 4: two passes (f8192_ring_kernel, then its XM form); FXC_X8192=0: off
     bool split8192 = false;        // nchan 8192, 2 antennas: pfb_split8192_kernel + the 4096-channel fused kernel
     cf* d_tw8192 = nullptr;        // [4096] w8192^(4095 - n')
     unsigned long long* d_stamps = nullptr;   // diagnostic builds only

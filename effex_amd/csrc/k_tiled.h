@@ -437,10 +437,13 @@ constexpr int kF8192Threads = G8192::P;                                         
 constexpr int kF8192WinLds = 7;
 constexpr int kF8192LdsCf = G8192::kRegion + 256 + 16 * 256 + kF8192WinLds * G8192::P * 2;
 
-template <int PH>
+// XM: instead of storing the spectrum, multiply the OTHER antenna's spectrum of the same frame (in0_row: natural order, written by
+// a launch of the plain kernel) by its conjugate and add to acc[n] = the sum at bin u + P n
+template <int PH, bool XM>
 __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict__ win_g, const f4* win_l, cf wu,
                                            const cf* twA_l, cf* reg, const cf* tw16, int u, const cf* stream_base,
-                                           unsigned stream_bytes, unsigned xoff, int64_t i, int64_t i1, cf* out_row, int64_t out_step) {
+                                           unsigned stream_bytes, unsigned xoff, int64_t i, int64_t i1, cf* out_row, int64_t out_step,
+                                           const cf* in0_row, cf (&acc)[XM ? 16 : 1]) {
     using G = G8192;
     cf v[16];
     {   // FIR out of the ring, window quads [r P + u] = taps 0 .. 3 of branch u + P r: the first kF8192WinLds groups from LDS, the
@@ -451,13 +454,14 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
         const cf (&x3)[16] = h[(PH + 1) & 3];
         __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4*>(win_g), 0, (int)(G::N * sizeof(f4)), 0x00020000);
         const unsigned woff = (unsigned)(u * (int)sizeof(f4));
+        constexpr int GQ = XM ? 2 : 4;      // (XM: the sums take 32 registers: two quads in flight instead of four)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 16 / GQ; ++g) {
             FXC_SCHED_FENCE();
-            f4 w[4];
+            f4 w[GQ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 4 * g + q;
+            for (int q = 0; q < GQ; ++q) {
+                const int r = GQ * g + q;
                 if (r < kF8192WinLds) {
                     w[q] = win_l[r * G::P + u];
                 } else {
@@ -469,8 +473,8 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 4 * g + q;
+            for (int q = 0; q < GQ; ++q) {
+                const int r = GQ * g + q;
                 cf a = fxc::cscale(x0[r], w[q].x);
                 a = fxc::cfma(w[q].y, x1[r], a);
                 a = fxc::cfma(w[q].z, x2[r], a);
@@ -525,14 +529,42 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
     wave_sync();
     G::loadC(reg, u, v);
     fxc::dft16(v);
-    tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, true);
+    if constexpr (!XM) {
+        tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, true);
+    } else {
+        // tiled_store_spectrum's transposition through the exchange rows, then antenna 0's bins u + P n from memory (requested before
+        // the barrier: v's registers are free once its LDS writes are out) times the conjugate of this antenna's
+        __syncthreads();
+        constexpr int C = 256 * G::R0;
+        const int b0 = G::bin_of(u, 0);
+        cf* wr = reg + b0 + (b0 >> 4);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) wr[(C + C / 16) * k2] = v[k2];
+        cf s0[16];
+        {
+            __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(in0_row + i * (int64_t)G::N), 0, (int)(G::N * sizeof(cf)), 0x00020000);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, (unsigned)(u * (int)sizeof(cf)), (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+                s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+            }
+        }
+        __syncthreads();
+        const cf* rd = reg + u + (u >> 4);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) acc[n] = fxc::cadd(acc[n], fxc::cmulc(s0[n], fxc::fused::lds_load(rd + (G::P + G::P / 16) * n)));
+    }
 }
 
+// stream_stride: samples from one stream's start to the next's (num_samp; 2 num_samp for one antenna of chunk pairs).  XM: the
+// streams are antenna 1 of n_streams chunk pairs, in0 = antenna 0's spectra [chunk][frame][N] (a launch of the plain kernel), spec =
+// raw[split][chunk][N], the sums over the split's frames of spec0 conj(spec1)
+template <bool XM>
 __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
                                                                    int64_t n_streams, int n_splits, const f4* __restrict__ win_g,
                                                                    const cf* __restrict__ tw0_g, const cf* __restrict__ twA_g,
                                                                    const cf* __restrict__ tw16_g, cf* __restrict__ spec, int spec_a,
-                                                                   int64_t s_base) {
+                                                                   int64_t s_base, int64_t stream_stride, const cf* __restrict__ in0) {
     using G = G8192;
     __shared__ __attribute__((aligned(16))) cf smem[kF8192LdsCf];
     cf* reg = smem;
@@ -548,12 +580,17 @@ __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __r
     const int64_t per = (n_pts + n_splits - 1) / n_splits;
     const unsigned stream_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf));
     const unsigned xoff = (unsigned)((G::P - 1 - u) * (int)sizeof(cf));
-    for (int64_t w = blockIdx.x; w < n_streams * n_splits; w += gridDim.x) {
-        const int64_t s = w % n_streams, split = w / n_streams;
+    // grid: (streams, splits) -- no division on the way to a work item
+    for (int64_t s = blockIdx.x; s < n_streams; s += gridDim.x) {
+        const int64_t split = blockIdx.y;
         const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
-        const cf* stream_base = x + s * num_samp;
-        cf* out_row = spec + spec_row(s_base + s, 0, n_pts, spec_a) * G::N;
+        const cf* stream_base = x + s * stream_stride;
+        cf* out_row = XM ? nullptr : spec + spec_row(s_base + s, 0, n_pts, spec_a) * G::N;
         const int64_t out_step = (int64_t)(spec_a > 0 ? spec_a : 1) * G::N;
+        const cf* in0_row = XM ? in0 + s * n_pts * G::N : nullptr;
+        cf acc[XM ? 16 : 1];
+#pragma unroll
+        for (int n = 0; n < (XM ? 16 : 1); ++n) acc[n] = fxc::mk(0.f, 0.f);
         cf h[4][16];
         // ring prologue: frame i0 -> slot 0, its history i0-1, i0-2, i0-3 -> slots 3, 2, 1 (zero before the stream's start)
 #pragma unroll
@@ -572,10 +609,22 @@ __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __r
             for (int r = 0; r < 16; ++r) h[0][r] = fxc::mk(0.f, 0.f);
         }
         for (int64_t i = i0; i < i1; i += 4) {
-            f8192_step<0>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i, i1, out_row, out_step);
-            if (i + 1 < i1) f8192_step<1>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 1, i1, out_row, out_step);
-            if (i + 2 < i1) f8192_step<2>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 2, i1, out_row, out_step);
-            if (i + 3 < i1) f8192_step<3>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 3, i1, out_row, out_step);
+            f8192_step<0, XM>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i, i1, out_row, out_step, in0_row, acc);
+            if (i + 1 < i1) f8192_step<1, XM>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 1, i1, out_row, out_step, in0_row, acc);
+            if (i + 2 < i1) f8192_step<2, XM>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 2, i1, out_row, out_step, in0_row, acc);
+            if (i + 3 < i1) f8192_step<3, XM>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 3, i1, out_row, out_step, in0_row, acc);
+        }
+        if constexpr (XM) {
+            __syncthreads();      // (the last frame's exchange rows are read: the next work item's first store waits on its own barrier anyway)
+            // (a buffer store: the row's 64-bit address per thread would be a register pair live across the whole run)
+            __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(spec + (split * n_streams + s) * G::N, 0, (int)(G::N * sizeof(cf)), 0x00020000);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                v2u32 d;
+                d[0] = __float_as_uint(acc[n].x);
+                d[1] = __float_as_uint(acc[n].y);
+                __builtin_amdgcn_raw_buffer_store_b64(d, rr, (unsigned)(u * (int)sizeof(cf)), (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+            }
         }
     }
 }

@@ -675,6 +675,36 @@ def test_tiled_path_matches_oracle(plan_mod, torch, nchan, ntaps, n_chunks, fram
         assert rel_err(rows, g.fx_rows(xd, "SPECTRUM").cpu().numpy()) < 4e-6
 
 
+@pytest.mark.parametrize("ntaps,n_chunks,frames,extra", [(4, 300, 2, 0), (4, 2, 1100, 3), (1, 5, 9, 8191), (3, 1, 1, 0), (2, 17, 33, 100)])
+def test_8192_channels_in_two_passes(plan_mod, torch, monkeypatch, ntaps, n_chunks, frames, extra):
+    """--nfft 8192 with two antennas and up to four taps: f8192_ring_kernel writes antenna 0's spectra, its XM form runs antenna 1
+    through the same stages and multiplies by them as it goes (2 x the algorithmic bytes; the split into two 4096-channel problems
+    moves 3 x) -- many chunks of few frames, runs longer than the float32 row limit, a one-frame chunk, a ragged tail of almost a
+    frame; against the oracle (effex.py:490-527), the float64 mean of the rows, and the split route (FXC_X8192=0)."""
+    nchan = 8192
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(8192 + n_chunks, n_chunks, 2, num_samp)
+    window = design_window(ntaps, nchan)
+    xd = torch.from_numpy(x).cuda()
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as p:
+        assert p.path == "tiled" and p.info["block"] == 512, p.info
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, -2e-7)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        for c in sorted({0, n_chunks // 2, n_chunks - 1}):
+            ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, -2e-7, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        np.testing.assert_array_equal(p.fx_rows(xd, "SPECTRUM").cpu().numpy(), rows)
+        p.fx_accumulate(xd[: n_chunks // 3 + 1])
+        if n_chunks // 3 + 1 < n_chunks:
+            p.fx_accumulate(xd[n_chunks // 3 + 1:])
+        assert rel_err(p.finalize("SPECTRUM"), rows.astype(np.complex128).mean(axis=0)) < 2e-6
+    monkeypatch.setenv("FXC_X8192", "0")
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as q:
+        assert q.info["block"] == 1024
+        q.set_delay(gi.BANDWIDTH, gi.FREQUENCY, -2e-7)
+        assert rel_err(q.fx_rows(xd, "SPECTRUM").cpu().numpy(), rows) < 2e-6
+
+
 @pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [
     (256, 4, 3, 40, 7), (256, 4, 1, 1024, 0), (128, 4, 5, 33, 100), (64, 4, 2, 500, 3), (32, 4, 9, 70, 1), (16, 4, 4, 300, 0),
     (256, 3, 2, 9, 0), (128, 1, 7, 5, 2), (64, 2, 300, 3, 0), (16, 4, 1, 16384, 5), (32, 4, 1, 1, 0), (256, 4, 700, 2, 0),
