@@ -732,10 +732,10 @@ int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, 
         const int64_t want = (2 * (int64_t)p->cu_count + nc - 1) / nc;
         const int f_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / 8));
         const dim3 grid_f((unsigned)std::min<int64_t>(nc, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / f_splits)), (unsigned)f_splits);
-        hipLaunchKernelGGL(f8192_ring_kernel<false>, grid_f, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, nc, f_splits,
+        hipLaunchKernelGGL((f8192_ring_kernel<false, true>), grid_f, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, nc, f_splits,
                            p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, s0, 0, (int64_t)0, 2 * p->num_samp, (const cf*)nullptr);
         const dim3 grid_x((unsigned)std::min<int64_t>(nc, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / n_splits)), (unsigned)n_splits);
-        hipLaunchKernelGGL(f8192_ring_kernel<true>, grid_x, dim3(kF8192Threads), 0, p->stream, x + p->num_samp, p->num_samp, p->n_pts, nc,
+        hipLaunchKernelGGL((f8192_ring_kernel<true, true>), grid_x, dim3(kF8192Threads), 0, p->stream, x + p->num_samp, p->num_samp, p->n_pts, nc,
                            n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw, 0, (int64_t)0, 2 * p->num_samp, (const cf*)s0);
         kt.stop();
         FXC_HIP(p, hipGetLastError());
@@ -762,7 +762,7 @@ int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int 
         const int n_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / 8));
         const int grid_x = (int)std::min<int64_t>(n_streams, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / n_splits));
         const dim3 grid((unsigned)grid_x, (unsigned)n_splits);
-        hipLaunchKernelGGL(f8192_ring_kernel<false>, grid, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, n_streams, n_splits,
+        hipLaunchKernelGGL((f8192_ring_kernel<false, false>), grid, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, n_streams, n_splits,
                            p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, spec, spec_a, (int64_t)0, p->num_samp, (const cf*)nullptr);
         kt8.stop();
         FXC_HIP(p, hipGetLastError());

@@ -435,11 +435,14 @@ constexpr int kF8192Threads = G8192::P;                                         
 // exchange rows of one stream + w256 table + the stage-A table + the window quads of the first kF8192WinLds branch groups (the
 // other 16 - kF8192WinLds groups -- the window is 128 KiB -- come from L2 every frame): 158 KiB
 constexpr int kF8192WinLds = 7;
+
 constexpr int kF8192LdsCf = G8192::kRegion + 256 + 16 * 256 + kF8192WinLds * G8192::P * 2;
 
-// XM: instead of storing the spectrum, multiply the OTHER antenna's spectrum of the same frame (in0_row: natural order, written by
-// a launch of the plain kernel) by its conjugate and add to acc[n] = the sum at bin u + P n
-template <int PH, bool XM>
+// PRIV: the spectrum leaves the registers as it is -- output k2 of thread u at [k2 P + (P - 1 - u)] of the frame's row (bin_of(u, k2)
+// there; the offset register of the sample loads serves): a layout private to the two-pass route, coalesced without the transposition through LDS and its two barriers.  XM: instead of
+// storing the spectrum, multiply the OTHER antenna's spectrum of the same frame (in0_row: PRIV layout, written by a launch of the
+// <false, true> kernel) by its conjugate and add to acc[k2] = the sum at bin_of(u, k2)
+template <int PH, bool XM, bool PRIV, int kX8192Early>
 __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict__ win_g, const f4* win_l, cf wu,
                                            const cf* twA_l, cf* reg, const cf* tw16, int u, const cf* stream_base,
                                            unsigned stream_bytes, unsigned xoff, int64_t i, int64_t i1, cf* out_row, int64_t out_step,
@@ -527,39 +530,49 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
     wave_sync();       // the 16x16 transpose stays inside each 16-lane group: no s_barrier
     G::storeT(v, reg, u);
     wave_sync();
-    G::loadC(reg, u, v);
-    fxc::dft16(v);
-    if constexpr (!XM) {
-        tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, true);
-    } else {
-        // tiled_store_spectrum's transposition through the exchange rows, then antenna 0's bins u + P n from memory (requested before
-        // the barrier: v's registers are free once its LDS writes are out) times the conjugate of this antenna's
-        __syncthreads();
-        constexpr int C = 256 * G::R0;
-        const int b0 = G::bin_of(u, 0);
-        cf* wr = reg + b0 + (b0 >> 4);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) wr[(C + C / 16) * k2] = v[k2];
+    if constexpr (XM) {
+        // antenna 0's outputs of the same (thread, k2): kX8192Early of them requested before this antenna's last butterfly (no room
+        // for all sixteen beside the ring, the sums and the butterfly's own points), the rest behind it
         cf s0[16];
-        {
-            __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(in0_row + i * (int64_t)G::N), 0, (int)(G::N * sizeof(cf)), 0x00020000);
+        __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(in0_row + i * (int64_t)G::N), 0, (int)(G::N * sizeof(cf)), 0x00020000);
+#pragma unroll
+        for (int n = 0; n < kX8192Early; ++n) {
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, xoff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+            s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+        }
+        G::loadC(reg, u, v);
+        fxc::dft16(v);
+        FXC_SCHED_FENCE();
+#pragma unroll
+        for (int n = kX8192Early; n < 16; ++n) {
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, xoff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+            s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n) acc[n] = fxc::cadd(acc[n], fxc::cmulc(s0[n], v[n]));
+    } else {
+        G::loadC(reg, u, v);
+        fxc::dft16(v);
+        if constexpr (PRIV) {
+            __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(out_row + i * out_step, 0, (int)(G::N * sizeof(cf)), 0x00020000);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
-                const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, (unsigned)(u * (int)sizeof(cf)), (unsigned)(G::P * n * (int)sizeof(cf)), 0);
-                s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
+                v2u32 d;
+                d[0] = __float_as_uint(v[n].x);
+                d[1] = __float_as_uint(v[n].y);
+                __builtin_amdgcn_raw_buffer_store_b64(d, rr, xoff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
             }
+        } else {
+            tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, true);
         }
-        __syncthreads();
-        const cf* rd = reg + u + (u >> 4);
-#pragma unroll
-        for (int n = 0; n < 16; ++n) acc[n] = fxc::cadd(acc[n], fxc::cmulc(s0[n], fxc::fused::lds_load(rd + (G::P + G::P / 16) * n)));
     }
 }
 
 // stream_stride: samples from one stream's start to the next's (num_samp; 2 num_samp for one antenna of chunk pairs).  XM: the
-// streams are antenna 1 of n_streams chunk pairs, in0 = antenna 0's spectra [chunk][frame][N] (a launch of the plain kernel), spec =
+// streams are antenna 1 of n_streams chunk pairs, in0 = antenna 0's spectra [chunk][frame][N] in the PRIV layout (a launch of the <false, true> kernel), spec =
 // raw[split][chunk][N], the sums over the split's frames of spec0 conj(spec1)
-template <bool XM>
+// EARLY: how many of antenna 0's sixteen values a thread requests before its last butterfly (8 / 12 / 16 measured alike: 1.93 - 1.96 ms)
+template <bool XM, bool PRIV, int EARLY = 12>
 __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
                                                                    int64_t n_streams, int n_splits, const f4* __restrict__ win_g,
                                                                    const cf* __restrict__ tw0_g, const cf* __restrict__ twA_g,
@@ -609,20 +622,34 @@ __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __r
             for (int r = 0; r < 16; ++r) h[0][r] = fxc::mk(0.f, 0.f);
         }
         for (int64_t i = i0; i < i1; i += 4) {
-            f8192_step<0, XM>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i, i1, out_row, out_step, in0_row, acc);
-            if (i + 1 < i1) f8192_step<1, XM>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 1, i1, out_row, out_step, in0_row, acc);
-            if (i + 2 < i1) f8192_step<2, XM>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 2, i1, out_row, out_step, in0_row, acc);
-            if (i + 3 < i1) f8192_step<3, XM>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 3, i1, out_row, out_step, in0_row, acc);
+            f8192_step<0, XM, PRIV, EARLY>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i, i1, out_row, out_step, in0_row, acc);
+            if (i + 1 < i1) f8192_step<1, XM, PRIV, EARLY>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 1, i1, out_row, out_step, in0_row, acc);
+            if (i + 2 < i1) f8192_step<2, XM, PRIV, EARLY>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 2, i1, out_row, out_step, in0_row, acc);
+            if (i + 3 < i1) f8192_step<3, XM, PRIV, EARLY>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 3, i1, out_row, out_step, in0_row, acc);
         }
         if constexpr (XM) {
-            __syncthreads();      // (the last frame's exchange rows are read: the next work item's first store waits on its own barrier anyway)
-            // (a buffer store: the row's 64-bit address per thread would be a register pair live across the whole run)
+            // the sums sit at bin_of(u, k2): through the exchange rows into natural order, once per run (tiled_store_spectrum's
+            // transposition; buffer stores -- the row's 64-bit address per thread would be a register pair live across the run)
+            __syncthreads();
+            constexpr int C = 256 * G::R0;
+            // u again, from a register the run keeps anyway (the sample loads' offset), behind a barrier for the optimiser: the two
+            // LDS addresses below -- or u itself -- hoisted out of the run were spilled
+            unsigned xo = xoff;
+            asm volatile("" : "+v"(xo));
+            const int uu = (int)(G::P - 1) - (int)(xo >> 3);
+            const int b0 = G::bin_of(uu, 0);
+            cf* wr = reg + b0 + (b0 >> 4);
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) wr[(C + C / 16) * k2] = acc[k2];
+            __syncthreads();
+            const cf* rd = reg + uu + (uu >> 4);
             __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(spec + (split * n_streams + s) * G::N, 0, (int)(G::N * sizeof(cf)), 0x00020000);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
+                const cf a = fxc::fused::lds_load(rd + (G::P + G::P / 16) * n);
                 v2u32 d;
-                d[0] = __float_as_uint(acc[n].x);
-                d[1] = __float_as_uint(acc[n].y);
+                d[0] = __float_as_uint(a.x);
+                d[1] = __float_as_uint(a.y);
                 __builtin_amdgcn_raw_buffer_store_b64(d, rr, (unsigned)(u * (int)sizeof(cf)), (unsigned)(G::P * n * (int)sizeof(cf)), 0);
             }
         }
