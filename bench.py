@@ -397,7 +397,7 @@ def dry_run_dist(args):
 def other_configs(x, dev, reps=5):
     """Short, untimed-region runs of the other single-GPU BASELINE configs on the resident synthetic bytes (viewed with
     their own shapes): configs[2] continuum streaming limit (nchan = 1, num_samp = 2^20) and configs[4] (8 antennas,
-    28 baselines, nchan 4096), plus two three-pass shapes (32 taps, 8192 channels) and a channel count that is not a power
+    28 baselines, nchan 4096), plus a three-pass and a two-pass shape (32 taps; 8192 channels) and a channel count that is not a power
     of two (1000, 3000).  HIP events around four calls back to
     back (results collected one call behind, as the headline loop does), per call, median of `reps`."""
     import numpy as np
@@ -447,7 +447,8 @@ def other_configs(x, dev, reps=5):
     run("configs[4]: 8 antennas, 28 baselines, nchan=4096, num_samp=262144, integrated", 8, NCHAN, NUM_SAMP, 512, None,
         "SPECTRUM", False)
     # not BASELINE configs: the reference test's own shape (tests/test_effex.py:62-66) and the largest --nfft of its CLI
-    # examples; both are three-pass routes (3 x the algorithmic traffic by construction)
+    # examples; the first is a three-pass route (3 x the algorithmic traffic by construction), the second two passes
+    # (antenna 0's spectra through HBM once: DESIGN.md 6)
     run("reference test shape: 2 antennas, nchan=2048, ntaps=32, num_samp=262144, integrated", 2, 2048, NUM_SAMP, 1024, None,
         "SPECTRUM", False, ntaps=32)
     run("--nfft 8192: 2 antennas, nchan=8192, ntaps=4, num_samp=262144, integrated", 2, 8192, NUM_SAMP, 1024, None,
