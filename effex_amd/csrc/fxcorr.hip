@@ -1291,7 +1291,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
     const size_t row_elems = mode == FXC_MODE_SPECTRUM ? (size_t)p->n_base * p->nchan * sizeof(cf) : (size_t)p->n_base * sizeof(cd);
     // chunks per pass: at most 65535 streams (a grid dimension of the conditioning kernels), and plans without the
     // fused ingest convert a pass into a complex64 staging buffer that stays within the workspace target
-    const bool fused_in = p->n_ant == 2 && !p->prefilter && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && (p->tiled_ring || p->small)) ||
+    const bool fused_in = p->n_ant == 2 && !p->prefilter && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && (p->tiled_ring || p->small || p->x8192)) ||
                                                               (p->path == FXC_PATH_GENERIC && p->mixed_xf && env_int("FXC_MIXED_U8", 1)));
     int64_t per_pass = std::min<int64_t>(16384, 65535 / p->n_ant);
     if (!fused_in) per_pass = std::min<int64_t>(per_pass, ws_target() / ((int64_t)p->n_ant * p->num_samp * (int64_t)sizeof(cf)));

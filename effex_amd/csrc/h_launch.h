@@ -722,21 +722,31 @@ int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, 
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
     }
-    if (p->x8192 && !dc_u8 && p->num_samp < (1ll << 28)) {
+    if (p->x8192 && p->num_samp < (1ll << 28)) {
         // 8192 channels, two antennas, up to four taps, in TWO passes (2 x the algorithmic bytes; the split into two 4096-channel
-        // problems and the pair kernel move 3 x): f8192_ring_kernel writes antenna 0's spectra, its XM form runs antenna 1 through
-        // the same stages and multiplies by them as it goes -- raw[split][chunk][N] like the tiled kernels'
+        // problems and the pair kernel move 3 x): f8192_ring_kernel writes antenna 0's spectra (in register order: a layout private
+        // to this route), its XM form runs antenna 1 through the same stages and multiplies by them as it goes --
+        // raw[split][chunk][N] like the tiled kernels'.  Bytes in (dc_u8: the conversion offsets [chunk][2]): converted on their way
+        // into the ring
         int rc = grow(p, &p->d_pre, &p->pre_bytes, (size_t)nc * p->n_pts * p->nchan * sizeof(cf));
         if (rc) return rc;
         cf* s0 = static_cast<cf*>(p->d_pre);
         const int64_t want = (2 * (int64_t)p->cu_count + nc - 1) / nc;
         const int f_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / 8));
         const dim3 grid_f((unsigned)std::min<int64_t>(nc, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / f_splits)), (unsigned)f_splits);
-        hipLaunchKernelGGL((f8192_ring_kernel<false, true>), grid_f, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, nc, f_splits,
-                           p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, s0, 0, (int64_t)0, 2 * p->num_samp, (const cf*)nullptr);
         const dim3 grid_x((unsigned)std::min<int64_t>(nc, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / n_splits)), (unsigned)n_splits);
-        hipLaunchKernelGGL((f8192_ring_kernel<true, true>), grid_x, dim3(kF8192Threads), 0, p->stream, x + p->num_samp, p->num_samp, p->n_pts, nc,
-                           n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw, 0, (int64_t)0, 2 * p->num_samp, (const cf*)s0);
+        // antenna 1's stream of the first chunk: num_samp samples (of 8 bytes, or of 2) behind antenna 0's
+        const cf* x1 = reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf)));
+#define FXC_X8192_LAUNCH(U8)                                                                                                                  \
+    do {                                                                                                                                      \
+        hipLaunchKernelGGL((f8192_ring_kernel<false, true, U8>), grid_f, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, nc,        \
+                           f_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, s0, 0, (int64_t)0, 2 * p->num_samp, (const cf*)nullptr, dc_u8, 0); \
+        hipLaunchKernelGGL((f8192_ring_kernel<true, true, U8>), grid_x, dim3(kF8192Threads), 0, p->stream, x1, p->num_samp, p->n_pts, nc,        \
+                           n_splits, p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, raw, 0, (int64_t)0, 2 * p->num_samp, (const cf*)s0, dc_u8, 1);     \
+    } while (0)
+        if (dc_u8) FXC_X8192_LAUNCH(true);
+        else FXC_X8192_LAUNCH(false);
+#undef FXC_X8192_LAUNCH
         kt.stop();
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;
@@ -763,7 +773,7 @@ int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int 
         const int grid_x = (int)std::min<int64_t>(n_streams, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / n_splits));
         const dim3 grid((unsigned)grid_x, (unsigned)n_splits);
         hipLaunchKernelGGL((f8192_ring_kernel<false, false>), grid, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, n_streams, n_splits,
-                           p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, spec, spec_a, (int64_t)0, p->num_samp, (const cf*)nullptr);
+                           p->d_win4, p->d_tw0, p->d_tw1, p->d_tw2, spec, spec_a, (int64_t)0, p->num_samp, (const cf*)nullptr, (const cf*)nullptr, 0);
         kt8.stop();
         FXC_HIP(p, hipGetLastError());
         return FXC_OK;

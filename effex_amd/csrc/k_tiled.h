@@ -442,12 +442,14 @@ constexpr int kF8192LdsCf = G8192::kRegion + 256 + 16 * 256 + kF8192WinLds * G81
 // there; the offset register of the sample loads serves): a layout private to the two-pass route, coalesced without the transposition through LDS and its two barriers.  XM: instead of
 // storing the spectrum, multiply the OTHER antenna's spectrum of the same frame (in0_row: PRIV layout, written by a launch of the
 // <false, true> kernel) by its conjugate and add to acc[k2] = the sum at bin_of(u, k2)
-template <int PH, bool XM, bool PRIV, int kX8192Early>
+template <int PH, bool XM, bool PRIV, int kX8192Early, bool U8>
 __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict__ win_g, const f4* win_l, cf wu,
                                            const cf* twA_l, cf* reg, const cf* tw16, int u, const cf* stream_base,
                                            unsigned stream_bytes, unsigned xoff, int64_t i, int64_t i1, cf* out_row, int64_t out_step,
-                                           const cf* in0_row, cf (&acc)[XM ? 16 : 1]) {
+                                           const cf* in0_row, cf (&acc)[XM ? 16 : 1], cf off8) {
     using G = G8192;
+    if (U8) convert_frame_u8(h[PH], off8);      // the byte pairs fetched a step ago become the samples of slot PH
+    const unsigned poff = U8 ? xoff * 4u : xoff;      // (P - 1 - u) complex64 elements, in bytes: the PRIV layout's offset
     cf v[16];
     {   // FIR out of the ring, window quads [r P + u] = taps 0 .. 3 of branch u + P r: the first kF8192WinLds groups from LDS, the
         // rest straight from their table (L2), four at a time
@@ -488,7 +490,10 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
     // the oldest slot is dead: the next frame of the run goes there, in flight through the stages below (the current one again
     // at the end of the run: never used, and no branch guards a definition of ring registers)
     FXC_SCHED_FENCE();
-    tiled_load_part<G, 0, 16>(h[(PH + 1) & 3], stream_base, stream_bytes, xoff, (i + 1 < i1) ? i + 1 : i);
+    if (U8)
+        tiled_load_part_u8<G, 0, 16>(h[(PH + 1) & 3], stream_base, stream_bytes, xoff, (i + 1 < i1) ? i + 1 : i);
+    else
+        tiled_load_part<G, 0, 16>(h[(PH + 1) & 3], stream_base, stream_bytes, xoff, (i + 1 < i1) ? i + 1 : i);
     FXC_SCHED_FENCE();
     {   // pre-stage (R0 = 2): slots g and g + 8, twiddle w8192^(u + 512 g) = w8192^u w16^g on the second: the thread's own factor
         // (a register pair) times a constant
@@ -537,7 +542,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
         __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(in0_row + i * (int64_t)G::N), 0, (int)(G::N * sizeof(cf)), 0x00020000);
 #pragma unroll
         for (int n = 0; n < kX8192Early; ++n) {
-            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, xoff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
             s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
         }
         G::loadC(reg, u, v);
@@ -545,7 +550,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
         FXC_SCHED_FENCE();
 #pragma unroll
         for (int n = kX8192Early; n < 16; ++n) {
-            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, xoff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
             s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
         }
 #pragma unroll
@@ -560,7 +565,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
                 v2u32 d;
                 d[0] = __float_as_uint(v[n].x);
                 d[1] = __float_as_uint(v[n].y);
-                __builtin_amdgcn_raw_buffer_store_b64(d, rr, xoff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(d, rr, poff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
             }
         } else {
             tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, true);
@@ -572,13 +577,16 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
 // streams are antenna 1 of n_streams chunk pairs, in0 = antenna 0's spectra [chunk][frame][N] in the PRIV layout (a launch of the <false, true> kernel), spec =
 // raw[split][chunk][N], the sums over the split's frames of spec0 conj(spec1)
 // EARLY: how many of antenna 0's sixteen values a thread requests before its last butterfly (8 / 12 / 16 measured alike: 1.93 - 1.96 ms)
-template <bool XM, bool PRIV, int EARLY = 12>
+// U8: the streams are interleaved unsigned bytes (I, Q), converted as x / 127.5 + dc[s * 2 + dc_ant] on their way into the ring
+template <bool XM, bool PRIV, bool U8 = false, int EARLY = 12>
 __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __restrict__ x, int64_t num_samp, int64_t n_pts,
                                                                    int64_t n_streams, int n_splits, const f4* __restrict__ win_g,
                                                                    const cf* __restrict__ tw0_g, const cf* __restrict__ twA_g,
                                                                    const cf* __restrict__ tw16_g, cf* __restrict__ spec, int spec_a,
-                                                                   int64_t s_base, int64_t stream_stride, const cf* __restrict__ in0) {
+                                                                   int64_t s_base, int64_t stream_stride, const cf* __restrict__ in0,
+                                                                   const cf* __restrict__ dc, int dc_ant) {
     using G = G8192;
+    constexpr int64_t kSampleBytes = U8 ? sizeof(unsigned short) : sizeof(cf);
     __shared__ __attribute__((aligned(16))) cf smem[kF8192LdsCf];
     cf* reg = smem;
     cf* tw16 = smem + G::kRegion;
@@ -590,14 +598,19 @@ __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __r
     for (int idx = u; idx < kF8192WinLds * G::P; idx += kF8192Threads) win_l[idx] = win_g[idx];
     const cf wu = tw0_g[8 * G::P + u];            // w8192^u (row g = 0 of the second half of the [16][P] pre-stage table)
     __syncthreads();
-    const int64_t per = (n_pts + n_splits - 1) / n_splits;
-    const unsigned stream_bytes = (unsigned)(num_samp * (int64_t)sizeof(cf));
-    const unsigned xoff = (unsigned)((G::P - 1 - u) * (int)sizeof(cf));
+    // (uniform, and said so: the 64-bit division runs on the vector unit, and left there the run's bounds and the conditions on them
+    // were vector registers;
+    // 32-bit: the scalar unit compares no 64-bit integers for order)
+    const int npts = (int)n_pts;
+    const int per = __builtin_amdgcn_readfirstlane((npts + n_splits - 1) / n_splits);
+    const unsigned stream_bytes = (unsigned)(num_samp * kSampleBytes);
+    const unsigned xoff = (unsigned)((G::P - 1 - u) * (int)kSampleBytes);
     // grid: (streams, splits) -- no division on the way to a work item
     for (int64_t s = blockIdx.x; s < n_streams; s += gridDim.x) {
-        const int64_t split = blockIdx.y;
-        const int64_t i0 = split * per, i1 = (i0 + per < n_pts) ? i0 + per : n_pts;
-        const cf* stream_base = x + s * stream_stride;
+        const int split = (int)blockIdx.y;
+        const int i0 = split * per, i1 = (i0 + per < npts) ? i0 + per : npts;
+        const cf* stream_base = reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + s * stream_stride * kSampleBytes);
+        const cf off8 = U8 ? dc[s * 2 + dc_ant] : fxc::mk(0.f, 0.f);
         cf* out_row = XM ? nullptr : spec + spec_row(s_base + s, 0, n_pts, spec_a) * G::N;
         const int64_t out_step = (int64_t)(spec_a > 0 ? spec_a : 1) * G::N;
         const cf* in0_row = XM ? in0 + s * n_pts * G::N : nullptr;
@@ -609,23 +622,31 @@ __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __r
 #pragma unroll
         for (int d = 1; d < 4; ++d) {
             if (i0 - d >= 0 && i0 < i1) {
-                tiled_load_part<G, 0, 16>(h[4 - d], stream_base, stream_bytes, xoff, i0 - d);
+                if (U8) {
+                    tiled_load_part_u8<G, 0, 16>(h[4 - d], stream_base, stream_bytes, xoff, i0 - d);
+                    convert_frame_u8(h[4 - d], off8);
+                } else {
+                    tiled_load_part<G, 0, 16>(h[4 - d], stream_base, stream_bytes, xoff, i0 - d);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[4 - d][r] = fxc::mk(0.f, 0.f);
             }
         }
         if (i0 < i1) {
-            tiled_load_part<G, 0, 16>(h[0], stream_base, stream_bytes, xoff, i0);
+            if (U8)
+                tiled_load_part_u8<G, 0, 16>(h[0], stream_base, stream_bytes, xoff, i0);      // (converted by its step)
+            else
+                tiled_load_part<G, 0, 16>(h[0], stream_base, stream_bytes, xoff, i0);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[0][r] = fxc::mk(0.f, 0.f);
         }
-        for (int64_t i = i0; i < i1; i += 4) {
-            f8192_step<0, XM, PRIV, EARLY>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i, i1, out_row, out_step, in0_row, acc);
-            if (i + 1 < i1) f8192_step<1, XM, PRIV, EARLY>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 1, i1, out_row, out_step, in0_row, acc);
-            if (i + 2 < i1) f8192_step<2, XM, PRIV, EARLY>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 2, i1, out_row, out_step, in0_row, acc);
-            if (i + 3 < i1) f8192_step<3, XM, PRIV, EARLY>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 3, i1, out_row, out_step, in0_row, acc);
+        for (int i = i0; i < i1; i += 4) {
+            f8192_step<0, XM, PRIV, EARLY, U8>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i, i1, out_row, out_step, in0_row, acc, off8);
+            if (i + 1 < i1) f8192_step<1, XM, PRIV, EARLY, U8>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 1, i1, out_row, out_step, in0_row, acc, off8);
+            if (i + 2 < i1) f8192_step<2, XM, PRIV, EARLY, U8>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 2, i1, out_row, out_step, in0_row, acc, off8);
+            if (i + 3 < i1) f8192_step<3, XM, PRIV, EARLY, U8>(h, win_g, win_l, wu, twA_l, reg, tw16, u, stream_base, stream_bytes, xoff, i + 3, i1, out_row, out_step, in0_row, acc, off8);
         }
         if constexpr (XM) {
             // the sums sit at bin_of(u, k2): through the exchange rows into natural order, once per run (tiled_store_spectrum's
@@ -636,7 +657,7 @@ __global__ __launch_bounds__(kF8192Threads) void f8192_ring_kernel(const cf* __r
             // LDS addresses below -- or u itself -- hoisted out of the run were spilled
             unsigned xo = xoff;
             asm volatile("" : "+v"(xo));
-            const int uu = (int)(G::P - 1) - (int)(xo >> 3);
+            const int uu = (int)(G::P - 1) - (int)(xo >> (U8 ? 1 : 3));
             const int b0 = G::bin_of(uu, 0);
             cf* wr = reg + b0 + (b0 >> 4);
 #pragma unroll

@@ -698,6 +698,18 @@ def test_8192_channels_in_two_passes(plan_mod, torch, monkeypatch, ntaps, n_chun
         if n_chunks // 3 + 1 < n_chunks:
             p.fx_accumulate(xd[n_chunks // 3 + 1:])
         assert rel_err(p.finalize("SPECTRUM"), rows.astype(np.complex128).mean(axis=0)) < 2e-6
+        # the receivers' bytes (uint8 I, Q; effex.py:391-395 converts and de-means on the host): converted on their way into both
+        # passes' rings -- against the conversion pass + the same route, and the oracle on the oracle's conversion
+        nb = min(n_chunks, 5)
+        u8 = torch.from_numpy(np.random.default_rng(frames).integers(0, 256, size=(nb, 2, num_samp, 2), dtype=np.uint8)).cuda()
+        by = p.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()
+        assert rel_err(by, p.fx_rows(p.convert_u8(u8, remove_dc=True)).cpu().numpy()) < TOL_VIS
+        a = fx_oracle.u8_to_complex(u8[:1].cpu().numpy())[0]
+        ref = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(a[0]), fx_oracle.remove_dc(a[1]), ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY,
+                                  -2e-7, "SPECTRUM")
+        assert rel_err(by[0, 0], ref) < TOL_VIS
+        p.fx_accumulate_u8(u8, remove_dc=True)
+        assert rel_err(p.finalize("SPECTRUM"), by.astype(np.complex128).mean(axis=0)) < 2e-6
     monkeypatch.setenv("FXC_X8192", "0")
     with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as q:
         assert q.info["block"] == 1024
