@@ -105,7 +105,9 @@ int fxc_plan_get_info(const fxc_plan* plan, fxc_info* info);
  * complex64 samples, 1: F+X from the receivers' bytes, 2: the F stage alone (fxc_channelize; the F pass of 3 and more
  * antennas) -- for the device architecture `arch` ("gfx950"; NULL: the current
  * device's), without a device and without a plan: the library's embedded kernel source through hiprtc.  FXC_OK and a one-line
- * description in `report` (may be NULL); FXC_ERR_UNSUPPORTED when the shape has no such kernel (plans of that shape run the
+ * description in `report` (may be NULL: "nchan= ntaps= tpr= slots= frames_per_step= stages= lds_bytes= code_bytes= vgprs= scratch=
+ * resident= lean= rows=" -- threads per frame, frames side by side in a workgroup, frames per step, the stage radices in order,
+ * whether taps and twiddles come from tables (above 2048 channels), streams per workgroup); FXC_ERR_UNSUPPORTED when the shape has no such kernel (plans of that shape run the
  * any-shape kernel); FXC_ERR_HIP with the compiler's log in fxc_last_error(NULL) when the build fails.
  * (The reference takes any integer --resolution, effex.py:733-739; this is where the build meets that freedom.) */
 int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* report, int report_bytes);
