@@ -149,7 +149,7 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
 // (N / 2 threads per frame leave the later stages a few butterflies each: 600 channels 3.4 ms against 1.75), then the fuller
 // first stage, then the smaller radix (fewer ring registers).
 // streams per workgroup of the build for (n, variant): F only above 4096 channels carries one (sixteen points a thread)
-inline int spec_rows(int n, int variant) { return (variant == 2 && n > 4096) ? 1 : 2; }
+inline int spec_rows(int n, int variant) { return (variant == 2 && n > env_int("FXC_RTC_ROWS1_ABOVE", 4096)) ? 1 : 2; }      // (developer knob)
 
 std::vector<int> spec_first_radices(int n, int taps, int rows = 2) {
     struct Cand {
