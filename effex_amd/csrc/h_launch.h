@@ -200,7 +200,12 @@ int64_t spec_wg_splits(const fxc_plan* p, const SpecKernel* k, int64_t n_groups,
     const SpecShape& sh = k->shape;
     const int64_t cap = (int64_t)p->cu_count * k->wgs_per_cu;
     const int64_t ws_lo = sums ? std::max<int64_t>(1, (p->n_pts + sh.slots * kRowSpectra - 1) / (sh.slots * kRowSpectra)) : 1;
-    const int64_t ws_hi = std::max<int64_t>(ws_lo, std::min<int64_t>(64, p->n_pts / (16 * (int64_t)sh.slots)));
+    // runs of sixteen frames at least (a run re-reads ntaps - 1 frames of history and loads its taps and twiddles) -- unless that
+    // leaves most of the device idle: a call over one chunk pair (the drop-in's _run_task, effex.py:490-494) is about latency, and
+    // takes runs of two
+    const int64_t few = std::max<int64_t>(n_groups, 1) * std::max<int64_t>(1, p->n_pts / (16 * (int64_t)sh.slots)) < cap;
+    const int64_t min_run = few ? 2 : 16;
+    const int64_t ws_hi = std::max<int64_t>(ws_lo, std::min<int64_t>(64, p->n_pts / (min_run * (int64_t)sh.slots)));
     int64_t best = ws_lo;
     double best_cost = 1e300;
     for (int64_t ws = ws_lo; ws <= ws_hi; ++ws) {
@@ -642,7 +647,10 @@ int small_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int 
 int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only) {
     const int64_t cap = f_only ? p->tiled_grid_max_f : p->tiled_grid_max;
     const int64_t want = (2 * cap + n_chunks - 1) / n_chunks;
-    const int64_t most = std::max<int64_t>(1, p->n_pts / 8);
+    // runs of eight frames at least -- the two-pass 8192-channel route (one workgroup per CU, 8 us a frame) with a handful of chunks:
+    // of one (latency: see spec_wg_splits)
+    const bool few = p->x8192 && n_chunks * std::max<int64_t>(1, p->n_pts / 8) < p->cu_count;
+    const int64_t most = std::max<int64_t>(1, p->n_pts / (few ? 1 : 8));
     const int64_t fill = std::max<int64_t>(1, std::min<int64_t>(std::min(want, most), 256));
     if (f_only) return (int)fill;
     // F+X: a work item sums its frames in float32, like the headline kernel's rows at most kRowSpectra of them (small
@@ -732,7 +740,8 @@ int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, 
         if (rc) return rc;
         cf* s0 = static_cast<cf*>(p->d_pre);
         const int64_t want = (2 * (int64_t)p->cu_count + nc - 1) / nc;
-        const int f_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / 8));
+        const bool few = nc * std::max<int64_t>(1, p->n_pts / 8) < p->cu_count;
+        const int f_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / (few ? 1 : 8)));
         const dim3 grid_f((unsigned)std::min<int64_t>(nc, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / f_splits)), (unsigned)f_splits);
         const dim3 grid_x((unsigned)std::min<int64_t>(nc, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / n_splits)), (unsigned)n_splits);
         // antenna 1's stream of the first chunk: num_samp samples (of 8 bytes, or of 2) behind antenna 0's
