@@ -778,7 +778,8 @@ int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int 
         // for two rounds of the CUs when the streams are few
         KernelTimer kt8(p);
         const int64_t want = (2 * (int64_t)p->cu_count + n_streams - 1) / n_streams;
-        const int n_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / 8));
+        const bool few = n_streams * std::max<int64_t>(1, p->n_pts / 8) < p->cu_count;      // (one stream: _spectrometer_poly itself -- latency)
+        const int n_splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, p->n_pts / (few ? 1 : 8)));
         const int grid_x = (int)std::min<int64_t>(n_streams, std::max<int64_t>(1, (int64_t)p->cu_count * 8 / n_splits));
         const dim3 grid((unsigned)grid_x, (unsigned)n_splits);
         hipLaunchKernelGGL((f8192_ring_kernel<false, false>), grid, dim3(kF8192Threads), 0, p->stream, x, p->num_samp, p->n_pts, n_streams, n_splits,
