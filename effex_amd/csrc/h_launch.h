@@ -205,7 +205,10 @@ int64_t spec_wg_splits(const fxc_plan* p, const SpecKernel* k, int64_t n_groups,
     // takes runs of two
     const int64_t few = std::max<int64_t>(n_groups, 1) * std::max<int64_t>(1, p->n_pts / (16 * (int64_t)sh.slots)) < cap;
     const int64_t min_run = few ? 2 : 16;
-    const int64_t ws_hi = std::max<int64_t>(ws_lo, std::min<int64_t>(64, p->n_pts / (min_run * (int64_t)sh.slots)));
+    // (... and of at most 256 rows per chunk: what reads the rows of a single chunk -- rows_spectrum_kernel -- adds them up one thread
+    // per bin; 12 channels, 64 slots a workgroup: 4 096 rows and 1.1 ms per _run_task with 64 splits)
+    const int64_t row_cap = few ? std::max<int64_t>(1, 256 / sh.slots) : 64;
+    const int64_t ws_hi = std::max<int64_t>(ws_lo, std::min<int64_t>(std::min<int64_t>(64, row_cap), p->n_pts / (min_run * (int64_t)sh.slots)));
     int64_t best = ws_lo;
     double best_cost = 1e300;
     for (int64_t ws = ws_lo; ws <= ws_hi; ++ws) {

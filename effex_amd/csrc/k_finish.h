@@ -59,8 +59,22 @@ __global__ void rows_spectrum_kernel(const cf* __restrict__ raw, cf* __restrict_
         const int k = (int)(idx % nchan);
         const int64_t row = idx / nchan;
         float ar = 0.f, ai = 0.f;
-        for (int s = 0; s < n_splits; ++s) {
-            const cf r = raw[s * split_stride + row * nchan + raw_index(k, slots)];
+        // sixteen loads in flight, added in the order of the splits (one at a time a bin of a single chunk with 256 rows -- few
+        // channels, many slots -- waited out 256 trips to L2: 0.1 ms)
+        const cf* src = raw + row * nchan + raw_index(k, slots);
+        int s = 0;
+        for (; s + 16 <= n_splits; s += 16) {
+            cf r[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) r[q] = src[(s + q) * split_stride];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                ar += r[q].x;
+                ai += r[q].y;
+            }
+        }
+        for (; s < n_splits; ++s) {
+            const cf r = src[s * split_stride];
             ar += r.x;
             ai += r.y;
         }
