@@ -101,6 +101,26 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return r;
 }
 
+// sum over the splits of one bin's raw values, in split order, sixteen loads in flight (see rows_spectrum_kernel)
+__device__ __forceinline__ void sum_splits(const cf* src, int n_splits, int64_t split_stride, double& xr, double& xi) {
+    int s = 0;
+    for (; s + 16 <= n_splits; s += 16) {
+        cf r[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = src[(s + q) * split_stride];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            xr += r[q].x;
+            xi += r[q].y;
+        }
+    }
+    for (; s < n_splits; ++s) {
+        const cf r = src[s * split_stride];
+        xr += r.x;
+        xi += r.y;
+    }
+}
+
 // CONTINUUM rows: out[row] = mean_k( raw * conj(rot) / n_pts ) / bandwidth   (effex.py:523-524); one WG per row, of
 // kContinuumThreads threads: a reference-sized call is a single row whose frames the F+X kernel spread over the whole grid,
 // so each bin gathers up to grid - 1 leading-part rows -- 72 us with 256 threads, the largest item of that call
@@ -115,11 +135,7 @@ __global__ __launch_bounds__(kContinuumThreads) void rows_continuum_kernel(const
         double ar = 0.0, ai = 0.0;
         for (int k = threadIdx.x; k < nchan; k += blockDim.x) {
             double xr = 0.0, xi = 0.0;
-            for (int s = 0; s < n_splits; ++s) {
-                const cf r = raw[s * split_stride + row * nchan + raw_index(k, slots)];
-                xr += r.x;
-                xi += r.y;
-            }
+            sum_splits(raw + row * nchan + raw_index(k, slots), n_splits, split_stride, xr, xi);
             float lr_re = 0.f, lr_im = 0.f;
             add_lead_rows(raw, lead, row, nchan, k, slots, lr_re, lr_im);
             xr += lr_re;
@@ -153,11 +169,7 @@ __global__ __launch_bounds__(256) void rows_continuum_part_kernel(const cf* __re
     double ar = 0.0, ai = 0.0;
     for (int k = k_lo + threadIdx.x; k < k_hi; k += blockDim.x) {
         double xr = 0.0, xi = 0.0;
-        for (int s = 0; s < n_splits; ++s) {
-            const cf r = raw[s * split_stride + row * nchan + raw_index(k, slots)];
-            xr += r.x;
-            xi += r.y;
-        }
+        sum_splits(raw + row * nchan + raw_index(k, slots), n_splits, split_stride, xr, xi);
         float lr_re = 0.f, lr_im = 0.f;
         add_lead_rows(raw, lead, row, nchan, k, slots, lr_re, lr_im);
         xr += lr_re;
