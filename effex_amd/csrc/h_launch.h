@@ -619,12 +619,12 @@ int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only = false);
 
 // F-stage only (see tiled_channelize): n_streams consecutive streams -> natural-order spectra, pairs of streams per item
 int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only);
-int64_t prefilter_streams_per_pass(const fxc_plan* p);
+int64_t tiled_streams_per_pass(const fxc_plan* p);
 int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_out);
 
 int small_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int spec_a) {
     KernelTimer kt(p);
-    const int64_t per_pass = prefilter_streams_per_pass(p);      // everything at once unless the pre-filter bounds a pass
+    const int64_t per_pass = tiled_streams_per_pass(p);      // everything at once unless the pre-filter bounds a pass
     for (int64_t s0 = 0; s0 < n_streams; s0 += per_pass) {
         const int64_t ns = std::min(per_pass, n_streams - s0);
         const cf* xs = x + s0 * p->num_samp;
@@ -662,8 +662,9 @@ int tiled_splits(const fxc_plan* p, int64_t n_chunks, bool f_only) {
     return (int)std::max(fill, exact);
 }
 
-// streams the pre-filter handles per pass (its output stays within the workspace target)
-int64_t prefilter_streams_per_pass(const fxc_plan* p) {
+// streams of the tiled path per pass: what a pass keeps beside the raw rows -- the pre-filter's output, or antenna 0's spectra of the
+// two-pass 8192-channel route -- stays within the workspace target
+int64_t tiled_streams_per_pass(const fxc_plan* p) {
     if (p->x8192) {       // 8192 channels in two passes: antenna 0's spectra of a pass stay within the workspace target
         const int64_t chunks = std::max<int64_t>(1, ws_target() / (p->n_pts * (int64_t)p->nchan * (int64_t)sizeof(cf)));
         return 2 * std::min<int64_t>(chunks, 1 << 20);
@@ -719,7 +720,7 @@ int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_ou
     return FXC_OK;
 }
 
-// raw[split][c][k] (natural bin order) for nc chunks starting at x (nc * 2 <= prefilter_streams_per_pass())
+// raw[split][c][k] (natural bin order) for nc chunks starting at x (nc * 2 <= tiled_streams_per_pass())
 int tiled_raw_sums(fxc_plan* p, const cf* x, int64_t nc, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
     KernelTimer kt(p);
     if (p->small) {
@@ -792,7 +793,7 @@ int tiled_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int 
         return FXC_OK;
     }
     KernelTimer kt(p);
-    const int64_t per_pass = prefilter_streams_per_pass(p);
+    const int64_t per_pass = tiled_streams_per_pass(p);
     for (int64_t s0 = 0; s0 < n_streams; s0 += per_pass) {
         const int64_t ns = std::min(per_pass, n_streams - s0);
         const cf* xs = x + s0 * p->num_samp;

@@ -69,7 +69,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         const int64_t in_bytes = (int64_t)2 * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         const int n_splits = tiled_splits(p, n_chunks);
         const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
-        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, prefilter_streams_per_pass(p) / 2),
+        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, tiled_streams_per_pass(p) / 2),
                                                                   ws_target() / (row_bytes * n_splits)));
         const int64_t raw_bytes = (cb * n_splits * row_bytes + 255) / 256 * 256;
         const int64_t part_bytes = fold_part_bytes(p);
@@ -234,7 +234,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         const int64_t in_bytes = (int64_t)2 * p->num_samp * (dc_u8 ? 2 : (int64_t)sizeof(cf));   // per chunk
         const int n_splits = tiled_splits(p, n_chunks);
         const int64_t row_bytes = (int64_t)N * (int64_t)sizeof(cf);
-        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, prefilter_streams_per_pass(p) / 2),
+        const int64_t cb = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, tiled_streams_per_pass(p) / 2),
                                                                   ws_target() / (row_bytes * n_splits)));
         int rc = ensure_ws(p, cb * n_splits * row_bytes);
         if (rc) return rc;
