@@ -374,6 +374,15 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                         std::fprintf(stderr, "libfxcorr: no specialised kernel for %d channels: %s\n", N, k->error.c_str());
                 }
             }
+            // above 4096 channels there is no such kernel (sixteen points of two antennas: 256 registers of ring), but the F stage
+            // alone has one: complex64 input takes it, and xmul_kernel (h_launch.h::mixed_one_pass)
+            if (p->mixed_xf && !p->spec && N > 4096 && T <= 4 && p->rtc && p->num_samp < (1ll << 28) && env_int("FXC_MIXED_XF_BYTES_ONLY", 1) &&
+                !spec_first_radices(N, T, spec_rows(N, kSpecFOnly)).empty()) {
+                const SpecKernel* k = spec_kernel(p->device, N, T, kSpecFOnly);
+                p->spec_f_tried = true;
+                p->spec_f = k->fn ? k : nullptr;
+                p->xf_bytes_only = p->spec_f != nullptr;
+            }
         }
     }
     // generic FFT twiddles exp(+2 pi i j / N): [N/2] for the radix-2 kernel, [N] for the mixed-radix kernel and the direct DFT

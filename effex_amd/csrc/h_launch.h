@@ -224,14 +224,15 @@ int64_t spec_wg_splits(const fxc_plan* p, const SpecKernel* k, int64_t n_groups,
     return best;
 }
 
-XGeom x_geometry(const fxc_plan* p, int64_t n_chunks) {
+// xf: this call takes the mixed-radix kernel that does F and X in one pass (mixed_xf plans; h_run.h::mixed_one_pass)
+XGeom x_geometry(const fxc_plan* p, int64_t n_chunks, bool xf) {
     XGeom g;
-    if (p->mixed_xf && p->spec) {
+    if (xf && p->spec) {
         g.kx = 1;
         g.n_splits = (int)(spec_wg_splits(p, p->spec, n_chunks, true) * p->spec->shape.slots);
         return g;
     }
-    if (p->mixed_xf) {
+    if (xf) {
         // workgroups = chunks x splits: eight per CU when the frames allow it, runs of four frame groups at least
         const int rpw = std::max(256, p->mixed_tpr) / p->mixed_tpr;
         const int64_t gps = (p->n_pts + rpw - 1) / rpw;
@@ -254,10 +255,15 @@ XGeom x_geometry(const fxc_plan* p, int64_t n_chunks) {
     return g;
 }
 
+// F and X in one pass for this call?  mixed_xf plans above 4096 channels that have the F stage built for their channel count
+// (fx_spec.h, one stream per workgroup) take it for complex64 input -- F pass + xmul_kernel: 4500 channels 4.39 -> 3.43 ms -- and keep
+// the one-pass kernel for the receivers' bytes, which it converts itself (3.5 ms against 5.0 through the conversion pass)
+bool mixed_one_pass(const fxc_plan* p, bool bytes_in) { return p->mixed_xf && (bytes_in || !p->xf_bytes_only); }
+
 // chunks per pass on the generic path so that spectra + raw sums fit the workspace target
 int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom& g, int64_t* spec_bytes,
-                                int64_t* raw_bytes) {
-    const int64_t spec_per_chunk = p->mixed_xf ? 0 : (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
+                                int64_t* raw_bytes, bool xf) {
+    const int64_t spec_per_chunk = xf ? 0 : (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
     const int64_t raw_per_chunk = (int64_t)g.n_splits * p->n_base * p->nchan * (int64_t)sizeof(cf);
     int64_t cb = ws_target() / std::max<int64_t>(1, spec_per_chunk + raw_per_chunk);
     if (cb < 1) cb = 1;

@@ -71,6 +71,7 @@ struct fxc_plan {
     bool mixed_xeng = false;       // 3 .. 64 antennas: F-only mixed kernel (antenna-interleaved spectra) + the X-engines
     bool mixed_xf_twl = true;      // ... with the twiddle table in LDS (up to 4096 channels; from L2 up to 5120)
     bool mixed_xf = false;         // two antennas: the same kernel multiplies and integrates too (no spectra in HBM)
+    bool xf_bytes_only = false;    // ... for the receivers' bytes only: complex64 input takes the F stage built for the channel count + xmul_kernel
     // ... and, where the shape allows, in the build of fx_spec.h made for exactly this channel count (h_rtc.h); spec_u8: its
     // byte-ingest twin, compiled when bytes first arrive
     const SpecKernel* spec = nullptr;

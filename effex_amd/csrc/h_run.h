@@ -86,9 +86,10 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
             if (rc) return rc;
         }
     } else {
-        const XGeom g = x_geometry(p, n_chunks);
+        const bool xf = mixed_one_pass(p, dc_u8 != nullptr);
+        const XGeom g = x_geometry(p, n_chunks, xf);
         int64_t spec_bytes, raw_bytes;
-        const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes);
+        const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes, xf);
         raw_bytes = (raw_bytes + 255) / 256 * 256;
         int rc = ensure_ws(p, spec_bytes + raw_bytes + fold_part_bytes(p));
         if (rc) return rc;
@@ -98,7 +99,7 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
             const int64_t nc = std::min(cb, n_chunks - c0);
             KernelTimer kt(p);
-            if (p->mixed_xf) {
+            if (xf) {
                 // (bytes in: two per sample, and the offsets of this pass's streams)
                 rc = dc_u8 ? mixed_fx_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * 2 * p->num_samp * 2),
                                                nc, g.n_splits, raw, dc_u8 + c0 * 2)
@@ -255,9 +256,10 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         }
         return FXC_OK;
     }
-    const XGeom g = x_geometry(p, n_chunks);
+    const bool xf = mixed_one_pass(p, dc_u8 != nullptr);
+    const XGeom g = x_geometry(p, n_chunks, xf);
     int64_t spec_bytes, raw_bytes;
-    const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes);
+    const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes, xf);
     int rc = ensure_ws(p, spec_bytes + raw_bytes);
     if (rc) return rc;
     cf* spec = reinterpret_cast<cf*>(p->d_ws);
@@ -265,7 +267,7 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
     for (int64_t c0 = 0; c0 < n_chunks; c0 += cb) {
         const int64_t nc = std::min(cb, n_chunks - c0);
         KernelTimer kt(p);
-        if (p->mixed_xf) {
+        if (xf) {
             rc = dc_u8 ? mixed_fx_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * 2 * p->num_samp * 2),
                                            nc, g.n_splits, raw, dc_u8 + c0 * 2)
                        : mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
