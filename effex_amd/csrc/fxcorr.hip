@@ -338,8 +338,9 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             }
         }
         p->rtc = env_int("FXC_RTC", 1) != 0;      // (read once, when the plan is made)
-        if (p->mixed && p->rtc && N > spec_lean_above() && T <= 4 && !p->d_win4) {
-            // the lean builds of fx_spec.h (above 2048 channels) read a point's taps as one quad from L2: [N][4], zeros beyond T
+        if (p->mixed && p->rtc && N <= 8192 && T <= 4 && !p->d_win4) {
+            // the lean builds of fx_spec.h (above 2048 channels, or with a prime factor of 17 ... 23) read a point's taps as one quad from
+            // L2: [N][4], zeros beyond T
             std::vector<f4> w4((size_t)N);
             for (int m = 0; m < N; ++m) {
                 f4 w;

@@ -106,9 +106,11 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
     if (n < 2 || n > 8192 || taps < 1 || taps > 4) return s;
     const fxc::MixedPlan mp = fxc::mixed_factor(n);
     if (mp.n_stages < 1) return s;
+    bool big = false;
     for (int i = 0; i < mp.n_stages; ++i) {
         const int r = mp.radix[i];
-        if (!(r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 11 || r == 13)) return s;
+        if (!(r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 11 || r == 13 || r == 17 || r == 19 || r == 23)) return s;
+        if (r > 13) big = true;      // (a register butterfly of 17 ... 23 points: only beside the lean build's few persistent registers)
         s.radix[i] = r;
     }
     s.n = n;
@@ -135,7 +137,8 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
     if (s.radix[0] * j0 > (rows == 1 ? 16 : 8)) return s;      // (the ring: 128 registers at most)
     s.rows = rows;
     s.u = u;
-    s.lean = n > spec_lean_above();
+    s.lean = n > spec_lean_above() || big;
+    if (big && !env_int("FXC_RTC_BIG_PRIMES", 1)) return s;
     if (s.lean && s.n_stages < 2) return s;
     if (u != 1 && (u != 2 || s.n_stages < 2)) return s;      // (whether two frames' rows cost a resident workgroup: spec_search)
     if (s.lds_bytes() > (size_t)(160 * 1024)) return s;
@@ -158,9 +161,14 @@ std::vector<int> spec_first_radices(int n, int taps, int rows = 2) {
     std::vector<Cand> c;
     const SpecShape base = spec_shape(n, taps, 0, 1, rows);
     if (!base.n) return {};
-    for (int r : {3, 4, 5, 7, 2, 11, 13}) {
+    for (int r : {3, 4, 5, 7, 2, 11, 13, 17, 19, 23}) {
         const SpecShape s = spec_shape(n, taps, r, 1, rows);
         if (!s.ok || s.threads() > 512) continue;      // (more than 512 threads leave under 256 registers a thread: the ring does not fit)
+        bool big = false;
+        for (int i = 0; i < s.n_stages; ++i) big = big || s.radix[i] > 13;
+        // (a butterfly of 17 ... 23 points takes 220 - 400 registers with the ring: one wave a SIMD, so 256 threads at most -- 1700 / 1900 /
+        // 2040 channels on 512 threads spilled 150 - 240 B after 7 s of compiling)
+        if (big && s.threads() > 256) continue;
         const int nb0 = n / r, j0 = (nb0 + s.tpr - 1) / s.tpr;
         const int waste = 20 - 20 * nb0 / (s.tpr * j0);                 // idle lanes of the first stage, in twentieths
         c.push_back({r, s.threads() % 256 != 0, r == 2, waste});

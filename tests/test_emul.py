@@ -267,12 +267,14 @@ def test_specialised_kernel_shapes():
     """Which channel counts get a kernel of their own (h_rtc.h::spec_shape): every prime factor a register butterfly, up to
     four taps, the first stage's points within the ring; the others keep the any-shape kernel (FXC_ERR_UNSUPPORTED here)."""
     from effex_amd import _lib
-    for nchan, ntaps in ((997, 4), (143, 4), (1000, 5), (2 * 17, 4), (16384, 4)):
+    for nchan, ntaps in ((997, 4), (1000, 5), (2 * 29, 4), (16384, 4), (1700, 4)):      # (1700 = 4 x 25 x 17 needs 448 threads: a 17-point butterfly has room on 256)
         assert _spec_shape(nchan, ntaps)[0] == _lib.FXC_ERR_UNSUPPORTED, (nchan, ntaps)
     rc, (flags, tpr, slots) = _spec_shape(1000, 4)
     assert rc == 0 and (tpr, slots) == (256, 1) and "-DFXM_RADICES=4,2,5,5,5" in flags
     rc, (flags, tpr, slots) = _spec_shape(96, 4)
     assert (tpr, slots) == (32, 8)
+    rc, (flags, tpr, slots) = _spec_shape(2 * 17, 4)      # prime factors 17 ... 23: the lean build (registers for the butterfly)
+    assert rc == 0 and "-DFXM_LEAN=1" in flags and "-DFXM_RADICES=2,17" in flags
 
 
 @pytest.mark.parametrize("nchan,ntaps,n_pts,wg_splits,u8", [
@@ -280,7 +282,8 @@ def test_specialised_kernel_shapes():
     (7, 1, 5, 1, False), (250, 4, 13, 2, False), (720, 3, 7, 2, False), (1001, 4, 6, 1, False), (1536, 4, 6, 1, False),
     (20, 4, 33, 1, True), (4, 4, 40, 1, False),
     # above 2048 channels: the lean build (taps and first twiddles from tables, two first-stage butterflies a thread at 4000)
-    (3000, 4, 6, 2, False), (4000, 4, 5, 1, False), (2560, 3, 5, 1, False), (2400, 4, 7, 1, False)])
+    (3000, 4, 6, 2, False), (4000, 4, 5, 1, False), (2560, 3, 5, 1, False), (2400, 4, 7, 1, False),
+    (340, 4, 9, 1, False), (2 * 19, 2, 40, 1, False), (460, 4, 5, 2, True)])      # prime factors 17, 19, 23
 @pytest.mark.parametrize("frames_per_step", [1, 2])
 def test_specialised_kernel_matches_oracle(tmp_path, monkeypatch, nchan, ntaps, n_pts, wg_splits, u8, frames_per_step):
     """fx_spec.h -- the two-antenna F+X kernel compiled per channel count -- run on the host (tests/emul/emul_spec.cpp: one

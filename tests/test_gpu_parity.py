@@ -957,7 +957,9 @@ def test_specialised_f_stage_on_the_device(plan_mod, torch, monkeypatch, n_ant, 
     (1000, 4, 700, 40, 3), (1000, 4, 3, 262, 144), (96, 4, 2100, 25, 0), (1536, 4, 5, 170, 1), (720, 3, 64, 33, 2), (250, 2, 9, 1000, 0),
     (12, 4, 3, 20000, 5), (2000, 4, 1, 131, 0), (1001, 4, 2, 11, 0), (600, 1, 40, 50, 7), (20, 4, 1, 1, 0), (7, 1, 300, 90, 0),
     # above 2048 channels: the lean build (taps and first twiddles from tables in L2)
-    (3000, 4, 300, 21, 7), (4000, 4, 2, 65, 0), (2560, 3, 5, 40, 1), (2400, 4, 700, 9, 0), (3072, 2, 3, 1, 0)])
+    (3000, 4, 300, 21, 7), (4000, 4, 2, 65, 0), (2560, 3, 5, 40, 1), (2400, 4, 700, 9, 0), (3072, 2, 3, 1, 0),
+    # prime factors 17 ... 23: the lean build on at most 256 threads
+    (1020, 4, 40, 30, 3), (34, 4, 5, 700, 1), (1140, 3, 2, 9, 0), (460, 4, 300, 11, 0)])
 def test_specialised_kernel_on_the_device(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
     """The F+X kernel compiled for one channel count when the plan is made (fx_spec.h through hiprtc, h_rtc.h) -- every shape
     class the host emulation covers (tests/test_emul.py), here on the device and at launch sizes that take several rounds of

@@ -38,7 +38,7 @@ def main():
     while time.time() < t_end:
         nchan = int(rng.integers(args.min_nchan, args.max_nchan))
         ntaps = int(rng.choice([1, 2, 3, 4, 4, 4]))
-        if nchan & (nchan - 1) == 0 and nchan >= 16:      # the powers of two from 16 on have tuned kernels of their own
+        if nchan & (nchan - 1) == 0:      # the powers of two have kernels of their own (tuned from 16 on, the generic radix-2 below)
             continue
         if lib.fxc_spec_probe(nchan, ntaps, 0, None, None, 0) != 0:
             continue
