@@ -130,7 +130,7 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
         s.tpr = 1;
         while (s.tpr < nb0) s.tpr <<= 1;
     } else {
-        j0 = n > spec_lean_above() ? (nb0 + 511) / 512 : (nb0 + 1023) / 1024;
+        j0 = big ? (nb0 + 255) / 256 : (n > spec_lean_above() ? (nb0 + 511) / 512 : (nb0 + 1023) / 1024);      // (big: one wave a SIMD, see spec_first_radices)
         s.tpr = ((nb0 + j0 - 1) / j0 + 63) / 64 * 64;
     }
     s.slots = std::max(1, 256 / s.tpr);

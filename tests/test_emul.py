@@ -267,7 +267,7 @@ def test_specialised_kernel_shapes():
     """Which channel counts get a kernel of their own (h_rtc.h::spec_shape): every prime factor a register butterfly, up to
     four taps, the first stage's points within the ring; the others keep the any-shape kernel (FXC_ERR_UNSUPPORTED here)."""
     from effex_amd import _lib
-    for nchan, ntaps in ((997, 4), (1000, 5), (2 * 29, 4), (16384, 4), (1700, 4)):      # (1700 = 4 x 25 x 17 needs 448 threads: a 17-point butterfly has room on 256)
+    for nchan, ntaps in ((997, 4), (1000, 5), (2 * 29, 4), (16384, 4), (2 * 1700, 4)):      # (3400 = 8 x 25 x 17: a 17-point butterfly has room on 256 threads, 2048 channels at most)
         assert _spec_shape(nchan, ntaps)[0] == _lib.FXC_ERR_UNSUPPORTED, (nchan, ntaps)
     rc, (flags, tpr, slots) = _spec_shape(1000, 4)
     assert rc == 0 and (tpr, slots) == (256, 1) and "-DFXM_RADICES=4,2,5,5,5" in flags
@@ -283,7 +283,7 @@ def test_specialised_kernel_shapes():
     (20, 4, 33, 1, True), (4, 4, 40, 1, False),
     # above 2048 channels: the lean build (taps and first twiddles from tables, two first-stage butterflies a thread at 4000)
     (3000, 4, 6, 2, False), (4000, 4, 5, 1, False), (2560, 3, 5, 1, False), (2400, 4, 7, 1, False),
-    (340, 4, 9, 1, False), (2 * 19, 2, 40, 1, False), (460, 4, 5, 2, True)])      # prime factors 17, 19, 23
+    (340, 4, 9, 1, False), (2 * 19, 2, 40, 1, False), (460, 4, 5, 2, True), (1700, 4, 5, 1, False)])      # prime factors 17, 19, 23
 @pytest.mark.parametrize("frames_per_step", [1, 2])
 def test_specialised_kernel_matches_oracle(tmp_path, monkeypatch, nchan, ntaps, n_pts, wg_splits, u8, frames_per_step):
     """fx_spec.h -- the two-antenna F+X kernel compiled per channel count -- run on the host (tests/emul/emul_spec.cpp: one

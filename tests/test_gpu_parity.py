@@ -959,7 +959,7 @@ def test_specialised_f_stage_on_the_device(plan_mod, torch, monkeypatch, n_ant, 
     # above 2048 channels: the lean build (taps and first twiddles from tables in L2)
     (3000, 4, 300, 21, 7), (4000, 4, 2, 65, 0), (2560, 3, 5, 40, 1), (2400, 4, 700, 9, 0), (3072, 2, 3, 1, 0),
     # prime factors 17 ... 23: the lean build on at most 256 threads
-    (1020, 4, 40, 30, 3), (34, 4, 5, 700, 1), (1140, 3, 2, 9, 0), (460, 4, 300, 11, 0)])
+    (1020, 4, 40, 30, 3), (34, 4, 5, 700, 1), (1140, 3, 2, 9, 0), (460, 4, 300, 11, 0), (1900, 4, 3, 137, 5), (2040, 4, 200, 7, 0)])
 def test_specialised_kernel_on_the_device(plan_mod, torch, nchan, ntaps, n_chunks, frames, extra):
     """The F+X kernel compiled for one channel count when the plan is made (fx_spec.h through hiprtc, h_rtc.h) -- every shape
     class the host emulation covers (tests/test_emul.py), here on the device and at launch sizes that take several rounds of
