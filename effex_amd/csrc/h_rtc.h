@@ -82,6 +82,8 @@ RtcApi* rtc_api() {
 }
 
 // how fx_spec.h is cut for one channel count: stage order, threads per slot, slots per workgroup
+enum SpecVariant { kSpecC64 = 0, kSpecU8 = 1, kSpecFOnly = 2 };      // F + X from complex64 / from the receivers' bytes, the F stage alone
+
 constexpr int kSpecLeanAbove = 2048;
 inline int spec_lean_above() { return env_int("FXC_RTC_LEAN_ABOVE", kSpecLeanAbove); }      // (developer knob)
 
@@ -152,7 +154,7 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
 // (N / 2 threads per frame leave the later stages a few butterflies each: 600 channels 3.4 ms against 1.75), then the fuller
 // first stage, then the smaller radix (fewer ring registers).
 // streams per workgroup of the build for (n, variant): F only above 4096 channels carries one (sixteen points a thread)
-inline int spec_rows(int n, int variant) { return (variant == 2 && n > env_int("FXC_RTC_ROWS1_ABOVE", 4096)) ? 1 : 2; }      // (developer knob)
+inline int spec_rows(int n, int variant) { return (variant == kSpecFOnly && n > env_int("FXC_RTC_ROWS1_ABOVE", 4096)) ? 1 : 2; }      // (developer knob)
 
 std::vector<int> spec_first_radices(int n, int taps, int rows = 2) {
     struct Cand {
@@ -249,7 +251,6 @@ long long code_object_int(const std::vector<char>& image, const char* key) {
 }
 
 // the builds of fx_spec.h: F+X from complex64 samples, F+X from the receivers' bytes, the F stage alone
-enum SpecVariant { kSpecC64 = 0, kSpecU8 = 1, kSpecFOnly = 2 };
 
 // Code objects on disk: a build is keyed by everything that goes into it -- the three sources as embedded, the options, the
 // architecture, the compiler's version -- and kept under $FXC_RTC_CACHE (default $XDG_CACHE_HOME/fxcorr or ~/.cache/fxcorr; "0"
