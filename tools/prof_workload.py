@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: one named workload a few times, for rocprofv3 (kernel trace / PMC passes; tools/collect_profiles.sh).
 
-    python3 tools/prof_workload.py 8ant | stream1 | nfft2048 | taps32 | nfft256 | nfft16 | 16ant | 32ant | res1000 | res3000 | nfft8192 [reps]
+    python3 tools/prof_workload.py 8ant | stream1 | nfft2048 | taps32 | nfft256 | nfft16 | 16ant | 32ant | res1000 | res3000 | res6000 | nfft8192 [reps]
 """
 import os
 import sys
@@ -23,6 +23,7 @@ WORKLOADS = {
     "32ant": (32, 4096, 4, 2 ** 18, 64, "SPECTRUM", False),          # 496 baselines
     "res1000": (2, 1000, 4, 2 ** 18, 1024, "SPECTRUM", False),       # --resolution 1000: mixed-radix kernel, F and X in one pass
     "nfft8192": (2, 8192, 4, 2 ** 18, 1024, "SPECTRUM", False),      # --nfft 8192: two passes (f8192_ring_kernel, then its XM form)
+    "res6000": (2, 6000, 4, 2 ** 18, 1024, "SPECTRUM", False),       # --resolution 6000: the F stage built for the channel count + xmul_kernel
     "res3000": (2, 3000, 4, 2 ** 18, 1024, "SPECTRUM", False),       # --resolution 3000: the lean build of fx_spec.h (above 2048 channels)
     "res1000t1": (2, 1000, 1, 2 ** 18, 1024, "SPECTRUM", False),     # ... with one tap: every sample read once (calibrates FETCH_SIZE)
 }
