@@ -132,7 +132,10 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
         s.tpr = 1;
         while (s.tpr < nb0) s.tpr <<= 1;
     } else {
-        j0 = big ? (nb0 + 255) / 256 : (n > spec_lean_above() ? (nb0 + 511) / 512 : (nb0 + 1023) / 1024);      // (big: one wave a SIMD, see spec_first_radices)
+        // threads a frame at most: 1024 up to 2048 channels (spec_first_radices keeps the shapes of up to 512), 512 above, 256 with a
+        // butterfly of 17 ... 23 points (one wave a SIMD, see spec_first_radices).  FXC_RTC_TPR_MAX: developer knob
+        const int tmax = big ? 256 : env_int("FXC_RTC_TPR_MAX", n > spec_lean_above() ? 512 : 1024);
+        j0 = (nb0 + tmax - 1) / tmax;
         s.tpr = ((nb0 + j0 - 1) / j0 + 63) / 64 * 64;
     }
     s.slots = std::max(1, 256 / s.tpr);
