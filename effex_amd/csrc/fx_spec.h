@@ -43,7 +43,7 @@
 #define FXM_ABL 0
 #endif
 // FXM_LEAN 1: the build for frames of more than 2048 channels (a thread carries up to eight points of each antenna: 128
-// registers of ring) -- nothing but the ring and the sums stays in registers from step to step.  The window taps come from L2
+// registers of ring) and for shapes with a prime factor of 17 ... 23 (the butterfly's registers) -- nothing but the ring and the sums stays in registers from step to step.  The window taps come from L2
 // every step (Args::h4: the four taps of a point in one 16-byte load); of a butterfly's twiddles only the first is fetched
 // (Args::tw1, a table by stage, butterfly and thread -- consecutive lanes read consecutive entries -- requested one stage ahead
 // of its use), the others are its powers (a few complex multiplies a stage, shared by the rows of the step); the output offsets
@@ -605,7 +605,7 @@ struct Body {
     // ring slots those points have just left, the butterfly into LDS -- so that only R0 points' taps and sums are live at once
     template <int P>
     FXC_HD void step_lean(long long f, long long f_end, const bool (&live)[U]) {
-        static_assert(!LEAN || S >= 2, "the lean build is for frames of thousands of channels");
+        static_assert(!LEAN || S >= 2, "the lean build needs a first stage into LDS (h_rtc.h::spec_shape)");
         const fxc::Roots<R0> rt = fxc::load_roots<R0>(ar.tw, nb_of(0));
         pk2 w1[j_of(1)];
         load_tw1<1>(w1);
