@@ -806,7 +806,7 @@ int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* re
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return fail(nullptr, FXC_ERR_NODEVICE, "no HIP device to take the architecture from");
-        target = prop.gcnArchName;
+        target = spec_arch(prop.gcnArchName);
     }
     const SpecBuild b = spec_search(nchan, ntaps, variant, target.c_str());
     if (b.image.empty()) return fail(nullptr, b.scratch ? FXC_ERR_UNSUPPORTED : FXC_ERR_HIP, "%s", b.error.c_str());

@@ -321,6 +321,15 @@ void spec_cache_store(const std::string& dir, const std::string& path, const std
     if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
 }
 
+// The target the kernels are built for: the device's architecture without its feature suffix ("gfx950:sramecc+:xnack-" -> "gfx950"),
+// like the library itself (--offload-arch=gfx950) -- so a code object built where there is no device (fxc_spec_probe, the CPU test
+// suite, a build step) is the one a plan on the device looks up in the cache
+std::string spec_arch(const char* gcn_arch_name) {
+    std::string a = gcn_arch_name ? gcn_arch_name : "";
+    const size_t colon = a.find(':');
+    return colon == std::string::npos ? a : a.substr(0, colon);
+}
+
 // fx_spec.h for one shape -> a code object for `arch` (e.g. "gfx950:sramecc+:xnack-"); needs no device
 bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::vector<char>& image, std::string& error) {
     RtcApi* api = rtc_api();
@@ -452,7 +461,7 @@ const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
         k->error = "hipGetDeviceProperties failed";
         return k;
     }
-    SpecBuild b = spec_search(n, taps, variant, prop.gcnArchName);
+    SpecBuild b = spec_search(n, taps, variant, spec_arch(prop.gcnArchName).c_str());
     if (b.image.empty()) {
         k->error = b.error;
         return k;
