@@ -1702,6 +1702,39 @@ def test_resolution_1000_at_full_size(plan_mod, torch):
             assert rel_err(rows[c, 0], ref) < TOL_VIS, c
 
 
+@pytest.mark.parametrize("nchan", [8192, 3000])
+def test_new_routes_at_full_size(plan_mod, torch, nchan):
+    """BASELINE configs[1]'s size (1 024 chunk pairs of 2^18 samples, 4.3 GB resident, generated on the device) on this round's routes
+    -- --nfft 8192 in two passes, --resolution 3000 on the lean build of the kernel per channel count -- through properties that do
+    not need the oracle at that size: the integration is the mean of the rows, doubling the input quadruples every row bit for
+    bit, swapping the antennas conjugates it, the receivers' bytes agree with their conversion; chunks 0 and 1023 against the oracle."""
+    from effex_amd.plan import synth_fill
+    num_samp, n_chunks = 2 ** 18, 1024
+    x = torch.empty((n_chunks, 2, num_samp), dtype=torch.complex64, device="cuda")
+    synth_fill(x, 777 + nchan)
+    window = design_window(4, nchan)
+    with plan_mod.FxPlan(2, nchan, 4, num_samp, window=window) as p:
+        assert p.info["block"] == 512 and (nchan == 8192 or p.info["specialised"] & 1), p.info
+        rows = p.fx_rows(x).cpu().numpy()
+        p.fx_accumulate(x[:300])
+        p.fx_accumulate(x[300:])
+        integ = p.finalize("SPECTRUM")
+        assert rel_err(integ, rows.astype(np.complex128).mean(axis=0)) < 2e-6
+        sub = x[500:516]
+        rows16 = p.fx_rows(sub).cpu().numpy()          # (16 chunk pairs split their frames differently from 1 024: not bit for bit)
+        assert rel_err(rows16, rows[500:516]) < 1e-6
+        np.testing.assert_array_equal(p.fx_rows(sub * 2.0).cpu().numpy(), 4.0 * rows16)
+        swapped = p.fx_rows(sub.flip(1).contiguous()).cpu().numpy()
+        assert rel_err(swapped, np.conj(rows16)) < 1e-6
+        u8 = torch.randint(0, 256, (64, 2, num_samp, 2), dtype=torch.uint8, device="cuda")
+        by = p.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()
+        assert rel_err(by, p.fx_rows(p.convert_u8(u8, remove_dc=True)).cpu().numpy()) < TOL_VIS
+        for c in (0, n_chunks - 1):
+            xc = x[c].cpu().numpy()
+            ref = fx_oracle.pfb_xcorr(xc[0], xc[1], 4, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+
+
 @pytest.mark.parametrize("n_ant", [2, 3])
 def test_any_channel_count_with_a_small_workspace(plan_mod, torch, n_ant):
     """The mixed-radix path in passes bounded by the workspace target (1 MiB in a child process: raw sums only with two
