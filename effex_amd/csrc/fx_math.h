@@ -34,6 +34,44 @@ FXC_HD int range_begin(int b, int n, int g) { return (int)((long long)b * n / g)
 FXC_HD int range_owner(int f, int n, int g) { return (int)((((long long)f + 1) * g + n - 1) / n - 1); }
 
 FXC_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+
+// FXC_STREAM_AUX: cache policy of the streaming accesses outside the headline kernel (the samples on their way into a ring, spectra
+// on their way from an F pass to an X pass): 0 default policy, 2 nontemporal
+#ifndef FXC_STREAM_AUX
+#define FXC_STREAM_AUX 0
+#endif
+
+// Streaming accesses -- data a kernel touches once (spectra on their way from an F pass to an X pass): the nontemporal hint keeps
+// them from displacing what the caches are for.  Host build: plain accesses.
+FXC_HD cf nt_load(const cf* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float nt_v2f __attribute__((ext_vector_type(2)));
+    const nt_v2f v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2f*>(p));
+    cf r;
+    r.x = v[0];
+    r.y = v[1];
+    return r;
+#else
+    return *p;
+#endif
+}
+FXC_HD void nt_store(cf* p, cf v);
+FXC_HD cf st_load(const cf* p) { return FXC_STREAM_AUX ? nt_load(p) : *p; }
+FXC_HD void st_store(cf* p, cf v) {
+    if (FXC_STREAM_AUX) nt_store(p, v);
+    else *p = v;
+}
+FXC_HD void nt_store(cf* p, cf v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float nt_v2f __attribute__((ext_vector_type(2)));
+    nt_v2f w;
+    w[0] = v.x;
+    w[1] = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_v2f*>(p));
+#else
+    *p = v;
+#endif
+}
 FXC_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
 FXC_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
 FXC_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }

@@ -369,11 +369,11 @@ struct Body {
 #if defined(__HIP_DEVICE_COMPILE__)
                         const unsigned cst = (unsigned)((R0 - 1 - r) * nb_of(0)) * (unsigned)kElem;
                         if constexpr (U8) {
-                            const unsigned raw = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc[a], voff, cst, 0);
+                            const unsigned raw = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc[a], voff, cst, FXC_STREAM_AUX);
                             const pk2 bytes = {(float)(raw & 0xFFu), (float)(raw >> 8)};
                             v = pk_fma(bytes, pk_splat(1.0f / 127.5f), off8[a]);
                         } else {
-                            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc[a], voff, cst, 0);
+                            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc[a], voff, cst, FXC_STREAM_AUX);
                             v = pk2{__uint_as_float(d[0]), __uint_as_float(d[1])};
                         }
 #else
@@ -498,7 +498,7 @@ struct Body {
                 if (row_ok[a]) {
                     cf* d = row_out[a] + frame * (long long)ar.ant * N + lt + j * TPR;
 #pragma unroll
-                    for (int q = 0; q < R; ++q) d[q * (N / R)] = unpk(o[a][q]);
+                    for (int q = 0; q < R; ++q) fxc::st_store(d + q * (N / R), unpk(o[a][q]));
                 }
         } else {
 #pragma unroll

@@ -345,6 +345,7 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXM_NST=" + std::to_string(shape.n_stages), "-DFXM_RADICES=" + radices,
                                      "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)), "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly)),
                                      "-DFXM_U=" + std::to_string(shape.u), "-DFXM_LEAN=" + std::to_string((int)shape.lean), "-DFXM_ROWS=" + std::to_string(shape.rows),
+                                     "-DFXC_STREAM_AUX=" + std::to_string((int)FXC_STREAM_AUX),
                                      "-DFXM_ABL=" + std::to_string(spec_ablation())};      // (timing ablations: wrong results, developer library only)
     const std::string dir = spec_cache_dir();
     const std::string cached = dir.empty() ? std::string() : dir + "/" + spec_cache_key(opts, api) + ".co";

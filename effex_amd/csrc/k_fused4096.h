@@ -25,7 +25,8 @@ __device__ __forceinline__ void permlane32_swap(cf& a, cf& b) {
 typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
 typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 #ifndef FXC_LOAD_AUX
-#define FXC_LOAD_AUX 0   // cache policy of the IQ stream loads: bit 0 sc0, bit 1 nt, bit 4 sc1
+#define FXC_LOAD_AUX 2   // cache policy of the IQ stream loads: bit 0 sc0, bit 1 nt, bit 4 sc1.  nt (the samples are read once): the
+                         // headline kernel 8.57 - 8.66 -> 8.47 - 8.49 ms, the F-only variant of 8 antennas - 1.6 % (profiles/r05/experiments.md 10)
 #endif
 template <int R0, int CNT>
 __device__ __forceinline__ void load_frame_part(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned voff,
@@ -226,6 +227,9 @@ __device__ __forceinline__ cf dck_offset(unsigned* acc, unsigned* red, int tid, 
     return fxc::mk((float)(-mr / 127.5), (float)(-mi / 127.5));
 }
 
+#ifndef FXC_SPEC_STORE_AUX
+#define FXC_SPEC_STORE_AUX 2      // cache policy of the F-only spectra stores: nt (written once, read by the X pass: 8 antennas 2.35 -> 2.19 ms)
+#endif
 template <int PH, bool SPEC_OUT, bool U8, bool DCK>
 __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, const cf* dc, const f4* win, cf* region,
                                            const cf* tw2, int tid, const cf* x, int64_t num_samp, unsigned chunk_bytes,
@@ -320,7 +324,7 @@ __device__ __forceinline__ void fused_step(fxc::fused::State& s, U8State& u8, co
         for (int m = 0; m < 8; ++m) {
             v4u32 d = {__float_as_uint(v[2 * m].x), __float_as_uint(v[2 * m].y), __float_as_uint(v[2 * m + 1].x),
                        __float_as_uint(v[2 * m + 1].y)};
-            __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff0 + (unsigned)(m * 512 * sizeof(cf)), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff0 + (unsigned)(m * 512 * sizeof(cf)), 0, FXC_SPEC_STORE_AUX);
         }
     } else {
         // lanes 0-31 hold antenna 0, lanes 32-63 antenna 1 of the same bins: after the swap each lane has both

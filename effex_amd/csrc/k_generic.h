@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void xmul_kernel(const cf* __restrict__ spec, 
             const cf* sa = spec + ((c * n_ant + a) * n_pts) * nchan + k;
             const cf* sb = spec + ((c * n_ant + b) * n_pts) * nchan + k;
             for (int64_t i = (int64_t)split * iy + ti; i < n_pts; i += (int64_t)iy * n_splits) {
-                const cf u = sa[i * nchan], w = sb[i * nchan];
+                const cf u = fxc::st_load(sa + i * nchan), w = fxc::st_load(sb + i * nchan);
                 ar += u.x * w.x + u.y * w.y;
                 ai += u.y * w.x - u.x * w.y;
             }

@@ -103,7 +103,7 @@ __device__ __forceinline__ void tiled_store_spectrum(const cf (&v)[16], cf* reg,
         const cf* rd = reg + u + (u >> 4);
         cf* dst = out_row + u;
 #pragma unroll
-        for (int n = 0; n < 16; ++n) dst[G::P * n] = fxc::fused::lds_load(rd + (G::P + G::P / 16) * n);
+        for (int n = 0; n < 16; ++n) fxc::st_store(dst + G::P * n, fxc::fused::lds_load(rd + (G::P + G::P / 16) * n));
     }
 }
 
@@ -256,7 +256,7 @@ __device__ __forceinline__ void tiled_load_part(cf (&xr)[16], const cf* chunk_ba
     const unsigned soff = (unsigned)(frame * G::N * (int64_t)sizeof(cf));
 #pragma unroll
     for (int r = R0; r < R0 + CNT; ++r) {
-        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(cf)), 0);
+        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(cf)), FXC_STREAM_AUX);
         xr[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
     }
 }
@@ -271,7 +271,7 @@ __device__ __forceinline__ void tiled_load_part_u8(cf (&xr)[16], const cf* chunk
 #pragma unroll
     for (int r = R0; r < R0 + CNT; ++r)
         xr[r].x = __uint_as_float(
-            (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(unsigned short)), 0));
+            (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(unsigned short)), FXC_STREAM_AUX));
 }
 
 template <class G>
@@ -542,7 +542,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
         __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(in0_row + i * (int64_t)G::N), 0, (int)(G::N * sizeof(cf)), 0x00020000);
 #pragma unroll
         for (int n = 0; n < kX8192Early; ++n) {
-            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_STREAM_AUX);
             s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
         }
         G::loadC(reg, u, v);
@@ -550,7 +550,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
         FXC_SCHED_FENCE();
 #pragma unroll
         for (int n = kX8192Early; n < 16; ++n) {
-            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_STREAM_AUX);
             s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
         }
 #pragma unroll
@@ -565,7 +565,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
                 v2u32 d;
                 d[0] = __float_as_uint(v[n].x);
                 d[1] = __float_as_uint(v[n].y);
-                __builtin_amdgcn_raw_buffer_store_b64(d, rr, poff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(d, rr, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_STREAM_AUX);
             }
         } else {
             tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, true);
