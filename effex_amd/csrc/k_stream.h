@@ -76,6 +76,9 @@ __device__ __forceinline__ v4f32 wave_shr1(v4f32 v) {
     return r;
 }
 
+#ifndef FXC_STREAM1_NT
+#define FXC_STREAM1_NT 1      // nontemporal sample loads in the continuum streaming kernel: 5.52 - 5.74 -> 5.39 - 5.58 ms (profiles/r05/experiments.md 10)
+#endif
 __global__ __launch_bounds__(256) void stream1_t4_kernel(const cf* __restrict__ x, cf* __restrict__ raw, int64_t num_samp,
                                                             float h0, float h1, float h2, float h3, int64_t n_chunks) {
     __shared__ cf red[256];
@@ -92,7 +95,11 @@ __global__ __launch_bounds__(256) void stream1_t4_kernel(const cf* __restrict__ 
     for (int64_t base = p0 + wave * 62; base < p1; base += 4 * 62) {      // wave-uniform trip count
         const int64_t m = base + lane - 2;
         const bool in_range = m >= 0 && m < pairs;
+#if FXC_STREAM1_NT
+        const v4f32 a2 = in_range ? __builtin_nontemporal_load(s0 + m) : zero, b2 = in_range ? __builtin_nontemporal_load(s1 + m) : zero;
+#else
         const v4f32 a2 = in_range ? s0[m] : zero, b2 = in_range ? s1[m] : zero;
+#endif
         const v4f32 a1 = wave_shr1(a2), b1 = wave_shr1(b2);
         const v4f32 a0 = wave_shr1(a1), b0 = wave_shr1(b1);
         const float y0er = h0 * a2[0] + h1 * a1[2] + h2 * a1[0] + h3 * a0[2];
