@@ -248,7 +248,12 @@ __global__ __launch_bounds__(G::kThreads) void fx_tiled_kernel(const cf* __restr
 
 // ntaps <= 4, nchan <= 2048 variant of the tiled kernel: every IQ sample is fetched once into a VGPR ring of
 // four frames (as in fx_fused4096_kernel) and the window sits in LDS.
-template <class G, int R0, int CNT>
+// AUX: cache policy of the loads.  The F + X ring kernels' steady-state loads are nontemporal (FXC_TILED_RING_AUX: 512 / 1024 / 2048
+// channels - 1 ... 2 %); the 8192-channel ring kernels' are not (+ 4 % with it), nor the F-only variant's (profiles/r05/experiments.md 10)
+#ifndef FXC_TILED_RING_AUX
+#define FXC_TILED_RING_AUX 2
+#endif
+template <class G, int R0, int CNT, int AUX = 0>
 __device__ __forceinline__ void tiled_load_part(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes, unsigned xoff,
                                                 int64_t frame) {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
@@ -256,13 +261,13 @@ __device__ __forceinline__ void tiled_load_part(cf (&xr)[16], const cf* chunk_ba
     const unsigned soff = (unsigned)(frame * G::N * (int64_t)sizeof(cf));
 #pragma unroll
     for (int r = R0; r < R0 + CNT; ++r) {
-        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(cf)), FXC_STREAM_AUX);
+        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(cf)), AUX);
         xr[r] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
     }
 }
 
 // uint8 ingest (see load_frame_part_u8): chunk_base then points at byte pairs
-template <class G, int R0, int CNT>
+template <class G, int R0, int CNT, int AUX = 0>
 __device__ __forceinline__ void tiled_load_part_u8(cf (&xr)[16], const cf* chunk_base, unsigned chunk_bytes,
                                                    unsigned xoff, int64_t frame) {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(chunk_base), 0, (int)chunk_bytes,
@@ -271,7 +276,7 @@ __device__ __forceinline__ void tiled_load_part_u8(cf (&xr)[16], const cf* chunk
 #pragma unroll
     for (int r = R0; r < R0 + CNT; ++r)
         xr[r].x = __uint_as_float(
-            (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(unsigned short)), FXC_STREAM_AUX));
+            (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, soff + (unsigned)(G::P * (15 - r) * sizeof(unsigned short)), AUX));
 }
 
 template <class G>
@@ -287,9 +292,9 @@ struct TiledRing {
     do {                                                                                        \
         FXC_SCHED_FENCE();                                                                      \
         if (U8)                                                                                 \
-            tiled_load_part_u8<G, R0, 4>(nx, chunk_base, chunk_bytes, xoff, nframe);            \
+            tiled_load_part_u8<G, R0, 4, SPEC ? 0 : FXC_TILED_RING_AUX>(nx, chunk_base, chunk_bytes, xoff, nframe); \
         else                                                                                    \
-            tiled_load_part<G, R0, 4>(nx, chunk_base, chunk_bytes, xoff, nframe);               \
+            tiled_load_part<G, R0, 4, SPEC ? 0 : FXC_TILED_RING_AUX>(nx, chunk_base, chunk_bytes, xoff, nframe); \
         FXC_SCHED_FENCE();                                                                      \
     } while (0)
 
