@@ -56,6 +56,10 @@
 #ifndef FXM_ROWS
 #define FXM_ROWS 2
 #endif
+// FXM_LD_AUX: cache policy of the F + X builds' sample loads (h_rtc.h; 0 default, 2 nontemporal)
+#ifndef FXM_LD_AUX
+#define FXM_LD_AUX 0
+#endif
 
 namespace fxm {
 
@@ -341,6 +345,7 @@ struct Body {
     // thread (it carries the frame: slots inside one wave are at different frames), the point's place in the frame is an
     // immediate, the antenna a buffer descriptor of its own.
     static constexpr int kElem = U8 ? 2 : 8;                  // bytes per sample
+    static constexpr int kLoadAux = FONLY ? FXC_STREAM_AUX : FXM_LD_AUX;      // cache policy of the sample loads (2: nontemporal)
     template <int P>
     FXC_HD void load_frame(long long f, bool valid) {
 #pragma unroll
@@ -369,11 +374,11 @@ struct Body {
 #if defined(__HIP_DEVICE_COMPILE__)
                         const unsigned cst = (unsigned)((R0 - 1 - r) * nb_of(0)) * (unsigned)kElem;
                         if constexpr (U8) {
-                            const unsigned raw = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc[a], voff, cst, FXC_STREAM_AUX);
+                            const unsigned raw = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc[a], voff, cst, kLoadAux);
                             const pk2 bytes = {(float)(raw & 0xFFu), (float)(raw >> 8)};
                             v = pk_fma(bytes, pk_splat(1.0f / 127.5f), off8[a]);
                         } else {
-                            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc[a], voff, cst, FXC_STREAM_AUX);
+                            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc[a], voff, cst, kLoadAux);
                             v = pk2{__uint_as_float(d[0]), __uint_as_float(d[1])};
                         }
 #else

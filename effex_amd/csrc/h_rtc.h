@@ -84,6 +84,7 @@ RtcApi* rtc_api() {
 // how fx_spec.h is cut for one channel count: stage order, threads per slot, slots per workgroup
 enum SpecVariant { kSpecC64 = 0, kSpecU8 = 1, kSpecFOnly = 2 };      // F + X from complex64 / from the receivers' bytes, the F stage alone
 
+constexpr int kSpecLoadAux = 0;      // cache policy of the F + X builds' sample loads (FXC_RTC_LD_AUX: developer knob)
 constexpr int kSpecLeanAbove = 2048;
 inline int spec_lean_above() { return env_int("FXC_RTC_LEAN_ABOVE", kSpecLeanAbove); }      // (developer knob)
 
@@ -346,6 +347,7 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)), "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly)),
                                      "-DFXM_U=" + std::to_string(shape.u), "-DFXM_LEAN=" + std::to_string((int)shape.lean), "-DFXM_ROWS=" + std::to_string(shape.rows),
                                      "-DFXC_STREAM_AUX=" + std::to_string((int)FXC_STREAM_AUX),
+                                     "-DFXM_LD_AUX=" + std::to_string(env_int("FXC_RTC_LD_AUX", kSpecLoadAux)),
                                      "-DFXM_ABL=" + std::to_string(spec_ablation())};      // (timing ablations: wrong results, developer library only)
     const std::string dir = spec_cache_dir();
     const std::string cached = dir.empty() ? std::string() : dir + "/" + spec_cache_key(opts, api) + ".co";
