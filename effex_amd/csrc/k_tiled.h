@@ -89,6 +89,9 @@ __device__ __forceinline__ void tiled_fir2(cf (&v0)[16], cf (&v1)[16], bool two,
 // bin_of(u, k2) in v[k2]; the exchange region serves as a transposition buffer (bin k at k + (k >> 4): the
 // 16 lanes of a group write 17 or R0 + 1/16 slots apart, conflict-free) and the rows go out 256 B per half-wave.
 // valid: this lane's stream exists (an odd stream count leaves the last pair half empty).
+#ifndef FXC_TILED_ST_NT
+#define FXC_TILED_ST_NT 0      // nontemporal stores of the F-only tiled kernels' spectra
+#endif
 template <class G>
 __device__ __forceinline__ void tiled_store_spectrum(const cf (&v)[16], cf* reg, int u, cf* out_row, bool valid) {
     __syncthreads();   // every wave holds its stage-C outputs in registers: the rows can be overwritten
@@ -103,7 +106,11 @@ __device__ __forceinline__ void tiled_store_spectrum(const cf (&v)[16], cf* reg,
         const cf* rd = reg + u + (u >> 4);
         cf* dst = out_row + u;
 #pragma unroll
-        for (int n = 0; n < 16; ++n) fxc::st_store(dst + G::P * n, fxc::fused::lds_load(rd + (G::P + G::P / 16) * n));
+        for (int n = 0; n < 16; ++n) {
+            const cf o = fxc::fused::lds_load(rd + (G::P + G::P / 16) * n);
+            if (FXC_TILED_ST_NT) fxc::nt_store(dst + G::P * n, o);
+            else fxc::st_store(dst + G::P * n, o);
+        }
     }
 }
 
