@@ -24,6 +24,9 @@ __device__ __forceinline__ void permlane32_swap(cf& a, cf& b) {
 // Buffer loads: one VGPR byte offset per thread, everything that varies with chunk / frame / r is scalar.
 typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
 typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+#ifndef FXC_LOAD_AUX_U8
+#define FXC_LOAD_AUX_U8 2      // ... of the byte-pair loads of the uint8 ingest: nt, 4 096 chunk pairs 3.61 - 3.65 -> 3.45 - 3.55 ms
+#endif
 #ifndef FXC_LOAD_AUX
 #define FXC_LOAD_AUX 2   // cache policy of the IQ stream loads: bit 0 sc0, bit 1 nt, bit 4 sc1.  nt (the samples are read once): the
                          // headline kernel 8.57 - 8.66 -> 8.47 - 8.49 ms, the F-only variant of 8 antennas - 1.6 % (profiles/r05/experiments.md 10)
@@ -52,7 +55,7 @@ __device__ __forceinline__ void load_frame_part_u8(cf (&xr)[16], const unsigned 
 #pragma unroll
     for (int r = R0; r < R0 + CNT; ++r)   // the byte pair waits in the slot's own register (bit pattern in .x)
         xr[r].x = __uint_as_float(
-            (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff + (unsigned)(256 * (15 - r) * sizeof(unsigned short)), 0));
+            (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff + (unsigned)(256 * (15 - r) * sizeof(unsigned short)), FXC_LOAD_AUX_U8));
 }
 
 // byte pair -> complex64: (b - 127.5) / 127.5 minus the chunk's mean = b / 127.5 + off, off = -mean_byte / 127.5
