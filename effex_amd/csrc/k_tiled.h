@@ -446,6 +446,13 @@ using G8192 = fxc::tiled::Geo<2, true>;
 constexpr int kF8192Threads = G8192::P;                                          // 512
 // exchange rows of one stream + w256 table + the stage-A table + the window quads of the first kF8192WinLds branch groups (the
 // other 16 - kF8192WinLds groups -- the window is 128 KiB -- come from L2 every frame): 158 KiB
+// cache policy of the two-pass route's private spectra: pass 1's stores, pass 2's loads (0 default, 2 nontemporal)
+#ifndef FXC_X8192_ST_AUX
+#define FXC_X8192_ST_AUX FXC_STREAM_AUX
+#endif
+#ifndef FXC_X8192_LD_AUX
+#define FXC_X8192_LD_AUX FXC_STREAM_AUX
+#endif
 constexpr int kF8192WinLds = 7;
 
 constexpr int kF8192LdsCf = G8192::kRegion + 256 + 16 * 256 + kF8192WinLds * G8192::P * 2;
@@ -554,7 +561,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
         __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(in0_row + i * (int64_t)G::N), 0, (int)(G::N * sizeof(cf)), 0x00020000);
 #pragma unroll
         for (int n = 0; n < kX8192Early; ++n) {
-            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_STREAM_AUX);
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_X8192_LD_AUX);
             s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
         }
         G::loadC(reg, u, v);
@@ -562,7 +569,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
         FXC_SCHED_FENCE();
 #pragma unroll
         for (int n = kX8192Early; n < 16; ++n) {
-            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_STREAM_AUX);
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_X8192_LD_AUX);
             s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
         }
 #pragma unroll
@@ -577,7 +584,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
                 v2u32 d;
                 d[0] = __float_as_uint(v[n].x);
                 d[1] = __float_as_uint(v[n].y);
-                __builtin_amdgcn_raw_buffer_store_b64(d, rr, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_STREAM_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(d, rr, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_X8192_ST_AUX);
             }
         } else {
             tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, true);
