@@ -16,8 +16,14 @@
 //
 // Options (all required): FXM_N channels, FXM_T taps (1..4), FXM_TPR threads per slot (a slot = the threads that carry
 // one frame pair), FXM_SLOTS slots per workgroup (each with its own contiguous run of frames), FXM_NST stages,
-// FXM_RADICES their radices (comma list; product = N; 2, 3, 4, 5, 7, 11, 13), FXM_U8 (1: samples are the receivers'
-// interleaved unsigned bytes, converted as pyrtlsdr does behind effex.py:652 with the per-stream offset of k_conditioning.h).
+// FXM_RADICES their radices (comma list; product = N; primes up to 23, 4, and composites of them -- 6, 8, 9, 10, 12, 15, 16, 20,
+// 25 ... -- which run as Good-Thomas / Cooley-Tukey butterflies in registers: one trip through LDS instead of two or three),
+// FXM_U8 (1: samples are the receivers' interleaved unsigned bytes, converted as pyrtlsdr does behind effex.py:652 with the
+// per-stream offset of k_conditioning.h).
+// Optional (h_rtc.h::spec_layout chooses them): FXM_GROUPS rows per work item of each stage (comma list; a stage's items are
+// (butterfly, group of rows) pairs dealt over the slot's threads, so that a stage with few butterflies -- a large radix -- still
+// fills the lanes), FXM_PLANE0 / FXM_PADS where the stages put their outputs in LDS (stores and loads free of bank conflicts),
+// FXM_TWFULL the largest radix whose R - 1 twiddles all stay in registers (beyond: the first, and its powers every step).
 //
 // Compiles as device code under hiprtc / hipcc and as plain C++ under g++: tests/emul/emul_spec.cpp runs the same body
 // with one host thread per GPU thread and a real barrier (test infrastructure only).
@@ -60,6 +66,12 @@
 #ifndef FXM_LD_AUX
 #define FXM_LD_AUX 0
 #endif
+#ifndef FXM_PLANE0
+#define FXM_PLANE0 0     // > 0: the first stage stores output q of butterfly b at q PLANE0 + b (consecutive lanes, consecutive addresses)
+#endif
+#ifndef FXM_TWFULL
+#define FXM_TWFULL 13
+#endif
 
 namespace fxm {
 
@@ -89,6 +101,7 @@ constexpr int THREADS = TPR * SLOTS;
 constexpr int NS = T + U - 1;
 constexpr int gcd_of(int a, int b) { return b == 0 ? a : gcd_of(b, a % b); }
 constexpr int UNR = NS / gcd_of(NS, U);
+constexpr int ROWS = NA * U;                     // rows a step carries: (frame u, antenna a) -> u * NA + a
 
 constexpr int ns_of(int s) {
     int v = 1;
@@ -96,27 +109,69 @@ constexpr int ns_of(int s) {
     return v;
 }
 constexpr int nb_of(int s) { return N / kRadix[s]; }
-constexpr int j_of(int s) { return (nb_of(s) + TPR - 1) / TPR; }        // butterflies of stage s per thread
-constexpr bool full_of(int s) { return j_of(s) * TPR == nb_of(s); }     // ... and every thread has all of them
-constexpr int tw_per(int s) { return LEAN ? 1 : kRadix[s] - 1; }         // twiddle registers of one butterfly of stage s
+// Work items: stage 0's are its butterflies (a thread runs the FIR of its butterflies' points for every row); a later stage's are
+// (butterfly b, group g of grp(s) rows) pairs, item i = g nb + b, dealt over the slot's threads as i = lt + j TPR.  The last stage of
+// the F + X build keeps both antennas of a frame in one item (the X product is formed in the thread's registers).
+#ifdef FXM_GROUPS
+constexpr int kGroupIn[S] = {FXM_GROUPS};
+constexpr int grp(int s) { return (s == 0 || kGroupIn[s] <= 0) ? ROWS : kGroupIn[s]; }
+#else
+constexpr int grp(int) { return ROWS; }
+#endif
+#ifdef FXM_PADS
+constexpr int kPadIn[S] = {FXM_PADS};
+constexpr int pad_of(int s) { return kPadIn[s]; }
+#else
+constexpr int pad_of(int) { return 0; }
+#endif
+constexpr int ngrp(int s) { return ROWS / grp(s); }
+constexpr int items_of(int s) { return nb_of(s) * ngrp(s); }
+constexpr int j_of(int s) { return (items_of(s) + TPR - 1) / TPR; }     // items of stage s per thread
+constexpr bool full_of(int s) { return j_of(s) * TPR == items_of(s); }  // ... and every thread has all of them
+constexpr int tw_per(int s) { return (LEAN || kRadix[s] > FXM_TWFULL) ? 1 : kRadix[s] - 1; }   // twiddle registers of one item of stage s
 constexpr int tw_base(int s) {                                          // first twiddle register of stage s (s >= 1)
     int c = 0;
     for (int i = 1; i < s; ++i) c += j_of(i) * tw_per(i);
     return c;
 }
-constexpr int ob_base(int s) {                                          // first output-offset register of stage s (1 <= s <= S-2)
+constexpr int ob_base(int s) {                                          // first offset register of stage s (1 <= s <= S-1)
     int c = 0;
     for (int i = 1; i < s; ++i) c += j_of(i);
     return c;
 }
 constexpr int R0 = kRadix[0], J0 = j_of(0), PTS = R0 * J0;              // a thread's points: m = lt + j TPR + r N/R0
 constexpr int RL = kRadix[S - 1], JL = j_of(S - 1);
-constexpr int TWC = LEAN ? 0 : tw_base(S), OBC = LEAN ? 0 : ob_base(S > 1 ? S - 1 : 1);
+constexpr int TWC = LEAN ? 0 : tw_base(S), OBC = LEAN ? 0 : ob_base(S > 1 ? S - 1 : 1), IBC = LEAN ? 0 : ob_base(S);
 constexpr int TW1C = tw_base(S);                 // LEAN: rows of Args::tw1, [TW1C][TPR]
 constexpr bool SWAP = S >= 2 && S % 2 == 0;      // the last stage reads the buffer the next frame's first stage writes: alternate them
-constexpr int ROW = N;                           // one antenna's row; a slot's LDS: [buffer X | Y][frame of the step][antenna][N]
-constexpr int ROWS = NA * U;                     // rows a step carries: (frame u, antenna a) -> u * NA + a
-constexpr int LDS_PER_SLOT = S >= 2 ? 2 * ROWS * N : 0; // complex64 elements
+
+// Where a stage's outputs stand in LDS.  The buffer stage s writes (stage s + 1 reads it) holds the Stockham order x = (b - k) R + k +
+// q ns of fx_mixed.h in blocks of ns_of(s + 1) elements -- the outputs of the ns butterflies that share b - k -- with pad_of(s) unused
+// elements behind each block: a lane group's runs of ns consecutive elements then fall on different banks.  The first stage's buffer
+// may instead be PLANES: output q of butterfly b at q P0 + b -- a wave's stores of one q are consecutive, and the R0 runs a wave of the
+// second stage reads (its butterflies' inputs r are nb / R0 apart within one plane) tile the banks when P0 is chosen for it.  Either way a
+// thread's addresses are one base register plus immediates.
+constexpr int P0 = FXM_PLANE0;
+constexpr int blk_of(int s) { return ns_of(s + 1); }
+constexpr int len_of(int s) { return (s == 0 && P0 > 0) ? R0 * P0 : N + (N / blk_of(s)) * pad_of(s); }
+constexpr int row_stride() {
+    int m = N;
+    for (int s = 0; s + 1 < S; ++s) m = len_of(s) > m ? len_of(s) : m;
+    return m;
+}
+constexpr int RS = row_stride();                 // one row of a stage buffer; a slot's LDS: [buffer X | Y][row][RS]
+constexpr int rd_stride(int s) {                 // between inputs r and r + 1 of a butterfly of stage s >= 1 (blk_of(s - 1) and R0 divide nb_of(s))
+    return (s == 1 && P0 > 0) ? nb_of(s) / R0 : nb_of(s) + (nb_of(s) / blk_of(s - 1)) * pad_of(s - 1);
+}
+constexpr int rd_pos(int s, int b) {             // ... and where input 0 of its butterfly b stands
+    return (s == 1 && P0 > 0) ? (b % R0) * P0 + b / R0 : b + (b / blk_of(s - 1)) * pad_of(s - 1);
+}
+constexpr int wr_pos(int s, int b) {             // where butterfly b of stage s (1 <= s <= S - 2) puts its output 0; output q stands q ns_of(s) further
+    return (b / ns_of(s)) * (blk_of(s) + pad_of(s)) + b % ns_of(s);
+}
+constexpr int item_bfly_of(int s, int i) { return i >= items_of(s) ? 0 : i % nb_of(s); }      // the butterfly of item i of stage s (0 where there is none)
+constexpr bool plain_reads(int s) { return ngrp(s) == 1 && !(s == 1 && P0 > 0) && pad_of(s - 1) == 0; }     // item j's input 0 stands at lt + j TPR
+constexpr int LDS_PER_SLOT = S >= 2 ? 2 * ROWS * RS : 0; // complex64 elements
 
 static_assert(ns_of(S) == N, "the radices multiply to N");
 static_assert(T >= 1 && T <= 4, "one to four taps (the ring lives in registers)");
@@ -124,13 +179,16 @@ static_assert(U == 1 || U == 2, "one or two frames per step");
 static_assert(NA == 2 || (NA == 1 && FONLY), "one stream per workgroup: the F stage alone");
 static_assert(!(FONLY && U8), "the byte ingest is the two-antenna kernel's");
 static_assert(SLOTS >= 1 && (SLOTS == 1 || TPR % 64 == 0 || 64 % TPR == 0), "slots do not straddle waves");
+static_assert(FONLY || S == 1 || grp(S - 1) % NA == 0, "the last stage's items hold both antennas of a frame");
+static_assert(P0 == 0 || (S >= 2 && P0 >= nb_of(0)), "planes hold the first stage's butterflies");
 
 // per-thread state, all of it registers once the loops below are unrolled
 struct Thread {
     pk2 ring[NA][PTS][NS];            // frame g's samples of the thread's points in slot g mod NS (g counted from the run's first frame)
-    pk2 tw[TWC > 0 ? TWC : 1];       // twiddles of the thread's butterflies in stages 1 .. S-1
-    int ob[OBC > 0 ? OBC : 1];       // where the butterflies of stages 1 .. S-2 put their outputs
-    pk2 xacc[FONLY ? 1 : JL * RL];               // sum over the run of s0 conj(s1) at the bins the thread's last butterflies produce
+    pk2 tw[TWC > 0 ? TWC : 1];       // twiddles of the thread's items in stages 1 .. S-1
+    int ob[OBC > 0 ? OBC : 1];       // where the items of stages 1 .. S-2 put their outputs
+    int ib[IBC > 0 ? IBC : 1];       // where the items of stages 1 .. S-1 find their inputs (kept only where it is not lt + j TPR)
+    pk2 xacc[FONLY ? 1 : JL * RL];               // sum over the run of s0 conj(s1) at the bins the thread's last items produce
 };
 
 // Complex arithmetic on register pairs with the operand modifiers of the packed instructions (op_sel picks the half of a
@@ -196,16 +254,121 @@ FXC_HD pk2 x_acc_hi(pk2 t, pk2 a, pk2 b) {   // t + b.y (a.y, -a.x)
 #endif
 }
 
+// The roots of unity the butterflies need, as literals: cos and sin of 2 pi m / R evaluated at compile time in float64 (octant
+// reduction on the integers, Taylor series below pi / 4) and rounded once to float32 -- what the table Args::tw holds for the same
+// angle, without a scalar load (and its wait on the counter the LDS operations share) in the frame loop.
+constexpr double kHalfPi = 1.57079632679489661923132169163975144;
+constexpr double c_sin_small(double x) {
+    const double x2 = x * x;
+    double term = x, sum = x;
+    for (int n = 1; n <= 12; ++n) {
+        term *= -x2 / (double)((2 * n) * (2 * n + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double c_cos_small(double x) {
+    const double x2 = x * x;
+    double term = 1.0, sum = 1.0;
+    for (int n = 1; n <= 12; ++n) {
+        term *= -x2 / (double)((2 * n - 1) * (2 * n));
+        sum += term;
+    }
+    return sum;
+}
+struct RootCS {
+    float c, s;
+};
+constexpr RootCS c_root(int m, int R) {          // exp(+2 pi i m / R)
+    m %= R;
+    if (m < 0) m += R;
+    const int q = (4 * m) / R, mm = 4 * m - q * R;      // the angle is (pi / 2) (q + mm / R)
+    double c = 1.0, s = 0.0;
+    if (2 * mm <= R) {
+        const double th = kHalfPi * (double)mm / (double)R;
+        c = c_cos_small(th);
+        s = c_sin_small(th);
+    } else {
+        const double th = kHalfPi * (double)(R - mm) / (double)R;
+        c = c_sin_small(th);
+        s = c_cos_small(th);
+    }
+    switch (q) {
+        case 0: return RootCS{(float)c, (float)s};
+        case 1: return RootCS{(float)-s, (float)c};
+        case 2: return RootCS{(float)-c, (float)-s};
+        default: return RootCS{(float)s, (float)-c};
+    }
+}
+template <int R>
+struct RootTab {
+    float c[R], s[R];
+};
+template <int R>
+constexpr RootTab<R> make_roots() {
+    RootTab<R> t{};
+    for (int m = 0; m < R; ++m) {
+        const RootCS r = c_root(m, R);
+        t.c[m] = r.c;
+        t.s[m] = r.s;
+    }
+    return t;
+}
+template <int R>
+struct RootsOf {
+    static constexpr RootTab<R> tab = make_roots<R>();
+};
+
+// a times the literal (c, s): two instructions on the device, the literal in a scalar register pair
+FXC_HD pk2 cmul_k(pk2 a, float c, float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const pk2 k = {c, s};
+    pk2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(k));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(k), "v"(t));
+    return r;
+#else
+    return pk2{a[0] * c - a[1] * s, a[0] * s + a[1] * c};
+#endif
+}
+
+// How a composite radix R = A B runs in registers.  split_a(R) = A (0: R is 2, 4 or an odd prime -- a butterfly of its own):
+// coprime A, B (6, 10, 12, 15, 20 ...): Good-Thomas -- input (B n1 + A n2) mod R, output the k with k = k1 mod A, k = k2 mod B, no
+// twiddles in between; a prime power (8, 9, 16, 25 ...): Cooley-Tukey -- input n1 + A n2, the B-point transforms over n2, the
+// literal twiddles w_R^(n1 k2), the A-point transforms over n1, output B k1 + k2.
+constexpr int split_a(int R) {
+    if (R == 2 || R == 4) return 0;
+    int p2 = 1;
+    while (R % (2 * p2) == 0) p2 *= 2;
+    if (p2 > 1 && p2 < R) return p2;
+    if (p2 == R) return 4;                        // 8 = 4 x 2, 16 = 4 x 4, 32 = 4 x 8
+    int p = 3;
+    while (R % p != 0) p += 2;
+    if (p == R) return 0;
+    int pk_ = p;
+    while (R % (pk_ * p) == 0) pk_ *= p;
+    if (pk_ < R) return pk_;                      // 15 = 3 x 5, 45 = 9 x 5
+    int a = p;                                    // R = p^k: p^(k / 2)
+    while (a * a * p * p <= R) a *= p;
+    return a;
+}
+constexpr int inv_mod(int a, int m) {            // a^-1 mod m (coprime; 0 for m = 1)
+    for (int x = 1; x < m; ++x)
+        if ((a * x) % m == 1) return x;
+    return 0;
+}
+
 // R-point DFT, kernel exp(+2 pi i q r / R), of v[0..R) into o[0..R) (registers): fx_mixed.h's dft_store with the +- i
 // rotations folded into the additions.  Odd R: outputs q and R - q are P +- i Q, P = v0 + sum a_r cos, Q = sum d_r sin with
 // a_r = v_r + v_{R-r}, d_r = v_r - v_{R-r}.
 template <int R>
-FXC_HD void dft_regs(pk2 (&v)[R], const fxc::Roots<R>& rt, pk2 (&o)[R]) {
+FXC_HD void dft_regs(pk2 (&v)[R], pk2 (&o)[R]) {
 #if (FXM_ABL & 4)
 #pragma unroll
     for (int q = 0; q < R; ++q) o[q] = v[q];
     return;
 #endif
+    constexpr int A = split_a(R);
     if constexpr (R == 2) {
         o[0] = v[0] + v[1];
         o[1] = v[0] - v[1];
@@ -215,7 +378,7 @@ FXC_HD void dft_regs(pk2 (&v)[R], const fxc::Roots<R>& rt, pk2 (&o)[R]) {
         o[1] = add_i(t1, t3);
         o[2] = t0 - t2;
         o[3] = sub_i(t1, t3);
-    } else {
+    } else if constexpr (A == 0) {
         static_assert(R % 2 == 1, "odd radix");
         constexpr int H = (R - 1) / 2;
         pk2 sum = v[0];
@@ -232,14 +395,13 @@ FXC_HD void dft_regs(pk2 (&v)[R], const fxc::Roots<R>& rt, pk2 (&o)[R]) {
         for (int r = 1; r <= H; ++r)                           // (r outside: consecutive instructions belong to different outputs)
 #pragma unroll
             for (int q = 1; q <= H; ++q) {
-                const int m = (q * r) % R;                     // cos(2 pi m / R), sin(2 pi m / R) from the half table
-                const pk2 ww = rt.w[m <= H ? m : R - m];
-                const float sn = m <= H ? ww[1] : -ww[1];
+                const int m = (q * r) % R;                     // cos(2 pi m / R), sin(2 pi m / R)
+                const float cs = RootsOf<R>::tab.c[m], sn = RootsOf<R>::tab.s[m];
                 if (r == 1) {
-                    pacc[q] = pk_fma(pk_splat(ww[0]), v[r], v[0]);
+                    pacc[q] = pk_fma(pk_splat(cs), v[r], v[0]);
                     qacc[q] = pk_splat(sn) * v[R - r];
                 } else {
-                    pacc[q] = pk_fma(pk_splat(ww[0]), v[r], pacc[q]);
+                    pacc[q] = pk_fma(pk_splat(cs), v[r], pacc[q]);
                     qacc[q] = pk_fma(pk_splat(sn), v[R - r], qacc[q]);
                 }
             }
@@ -248,12 +410,58 @@ FXC_HD void dft_regs(pk2 (&v)[R], const fxc::Roots<R>& rt, pk2 (&o)[R]) {
             o[q] = add_i(pacc[q], qacc[q]);
             o[R - q] = sub_i(pacc[q], qacc[q]);
         }
+    } else {
+        constexpr int B = R / A;
+        pk2 y[R];
+        if constexpr (gcd_of(A, B) == 1) {
+#pragma unroll
+            for (int n2 = 0; n2 < B; ++n2) {                   // A-point transforms over n1: y[k1 B + n2]
+                pk2 t[A], u[A];
+#pragma unroll
+                for (int n1 = 0; n1 < A; ++n1) t[n1] = v[(B * n1 + A * n2) % R];
+                dft_regs<A>(t, u);
+#pragma unroll
+                for (int k1 = 0; k1 < A; ++k1) y[k1 * B + n2] = u[k1];
+            }
+            constexpr int ea = B * inv_mod(B % A, A), eb = A * inv_mod(A % B, B);      // k = k1 ea + k2 eb mod R
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) {                   // B-point transforms over n2
+                pk2 t[B], u[B];
+#pragma unroll
+                for (int n2 = 0; n2 < B; ++n2) t[n2] = y[k1 * B + n2];
+                dft_regs<B>(t, u);
+#pragma unroll
+                for (int k2 = 0; k2 < B; ++k2) o[(k1 * ea + k2 * eb) % R] = u[k2];
+            }
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < A; ++n1) {                   // B-point transforms over n2, then the twiddles w_R^(n1 k2): y[n1 B + k2]
+                pk2 t[B], u[B];
+#pragma unroll
+                for (int n2 = 0; n2 < B; ++n2) t[n2] = v[n1 + A * n2];
+                dft_regs<B>(t, u);
+#pragma unroll
+                for (int k2 = 0; k2 < B; ++k2) {
+                    const int m = (n1 * k2) % R;
+                    y[n1 * B + k2] = m == 0 ? u[k2] : cmul_k(u[k2], RootsOf<R>::tab.c[m], RootsOf<R>::tab.s[m]);
+                }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < B; ++k2) {                   // A-point transforms over n1
+                pk2 t[A], u[A];
+#pragma unroll
+                for (int n1 = 0; n1 < A; ++n1) t[n1] = y[n1 * B + k2];
+                dft_regs<A>(t, u);
+#pragma unroll
+                for (int k1 = 0; k1 < A; ++k1) o[B * k1 + k2] = u[k1];
+            }
+        }
     }
 }
 template <int R>
-FXC_HD void dft_to(pk2 (&v)[R], const fxc::Roots<R>& rt, cf* d, int ds) {      // ... into d[q * ds]
+FXC_HD void dft_to(pk2 (&v)[R], cf* d, int ds) {      // ... into d[q * ds]
     pk2 o[R];
-    dft_regs<R>(v, rt, o);
+    dft_regs<R>(v, o);
 #if (FXM_ABL & 2)
     if (ds >= 0) return;          // (never true at run time as far as the compiler knows: ds is data)
 #endif
@@ -298,20 +506,43 @@ struct Body {
 
     FXC_HD Body(Ctx& c, const Args& a) : cx(c), ar(a) {}
 
-    FXC_HD static bool has_bfly(int s, int j, int lt_) { return full_of(s) || j + 1 < j_of(s) || lt_ + j * TPR < nb_of(s); }
+    FXC_HD static bool has_item(int s, int j, int lt_) { return full_of(s) || j + 1 < j_of(s) || lt_ + j * TPR < items_of(s); }
 
-    // ---- once per launch: taps, twiddles, output offsets
+    // item i of stage s >= 1 (i = g nb + b; any valid index for a thread without it): its butterfly, and where its rows' inputs and
+    // outputs stand in the stage buffers (row a of the item: a RS further)
+    template <int s>
+    FXC_HD static int item_bfly(int i) {
+        constexpr int nb = nb_of(s);
+        if (i >= items_of(s)) i = 0;
+        return ngrp(s) > 1 ? i % nb : i;
+    }
+    template <int s>
+    FXC_HD static int item_in(int i) {
+        constexpr int nb = nb_of(s);
+        if (i >= items_of(s)) i = 0;
+        const int g = ngrp(s) > 1 ? i / nb : 0, b = i - g * nb;
+        return g * grp(s) * RS + rd_pos(s, b);
+    }
+    template <int s>
+    FXC_HD static int item_out(int i) {
+        constexpr int nb = nb_of(s);
+        if (i >= items_of(s)) i = 0;
+        const int g = ngrp(s) > 1 ? i / nb : 0, b = i - g * nb;
+        return g * grp(s) * RS + wr_pos(s, b);
+    }
+
+    // ---- once per launch: taps, twiddles, offsets
     FXC_HD void init() {
         lt = cx.tid() % TPR;
         slot = cx.tid() / TPR;
         bx = cx.lds() + slot * LDS_PER_SLOT;
-        by = bx + ROWS * N;
+        by = bx + ROWS * RS;
         if constexpr (!LEAN) {
 #pragma unroll
             for (int j = 0; j < J0; ++j)
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
-                    const bool ok = has_bfly(0, j, lt);
+                    const bool ok = has_item(0, j, lt);
                     const int m = ok ? lt + j * TPR + r * nb_of(0) : 0;      // (an unconditional load and a select: a branch here kept the taps on the stack)
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
@@ -327,17 +558,45 @@ struct Body {
     template <int s>
     FXC_HD void init_stage() {
         if constexpr (s < S) {
-            constexpr int R = kRadix[s], nb = nb_of(s), ns = ns_of(s), tmul = nb / ns;
+            constexpr int nb = nb_of(s), ns = ns_of(s), tmul = nb / ns;
 #pragma unroll
             for (int j = 0; j < j_of(s); ++j) {
-                int b = lt + j * TPR;
-                if (b >= nb) b = 0;                       // (a thread without this butterfly: any valid index)
-                const int k = b % ns;
+                const int i = lt + j * TPR;
+                const int k = item_bfly<s>(i) % ns;
 #pragma unroll
                 for (int r = 1; r <= tw_per(s); ++r) th.tw[tw_base(s) + j * tw_per(s) + r - 1] = pk(ar.tw[r * k * tmul]);
-                if constexpr (s < S - 1 && !LEAN) th.ob[ob_base(s) + j] = (b - k) * R + k;
+                if constexpr (s < S - 1) th.ob[ob_base(s) + j] = item_out<s>(i);
+                if constexpr (!plain_reads(s)) th.ib[ob_base(s) + j] = item_in<s>(i);
             }
             init_stage<s + 1>();
+        }
+    }
+    // where item j of stage s finds its inputs / puts its outputs: registers, or (LEAN) recomputed every step -- hoisted out of the
+    // step loop these offsets are registers again, hence the asm
+    template <int s>
+    FXC_HD int in_of(int j) const {
+        if constexpr (plain_reads(s)) {
+            return lt + j * TPR;
+        } else if constexpr (LEAN) {
+            int i = lt + j * TPR;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(i));
+#endif
+            return item_in<s>(i);
+        } else {
+            return th.ib[ob_base(s) + j];
+        }
+    }
+    template <int s>
+    FXC_HD int out_of(int j) const {
+        if constexpr (LEAN) {
+            int i = lt + j * TPR;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(i));
+#endif
+            return item_out<s>(i);
+        } else {
+            return th.ob[ob_base(s) + j];
         }
     }
 
@@ -368,7 +627,7 @@ struct Body {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
                     const int m = lt + j * TPR + r * nb_of(0);
-                    const bool ok = valid && has_bfly(0, j, lt) && !(FXM_ABL & 8) && (!FONLY || row_ok[a]);
+                    const bool ok = valid && has_item(0, j, lt) && !(FXM_ABL & 8) && (!FONLY || row_ok[a]);
                     pk2 v = pk_splat(0.f);
                     if (ok) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -397,7 +656,7 @@ struct Body {
             }
     }
 
-    // LEAN: the first twiddles of the thread's butterflies of stage s, from the table
+    // LEAN: the first twiddles of the thread's items of stage s, from the table
     template <int s>
     FXC_HD void load_tw1(pk2 (&w1)[j_of(s)]) {
 #pragma unroll
@@ -411,19 +670,118 @@ struct Body {
 #endif
         }
     }
-    // the twiddles w^1 .. w^(R-1) of butterfly j of stage s: registers, or (LEAN) powers of the first
+    // The twiddles of item j of stage s.  Kept whole (tw_per = R - 1): w[r] = w^r from the registers.  Else only w^1 is kept (LEAN: it
+    // comes from the table) and the others are its powers, formed every step: for a prime radix all of them, w^r = w^(r/2) w^(r - r/2) (the
+    // shortest chains); for a composite radix R = A B only the base powers w^a (a < A, in w[a]) and w^(A c) (c < B, in wc[c]) -- the
+    // butterfly forms w^(a + A c) = w^a w^(A c) where it needs it, so that no more than A + B of them are ever live.
     template <int s>
-    FXC_HD void stage_tw(int j, pk2 (&w)[kRadix[s]], const pk2* w1) {
-        constexpr int R = kRadix[s];
-        if constexpr (!LEAN) {
+    static constexpr bool whole_tw() { return tw_per(s) == kRadix[s] - 1 && !LEAN; }
+    template <int s>
+    static constexpr int base_a() { return split_a(kRadix[s]) > 0 ? split_a(kRadix[s]) : kRadix[s]; }
+    template <int s>
+    FXC_HD void stage_tw(int j, pk2 (&w)[kRadix[s]], pk2 (&wc)[kRadix[s] / base_a<s>()], const pk2* w1) {
+        constexpr int R = kRadix[s], A = base_a<s>(), B = R / A;
+        if constexpr (whole_tw<s>()) {
 #pragma unroll
             for (int r = 1; r < R; ++r) w[r] = th.tw[tw_base(s) + j * (R - 1) + r - 1];
         } else {
-            w[1] = w1[j];
+            w[1] = LEAN ? w1[j] : th.tw[tw_base(s) + j];
 #pragma unroll
-            for (int r = 2; r < R; ++r) {      // w^r = w^(r/2) w^(r - r/2): the shortest chains
+            for (int r = 2; r < A; ++r) {
                 const pk2 a = w[r / 2], b = w[r - r / 2];
                 w[r] = cmul_hi(a, b, cmul_lo(a, b));
+            }
+            if constexpr (B > 1) {
+                const pk2 a = w[A / 2], b = w[A - A / 2];
+                wc[1] = cmul_hi(a, b, cmul_lo(a, b));
+#pragma unroll
+                for (int c = 2; c < B; ++c) {
+                    const pk2 x = wc[c / 2], y = wc[c - c / 2];
+                    wc[c] = cmul_hi(x, y, cmul_lo(x, y));
+                }
+            }
+        }
+    }
+    // w^n for input n of a composite butterfly of stage s (n >= 1)
+    template <int s>
+    FXC_HD pk2 tw_at(int n, const pk2 (&w)[kRadix[s]], const pk2 (&wc)[kRadix[s] / base_a<s>()]) {
+        constexpr int A = base_a<s>();
+        if constexpr (whole_tw<s>()) {
+            return w[n];
+        } else {
+            const int a = n % A, c = n / A;
+            if (c == 0) return w[a];
+            if (a == 0) return wc[c];
+            return cmul_hi(w[a], wc[c], cmul_lo(w[a], wc[c]));
+        }
+    }
+
+    // One butterfly of stage s >= 1 for one row: inputs p[r rs] (LDS), times the twiddles, through the R-point transform into o.  A
+    // composite radix runs its first level group by group (load A or B inputs, twiddle, transform), so that the inputs of the next group
+    // need not be live while this one is in flight.
+    template <int s>
+    FXC_HD void stage_bfly(const cf* p, const pk2 (&w)[kRadix[s]], const pk2 (&wc)[kRadix[s] / base_a<s>()], pk2 (&o)[kRadix[s]]) {
+        constexpr int R = kRadix[s], rs = rd_stride(s), A = split_a(R);
+        if constexpr (A == 0) {
+            pk2 v[R], t[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = pk(p[r * rs]);
+#pragma unroll
+            for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], w[r]);
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], w[r], t[r]);
+            dft_regs<R>(v, o);
+        } else {
+            constexpr int B = R / A;
+            constexpr bool PFA = gcd_of(A, B) == 1;
+            constexpr int GN = PFA ? B : A, GL = PFA ? A : B;       // groups of the first level, inputs of each
+            pk2 y[R];
+#pragma unroll
+            for (int g = 0; g < GN; ++g) {
+                pk2 v[GL], t[GL], u[GL];
+#pragma unroll
+                for (int i = 0; i < GL; ++i) v[i] = pk(p[(PFA ? (B * i + A * g) % R : g + A * i) * rs]);
+#pragma unroll
+                for (int i = 0; i < GL; ++i) {
+                    const int n = PFA ? (B * i + A * g) % R : g + A * i;
+                    if (n > 0) {
+                        const pk2 wn = tw_at<s>(n, w, wc);
+                        t[i] = cmul_lo(v[i], wn);
+                        v[i] = cmul_hi(v[i], wn, t[i]);
+                    }
+                }
+                dft_regs<GL>(v, u);
+#pragma unroll
+                for (int k = 0; k < GL; ++k) {
+                    if constexpr (PFA) {
+                        y[k * B + g] = u[k];
+                    } else {
+                        const int m = (g * k) % R;
+                        y[g * B + k] = m == 0 ? u[k] : cmul_k(u[k], RootsOf<R>::tab.c[m], RootsOf<R>::tab.s[m]);
+                    }
+                }
+            }
+            if constexpr (PFA) {
+                constexpr int ea = B * inv_mod(B % A, A), eb = A * inv_mod(A % B, B);
+#pragma unroll
+                for (int k1 = 0; k1 < A; ++k1) {
+                    pk2 t[B], u[B];
+#pragma unroll
+                    for (int n2 = 0; n2 < B; ++n2) t[n2] = y[k1 * B + n2];
+                    dft_regs<B>(t, u);
+#pragma unroll
+                    for (int k2 = 0; k2 < B; ++k2) o[(k1 * ea + k2 * eb) % R] = u[k2];
+                }
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < B; ++k2) {
+                    pk2 t[A], u[A];
+#pragma unroll
+                    for (int n1 = 0; n1 < A; ++n1) t[n1] = y[n1 * B + k2];
+                    dft_regs<A>(t, u);
+#pragma unroll
+                    for (int k1 = 0; k1 < A; ++k1) o[B * k1 + k2] = u[k1];
+                }
             }
         }
     }
@@ -431,77 +789,77 @@ struct Body {
     // ---- one middle stage: LDS -> LDS
     template <int s>
     FXC_HD void mid_stage(const cf* src, cf* dst, const pk2* w1 = nullptr) {
-        constexpr int R = kRadix[s], nb = nb_of(s), ns = ns_of(s);
-        const fxc::Roots<R> rt = fxc::load_roots<R>(ar.tw, nb);
+        constexpr int R = kRadix[s], ns = ns_of(s);
 #pragma unroll
         for (int j = 0; j < j_of(s); ++j) {
-            const int b = lt + j * TPR;
-            if (has_bfly(s, j, lt)) {
-                pk2 w[R];
-                stage_tw<s>(j, w, w1);
-                int ob;
-                if constexpr (LEAN) {
-                    int bb = b;
-#if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" : "+v"(bb));      // (recomputed every step: hoisted out of the step loop these offsets are registers again)
+            if (has_item(s, j, lt)) {
+                pk2 w[R], wc[R / base_a<s>()];
+                stage_tw<s>(j, w, wc, w1);
+                const int ib = in_of<s>(j), ob = out_of<s>(j);
+#pragma unroll
+                for (int a = 0; a < grp(s); ++a) {       // (every row of the item: the same indices and twiddles serve them all)
+                    pk2 o[R];
+                    stage_bfly<s>(src + a * RS + ib, w, wc, o);
+#if (FXM_ABL & 2)
+                    if (ns >= 0 && ar.wg_splits >= 0) continue;          // (never false at run time as far as the compiler knows)
 #endif
-                    ob = (bb - bb % ns) * R + bb % ns;
-                } else {
-                    ob = th.ob[LEAN ? 0 : ob_base(s) + j];
-                }
 #pragma unroll
-                for (int a = 0; a < ROWS; ++a) {       // (every row of the step: the same indices, twiddles and barrier serve them all)
-                    pk2 v[R], t[R];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) v[r] = pk(src[a * ROW + b + r * nb]);
-#pragma unroll
-                    for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], w[r]);
-#pragma unroll
-                    for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], w[r], t[r]);
-                    dft_to<R>(v, rt, dst + a * ROW + ob, ns);
+                    for (int q = 0; q < R; ++q) dst[a * RS + ob + q * ns] = unpk(o[q]);
                 }
             }
         }
     }
 
-    // ---- the last stage (s = S - 1 >= 1): LDS -> registers -> X.  live[u]: frame u of the step exists for this slot
-    FXC_HD void last_stage(const cf* src, const bool (&live)[U], long long f, const pk2* w1 = nullptr) {
-        constexpr int s = S - 1, R = RL, nb = nb_of(s);
-        const fxc::Roots<R> rt = fxc::load_roots<R>(ar.tw, nb);
+    // ---- the last stage (s = S - 1 >= 1): LDS -> registers -> X.  f: the step's first frame; frames from f_end on do not exist for
+    // this slot (their rows hold the transform of zeros: nothing is added, nothing stored)
+    FXC_HD void last_stage(const cf* src, long long f, long long f_end, const pk2* w1 = nullptr) {
+        constexpr int s = S - 1, R = RL, G = grp(s), FR = G / NA > 0 ? G / NA : 1;
 #pragma unroll
         for (int j = 0; j < JL; ++j) {
-            const int b = lt + j * TPR;
-            pk2 w[R];
-            stage_tw<s>(j, w, w1);
+            if (!has_item(s, j, lt)) continue;
+            pk2 w[R], wc[R / base_a<s>()];
+            stage_tw<s>(j, w, wc, w1);
+            const int ib = in_of<s>(j);
+            // the item's rows: g G .. g G + G - 1 of the step's (frame u, antenna a) -> u NA + a
+            int g = 0;
+            if constexpr (ngrp(s) > 1) g = (lt + j * TPR) / nb_of(s);
+            const int bfly = ngrp(s) > 1 ? lt + j * TPR - g * nb_of(s) : lt + j * TPR;
+            if constexpr (G % NA == 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (live[u] && has_bfly(s, j, lt)) {
-                    pk2 o[NA][R];
+                for (int u = 0; u < FR; ++u) {
+                    const long long frame = f + g * FR + u;
+                    if (frame < f_end) {
+                        pk2 o[NA][R];
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) {
-                        pk2 v[R], t[R];
-#pragma unroll
-                        for (int r = 0; r < R; ++r) v[r] = pk(src[(u * NA + a) * ROW + b + r * nb]);
-#pragma unroll
-                        for (int r = 1; r < R; ++r) t[r] = cmul_lo(v[r], w[r]);
-#pragma unroll
-                        for (int r = 1; r < R; ++r) v[r] = cmul_hi(v[r], w[r], t[r]);
-                        dft_regs<R>(v, rt, o[a]);
-                        }
-                    emit<R>(o, j, f + u);
+                        for (int a = 0; a < NA; ++a) stage_bfly<s>(src + (u * NA + a) * RS + ib, w, wc, o[a]);
+                        emit<R>(o, j, bfly, frame);
+                    }
                 }
+            } else {
+                // F only, one row per item (G = 1 of NA = 2): row g = (frame u, stream a)
+                static_assert(G % NA == 0 || (FONLY && G == 1), "items of single rows: the F stage alone");
+                const int a = g % NA;
+                const long long frame = f + g / NA;
+                if (frame < f_end && (a ? row_ok[NA - 1] : row_ok[0])) {
+                    pk2 o[R];
+                    stage_bfly<s>(src + ib, w, wc, o);
+                    cf* d = (a ? row_out[NA - 1] : row_out[0]) + frame * (long long)ar.ant * N + bfly;
+#pragma unroll
+                    for (int q = 0; q < R; ++q) fxc::st_store(d + q * (N / R), unpk(o[q]));
+                }
+            }
         }
     }
 
     // the two rows' spectra of one butterfly of the last stage: X-multiplied into the thread's sums, or (F only) stored -- output q of
     // butterfly b is bin b + q N/R there, so the lanes of a wave write R runs of consecutive bins
     template <int R>
-    FXC_HD void emit(pk2 (&o)[NA][R], int j, long long frame) {
+    FXC_HD void emit(pk2 (&o)[NA][R], int j, int bfly, long long frame) {
         if constexpr (FONLY) {
 #pragma unroll
             for (int a = 0; a < NA; ++a)
                 if (row_ok[a]) {
-                    cf* d = row_out[a] + frame * (long long)ar.ant * N + lt + j * TPR;
+                    cf* d = row_out[a] + frame * (long long)ar.ant * N + bfly;
 #pragma unroll
                     for (int q = 0; q < R; ++q) fxc::st_store(d + q * (N / R), unpk(o[a][q]));
                 }
@@ -522,16 +880,22 @@ struct Body {
         }
     }
 
+    // the first stage's butterfly j of one row, out of registers into the slot's buffer (planes, or blocks of R0 with their padding)
+    FXC_HD void first_to_lds(pk2 (&v)[R0], int row, int j) {
+        const int b = lt + j * TPR;
+        if constexpr (P0 > 0)
+            dft_to<R0>(v, bx + row * RS + b, P0);
+        else
+            dft_to<R0>(v, bx + row * RS + b * (R0 + pad_of(0)), 1);      // ns = 1: o = b R0
+    }
+
     // ---- one step: the FIR of its U frames out of the ring, the first butterfly, the stages, X.  P = the ring slot of the
-    // step's first frame f.  live[u]: frame f + u exists for this slot (the slots of a workgroup take the same number of
-    // steps); f_end: the end of the slot's run (frames from there on are not loaded)
+    // step's first frame f.  Frame f + u exists for this slot while f + u < f_end (the slots of a workgroup take the same number of
+    // steps); frames from f_end on are not loaded
     template <int P>
     FXC_HD void step(long long f, long long f_end) {
-        bool live[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) live[u] = f + u < f_end;
         if constexpr (LEAN) {
-            step_lean<P>(f, f_end, live);
+            step_lean<P>(f, f_end);
             return;
         }
         pk2 acc[U][NA][PTS];
@@ -550,27 +914,26 @@ struct Body {
         // the U oldest slots are free now: the next step's frames go there, in flight through the stages below
         load_frame<(P + U) % NS>(f + U, f + U < f_end);
         if constexpr (U == 2) load_frame<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end);
-        const fxc::Roots<R0> rt = fxc::load_roots<R0>(ar.tw, nb_of(0));
         if constexpr (S == 1) {
 #pragma unroll
             for (int j = 0; j < J0; ++j)
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (live[u] && has_bfly(0, j, lt)) {
+                    if (f + u < f_end && has_item(0, j, lt)) {
                         pk2 o[NA][R0];
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
                             pk2 v[R0];
 #pragma unroll
                             for (int r = 0; r < R0; ++r) v[r] = acc[u][a][j * R0 + r];
-                            dft_regs<R0>(v, rt, o[a]);
+                            dft_regs<R0>(v, o[a]);
                         }
-                        emit<R0>(o, j, f + u);
+                        emit<R0>(o, j, lt + j * TPR, f + u);
                     }
         } else {
 #pragma unroll
             for (int j = 0; j < J0; ++j)
-                if (has_bfly(0, j, lt)) {
+                if (has_item(0, j, lt)) {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -578,12 +941,12 @@ struct Body {
                             pk2 v[R0];
 #pragma unroll
                             for (int r = 0; r < R0; ++r) v[r] = acc[u][a][j * R0 + r];
-                            dft_to<R0>(v, rt, bx + (u * NA + a) * ROW + (lt + j * TPR) * R0, 1);      // ns = 1: o = b R0
+                            first_to_lds(v, u * NA + a, j);
                         }
                 }
             cx.sync();
             mid_stages<1>(bx, by);
-            last_stage((S % 2 == 0) ? bx : by, live, f);      // stage S-2 wrote X when S is even
+            last_stage((S % 2 == 0) ? bx : by, f, f_end);      // stage S-2 wrote X when S is even
             if constexpr (SWAP) {
                 cf* t = bx;
                 bx = by;
@@ -594,24 +957,23 @@ struct Body {
 
     // LEAN: stage s reads rd and writes wr with the first twiddles w1; the next stage's are requested before, the last stage ends in X
     template <int s>
-    FXC_HD void lean_stages(cf* rd, cf* wr, const pk2 (&w1)[j_of(s)], const bool (&live)[U], long long f) {
+    FXC_HD void lean_stages(cf* rd, cf* wr, const pk2 (&w1)[j_of(s)], long long f, long long f_end) {
         if constexpr (s < S - 1) {
             pk2 nxt[j_of(s + 1)];
             load_tw1<s + 1>(nxt);
             mid_stage<s>(rd, wr, w1);
             cx.sync();
-            lean_stages<s + 1>(wr, rd, nxt, live, f);
+            lean_stages<s + 1>(wr, rd, nxt, f, f_end);
         } else {
-            last_stage(rd, live, f, w1);
+            last_stage(rd, f, f_end, w1);
         }
     }
 
     // LEAN (S >= 2): one first-stage butterfly at a time -- its points' taps from L2, their FIR, the next frames' samples into the
     // ring slots those points have just left, the butterfly into LDS -- so that only R0 points' taps and sums are live at once
     template <int P>
-    FXC_HD void step_lean(long long f, long long f_end, const bool (&live)[U]) {
+    FXC_HD void step_lean(long long f, long long f_end) {
         static_assert(!LEAN || S >= 2, "the lean build needs a first stage into LDS (h_rtc.h::spec_shape)");
-        const fxc::Roots<R0> rt = fxc::load_roots<R0>(ar.tw, nb_of(0));
         pk2 w1[j_of(1)];
         load_tw1<1>(w1);
 #pragma unroll
@@ -625,7 +987,7 @@ struct Body {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) hq[r][t] = __uint_as_float(q[t]);      // (past the table: zeros, and so are those lanes' samples)
 #else
-                const int m = has_bfly(0, j, lt) ? lt + j * TPR + r * nb_of(0) : 0;
+                const int m = has_item(0, j, lt) ? lt + j * TPR + r * nb_of(0) : 0;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) hq[r][t] = ar.h4[4 * m + t];
 #endif
@@ -644,15 +1006,15 @@ struct Body {
                         }
             load_points<(P + U) % NS>(f + U, f + U < f_end, j);
             if constexpr (U == 2) load_points<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end, j);
-            if (has_bfly(0, j, lt)) {
+            if (has_item(0, j, lt)) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) dft_to<R0>(acc[u][a], rt, bx + (u * NA + a) * ROW + (lt + j * TPR) * R0, 1);
+                    for (int a = 0; a < NA; ++a) first_to_lds(acc[u][a], u * NA + a, j);
             }
         }
         cx.sync();
-        lean_stages<1>(bx, by, w1, live, f);
+        lean_stages<1>(bx, by, w1, f, f_end);
         if constexpr (SWAP) {
             cf* t = bx;
             bx = by;
@@ -714,11 +1076,39 @@ struct Body {
         if constexpr (!FONLY) {
             // the thread's bins: the last stage's butterfly b puts output q at b + q N/RL (k = b there: ns = N/RL)
             cf* o = ar.out + ((long long)e * ar.n_chunks + chunk) * N;
+            constexpr int s = S - 1, nb = nb_of(S - 1);
+            if constexpr (S >= 2 && ngrp(s) > 1) {
+                // the frames of a step went to different threads: their sums meet in LDS (row g of the slot's buffer), the thread that
+                // had group 0 of a butterfly adds them up in group order
+                cf* red = cx.lds() + slot * LDS_PER_SLOT;
+                cx.sync();
 #pragma unroll
-            for (int j = 0; j < JL; ++j)
-                if (has_bfly(S - 1, j, lt))
+                for (int j = 0; j < JL; ++j)
+                    if (has_item(s, j, lt)) {
+                        const int i = lt + j * TPR, g = i / nb, b = i - g * nb;
 #pragma unroll
-                    for (int q = 0; q < RL; ++q) o[lt + j * TPR + q * nb_of(S - 1)] = unpk(th.xacc[j * RL + q]);
+                        for (int q = 0; q < RL; ++q) red[g * N + b + q * nb] = unpk(th.xacc[j * RL + q]);
+                    }
+                cx.sync();
+#pragma unroll
+                for (int j = 0; j < JL; ++j)
+                    if (has_item(s, j, lt) && lt + j * TPR < nb) {
+                        const int b = lt + j * TPR;
+#pragma unroll
+                        for (int q = 0; q < RL; ++q) {
+                            pk2 sum = pk(red[b + q * nb]);
+#pragma unroll
+                            for (int g = 1; g < ngrp(s); ++g) sum = sum + pk(red[g * N + b + q * nb]);
+                            o[b + q * nb] = unpk(sum);
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < JL; ++j)
+                    if (has_item(s, j, lt))
+#pragma unroll
+                        for (int q = 0; q < RL; ++q) o[lt + j * TPR + q * nb] = unpk(th.xacc[j * RL + q]);
+            }
         }
     }
 };

@@ -812,12 +812,11 @@ int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* re
     if (b.image.empty()) return fail(nullptr, b.scratch ? FXC_ERR_UNSUPPORTED : FXC_ERR_HIP, "%s", b.error.c_str());
     if (report && report_bytes > 0) {
         const SpecShape& sh = b.shape;
-        std::string radices;
-        for (int i = 0; i < sh.n_stages; ++i) radices += (i ? "," : "") + std::to_string(sh.radix[i]);
         std::snprintf(report, (size_t)report_bytes,
-                      "nchan=%d ntaps=%d tpr=%d slots=%d frames_per_step=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld resident=%d lean=%d rows=%d",
-                      sh.n, sh.taps, sh.tpr, sh.slots, sh.u, radices.c_str(), sh.lds_bytes(), b.image.size(), b.vgprs, b.scratch, b.resident,
-                      (int)sh.lean, sh.rows);
+                      "nchan=%d ntaps=%d tpr=%d slots=%d frames_per_step=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld resident=%d lean=%d rows=%d "
+                      "groups=%s pads=%s plane0=%d twfull=%d waves=%d",
+                      sh.n, sh.taps, sh.tpr, sh.slots, sh.u, sh.list(sh.radix).c_str(), sh.lds_bytes(), b.image.size(), b.vgprs, b.scratch, b.resident,
+                      (int)sh.lean, sh.rows, sh.list(sh.grp).c_str(), sh.list(sh.pad).c_str(), sh.plane0, sh.twfull, sh.waves);
     }
     return FXC_OK;
 }

@@ -86,7 +86,22 @@ enum SpecVariant { kSpecC64 = 0, kSpecU8 = 1, kSpecFOnly = 2 };      // F + X fr
 
 constexpr int kSpecLoadAux = 0;      // cache policy of the F + X builds' sample loads (FXC_RTC_LD_AUX: developer knob)
 constexpr int kSpecLeanAbove = 2048;
-inline int spec_lean_above() { return env_int("FXC_RTC_LEAN_ABOVE", kSpecLeanAbove); }      // (developer knob)
+
+// developer knobs of the search below exist in the developer library only (libfxcorr_dev.so): the shipped library's choices do not
+// depend on the process environment
+inline int dev_env_int(const char* name, int dflt) { return FXC_DEV_KERNELS ? env_int(name, dflt) : dflt; }
+inline int dev_env_list(const char* name, int* out, int cap) {      // "4,25,10" -> out[], the count (0: unset)
+    const char* e = FXC_DEV_KERNELS ? std::getenv(name) : nullptr;
+    int n = 0;
+    while (e && *e && n < cap) {
+        out[n++] = std::atoi(e);
+        while (*e && *e != ',') ++e;
+        if (*e == ',') ++e;
+    }
+    return n;
+}
+
+inline int spec_lean_above() { return dev_env_int("FXC_RTC_LEAN_ABOVE", kSpecLeanAbove); }
 
 struct SpecShape {
     bool ok = false;
@@ -94,9 +109,50 @@ struct SpecShape {
     int u = 1;                   // frames a slot carries through a step together
     int rows = 2;                // streams a workgroup carries: the two antennas / a pair of streams, or (F only, above 4096 channels) one
     bool lean = false;           // FXM_LEAN: taps and first twiddles from L2 tables, nothing but the ring and the sums kept in registers
+    // fx_spec.h's work items and LDS layout (spec_layout): rows per item of each stage (0: all the step's rows), the plane stride of the
+    // first stage's outputs (0: blocks), the padding behind each block of the buffer a stage writes, the largest radix whose twiddles
+    // all stay in registers, the waves per SIMD the register allocation is held to
+    int grp[fxc::kMixedMaxStages] = {0}, pad[fxc::kMixedMaxStages] = {0}, plane0 = 0, twfull = 13, waves = 1;
     int threads() const { return tpr * slots; }
-    size_t lds_bytes() const { return n_stages >= 2 ? (size_t)slots * 2 * rows * u * n * sizeof(cf) : 0; }
+    int n_rows() const { return rows * u; }
+    int ns_of(int s) const {
+        int v = 1;
+        for (int i = 0; i < s; ++i) v *= radix[i];
+        return v;
+    }
+    int nb_of(int s) const { return n / radix[s]; }
+    int grp_of(int s) const { return (s == 0 || grp[s] <= 0) ? n_rows() : grp[s]; }
+    int items_of(int s) const { return nb_of(s) * (n_rows() / grp_of(s)); }
+    int j_of(int s) const { return (items_of(s) + tpr - 1) / tpr; }
+    int item_bfly(int s, int i) const { return i >= items_of(s) ? 0 : i % nb_of(s); }
+    int row_stride() const {     // fx_spec.h's RS
+        int m = n;
+        for (int s = 0; s + 1 < n_stages; ++s) {
+            const int len = (s == 0 && plane0 > 0) ? radix[0] * plane0 : n + (n / ns_of(s + 1)) * pad[s];
+            m = std::max(m, len);
+        }
+        return m;
+    }
+    size_t lds_bytes() const { return n_stages >= 2 ? (size_t)slots * 2 * n_rows() * row_stride() * sizeof(cf) : 0; }
+    std::string list(const int* v) const {
+        std::string t;
+        for (int i = 0; i < n_stages; ++i) t += (i ? "," : "") + std::to_string(v[i]);
+        return t;
+    }
 };
+
+// a radix fx_spec.h has a butterfly for: 2, 4, the odd primes up to 23, and products of those up to 32 (run in registers as
+// Good-Thomas / Cooley-Tukey butterflies)
+inline bool spec_radix_ok(int r, bool* big = nullptr) {
+    if (r < 2 || r > 32) return false;
+    int m = r;
+    for (int p : {2, 3, 5, 7, 11, 13, 17, 19, 23})
+        while (m % p == 0) {
+            m /= p;
+            if (p > 13 && big) *big = true;
+        }
+    return m == 1;
+}
 
 // Eligible: two antennas, up to four taps (the frame ring lives in registers), every prime factor has a register butterfly
 // (2, 3, 4, 5, 7, 11, 13), a thread's points (first radix x its first-stage butterflies) fit the ring (<= 8), the slots'
@@ -104,29 +160,20 @@ struct SpecShape {
 // it sets the threads per slot (N / first butterflies), the points a thread keeps in its ring (first of them) and the LDS
 // bank pattern of the first stage's stores (an odd stride is conflict-free).  `u`: frames per step.  Above 2048 channels: the
 // lean build (fx_spec.h, FXM_LEAN), up to 512 threads a frame with up to two first-stage butterflies each.
-SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
+SpecShape spec_shape_of(int n, int taps, const int* radix, int n_stages, int u = 1, int rows = 2) {
     SpecShape s;
-    if (n < 2 || n > 8192 || taps < 1 || taps > 4) return s;
-    const fxc::MixedPlan mp = fxc::mixed_factor(n);
-    if (mp.n_stages < 1) return s;
+    if (n < 2 || n > 8192 || taps < 1 || taps > 4 || n_stages < 1 || n_stages > fxc::kMixedMaxStages) return s;
     bool big = false;
-    for (int i = 0; i < mp.n_stages; ++i) {
-        const int r = mp.radix[i];
-        if (!(r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 11 || r == 13 || r == 17 || r == 19 || r == 23)) return s;
-        if (r > 13) big = true;      // (a register butterfly of 17 ... 23 points: only beside the lean build's few persistent registers)
-        s.radix[i] = r;
+    int prod = 1;
+    for (int i = 0; i < n_stages; ++i) {
+        if (!spec_radix_ok(radix[i], &big)) return s;      // (a register butterfly of 17 ... 23 points: only beside the lean build's few persistent registers)
+        s.radix[i] = radix[i];
+        prod *= radix[i];
     }
+    if (prod != n) return s;
     s.n = n;
     s.taps = taps;
-    s.n_stages = mp.n_stages;
-    if (first) {
-        int at = -1;
-        for (int i = 0; i < s.n_stages && at < 0; ++i)
-            if (s.radix[i] == first) at = i;
-        if (at < 0) return s;
-        for (int i = at; i > 0; --i) s.radix[i] = s.radix[i - 1];      // (the others keep their order)
-        s.radix[0] = first;
-    }
+    s.n_stages = n_stages;
     const int nb0 = n / s.radix[0];
     int j0 = 1;
     if (nb0 <= 64) {
@@ -135,7 +182,7 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
     } else {
         // threads a frame at most: 1024 up to 2048 channels (spec_first_radices keeps the shapes of up to 512), 512 above, 256 with a
         // butterfly of 17 ... 23 points (one wave a SIMD, see spec_first_radices).  FXC_RTC_TPR_MAX: developer knob
-        const int tmax = big ? 256 : env_int("FXC_RTC_TPR_MAX", n > spec_lean_above() ? 512 : 1024);
+        const int tmax = big ? 256 : dev_env_int("FXC_RTC_TPR_MAX", n > spec_lean_above() ? 512 : 1024);
         j0 = (nb0 + tmax - 1) / tmax;
         s.tpr = ((nb0 + j0 - 1) / j0 + 63) / 64 * 64;
     }
@@ -144,12 +191,180 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
     s.rows = rows;
     s.u = u;
     s.lean = n > spec_lean_above() || big;
-    if (big && !env_int("FXC_RTC_BIG_PRIMES", 1)) return s;
+    if (big && !dev_env_int("FXC_RTC_BIG_PRIMES", 1)) return s;
     if (s.lean && s.n_stages < 2) return s;
     if (u != 1 && (u != 2 || s.n_stages < 2)) return s;      // (whether two frames' rows cost a resident workgroup: spec_search)
     if (s.lds_bytes() > (size_t)(160 * 1024)) return s;
     s.ok = true;
     return s;
+}
+
+SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
+    const fxc::MixedPlan mp = fxc::mixed_factor(n);
+    if (mp.n_stages < 1) return SpecShape();
+    int radix[fxc::kMixedMaxStages];
+    for (int i = 0; i < mp.n_stages; ++i) radix[i] = mp.radix[i];
+    if (first) {
+        int at = -1;
+        for (int i = 0; i < mp.n_stages && at < 0; ++i)
+            if (radix[i] == first) at = i;
+        if (at < 0) return SpecShape();
+        for (int i = at; i > 0; --i) radix[i] = radix[i - 1];      // (the others keep their order)
+        radix[0] = first;
+    }
+    return spec_shape_of(n, taps, radix, mp.n_stages, u, rows);
+}
+
+// ---- fx_spec.h's work items and LDS layout for a shape (what FXM_GROUPS / FXM_PLANE0 / FXM_PADS say)
+//
+// LDS banking of the 8-byte accesses (MI355X_MICROARCH.md, LDS): a ds_write_b64 is served in four groups of 16 consecutive lanes, bank =
+// dword address mod 32; a ds_read_b64 in two groups of 32 lanes, bank = dword address mod 64; each further distinct dword on a busy
+// bank of a group costs a cycle.  Extra cycles of one wave instruction whose lane l touches element elem[l] (-1: lane idle):
+inline int spec_lds_extra(const int* elem, int group, int banks) {
+    int extra = 0;
+    for (int g0 = 0; g0 < 64; g0 += group) {
+        int seen[64][8], cnt[64] = {0};
+        int worst = 1;
+        for (int l = g0; l < g0 + group; ++l) {
+            if (elem[l] < 0) continue;
+            for (int d = 0; d < 2; ++d) {
+                const int dw = 2 * elem[l] + d, bk = dw % banks;
+                bool dup = false;
+                for (int k = 0; k < cnt[bk] && k < 8; ++k) dup = dup || seen[bk][k] == dw;
+                if (!dup) {
+                    if (cnt[bk] < 8) seen[bk][cnt[bk]] = dw;
+                    ++cnt[bk];
+                    worst = std::max(worst, cnt[bk]);
+                }
+            }
+        }
+        extra += worst - 1;
+    }
+    return extra;
+}
+// ... of all the stores of stage s and all the loads of stage s + 1 of one step of one row group, with the buffer between them laid out
+// as (plane0, pad) say
+inline long spec_buffer_conflicts(const SpecShape& sh, int s, int plane0, int pad) {
+    const int R = sh.radix[s], ns = sh.ns_of(s), nb = sh.nb_of(s), blk = ns * R;
+    long extra = 0;
+    int elem[64];
+    for (int j = 0; j < sh.j_of(s); ++j)
+        for (int w0 = 0; w0 < sh.tpr; w0 += 64)
+            for (int q = 0; q < R; ++q) {
+                bool any = false;
+                for (int l = 0; l < 64; ++l) {
+                    const int i = w0 + l + j * sh.tpr;
+                    elem[l] = -1;
+                    if (w0 + l >= sh.tpr || i >= sh.items_of(s)) continue;
+                    const int b = i % nb;
+                    elem[l] = s == 0 ? (plane0 > 0 ? q * plane0 + b : b * (R + pad) + q) : (b / ns) * (blk + pad) + b % ns + q * ns;
+                    any = true;
+                }
+                if (any) extra += spec_lds_extra(elem, 16, 32);
+            }
+    const int s1 = s + 1, R1 = sh.radix[s1], nb1 = sh.nb_of(s1);
+    const int rs = (s == 0 && plane0 > 0) ? nb1 / sh.radix[0] : nb1 + (nb1 / blk) * pad;
+    for (int j = 0; j < sh.j_of(s1); ++j)
+        for (int w0 = 0; w0 < sh.tpr; w0 += 64)
+            for (int r = 0; r < R1; ++r) {
+                bool any = false;
+                for (int l = 0; l < 64; ++l) {
+                    const int i = w0 + l + j * sh.tpr;
+                    elem[l] = -1;
+                    if (w0 + l >= sh.tpr || i >= sh.items_of(s1)) continue;
+                    const int b = i % nb1;
+                    elem[l] = ((s == 0 && plane0 > 0) ? (b % sh.radix[0]) * plane0 + b / sh.radix[0] : b + (b / blk) * pad) + r * rs;
+                    any = true;
+                }
+                if (any) extra += spec_lds_extra(elem, 32, 64);
+            }
+    return extra;
+}
+
+// Vector instructions of one R-point butterfly with its R - 1 twiddle multiplies (fx_spec.h::stage_bfly; packed instructions), roughly
+inline int spec_bfly_cost(int r) {
+    switch (r) {
+        case 2: return 2 + 2;
+        case 3: return 8 + 4;
+        case 4: return 8 + 6;
+        case 5: return 18 + 8;
+        case 7: return 34 + 12;
+        default: break;
+    }
+    for (int a : {4, 2, 3, 5, 7, 11, 13})
+        if (r % a == 0 && r > a) {
+            const int b = r / a;
+            int g = a, h = b;
+            while (h) {
+                const int t = g % h;
+                g = h;
+                h = t;
+            }
+            // b butterflies of a points, a of b points (their own twiddle terms taken off again), the literals between them unless coprime
+            return b * (spec_bfly_cost(a) - 2 * (a - 1)) + a * (spec_bfly_cost(b) - 2 * (b - 1)) + (g == 1 ? 0 : 2 * (a - 1) * (b - 1)) + 2 * (r - 1);
+        }
+    return (r - 1) * (r - 1) / 2 + 4 * r;      // odd primes 11 ... 23
+}
+
+// Rows per item of every stage after the first: the divisor of the step's rows (a multiple of the antennas in the F + X build's last
+// stage) that costs a SIMD the fewest issue slots -- whole rounds of four waves x the item's butterflies -- and, among equals, the most rows
+// (fewer twiddle and offset registers).  Then where the stages' outputs stand (spec_buffer_conflicts), kept within the LDS the
+// unpadded rows already allowed a CU's resident workgroups.
+inline void spec_layout(SpecShape& sh, bool fonly) {
+    const int rows = sh.n_rows();
+    int forced[fxc::kMixedMaxStages];
+    const int nf = dev_env_list("FXC_RTC_GROUPS", forced, fxc::kMixedMaxStages);
+    for (int s = 1; s < sh.n_stages; ++s) {
+        const bool last = s == sh.n_stages - 1;
+        long best = -1;
+        for (int g = rows; g >= 1; --g) {
+            if (rows % g) continue;
+            if (last && !fonly && g % sh.rows) continue;
+            const int items = sh.nb_of(s) * (rows / g);
+            long slots = 0;                                   // issue slots of the busiest SIMD: its waves' items, one after the other
+            for (int i0 = 0; i0 < items; i0 += sh.tpr) {
+                const int waves = (std::min(items - i0, sh.tpr) + 63) / 64;
+                slots += (waves + 3) / 4;
+            }
+            const long cost = slots * ((long)g * spec_bfly_cost(sh.radix[s]) + (sh.radix[s] > sh.twfull ? 2 * (sh.radix[s] - 2) : 0));
+            if (best < 0 || cost < best) {
+                best = cost;
+                sh.grp[s] = g;
+            }
+        }
+        if (s < nf && forced[s] > 0 && rows % forced[s] == 0) sh.grp[s] = forced[s];
+    }
+    if (sh.n_stages < 2) return;
+    const size_t base_lds = sh.lds_bytes();
+    auto fits = [&](const SpecShape& t) {
+        const size_t b = t.lds_bytes();
+        return b <= (size_t)(160 * 1024) && (size_t)(160 * 1024) / b >= std::min<size_t>((size_t)(160 * 1024) / base_lds, 2);
+    };
+    int fpads[fxc::kMixedMaxStages];
+    const int npf = dev_env_list("FXC_RTC_PADS", fpads, fxc::kMixedMaxStages);
+    const int fplane = dev_env_int("FXC_RTC_PLANE0", -1);
+    if (!dev_env_int("FXC_RTC_LAYOUT", 1)) return;
+    for (int s = 0; s + 1 < sh.n_stages; ++s) {
+        long best = spec_buffer_conflicts(sh, s, 0, 0);
+        int best_plane = 0, best_pad = 0;
+        for (int pad = 1; pad < 16 && best > 0; ++pad) {
+            SpecShape t = sh;
+            t.pad[s] = pad;
+            if (!fits(t)) break;
+            const long c = spec_buffer_conflicts(sh, s, 0, pad);
+            if (c < best) best = c, best_pad = pad;
+        }
+        if (s == 0 && sh.radix[0] % 2 == 0)
+            for (int pl = sh.nb_of(0); pl < sh.nb_of(0) + 64 && best > 0; ++pl) {
+                SpecShape t = sh;
+                t.plane0 = pl;
+                if (!fits(t)) break;
+                const long c = spec_buffer_conflicts(sh, 0, pl, 0);
+                if (c < best) best = c, best_plane = pl, best_pad = 0;
+            }
+        if (s == 0) sh.plane0 = fplane >= 0 ? fplane : best_plane;
+        sh.pad[s] = s < npf ? fpads[s] : (s == 0 && sh.plane0 > 0 ? 0 : best_pad);
+    }
 }
 
 // The first-stage radices worth building for n channels, best guess first.  Measured (tools/sweep_spec_r0.sh, 14 channel counts,
@@ -158,7 +373,7 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
 // (N / 2 threads per frame leave the later stages a few butterflies each: 600 channels 3.4 ms against 1.75), then the fuller
 // first stage, then the smaller radix (fewer ring registers).
 // streams per workgroup of the build for (n, variant): F only above 4096 channels carries one (sixteen points a thread)
-inline int spec_rows(int n, int variant) { return (variant == kSpecFOnly && n > env_int("FXC_RTC_ROWS1_ABOVE", 4096)) ? 1 : 2; }      // (developer knob)
+inline int spec_rows(int n, int variant) { return (variant == kSpecFOnly && n > dev_env_int("FXC_RTC_ROWS1_ABOVE", 4096)) ? 1 : 2; }      // (developer knob)
 
 std::vector<int> spec_first_radices(int n, int taps, int rows = 2) {
     struct Cand {
@@ -221,11 +436,10 @@ std::vector<cf> spec_tw1_table(const SpecShape& sh) {
     std::vector<cf> t;
     int ns = sh.radix[0];
     for (int s = 1; s < sh.n_stages; ++s) {
-        const int nb = sh.n / sh.radix[s], jn = (nb + sh.tpr - 1) / sh.tpr, tmul = nb / ns;
+        const int nb = sh.nb_of(s), jn = sh.j_of(s), tmul = nb / ns;
         for (int j = 0; j < jn; ++j)
             for (int lt = 0; lt < sh.tpr; ++lt) {
-                int b = lt + j * sh.tpr;
-                if (b >= nb) b = 0;
+                const int b = sh.item_bfly(s, lt + j * sh.tpr);
                 const double ph = 6.283185307179586476925286766559 * (double)((b % ns) * tmul) / (double)sh.n;
                 t.push_back(fxc::mk((float)std::cos(ph), (float)std::sin(ph)));
             }
@@ -346,8 +560,10 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXM_NST=" + std::to_string(shape.n_stages), "-DFXM_RADICES=" + radices,
                                      "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)), "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly)),
                                      "-DFXM_U=" + std::to_string(shape.u), "-DFXM_LEAN=" + std::to_string((int)shape.lean), "-DFXM_ROWS=" + std::to_string(shape.rows),
+                                     "-DFXM_GROUPS=" + shape.list(shape.grp), "-DFXM_PADS=" + shape.list(shape.pad), "-DFXM_PLANE0=" + std::to_string(shape.plane0),
+                                     "-DFXM_TWFULL=" + std::to_string(shape.twfull), "-DFXM_WAVES=" + std::to_string(shape.waves),
                                      "-DFXC_STREAM_AUX=" + std::to_string((int)FXC_STREAM_AUX),
-                                     "-DFXM_LD_AUX=" + std::to_string(env_int("FXC_RTC_LD_AUX", kSpecLoadAux)),
+                                     "-DFXM_LD_AUX=" + std::to_string(dev_env_int("FXC_RTC_LD_AUX", kSpecLoadAux)),
                                      "-DFXM_ABL=" + std::to_string(spec_ablation())};      // (timing ablations: wrong results, developer library only)
     const std::string dir = spec_cache_dir();
     const std::string cached = dir.empty() ? std::string() : dir + "/" + spec_cache_key(opts, api) + ".co";
@@ -414,6 +630,44 @@ SpecBuild spec_build(const SpecShape& shape, int variant, const char* arch) {
     return b;
 }
 
+// one candidate: its work items and layout chosen (spec_layout), built for two waves per SIMD first where the workgroup is small
+// enough for two of them on a CU (a build that spills there is built again for one)
+SpecBuild spec_build_laid_out(SpecShape sh, int variant, const char* arch) {
+    spec_layout(sh, variant == kSpecFOnly);
+    if (dev_env_int("FXC_RTC_TWFULL", 0) > 0) sh.twfull = dev_env_int("FXC_RTC_TWFULL", 0);
+    const int force_waves = dev_env_int("FXC_RTC_WAVES", 0);
+    if (force_waves > 0) {
+        sh.waves = force_waves;
+        return spec_build(sh, variant, arch);
+    }
+    if (sh.threads() <= 256 && sh.n_stages >= 2) {
+        sh.waves = 2;
+        SpecBuild b = spec_build(sh, variant, arch);
+        if (!b.image.empty() && b.scratch == 0) return b;
+    }
+    sh.waves = 1;
+    return spec_build(sh, variant, arch);
+}
+
+// The stage lists worth building for n channels, best guess first: the prime-factor orders of spec_first_radices (fours, a two, the odd
+// primes ascending, one of them moved to the front).  FXC_RTC_RADICES (developer knob): exactly this list.
+std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows) {
+    std::vector<std::vector<int>> out;
+    int forced[fxc::kMixedMaxStages];
+    const int nf = dev_env_list("FXC_RTC_RADICES", forced, fxc::kMixedMaxStages);
+    if (nf > 0) {
+        out.emplace_back(forced, forced + nf);
+        return out;
+    }
+    std::vector<int> firsts = spec_first_radices(n, taps, rows);
+    if (const int want = dev_env_int("FXC_RTC_R0", 0)) firsts.assign(1, want);
+    for (int r : firsts) {
+        const SpecShape s = spec_shape(n, taps, r, 1, rows);
+        if (s.ok) out.emplace_back(s.radix, s.radix + s.n_stages);
+    }
+    return out;
+}
+
 // The build for (n, taps): the first candidate order that keeps two workgroups on a CU (else the best seen), with two frames per
 // step when that costs no resident workgroup (4 - 10 % where it fits: 1000 channels 206 -> 256 registers, 1.87 -> 1.73 ms; 96
 // channels with 3 first 150 -> 192 registers, three workgroups -> two, 1.25 -> 1.33 ms: one frame there).  Developer knobs:
@@ -422,21 +676,19 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
     SpecBuild best;
     best.error = "no specialised kernel for this channel count";
     const int rows = spec_rows(n, variant);
-    std::vector<int> firsts = spec_first_radices(n, taps, rows);
-    if (const int want = env_int("FXC_RTC_R0", 0)) firsts.assign(1, want);
-    const int force_u = env_int("FXC_RTC_U", 0);
+    const int force_u = dev_env_int("FXC_RTC_U", 0);
     int tried = 0;
-    for (int r : firsts) {
+    for (const std::vector<int>& list : spec_stage_lists(n, taps, rows)) {
         if (tried == 2) break;                       // (a compile is about a second: two orders at most)
-        const SpecShape one = spec_shape(n, taps, r, 1, rows);
+        const SpecShape one = spec_shape_of(n, taps, list.data(), (int)list.size(), 1, rows);
         if (!one.ok) continue;
         ++tried;
-        const SpecShape two = spec_shape(n, taps, r, 2, rows);
-        SpecBuild b = (force_u == 2 && two.ok) ? SpecBuild() : spec_build(one, variant, arch);
+        const SpecShape two = spec_shape_of(n, taps, list.data(), (int)list.size(), 2, rows);
+        SpecBuild b = (force_u == 2 && two.ok) ? SpecBuild() : spec_build_laid_out(one, variant, arch);
         if (two.ok && force_u != 1) {
-            SpecBuild b2 = spec_build(two, variant, arch);
+            SpecBuild b2 = spec_build_laid_out(two, variant, arch);
             if (b2.resident >= 1 && (b2.resident >= b.resident || force_u == 2)) b = std::move(b2);
-            else if (b.image.empty()) b = spec_build(one, variant, arch);      // (two frames were asked for and do not fit)
+            else if (b.image.empty()) b = spec_build_laid_out(one, variant, arch);      // (two frames were asked for and do not fit)
         }
         if (b.image.empty() || b.resident < 1) {
             if (best.image.empty() && !b.error.empty()) best.error = b.error;
@@ -449,11 +701,23 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
     return best;
 }
 
+// every developer knob that reaches a build, as part of the in-process cache's key (empty in the shipped library)
+std::string spec_knob_key() {
+    std::string k;
+    if (!FXC_DEV_KERNELS) return k;
+    for (const char* name : {"FXC_RTC_ABL", "FXC_RTC_R0", "FXC_RTC_U", "FXC_RTC_LEAN_ABOVE", "FXC_RTC_TPR_MAX", "FXC_RTC_LD_AUX", "FXC_RTC_ROWS1_ABOVE",
+                             "FXC_RTC_BIG_PRIMES", "FXC_RTC_RADICES", "FXC_RTC_GROUPS", "FXC_RTC_PADS", "FXC_RTC_PLANE0", "FXC_RTC_LAYOUT", "FXC_RTC_TWFULL",
+                             "FXC_RTC_WAVES"}) {
+        const char* e = std::getenv(name);
+        k += std::string(e ? e : "") + ";";
+    }
+    return k;
+}
+
 // compile (or find) the kernel for n channels on `device`; never nullptr -- a failed build is cached with its reason
 const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
     char key[256];
-    std::snprintf(key, sizeof key, "d%d n%d t%d v%d a%d r%d f%d l%d", device, n, taps, variant, spec_ablation(), env_int("FXC_RTC_R0", 0),
-                  env_int("FXC_RTC_U", 0), spec_lean_above());
+    std::snprintf(key, sizeof key, "d%d n%d t%d v%d %s", device, n, taps, variant, spec_knob_key().c_str());
     std::lock_guard<std::mutex> lock(g_spec_mutex);
     auto it = g_spec_cache.find(key);
     if (it != g_spec_cache.end()) return it->second;

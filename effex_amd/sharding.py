@@ -212,14 +212,15 @@ class ShardedRows(object):
             rowsink.create_shared(path, header, freqs if spectrum else None, row_len, dtype, n_chunks)
         self._barrier()
         shape_tail = (self.plan.n_baselines, self.plan.nchan) if spectrum else (self.plan.n_baselines,)
-        probe = read_chunks(lo, min(hi, lo + 1)) if hi > lo else None
-        if probe is not None and type(probe).__module__.startswith("torch"):
-            self._rows_from_device(path, lo, hi, read_chunks, mode, bandwidth, remove_dc, shape_tail, dtype, consumer)
+        # every batch is read exactly once (a reader may be sequential -- a file, a socket): the first one says where the samples live
+        first = read_chunks(lo, min(hi, lo + self.batch)) if hi > lo else None
+        if first is not None and type(first).__module__.startswith("torch"):
+            self._rows_from_device(path, lo, hi, read_chunks, mode, bandwidth, remove_dc, shape_tail, dtype, consumer, first)
         elif to_file:
             with rowsink.RowWindow(path, lo, hi) as win:
                 for b_lo in range(lo, hi, self.batch):
                     b_hi = min(hi, b_lo + self.batch)
-                    x = read_chunks(b_lo, b_hi)
+                    x = first if b_lo == lo else read_chunks(b_lo, b_hi)
                     dst = win.rows[b_lo - lo:b_hi - lo].reshape((b_hi - b_lo,) + shape_tail)
                     if str(getattr(x, "dtype", "")).endswith("uint8"):
                         self.plan.fx_rows_u8(x, mode, bandwidth, remove_dc=remove_dc, out=dst)
@@ -228,7 +229,7 @@ class ShardedRows(object):
         else:
             for b_lo in range(lo, hi, self.batch):
                 b_hi = min(hi, b_lo + self.batch)
-                x = read_chunks(b_lo, b_hi)
+                x = first if b_lo == lo else read_chunks(b_lo, b_hi)
                 u8 = str(getattr(x, "dtype", "")).endswith("uint8")
                 consumer(b_lo, (self.plan.fx_rows_u8 if u8 else self.plan.fx_rows)(x, mode, bandwidth, remove_dc=remove_dc))
         self._barrier()
@@ -237,7 +238,23 @@ class ShardedRows(object):
         self._barrier()                      # nobody returns (and reads the file) before the count is there
         return lo, hi
 
-    def _rows_from_device(self, path, lo, hi, read_chunks, mode, bandwidth, remove_dc, shape_tail, dtype, consumer):
+    def _rows_marker(self, x):
+        """A callable that returns once the rows queued so far are in their pinned slot.  The finishing kernel that writes the slot
+        runs on the PLAN's stream: torch's current stream when the plan follows it, else the stream the plan was given
+        (``set_stream``) -- or one of its own (``stream="owned"``), which only the plan itself can wait for."""
+        import torch
+        plan = self.plan
+        done = torch.cuda.Event()
+        if getattr(plan, "_follow", False):
+            done.record(torch.cuda.current_stream(x.device))
+            return done.synchronize
+        raw = int(getattr(plan, "_stream", -1))
+        if raw > 0:
+            done.record(torch.cuda.ExternalStream(raw, device=x.device))
+            return done.synchronize
+        return plan.sync
+
+    def _rows_from_device(self, path, lo, hi, read_chunks, mode, bandwidth, remove_dc, shape_tail, dtype, consumer, first=None):
         import concurrent.futures
         import torch
         from . import rowsink
@@ -266,18 +283,17 @@ class ShardedRows(object):
                 for job in busy[s]:
                     job.result()            # the file has this slot's previous rows
                 busy[s] = []
-                x = read_chunks(b_lo, b_hi)
+                x = first if (k == 0 and first is not None) else read_chunks(b_lo, b_hi)
                 view = slots[s][:b_hi - b_lo]
                 u8 = str(x.dtype).endswith("uint8")
                 (self.plan.fx_rows_u8 if u8 else self.plan.fx_rows)(x, mode, bandwidth, remove_dc=remove_dc, out=view)
-                done = torch.cuda.Event()
-                done.record(torch.cuda.current_stream(x.device))
+                done = self._rows_marker(x)
                 if pending is not None:     # batch k - 1, while batch k is on the device
-                    pending[2].synchronize()
+                    pending[2]()
                     deliver(pending[0], pending[1], pending[3])
                 pending = (b_lo, view, done, s)
             if pending is not None:
-                pending[2].synchronize()
+                pending[2]()
                 deliver(pending[0], pending[1], pending[3])
             for s in (0, 1):
                 for job in busy[s]:

@@ -48,7 +48,7 @@ int emul_spec_run(const void* x, const float* h, void* out, const void* tw, cons
             const int nb = fxm::nb_of(s), ns = fxm::ns_of(s);
             for (int j = 0; j < fxm::j_of(s); ++j, ++row)
                 for (int lt = 0; lt < fxm::TPR; ++lt) {
-                    const int b = lt + j * fxm::TPR < nb ? lt + j * fxm::TPR : 0;
+                    const int b = fxm::item_bfly_of(s, lt + j * fxm::TPR);
                     if (fxm::LEAN) tw1[(size_t)row * fxm::TPR + lt] = twc[(b % ns) * (nb / ns)];
                 }
         }

@@ -293,8 +293,15 @@ def test_sharded_rows_write_one_file_over_gloo(tmp_path, world, mode, n_chunks, 
     header = rowsink.header_line(1, 2.4e6, 1.4204e9, NUM_SAMP, NCHAN, 49.6, mode)
     freqs = rowsink.spectrum_freqs(NCHAN, 2.4e6, 1.4204e9)
     x = synth.synth_iq(1234, n_chunks, 2, NUM_SAMP) + np.complex64(0.05 - 0.02j)
+    reads = []                                        # a sequential reader (a file, a socket) must see every batch asked for once, in order
+
+    def read_once(lo, hi):
+        reads.append((lo, hi))
+        return x[lo:hi]
+
     sharding.ShardedRows(OracleRowsPlan(window, (2.4e6, 1.4204e9, 1e-6)), batch=batch).run(
-        single, header, freqs, lambda lo, hi: x[lo:hi], n_chunks, mode, 2.4e6, remove_dc=True)
+        single, header, freqs, read_once, n_chunks, mode, 2.4e6, remove_dc=True)
+    assert reads == [(lo, min(n_chunks, lo + batch)) for lo in range(0, n_chunks, batch)]
     assert open(path, "rb").read() == open(single, "rb").read()
     back = rowsink.RowFile(path)
     assert back.rows.shape == (n_chunks, NCHAN if mode == "SPECTRUM" else 1)

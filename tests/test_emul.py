@@ -249,8 +249,8 @@ def _spec_shape(nchan, ntaps, u8=False, fonly=False):
     reports threads per slot, slots and stage order), as the -D options the host emulation is built with."""
     import re
     from effex_amd import _lib
-    lib = _lib.load()
-    buf = ctypes.create_string_buffer(512)
+    lib = _lib.load(dev=bool(os.environ.get("FXC_RTC_U")))      # (the knob that forces the frames per step exists in the developer library only)
+    buf = ctypes.create_string_buffer(1024)
     rc = lib.fxc_spec_probe(nchan, ntaps, 2 if fonly else int(u8), b"gfx950", buf, len(buf))
     if rc != 0:
         return rc, None
@@ -258,7 +258,8 @@ def _spec_shape(nchan, ntaps, u8=False, fonly=False):
     stages = rep["stages"]
     flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=%d" % ntaps, "-DFXM_TPR=%s" % rep["tpr"], "-DFXM_SLOTS=%s" % rep["slots"],
              "-DFXM_NST=%d" % len(stages.split(",")), "-DFXM_RADICES=%s" % stages, "-DFXM_U8=%d" % int(u8),
-             "-DFXM_U=%s" % rep["frames_per_step"], "-DFXM_FONLY=%d" % int(fonly), "-DFXM_LEAN=%s" % rep["lean"], "-DFXM_ROWS=%s" % rep["rows"]]
+             "-DFXM_U=%s" % rep["frames_per_step"], "-DFXM_FONLY=%d" % int(fonly), "-DFXM_LEAN=%s" % rep["lean"], "-DFXM_ROWS=%s" % rep["rows"],
+             "-DFXM_GROUPS=%s" % rep["groups"], "-DFXM_PADS=%s" % rep["pads"], "-DFXM_PLANE0=%s" % rep["plane0"], "-DFXM_TWFULL=%s" % rep["twfull"]]
     assert re.fullmatch(r"[0-9,]+", stages) and int(rep["code_bytes"]) > 1000
     return 0, (flags, int(rep["tpr"]), int(rep["slots"]))
 

@@ -881,7 +881,8 @@ def test_rows_straight_into_pinned_host_memory(plan_mod, torch, nchan, mode):
     and byte samples and with the DC removal; an `out` that is not pinned memory is refused before anything is queued."""
     num_samp, n_chunks = nchan * 21 + 3, 37
     x = torch.from_numpy(synth.synth_iq(606, n_chunks, 2, num_samp)).cuda()
-    u8 = torch.randint(0, 256, (n_chunks, 2, num_samp, 2), dtype=torch.uint8, device="cuda")
+    u8 = torch.randint(0, 256, (n_chunks, 2, num_samp, 2), dtype=torch.uint8, device="cuda",
+                       generator=torch.Generator(device="cuda").manual_seed(884 + nchan))      # (seeded: the bound below is a measured one)
     with plan_mod.FxPlan(2, nchan, 4, num_samp) as p:
         p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 1e-7)
         ref = p.fx_rows(x, mode, gi.BANDWIDTH).cpu().numpy()
@@ -1726,7 +1727,8 @@ def test_new_routes_at_full_size(plan_mod, torch, nchan):
         np.testing.assert_array_equal(p.fx_rows(sub * 2.0).cpu().numpy(), 4.0 * rows16)
         swapped = p.fx_rows(sub.flip(1).contiguous()).cpu().numpy()
         assert rel_err(swapped, np.conj(rows16)) < 1e-6
-        u8 = torch.randint(0, 256, (64, 2, num_samp, 2), dtype=torch.uint8, device="cuda")
+        u8 = torch.randint(0, 256, (64, 2, num_samp, 2), dtype=torch.uint8, device="cuda",
+                           generator=torch.Generator(device="cuda").manual_seed(1729))      # (seeded: the bound below is a measured one)
         by = p.fx_rows_u8(u8, "SPECTRUM", remove_dc=True).cpu().numpy()
         assert rel_err(by, p.fx_rows(p.convert_u8(u8, remove_dc=True)).cpu().numpy()) < TOL_VIS
         for c in (0, n_chunks - 1):
@@ -2059,3 +2061,42 @@ def test_bench_rows_mode_two_ranks_write_the_single_rank_file(tmp_path):
         x = synth.synth_iq(1234, 1, 2, 262144, first_chunk=f)[0]
         ref = fx_oracle.pfb_xcorr(x[0], x[1], 4, 4096, window, 2.4e6, 1.4204e9, 0.0, "SPECTRUM")
         assert rel_err(np.asarray(back.rows[f]), ref) < TOL_VIS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stream", ["owned", "raw", None])
+def test_sharded_rows_wait_for_the_plans_own_stream(tmp_path, torch, stream):
+    """ShardedRows over device-resident samples with a plan that does NOT follow torch's current stream (one it owns, or a raw
+    stream handed to set_stream): the rows of a batch are written into a pinned slot by a kernel on the PLAN's stream, so the
+    slot may only be handed to the file writers once that stream has passed it -- every row of the file against the oracle, and
+    every batch read exactly once (effex.py:687-696 is the row-per-task writer this replaces)."""
+    from effex_amd import rowsink, sharding
+    from effex_amd.plan import FxPlan
+    nchan, ntaps, num_samp, n_chunks, batch = 1024, 4, 1024 * 64, 40, 8
+    window = design_window(ntaps, nchan)
+    x = synth.synth_iq(4321, n_chunks, 2, num_samp)
+    xd = torch.from_numpy(x).cuda()
+    side = torch.cuda.Stream()
+    plan = FxPlan(2, nchan, ntaps, num_samp, window=window, stream="owned" if stream == "owned" else None)
+    try:
+        if stream == "raw":
+            plan.set_stream(side.cuda_stream)
+        reads = []
+
+        def read_chunks(lo, hi):
+            reads.append((lo, hi))
+            return xd[lo:hi]
+
+        path = str(tmp_path / "rows.fxb")
+        header = rowsink.header_line(1, 2.4e6, 1.4204e9, num_samp, nchan, 49.6, "SPECTRUM")
+        freqs = rowsink.spectrum_freqs(nchan, 2.4e6, 1.4204e9)
+        torch.cuda.synchronize()
+        sharding.ShardedRows(plan, batch=batch).run(path, header, freqs, read_chunks, n_chunks, "SPECTRUM", 2.4e6)
+        assert reads == [(lo, min(n_chunks, lo + batch)) for lo in range(0, n_chunks, batch)]
+        back = np.asarray(rowsink.RowFile(path).rows)
+        assert back.shape == (n_chunks, nchan)
+        for c in range(n_chunks):
+            ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], ntaps, nchan, window, 2.4e6, 1.4204e9, 0.0, "SPECTRUM")
+            assert rel_err(back[c], ref) < TOL_VIS, c
+    finally:
+        plan.close()

@@ -36,7 +36,7 @@ def run_cases(args):
                 ns, nc = nchan * 37 + 5, 3
                 xs = synth.synth_iq(99 + nchan, nc, 2, ns)
                 window = design_window(args.taps, nchan)
-                with FxPlan(2, nchan, args.taps, ns, window=window) as small:
+                with FxPlan(2, nchan, args.taps, ns, window=window, dev=args.dev) as small:
                     rows = small.fx_rows(torch.from_numpy(xs).cuda(), "SPECTRUM").cpu().numpy()
                     small.fx_accumulate(torch.from_numpy(xs).cuda())
                     integ = small.finalize("SPECTRUM")

@@ -33,7 +33,28 @@ def round_up(x, digits=2):
     return math.ceil(x / 10 ** e - 1e-9) * 10 ** e
 
 
+def unseeded_draws():
+    """Lines of the test suite that draw random inputs without a seed: a bound measured over such a run does not reproduce."""
+    import re
+    bad = []
+    tests = os.path.join(ROOT, "tests")
+    for name in sorted(os.listdir(tests)):
+        if not name.endswith(".py"):
+            continue
+        lines = open(os.path.join(tests, name)).read().split("\n")
+        for i, line in enumerate(lines):
+            code = line.split("#")[0]
+            if re.search(r"torch\.(randint|randn|rand|normal)\(", code) and "generator=" not in code + lines[min(i + 1, len(lines) - 1)]:
+                bad.append("%s:%d: %s" % (name, i + 1, line.strip()))
+            if re.search(r"np\.random\.(rand|randn|randint|random|normal|uniform)\(", code) or re.search(r"default_rng\(\s*\)", code):
+                bad.append("%s:%d: %s" % (name, i + 1, line.strip()))
+    return bad
+
+
 def main():
+    bad = unseeded_draws()
+    if bad:
+        sys.exit("refusing to build the table: the suite draws unseeded inputs (measured bounds would not reproduce):\n  " + "\n  ".join(bad))
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "observed_errors.json")
     with open(src) as fh:
         seen = json.load(fh)
