@@ -50,7 +50,8 @@ class FxcInfo(ctypes.Structure):
                 ("ntaps", ctypes.c_int32), ("num_samp", ctypes.c_int64), ("n_pts", ctypes.c_int64),
                 ("path", ctypes.c_int32), ("grid", ctypes.c_int32), ("block", ctypes.c_int32),
                 ("lds_bytes", ctypes.c_int32), ("device", ctypes.c_int32), ("cu_count", ctypes.c_int32),
-                ("workspace_bytes", ctypes.c_int64), ("specialised", ctypes.c_int32), ("spec_vgprs", ctypes.c_int32)]
+                ("workspace_bytes", ctypes.c_int64), ("specialised", ctypes.c_int32), ("spec_vgprs", ctypes.c_int32),
+                ("spec_source", ctypes.c_int32), ("spec_seconds", ctypes.c_float)]
 
 
 class FxcCommDesc(ctypes.Structure):

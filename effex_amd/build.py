@@ -49,7 +49,60 @@ def build(force=False, verbose=False, dev=False):
     return lib
 
 
+# Channel counts whose run-time-compiled kernels (fx_spec.h through hiprtc) are ALSO built here, at build time, into csrc/rtc_prebuilt/ --
+# code objects keyed by source + options + architecture (not by compiler) that libfxcorr looks up before it touches hiprtc, so that a plan
+# for one of them costs a file read instead of 1 - 14 s of compiling (fxc_info.spec_source == 3).  Every variant that exists for the shape:
+# 0 F + X from complex64, 1 F + X from the receivers' bytes, 2 the F stage alone (fxc_channelize; 3+ antennas; above 4096 channels).
+PREBUILT_CHANNELS = (1000, 1200, 1500, 2000, 3000, 6000)
+PREBUILT_TAPS = (4,)
+PREBUILT_DIR = os.path.join(CSRC, "rtc_prebuilt")
+
+
+def prebuild(force=False, verbose=False):
+    """Fill csrc/rtc_prebuilt/ (needs no GPU: hiprtc cross-compiles for gfx950).  The developer library does the writing
+    (FXC_RTC_PREBUILD_DIR is one of its knobs); the shipped one only reads the directory."""
+    import ctypes
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("fx_spec.h", "fx_mixed.h", "fx_math.h", "h_rtc.h", "spec_tuned.h"):
+        path = os.path.join(CSRC, name)
+        if os.path.isfile(path):
+            h.update(open(path, "rb").read())
+    h.update(repr((PREBUILT_CHANNELS, PREBUILT_TAPS)).encode())
+    stamp, want = os.path.join(PREBUILT_DIR, "stamp.txt"), h.hexdigest()
+    if not force and os.path.isfile(stamp) and open(stamp).read().strip() == want:
+        return PREBUILT_DIR
+    shutil.rmtree(PREBUILT_DIR, ignore_errors=True)
+    os.makedirs(PREBUILT_DIR)
+    lib = ctypes.CDLL(build(dev=True))
+    lib.fxc_spec_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    saved = {k: os.environ.get(k) for k in ("FXC_RTC_PREBUILD_DIR", "FXC_RTC_CACHE")}
+    os.environ["FXC_RTC_PREBUILD_DIR"] = PREBUILT_DIR
+    os.environ["FXC_RTC_CACHE"] = "0"          # (compile: a cache hit of another compiler's build is not what should ship)
+    try:
+        for nchan in PREBUILT_CHANNELS:
+            for taps in PREBUILT_TAPS:
+                for variant in (0, 1, 2):
+                    report = ctypes.create_string_buffer(1024)
+                    rc = lib.fxc_spec_probe(nchan, taps, variant, b"gfx950", report, len(report))
+                    if verbose:
+                        print("prebuilt", nchan, taps, variant, rc, report.value.decode()[:160])
+                    if rc not in (0, -2):      # (-2: the shape has no such kernel, e.g. F + X above 4096 channels)
+                        raise RuntimeError("pre-building the kernel for %d channels, variant %d failed (%d)" % (nchan, variant, rc))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    with open(stamp, "w") as fh:
+        fh.write(want + "\n")
+    return PREBUILT_DIR
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--dev" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, dev=True))
+    if "--prebuilt" in sys.argv:
+        print(prebuild(force="--force" in sys.argv, verbose=True))

@@ -7,11 +7,11 @@
 #if !defined(__HIPCC_RTC__)      // (hiprtc brings the runtime's declarations itself: fx_spec.h is compiled through it)
 #include <hip/hip_runtime.h>
 #endif
-#define FXC_HD __host__ __device__ __forceinline__
-#define FXC_D __device__ __forceinline__
+#define FX_HD __host__ __device__ __forceinline__
+#define FX_D __device__ __forceinline__
 #else
-#define FXC_HD inline
-#define FXC_D inline
+#define FX_HD inline
+#define FX_D inline
 #endif
 
 namespace fxc {
@@ -30,10 +30,10 @@ struct __attribute__((aligned(16))) cd {
 
 // Frame-range work split of the fused kernel: n items over g workgroups, workgroup b owns [range_begin(b),
 // range_begin(b + 1)); range_owner(f) is the workgroup whose range holds item f.
-FXC_HD int range_begin(int b, int n, int g) { return (int)((long long)b * n / g); }
-FXC_HD int range_owner(int f, int n, int g) { return (int)((((long long)f + 1) * g + n - 1) / n - 1); }
+FX_HD int range_begin(int b, int n, int g) { return (int)((long long)b * n / g); }
+FX_HD int range_owner(int f, int n, int g) { return (int)((((long long)f + 1) * g + n - 1) / n - 1); }
 
-FXC_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+FX_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
 
 // FXC_STREAM_AUX: cache policy of the streaming accesses outside the headline kernel (the samples on their way into a ring, spectra
 // on their way from an F pass to an X pass): 0 default policy, 2 nontemporal
@@ -43,7 +43,7 @@ FXC_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
 
 // Streaming accesses -- data a kernel touches once (spectra on their way from an F pass to an X pass): the nontemporal hint keeps
 // them from displacing what the caches are for.  Host build: plain accesses.
-FXC_HD cf nt_load(const cf* p) {
+FX_HD cf nt_load(const cf* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float nt_v2f __attribute__((ext_vector_type(2)));
     const nt_v2f v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2f*>(p));
@@ -55,13 +55,13 @@ FXC_HD cf nt_load(const cf* p) {
     return *p;
 #endif
 }
-FXC_HD void nt_store(cf* p, cf v);
-FXC_HD cf st_load(const cf* p) { return FXC_STREAM_AUX ? nt_load(p) : *p; }
-FXC_HD void st_store(cf* p, cf v) {
+FX_HD void nt_store(cf* p, cf v);
+FX_HD cf st_load(const cf* p) { return FXC_STREAM_AUX ? nt_load(p) : *p; }
+FX_HD void st_store(cf* p, cf v) {
     if (FXC_STREAM_AUX) nt_store(p, v);
     else *p = v;
 }
-FXC_HD void nt_store(cf* p, cf v) {
+FX_HD void nt_store(cf* p, cf v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float nt_v2f __attribute__((ext_vector_type(2)));
     nt_v2f w;
@@ -72,23 +72,23 @@ FXC_HD void nt_store(cf* p, cf v) {
     *p = v;
 #endif
 }
-FXC_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
-FXC_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-FXC_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+FX_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+FX_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+FX_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 // a * conj(b)
-FXC_HD cf cmulc(cf a, cf b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+FX_HD cf cmulc(cf a, cf b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 // acc + a * conj(b) as four fused multiply-adds (two per component, no separate multiply or add)
-FXC_HD cf cmulc_acc(cf acc, cf a, cf b) {
+FX_HD cf cmulc_acc(cf acc, cf a, cf b) {
     return mk(__builtin_fmaf(a.y, b.y, __builtin_fmaf(a.x, b.x, acc.x)), __builtin_fmaf(-a.x, b.y, __builtin_fmaf(a.y, b.x, acc.y)));
 }
-FXC_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
+FX_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
 // multiply by +i
-FXC_HD cf muli(cf a) { return mk(-a.y, a.x); }
+FX_HD cf muli(cf a) { return mk(-a.y, a.x); }
 // a + s*b with real s
-FXC_HD cf cfma(float s, cf b, cf a) { return mk(a.x + s * b.x, a.y + s * b.y); }
+FX_HD cf cfma(float s, cf b, cf a) { return mk(a.x + s * b.x, a.y + s * b.y); }
 
 // 4-point DFT with kernel exp(+2*pi*i*n*k/4) (the channeliser's sign), in place.
-FXC_HD void dft4(cf& a, cf& b, cf& c, cf& d) {
+FX_HD void dft4(cf& a, cf& b, cf& c, cf& d) {
     cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = muli(csub(b, d));
     a = cadd(t0, t2);
     b = cadd(t1, t3);
@@ -105,7 +105,7 @@ FXC_HD void dft4(cf& a, cf& b, cf& c, cf& d) {
 //   w16^2, w16^6 = sqrt(1/2) (+-1 +- i):   u = (x -+ y, x +- y), scale R2
 //   w16^1, w16^3, w16^9 = C1 (1 + i t), C1 (t + i), -C1 (1 + i t) with C1 = cos(pi/8), t = tan(pi/8): two FMAs
 //   each for u, scale C1 -- and the two twiddled inputs of one butterfly share that scale.
-FXC_HD void dft16_a(cf (&v)[16]) {
+FX_HD void dft16_a(cf (&v)[16]) {
     const float T1 = 0.41421356237309504880f;  // tan(pi/8)
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) dft4(v[n0], v[4 + n0], v[8 + n0], v[12 + n0]);
@@ -122,7 +122,7 @@ FXC_HD void dft16_a(cf (&v)[16]) {
 }
 
 // dft4 whose third input arrives as c / R2 and whose second and fourth as b / C1, d / C1
-FXC_HD void dft4_scaled_c_bd(cf& a, cf& b, cf& c, cf& d) {
+FX_HD void dft4_scaled_c_bd(cf& a, cf& b, cf& c, cf& d) {
     const float R2 = 0.70710678118654752440f;  // sqrt(1/2)
     const float C1 = 0.92387953251128673848f;  // cos(pi/8)
     cf t0 = mk(__builtin_fmaf(R2, c.x, a.x), __builtin_fmaf(R2, c.y, a.y));
@@ -134,7 +134,7 @@ FXC_HD void dft4_scaled_c_bd(cf& a, cf& b, cf& c, cf& d) {
     d = mk(__builtin_fmaf(-C1, t3.x, t1.x), __builtin_fmaf(-C1, t3.y, t1.y));
 }
 // ... second and fourth inputs arrive as b / R2, d / R2: t2 = R2 (b + d), t3 = i R2 (b - d), folded into the outputs
-FXC_HD void dft4_bd_scaled(cf& a, cf& b, cf& c, cf& d) {
+FX_HD void dft4_bd_scaled(cf& a, cf& b, cf& c, cf& d) {
     const float R2 = 0.70710678118654752440f;
     cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = muli(csub(b, d));
     a = mk(__builtin_fmaf(R2, t2.x, t0.x), __builtin_fmaf(R2, t2.y, t0.y));
@@ -143,7 +143,7 @@ FXC_HD void dft4_bd_scaled(cf& a, cf& b, cf& c, cf& d) {
     d = mk(__builtin_fmaf(-R2, t3.x, t1.x), __builtin_fmaf(-R2, t3.y, t1.y));
 }
 
-FXC_HD void dft16_b(cf (&v)[16]) {
+FX_HD void dft16_b(cf (&v)[16]) {
     // after stage A: v[5], v[7], v[13], v[15] lack the factor C1, v[6], v[9], v[11], v[14] the factor R2
     dft4(v[0], v[1], v[2], v[3]);
     dft4_scaled_c_bd(v[4], v[5], v[6], v[7]);
@@ -163,7 +163,7 @@ FXC_HD void dft16_b(cf (&v)[16]) {
 // Stage B with every butterfly's four outputs handed to sink(k, Y[k]) (k = c + 4 d) as soon as they exist, so that
 // a caller can let its stores trickle out between the remaining butterflies instead of after all of them
 template <class Sink>
-FXC_HD void dft16_b_stream(cf (&v)[16], Sink&& sink) {
+FX_HD void dft16_b_stream(cf (&v)[16], Sink&& sink) {
     dft4(v[0], v[1], v[2], v[3]);
 #pragma unroll
     for (int d = 0; d < 4; ++d) sink(4 * d, v[d]);
@@ -178,7 +178,7 @@ FXC_HD void dft16_b_stream(cf (&v)[16], Sink&& sink) {
     for (int d = 0; d < 4; ++d) sink(3 + 4 * d, v[12 + d]);
 }
 
-FXC_HD void dft16(cf (&v)[16]) {
+FX_HD void dft16(cf (&v)[16]) {
     dft16_a(v);
     dft16_b(v);
 }

@@ -52,11 +52,11 @@ inline MixedPlan mixed_factor(int n) {
 // Two floats in one register pair: gfx950 runs v_pk_add/mul/fma_f32 at the rate of the scalar forms, so complex
 // arithmetic written on pairs costs half the issue slots (the stages are issue-bound, not LDS- or HBM-bound).
 typedef float pk2 __attribute__((vector_size(8)));
-FXC_HD pk2 pk(cf a) { pk2 r = {a.x, a.y}; return r; }
-FXC_HD cf unpk(pk2 a) { return mk(a[0], a[1]); }
-FXC_HD pk2 pk_splat(float s) { pk2 r = {s, s}; return r; }
-FXC_HD pk2 pk_muli(pk2 a) { pk2 r = {-a[1], a[0]}; return r; }     // times +i
-FXC_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) {
+FX_HD pk2 pk(cf a) { pk2 r = {a.x, a.y}; return r; }
+FX_HD cf unpk(pk2 a) { return mk(a[0], a[1]); }
+FX_HD pk2 pk_splat(float s) { pk2 r = {s, s}; return r; }
+FX_HD pk2 pk_muli(pk2 a) { pk2 r = {-a[1], a[0]}; return r; }     // times +i
+FX_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) {
 #if defined(__clang__)
     return __builtin_elementwise_fma(a, b, c);
 #else
@@ -64,7 +64,7 @@ FXC_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) {
 #endif
 }
 // a * w = a.x (w.x, w.y) + a.y (-w.y, w.x)
-FXC_HD pk2 pk_cmul(pk2 a, pk2 w) { return pk_fma(pk_splat(a[1]), pk_muli(w), pk_splat(a[0]) * w); }
+FX_HD pk2 pk_cmul(pk2 a, pk2 w) { return pk_fma(pk_splat(a[1]), pk_muli(w), pk_splat(a[0]) * w); }
 
 // the R-th roots of unity the odd butterflies need: w[m] = exp(+2 pi i m / R), m = 1 .. (R-1)/2, at stride N/R in the table
 template <int R>
@@ -72,7 +72,7 @@ struct Roots {
     pk2 w[(R - 1) / 2 + 1];
 };
 template <int R>
-FXC_HD Roots<R> load_roots(const cf* tw, int root_stride) {
+FX_HD Roots<R> load_roots(const cf* tw, int root_stride) {
     Roots<R> rt;
     rt.w[0] = pk_splat(1.f);
     if constexpr (R != 2 && R != 4) {
@@ -86,7 +86,7 @@ FXC_HD Roots<R> load_roots(const cf* tw, int root_stride) {
 // and an i-times-difference, outputs q and R - q leave as P +- Q with P = v0 + sum a_r cos(2 pi q r / R),
 // Q = sum b_r sin(2 pi q r / R) -- half the multiplies of the plain sum.
 template <int R>
-FXC_HD void dft_store(pk2 (&v)[R], const Roots<R>& rt, cf* d, int ds) {
+FX_HD void dft_store(pk2 (&v)[R], const Roots<R>& rt, cf* d, int ds) {
     if constexpr (R == 2) {
         d[0] = unpk(v[0] + v[1]);
         d[ds] = unpk(v[0] - v[1]);
@@ -130,12 +130,12 @@ FXC_HD void dft_store(pk2 (&v)[R], const Roots<R>& rt, cf* d, int ds) {
 
 // a / d for 0 <= a < 2^15 and 1 <= d < 2^15 with inv = 1.0f / d: (a + 1/2) / d is at least 1/(2d) away from an integer, and
 // the rounding of the product is below a / d * 2^-22 <= 2^-7 / d -- the truncation cannot land on the wrong side
-FXC_HD int small_div(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
+FX_HD int small_div(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
 
 // one stage, register butterflies: "thread" lt of tpr walks the butterflies lt, lt + tpr, ... of U rows that stand
 // row_stride elements apart in src and in dst -- one index computation and one set of twiddles for all of them
 template <int R, int U>
-FXC_HD void mixed_stage_reg(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int ns, int lt, int tpr) {
+FX_HD void mixed_stage_reg(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int ns, int lt, int tpr) {
     const int nb = n / R;
     const int tmul = nb / ns;          // N / (Ns R)
     const float inv_ns = 1.0f / (float)ns;
@@ -171,7 +171,7 @@ FXC_HD void mixed_stage_reg(const cf* src, cf* dst, int row_stride, const cf* tw
 
 // one stage, any radix: item (b, q) = one output of one butterfly; the R inputs are read from the row each time
 template <int U>
-FXC_HD void mixed_stage_any(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int radix, int ns, int lt, int tpr) {
+FX_HD void mixed_stage_any(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int radix, int ns, int lt, int tpr) {
     const int nb = n / radix;
     const int tmul = nb / ns;
     const float inv_ns = 1.0f / (float)ns, inv_nb = 1.0f / (float)nb;
@@ -203,7 +203,7 @@ FXC_HD void mixed_stage_any(const cf* src, cf* dst, int row_stride, const cf* tw
 // F-only kernel with two frames per slot would drop from five to four (360 channels 1.60 -> 1.74 ms) and goes without: the
 // host gives channel counts with these factors one frame per slot there (mixed_rows_per_slot_cap).
 template <int U, bool BIG_REG = (U == 1)>
-FXC_HD void mixed_stage(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int radix, int ns, int lt, int tpr) {
+FX_HD void mixed_stage(const cf* src, cf* dst, int row_stride, const cf* tw, int n, int radix, int ns, int lt, int tpr) {
     switch (radix) {
         case 2: mixed_stage_reg<2, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;
         case 3: mixed_stage_reg<3, U>(src, dst, row_stride, tw, n, ns, lt, tpr); break;

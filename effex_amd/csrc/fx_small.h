@@ -18,7 +18,7 @@ namespace small {
 
 // a window quad, read where it is used: the quads are the same for every frame of a lane, and hoisted out of the frame
 // loop they would take 64 VGPRs the ring needs
-FXC_HD f4 quad_load(const f4* p) {
+FX_HD f4 quad_load(const f4* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
@@ -46,11 +46,11 @@ struct Geo {
     static constexpr int kXchgPerWave = (64 / P) * kGroup;
 
     // element offset inside one frame of the sample feeding branch u + P r
-    static FXC_HD int sample_offset(int u, int r) { return (N - 1) - u - P * r; }
+    static FX_HD int sample_offset(int u, int r) { return (N - 1) - u - P * r; }
 
     // frame i sits in ring slot PH, (PH + 3) & 3 holds i - 1, ...; window quads [r P + u] = h[t N + u + P r], t = x, y, z, w
     template <int PH>
-    static FXC_HD void fir_ring(const cf (&h)[4][16], const f4* win, int u, cf (&v)[16]) {
+    static FX_HD void fir_ring(const cf (&h)[4][16], const f4* win, int u, cf (&v)[16]) {
         const cf (&x0)[16] = h[PH];
         const cf (&x1)[16] = h[(PH + 3) & 3];
         const cf (&x2)[16] = h[(PH + 2) & 3];
@@ -65,7 +65,7 @@ struct Geo {
         }
     }
 
-    static FXC_HD void twiddle(cf (&v)[16], const cf* tw, int u) {
+    static FX_HD void twiddle(cf (&v)[16], const cf* tw, int u) {
         cf t[16];
 #pragma unroll
         for (int k = 1; k < 16; ++k) t[k] = fxc::fused::lds_load(tw + u * 16 + k);       // wN^(u k)
@@ -74,19 +74,19 @@ struct Geo {
     }
 
     // grp: the rows of this item and antenna
-    static FXC_HD void store(const cf (&v)[16], cf* grp, int u) {
+    static FX_HD void store(const cf (&v)[16], cf* grp, int u) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int f = k * P + u;
             grp[f + (f >> 4)] = v[k];
         }
     }
-    static FXC_HD void load(const cf* grp, int u, cf (&v)[16]) {
+    static FX_HD void load(const cf* grp, int u, cf (&v)[16]) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = fxc::fused::lds_load(grp + 17 * u + q);
     }
 
-    static FXC_HD void transforms(cf (&v)[16]) {
+    static FX_HD void transforms(cf (&v)[16]) {
         if (P == 16) {
             dft16(v);
         } else if (P == 8) {
@@ -102,7 +102,7 @@ struct Geo {
     }
 
     // natural bin of value idx (0 .. 15) of lane u after `transforms`
-    static FXC_HD int bin_of(int u, int idx) { return u * (16 / P) + idx / P + 16 * (idx % P); }
+    static FX_HD int bin_of(int u, int idx) { return u * (16 / P) + idx / P + 16 * (idx % P); }
 };
 
 }  // namespace small

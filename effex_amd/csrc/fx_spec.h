@@ -197,7 +197,7 @@ struct Thread {
 // kernel's vector instructions).  Host build: the same values in plain C.
 // a w in two halves: callers run the first halves of several products, then the second halves (a packed instruction that
 // reads the result of the one just before it costs a wait state)
-FXC_HD pk2 cmul_lo(pk2 a, pk2 w) {           // a.x (w.x, w.y)
+FX_HD pk2 cmul_lo(pk2 a, pk2 w) {           // a.x (w.x, w.y)
 #if defined(__HIP_DEVICE_COMPILE__)
     pk2 t;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
@@ -206,7 +206,7 @@ FXC_HD pk2 cmul_lo(pk2 a, pk2 w) {           // a.x (w.x, w.y)
     return pk_splat(a[0]) * w;
 #endif
 }
-FXC_HD pk2 cmul_hi(pk2 a, pk2 w, pk2 t) {    // t + a.y (-w.y, w.x)
+FX_HD pk2 cmul_hi(pk2 a, pk2 w, pk2 t) {    // t + a.y (-w.y, w.x)
 #if defined(__HIP_DEVICE_COMPILE__)
     pk2 r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
@@ -215,7 +215,7 @@ FXC_HD pk2 cmul_hi(pk2 a, pk2 w, pk2 t) {    // t + a.y (-w.y, w.x)
     return pk_fma(pk_splat(a[1]), fxc::pk_muli(w), t);
 #endif
 }
-FXC_HD pk2 add_i(pk2 a, pk2 d) {             // a + i d
+FX_HD pk2 add_i(pk2 a, pk2 d) {             // a + i d
 #if defined(__HIP_DEVICE_COMPILE__)
     pk2 r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
@@ -224,7 +224,7 @@ FXC_HD pk2 add_i(pk2 a, pk2 d) {             // a + i d
     return pk2{a[0] - d[1], a[1] + d[0]};
 #endif
 }
-FXC_HD pk2 sub_i(pk2 a, pk2 d) {             // a - i d
+FX_HD pk2 sub_i(pk2 a, pk2 d) {             // a - i d
 #if defined(__HIP_DEVICE_COMPILE__)
     pk2 r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
@@ -234,7 +234,7 @@ FXC_HD pk2 sub_i(pk2 a, pk2 d) {             // a - i d
 #endif
 }
 // acc + a conj(b), likewise in two halves
-FXC_HD pk2 x_acc_lo(pk2 acc, pk2 a, pk2 b) { // acc + b.x (a.x, a.y)
+FX_HD pk2 x_acc_lo(pk2 acc, pk2 a, pk2 b) { // acc + b.x (a.x, a.y)
 #if defined(__HIP_DEVICE_COMPILE__)
     pk2 t;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "v"(b), "v"(acc));
@@ -243,7 +243,7 @@ FXC_HD pk2 x_acc_lo(pk2 acc, pk2 a, pk2 b) { // acc + b.x (a.x, a.y)
     return pk_fma(pk_splat(b[0]), a, acc);
 #endif
 }
-FXC_HD pk2 x_acc_hi(pk2 t, pk2 a, pk2 b) {   // t + b.y (a.y, -a.x)
+FX_HD pk2 x_acc_hi(pk2 t, pk2 a, pk2 b) {   // t + b.y (a.y, -a.x)
 #if defined(__HIP_DEVICE_COMPILE__)
     pk2 r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
@@ -320,7 +320,7 @@ struct RootsOf {
 };
 
 // a times the literal (c, s): two instructions on the device, the literal in a scalar register pair
-FXC_HD pk2 cmul_k(pk2 a, float c, float s) {
+FX_HD pk2 cmul_k(pk2 a, float c, float s) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const pk2 k = {c, s};
     pk2 t, r;
@@ -362,7 +362,7 @@ constexpr int inv_mod(int a, int m) {            // a^-1 mod m (coprime; 0 for m
 // rotations folded into the additions.  Odd R: outputs q and R - q are P +- i Q, P = v0 + sum a_r cos, Q = sum d_r sin with
 // a_r = v_r + v_{R-r}, d_r = v_r - v_{R-r}.
 template <int R>
-FXC_HD void dft_regs(pk2 (&v)[R], pk2 (&o)[R]) {
+FX_HD void dft_regs(pk2 (&v)[R], pk2 (&o)[R]) {
 #if (FXM_ABL & 4)
 #pragma unroll
     for (int q = 0; q < R; ++q) o[q] = v[q];
@@ -459,7 +459,7 @@ FXC_HD void dft_regs(pk2 (&v)[R], pk2 (&o)[R]) {
     }
 }
 template <int R>
-FXC_HD void dft_to(pk2 (&v)[R], cf* d, int ds) {      // ... into d[q * ds]
+FX_HD void dft_to(pk2 (&v)[R], cf* d, int ds) {      // ... into d[q * ds]
     pk2 o[R];
     dft_regs<R>(v, o);
 #if (FXM_ABL & 2)
@@ -504,27 +504,27 @@ struct Body {
     __amdgpu_buffer_rsrc_t rsrc[2], rsrc_h, rsrc_t;
 #endif
 
-    FXC_HD Body(Ctx& c, const Args& a) : cx(c), ar(a) {}
+    FX_HD Body(Ctx& c, const Args& a) : cx(c), ar(a) {}
 
-    FXC_HD static bool has_item(int s, int j, int lt_) { return full_of(s) || j + 1 < j_of(s) || lt_ + j * TPR < items_of(s); }
+    FX_HD static bool has_item(int s, int j, int lt_) { return full_of(s) || j + 1 < j_of(s) || lt_ + j * TPR < items_of(s); }
 
     // item i of stage s >= 1 (i = g nb + b; any valid index for a thread without it): its butterfly, and where its rows' inputs and
     // outputs stand in the stage buffers (row a of the item: a RS further)
     template <int s>
-    FXC_HD static int item_bfly(int i) {
+    FX_HD static int item_bfly(int i) {
         constexpr int nb = nb_of(s);
         if (i >= items_of(s)) i = 0;
         return ngrp(s) > 1 ? i % nb : i;
     }
     template <int s>
-    FXC_HD static int item_in(int i) {
+    FX_HD static int item_in(int i) {
         constexpr int nb = nb_of(s);
         if (i >= items_of(s)) i = 0;
         const int g = ngrp(s) > 1 ? i / nb : 0, b = i - g * nb;
         return g * grp(s) * RS + rd_pos(s, b);
     }
     template <int s>
-    FXC_HD static int item_out(int i) {
+    FX_HD static int item_out(int i) {
         constexpr int nb = nb_of(s);
         if (i >= items_of(s)) i = 0;
         const int g = ngrp(s) > 1 ? i / nb : 0, b = i - g * nb;
@@ -532,7 +532,7 @@ struct Body {
     }
 
     // ---- once per launch: taps, twiddles, offsets
-    FXC_HD void init() {
+    FX_HD void init() {
         lt = cx.tid() % TPR;
         slot = cx.tid() / TPR;
         bx = cx.lds() + slot * LDS_PER_SLOT;
@@ -556,7 +556,7 @@ struct Body {
         for (int i = 0; i < (FONLY ? 1 : JL * RL); ++i) th.xacc[i] = pk_splat(0.f);
     }
     template <int s>
-    FXC_HD void init_stage() {
+    FX_HD void init_stage() {
         if constexpr (s < S) {
             constexpr int nb = nb_of(s), ns = ns_of(s), tmul = nb / ns;
 #pragma unroll
@@ -574,7 +574,7 @@ struct Body {
     // where item j of stage s finds its inputs / puts its outputs: registers, or (LEAN) recomputed every step -- hoisted out of the
     // step loop these offsets are registers again, hence the asm
     template <int s>
-    FXC_HD int in_of(int j) const {
+    FX_HD int in_of(int j) const {
         if constexpr (plain_reads(s)) {
             return lt + j * TPR;
         } else if constexpr (LEAN) {
@@ -588,7 +588,7 @@ struct Body {
         }
     }
     template <int s>
-    FXC_HD int out_of(int j) const {
+    FX_HD int out_of(int j) const {
         if constexpr (LEAN) {
             int i = lt + j * TPR;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -606,12 +606,12 @@ struct Body {
     static constexpr int kElem = U8 ? 2 : 8;                  // bytes per sample
     static constexpr int kLoadAux = FONLY ? FXC_STREAM_AUX : FXM_LD_AUX;      // cache policy of the sample loads (2: nontemporal)
     template <int P>
-    FXC_HD void load_frame(long long f, bool valid) {
+    FX_HD void load_frame(long long f, bool valid) {
 #pragma unroll
         for (int j = 0; j < J0; ++j) load_points<P>(f, valid, j);
     }
     template <int P>
-    FXC_HD void load_points(long long f, bool valid, int j) {       // ... the points of first-stage butterfly j
+    FX_HD void load_points(long long f, bool valid, int j) {       // ... the points of first-stage butterfly j
 #if (FXM_ABL & 16)
         f &= 3;
 #endif
@@ -658,7 +658,7 @@ struct Body {
 
     // LEAN: the first twiddles of the thread's items of stage s, from the table
     template <int s>
-    FXC_HD void load_tw1(pk2 (&w1)[j_of(s)]) {
+    FX_HD void load_tw1(pk2 (&w1)[j_of(s)]) {
 #pragma unroll
         for (int j = 0; j < j_of(s); ++j) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -679,7 +679,7 @@ struct Body {
     template <int s>
     static constexpr int base_a() { return split_a(kRadix[s]) > 0 ? split_a(kRadix[s]) : kRadix[s]; }
     template <int s>
-    FXC_HD void stage_tw(int j, pk2 (&w)[kRadix[s]], pk2 (&wc)[kRadix[s] / base_a<s>()], const pk2* w1) {
+    FX_HD void stage_tw(int j, pk2 (&w)[kRadix[s]], pk2 (&wc)[kRadix[s] / base_a<s>()], const pk2* w1) {
         constexpr int R = kRadix[s], A = base_a<s>(), B = R / A;
         if constexpr (whole_tw<s>()) {
 #pragma unroll
@@ -704,7 +704,7 @@ struct Body {
     }
     // w^n for input n of a composite butterfly of stage s (n >= 1)
     template <int s>
-    FXC_HD pk2 tw_at(int n, const pk2 (&w)[kRadix[s]], const pk2 (&wc)[kRadix[s] / base_a<s>()]) {
+    FX_HD pk2 tw_at(int n, const pk2 (&w)[kRadix[s]], const pk2 (&wc)[kRadix[s] / base_a<s>()]) {
         constexpr int A = base_a<s>();
         if constexpr (whole_tw<s>()) {
             return w[n];
@@ -720,7 +720,7 @@ struct Body {
     // composite radix runs its first level group by group (load A or B inputs, twiddle, transform), so that the inputs of the next group
     // need not be live while this one is in flight.
     template <int s>
-    FXC_HD void stage_bfly(const cf* p, const pk2 (&w)[kRadix[s]], const pk2 (&wc)[kRadix[s] / base_a<s>()], pk2 (&o)[kRadix[s]]) {
+    FX_HD void stage_bfly(const cf* p, const pk2 (&w)[kRadix[s]], const pk2 (&wc)[kRadix[s] / base_a<s>()], pk2 (&o)[kRadix[s]]) {
         constexpr int R = kRadix[s], rs = rd_stride(s), A = split_a(R);
         if constexpr (A == 0) {
             pk2 v[R], t[R];
@@ -788,7 +788,7 @@ struct Body {
 
     // ---- one middle stage: LDS -> LDS
     template <int s>
-    FXC_HD void mid_stage(const cf* src, cf* dst, const pk2* w1 = nullptr) {
+    FX_HD void mid_stage(const cf* src, cf* dst, const pk2* w1 = nullptr) {
         constexpr int R = kRadix[s], ns = ns_of(s);
 #pragma unroll
         for (int j = 0; j < j_of(s); ++j) {
@@ -812,7 +812,7 @@ struct Body {
 
     // ---- the last stage (s = S - 1 >= 1): LDS -> registers -> X.  f: the step's first frame; frames from f_end on do not exist for
     // this slot (their rows hold the transform of zeros: nothing is added, nothing stored)
-    FXC_HD void last_stage(const cf* src, long long f, long long f_end, const pk2* w1 = nullptr) {
+    FX_HD void last_stage(const cf* src, long long f, long long f_end, const pk2* w1 = nullptr) {
         constexpr int s = S - 1, R = RL, G = grp(s), FR = G / NA > 0 ? G / NA : 1;
 #pragma unroll
         for (int j = 0; j < JL; ++j) {
@@ -854,7 +854,7 @@ struct Body {
     // the two rows' spectra of one butterfly of the last stage: X-multiplied into the thread's sums, or (F only) stored -- output q of
     // butterfly b is bin b + q N/R there, so the lanes of a wave write R runs of consecutive bins
     template <int R>
-    FXC_HD void emit(pk2 (&o)[NA][R], int j, int bfly, long long frame) {
+    FX_HD void emit(pk2 (&o)[NA][R], int j, int bfly, long long frame) {
         if constexpr (FONLY) {
 #pragma unroll
             for (int a = 0; a < NA; ++a)
@@ -872,7 +872,7 @@ struct Body {
     }
 
     template <int s>
-    FXC_HD void mid_stages(cf* rd, cf* wr) {       // stage s reads rd, writes wr; a barrier behind each
+    FX_HD void mid_stages(cf* rd, cf* wr) {       // stage s reads rd, writes wr; a barrier behind each
         if constexpr (s < S - 1) {
             mid_stage<s>(rd, wr);
             cx.sync();
@@ -881,7 +881,7 @@ struct Body {
     }
 
     // the first stage's butterfly j of one row, out of registers into the slot's buffer (planes, or blocks of R0 with their padding)
-    FXC_HD void first_to_lds(pk2 (&v)[R0], int row, int j) {
+    FX_HD void first_to_lds(pk2 (&v)[R0], int row, int j) {
         const int b = lt + j * TPR;
         if constexpr (P0 > 0)
             dft_to<R0>(v, bx + row * RS + b, P0);
@@ -893,7 +893,7 @@ struct Body {
     // step's first frame f.  Frame f + u exists for this slot while f + u < f_end (the slots of a workgroup take the same number of
     // steps); frames from f_end on are not loaded
     template <int P>
-    FXC_HD void step(long long f, long long f_end) {
+    FX_HD void step(long long f, long long f_end) {
         if constexpr (LEAN) {
             step_lean<P>(f, f_end);
             return;
@@ -957,7 +957,7 @@ struct Body {
 
     // LEAN: stage s reads rd and writes wr with the first twiddles w1; the next stage's are requested before, the last stage ends in X
     template <int s>
-    FXC_HD void lean_stages(cf* rd, cf* wr, const pk2 (&w1)[j_of(s)], long long f, long long f_end) {
+    FX_HD void lean_stages(cf* rd, cf* wr, const pk2 (&w1)[j_of(s)], long long f, long long f_end) {
         if constexpr (s < S - 1) {
             pk2 nxt[j_of(s + 1)];
             load_tw1<s + 1>(nxt);
@@ -972,7 +972,7 @@ struct Body {
     // LEAN (S >= 2): one first-stage butterfly at a time -- its points' taps from L2, their FIR, the next frames' samples into the
     // ring slots those points have just left, the butterfly into LDS -- so that only R0 points' taps and sums are live at once
     template <int P>
-    FXC_HD void step_lean(long long f, long long f_end) {
+    FX_HD void step_lean(long long f, long long f_end) {
         static_assert(!LEAN || S >= 2, "the lean build needs a first stage into LDS (h_rtc.h::spec_shape)");
         pk2 w1[j_of(1)];
         load_tw1<1>(w1);
@@ -1024,7 +1024,7 @@ struct Body {
 
     // UNR steps per trip: step k of a trip starts at ring slot (k U) mod NS
     template <int K>
-    FXC_HD void steps(long long f, long long f_end, long long i, long long n_steps) {
+    FX_HD void steps(long long f, long long f_end, long long i, long long n_steps) {
         if constexpr (K < UNR) {
             if (i + K < n_steps) {          // uniform over the workgroup
                 step<(K * U) % NS>(f + K * U, f_end);
@@ -1035,7 +1035,7 @@ struct Body {
 
     // frames f0 - (T - 1) .. f0 + U - 1 into their slots: frame g in slot (g - f0) mod NS
     template <int K>
-    FXC_HD void preload(long long f0, long long f_end) {
+    FX_HD void preload(long long f0, long long f_end) {
         if constexpr (K < NS) {
             const long long g = f0 - (T - 1) + K;
             load_frame<(K - (T - 1) + NS) % NS>(g, g >= 0 && g < f_end);
@@ -1043,7 +1043,7 @@ struct Body {
         }
     }
 
-    FXC_HD void run() {
+    FX_HD void run() {
         const long long chunk = cx.bid() / ar.wg_splits;
         const int sp = (int)(cx.bid() % ar.wg_splits);
         init();

@@ -29,14 +29,14 @@ namespace tiled {
 
 using fxc::fused::lds_load;
 
-FXC_HD void dft2(cf& a, cf& b) {
+FX_HD void dft2(cf& a, cf& b) {
     const cf t = csub(a, b);
     a = cadd(a, b);
     b = t;
 }
 
 // 8-point DFT, kernel exp(+2 pi i n k / 8), natural order in and out
-FXC_HD void dft8(cf& v0, cf& v1, cf& v2, cf& v3, cf& v4, cf& v5, cf& v6, cf& v7) {
+FX_HD void dft8(cf& v0, cf& v1, cf& v2, cf& v3, cf& v4, cf& v5, cf& v6, cf& v7) {
     const float R2 = 0.70710678118654752440f;
     dft4(v0, v2, v4, v6);   // E[0..3] in v0, v2, v4, v6
     dft4(v1, v3, v5, v7);   // O[0..3] in v1, v3, v5, v7
@@ -70,13 +70,13 @@ struct Geo {
     static constexpr int kLdsBytesRing = kLdsWin + N * 16;
     static constexpr int kAccPerThread = 8;
 
-    static FXC_HD int ant_of(int tid) { return (tid >> 5) & 1; }
-    static FXC_HD int u_of(int tid) { return (tid >> 6) * 32 + (tid & 31); }
-    static FXC_HD int pad16(int p) { return p + ((p >> 8) << 4); }
+    static FX_HD int ant_of(int tid) { return (tid >> 5) & 1; }
+    static FX_HD int u_of(int tid) { return (tid >> 6) * 32 + (tid & 31); }
+    static FX_HD int pad16(int p) { return p + ((p >> 8) << 4); }
 
     // PFB FIR for frame i of one antenna stream xa (chunk start), taps t = 0 .. min(ntaps-1, i): zero history
     // per chunk; v[r] = sum_t h[t N + m] x[(i - t) N + N - 1 - m], m = u + P r   
-    static FXC_HD void fir(const cf* xa, const float* win, int u, int64_t i, int ntaps, cf (&v)[16]) {
+    static FX_HD void fir(const cf* xa, const float* win, int u, int64_t i, int ntaps, cf (&v)[16]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = mk(0.f, 0.f);
         const int tmax = (int64_t)(ntaps - 1) < i ? ntaps - 1 : (int)i;
@@ -98,7 +98,7 @@ struct Geo {
     // ntaps <= 4 variant: the four frames the FIR needs live in a VGPR ring (slot PH = frame i, (PH+3)&3 = i-1,
     // ...), the window in LDS as f4 quads [r P + u] = h[t N + u + P r], t = x, y, z, w (zero beyond ntaps)
     template <int PH>
-    static FXC_HD void fir_ring(const cf (&h)[4][16], const f4* win, int u, cf (&v)[16]) {
+    static FX_HD void fir_ring(const cf (&h)[4][16], const f4* win, int u, cf (&v)[16]) {
         const cf (&x0)[16] = h[PH];
         const cf (&x1)[16] = h[(PH + 3) & 3];
         const cf (&x2)[16] = h[(PH + 2) & 3];
@@ -126,20 +126,20 @@ struct Geo {
         }
     }
     // element offset inside one frame of the sample feeding branch u + P r
-    static FXC_HD int sample_offset(int u, int r) { return (N - 1) - u - P * r; }
+    static FX_HD int sample_offset(int u, int r) { return (N - 1) - u - P * r; }
 
     // this thread's pre-stage twiddles from the [16][P] table wN^((u + P g) k) at slot g + G k
-    static FXC_HD void load_tw0(cf (&tw0)[16], const cf* table, int u) {
+    static FX_HD void load_tw0(cf (&tw0)[16], const cf* table, int u) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) tw0[r] = table[r * P + u];
     }
     // stage-A twiddles from the [16][256] table w4096^(n' k)
-    static FXC_HD void load_twA(cf (&twA)[16], const cf* table, int u) {
+    static FX_HD void load_twA(cf (&twA)[16], const cf* table, int u) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) twA[k] = table[k * 256 + (u & 255)];
     }
 
-    static FXC_HD void prestage(cf (&v)[16], const cf (&tw0)[16]) {
+    static FX_HD void prestage(cf (&v)[16], const cf (&tw0)[16]) {
         if (R0 == 2) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
@@ -164,18 +164,18 @@ struct Geo {
     }
 
     // exchange after the pre-stage: slot r' goes to position u + P r'
-    static FXC_HD void store0(const cf (&v)[16], cf* reg, int u) {
+    static FX_HD void store0(const cf (&v)[16], cf* reg, int u) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) reg[pad16(u + P * r)] = v[r];
     }
 
     // stage A (a = 3): butterfly u = (block, n'), positions block*4096 + n' + 256 q
-    static FXC_HD void loadA(const cf* reg, int u, cf (&v)[16]) {
+    static FX_HD void loadA(const cf* reg, int u, cf (&v)[16]) {
         const cf* b = reg + (u >> 8) * 4352 + (u & 255);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = lds_load(b + 272 * q);
     }
-    static FXC_HD void twiddleA_store(cf (&v)[16], const cf (&twA)[16], cf* reg, int u) {
+    static FX_HD void twiddleA_store(cf (&v)[16], const cf (&twA)[16], cf* reg, int u) {
         cf* b = reg + (u >> 8) * 4352 + (u & 255);
         b[0] = v[0];
 #pragma unroll
@@ -186,12 +186,12 @@ struct Geo {
     }
 
     // stage B: butterfly u = (b16, n'), positions b16*256 + n' + 16 q
-    static FXC_HD void loadB(const cf* reg, int u, cf (&v)[16]) {
+    static FX_HD void loadB(const cf* reg, int u, cf (&v)[16]) {
         const cf* b = reg + (u >> 4) * 272 + (u & 15);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = lds_load(b + 16 * q);
     }
-    static FXC_HD void twiddleB(cf (&v)[16], const cf* tw16, int u) {
+    static FX_HD void twiddleB(cf (&v)[16], const cf* tw16, int u) {
         const int n = u & 15;
         cf t[16];
 #pragma unroll
@@ -200,20 +200,20 @@ struct Geo {
         for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], t[k]);
     }
     // 16x16 transpose inside the 16-lane group: out k of lane n' -> slot [k][n'] of the group's 272
-    static FXC_HD void storeT(const cf (&v)[16], cf* reg, int u) {
+    static FX_HD void storeT(const cf (&v)[16], cf* reg, int u) {
         cf* b = reg + (u >> 4) * 272 + (u & 15);
 #pragma unroll
         for (int k = 0; k < 16; ++k) b[17 * k] = v[k];
     }
     // stage C: butterfly u reads positions 16 u + q
-    static FXC_HD void loadC(const cf* reg, int u, cf (&v)[16]) {
+    static FX_HD void loadC(const cf* reg, int u, cf (&v)[16]) {
         const cf* b = reg + (u >> 4) * 272 + (u & 15) * 17;
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = lds_load(b + q);
     }
 
     // natural bin of output k2 of stage C in butterfly u
-    static FXC_HD int bin_of(int u, int k2) {
+    static FX_HD int bin_of(int u, int k2) {
         if (A3) return (u >> 8) + R0 * (((u >> 4) & 15) + 16 * ((u & 15) + 16 * k2));
         return (u >> 4) + R0 * ((u & 15) + 16 * k2);
     }

@@ -55,6 +55,8 @@ ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError);
 }
 #endif
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -73,6 +75,17 @@ ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError);
 #ifndef FXC_DEV_KERNELS
 #define FXC_DEV_KERNELS 0
 #endif
+namespace {
+// an integer from the environment.  The shipped library reads FOUR variables, all documented in include/fxcorr.h: FXC_RTC, FXC_RTC_CACHE,
+// FXC_RTC_VERBOSE, FXC_WS_MB.  Every other route / tuning knob exists in the developer library only (libfxcorr_dev.so, -DFXC_DEV_KERNELS=1:
+// tests, tools/): FXC_DEV_ENV* below fold to their defaults in the shipped build, strings and all.
+int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+#define FXC_DEV_ENV(name) (FXC_DEV_KERNELS ? std::getenv(name) : static_cast<const char*>(nullptr))
+#define FXC_DEV_ENV_INT(name, dflt) (FXC_DEV_KERNELS ? env_int(name, dflt) : (dflt))
+}  // namespace
 #include "fx_fused4096.h"
 #include "fx_tiled.h"
 #include "fx_small.h"
@@ -93,7 +106,7 @@ constexpr int kBluPrimePerRatio = 45;  // prime factors beyond 45 nfft / N: the 
 constexpr int kBluMaxNfft = 10240;    // two chirp-z rows in the 160 KiB of LDS: up to 5120 channels
 constexpr int kMixedMaxN = 10240;    // two rows of complex64 in the 160 KiB of LDS (pfb_fft_mixed_kernel)
 size_t res_direct_bytes() {      // finalize results up to this size are written to host memory by the kernel (FXC_RES_DIRECT: developer knob, bytes)
-    static const size_t v = [] { const char* e = std::getenv("FXC_RES_DIRECT"); return e ? (size_t)std::atoll(e) : (size_t)(256 << 10); }();
+    static const size_t v = [] { const char* e = FXC_DEV_ENV("FXC_RES_DIRECT"); return e ? (size_t)std::atoll(e) : (size_t)(256 << 10); }();
     return v;
 }
 // upper bound of the lazily grown workspace (288 GB of HBM per GPU): a call over more chunks than fit runs in passes.
@@ -285,7 +298,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
     // generic F stage: every channel count that is not a power of two (and fits two LDS rows) takes the mixed-radix kernel;
     // FXC_GENERIC_FFT=mixed|radix2 moves the powers of two onto it / everything off it (developer knob)
     {
-        const char* gf = std::getenv("FXC_GENERIC_FFT");
+        const char* gf = FXC_DEV_ENV("FXC_GENERIC_FFT");
         const bool force_mixed = gf && !std::strcmp(gf, "mixed");
         // (off the powers of two "radix2" means the direct DFT, a kernel only the developer build has)
         const bool force_old = gf && !std::strcmp(gf, "radix2") && (p->pow2 || FXC_DEV_KERNELS);
@@ -297,7 +310,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             p->mixed_plan = fxc::mixed_factor(N);
             // (512 threads per row beyond 1320 channels, where three 256-thread workgroups stop fitting a CU's LDS: two antennas
             // 1350 ... 2000 channels 18 - 20 % faster, F only with two frames per slot 10 - 25 %; 1120 ... 1300 slower)
-            p->mixed_tpr = fxc::mixed_threads_per_row(N, env_int("FXC_MIXED_TPR", 1024), p->n_ant == 2, env_int("FXC_MIXED_WIDE_FROM", 1320));
+            p->mixed_tpr = fxc::mixed_threads_per_row(N, FXC_DEV_ENV_INT("FXC_MIXED_TPR", 1024), p->n_ant == 2, FXC_DEV_ENV_INT("FXC_MIXED_WIDE_FROM", 1320));
             if (p->mixed_plan.n_stages < 0) p->mixed = false;
         }
         if (p->mixed) {
@@ -310,7 +323,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             int m_pow2 = 1;
             while (m_pow2 < 2 * N - 1) m_pow2 <<= 1;
             int m = m_pow2;
-            if (env_int("FXC_BLU_SMOOTH", 1)) {
+            if (FXC_DEV_ENV_INT("FXC_BLU_SMOOTH", 1)) {
                 double best = 1e300;
                 for (int cand = 2 * N - 1; cand <= std::min(m_pow2, kBluMaxNfft); ++cand) {
                     int rest = cand;
@@ -329,7 +342,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
                 }
             }
             // measured (profiles/r04/experiments.md §7): the stage costs ~p, the chirp-z rows ~nfft / N; they cross near p = 45 nfft / N
-            const int p_min = env_int("FXC_BLU_MIN_PRIME", (int)((int64_t)kBluPrimePerRatio * m / N));
+            const int p_min = FXC_DEV_ENV_INT("FXC_BLU_MIN_PRIME", (int)((int64_t)kBluPrimePerRatio * m / N));
             if (pmax > p_min && m <= kBluMaxNfft) {
                 p->mixed_blu = true;
                 p->blu_nfft = m;
@@ -353,13 +366,13 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             FXC_HIP(p, hipMalloc(&p->d_win4, w4.size() * sizeof(f4)));
             FXC_HIP(p, hipMemcpy(p->d_win4, w4.data(), w4.size() * sizeof(f4), hipMemcpyHostToDevice));
         }
-        p->mixed_xeng = p->mixed && p->n_ant >= 3 && env_int("FXC_MIXED_XENGINE", 1);
-        if (p->mixed && !p->mixed_blu && p->n_ant == 2 && env_int("FXC_MIXED_XF", 1)) {
+        p->mixed_xeng = p->mixed && p->n_ant >= 3 && FXC_DEV_ENV_INT("FXC_MIXED_XENGINE", 1);
+        if (p->mixed && !p->mixed_blu && p->n_ant == 2 && FXC_DEV_ENV_INT("FXC_MIXED_XF", 1)) {
             const size_t rpw = (size_t)(std::max(256, p->mixed_tpr) / p->mixed_tpr);
             // four rows (two antennas x ping-pong) must fit the LDS, with the twiddle table beside them (up to 4096 channels) or
             // without (up to 5120)
             p->mixed_xf = rpw * 4 * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && N <= kMixedXPoints * p->mixed_tpr;
-            p->mixed_xf_twl = (rpw * 4 + 1) * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && env_int("FXC_MIXED_TWLDS", 1);
+            p->mixed_xf_twl = (rpw * 4 + 1) * (size_t)N * sizeof(cf) <= (size_t)(160 * 1024) && FXC_DEV_ENV_INT("FXC_MIXED_TWLDS", 1);
             // (without the table in LDS that kernel has no register butterflies for 11 / 13: such channel counts go through the
             // F-only kernel, which has, and xmul_kernel)
             if (!p->mixed_xf_twl && fxc::mixed_rows_per_slot_cap(p->mixed_plan) == 1) p->mixed_xf = false;
@@ -377,7 +390,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             }
             // above 4096 channels there is no such kernel (sixteen points of two antennas: 256 registers of ring), but the F stage
             // alone has one: complex64 input takes it, and xmul_kernel (h_launch.h::mixed_one_pass)
-            if (p->mixed_xf && !p->spec && N > 4096 && T <= 4 && p->rtc && p->num_samp < (1ll << 28) && env_int("FXC_MIXED_XF_BYTES_ONLY", 1) &&
+            if (p->mixed_xf && !p->spec && N > 4096 && T <= 4 && p->rtc && p->num_samp < (1ll << 28) && FXC_DEV_ENV_INT("FXC_MIXED_XF_BYTES_ONLY", 1) &&
                 !spec_first_radices(N, T, spec_rows(N, kSpecFOnly)).empty()) {
                 const SpecKernel* k = spec_kernel(p->device, N, T, kSpecFOnly);
                 p->spec_f_tried = true;
@@ -479,7 +492,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         FXC_HIP(p, hipMalloc(&p->d_tw2, tw2.size() * sizeof(cf)));
         FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
         p->fused_grid_max = p->cu_count;   // one 512-thread workgroup (136 KiB LDS) per CU
-        if (const char* e = std::getenv("FXC_FUSED_SEG")) p->fused_seg = std::max<int64_t>(1, std::atoll(e));   // developer knob
+        if (const char* e = FXC_DEV_ENV("FXC_FUSED_SEG")) p->fused_seg = std::max<int64_t>(1, std::atoll(e));   // developer knob
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<false, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         FXC_HIP(p, hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_fused4096_kernel<true, false>),
@@ -495,7 +508,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         const int P = N / 16;
         // more than four taps: pfb_prefilter_kernel applies the FIR first (k_prepass.h), the wave-local kernel then runs with
         // one unit tap -- the route the tiled channel counts take (FXC_PREFILTER=1: developer knob, the same at <= 4 taps)
-        const char* pre_env_s = std::getenv("FXC_PREFILTER");
+        const char* pre_env_s = FXC_DEV_ENV("FXC_PREFILTER");
         p->prefilter = (T > 4 || (pre_env_s && std::atoi(pre_env_s) == 1));
         if (p->prefilter) {
             p->pre_tp = T <= 8 ? 8 : (T <= 16 ? 16 : 32);
@@ -560,7 +573,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             FXC_HIP(p, hipMemcpy(p->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
         }
         // more than four taps (or FXC_PREFILTER=1, a developer knob to compare at <= 4): the FIR runs as its own pass
-        const char* pre_env = std::getenv("FXC_PREFILTER");
+        const char* pre_env = FXC_DEV_ENV("FXC_PREFILTER");
         p->prefilter = (T > 4 || (pre_env && std::atoi(pre_env) == 1));
         if (p->prefilter) {
             p->pre_tp = T <= 8 ? 8 : (T <= 16 ? 16 : 32);
@@ -573,10 +586,10 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
             FXC_HIP(p, hipMemcpy(p->d_ones, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         // nchan 8192, two antennas, up to 16 taps: the split into two 4096-channel problems (FXC_SPLIT8192=0: off)
-        const char* split_env = std::getenv("FXC_SPLIT8192");
+        const char* split_env = FXC_DEV_ENV("FXC_SPLIT8192");
         // ... up to four taps: two passes instead (f8192_ring_kernel and its XM form, h_launch.h::tiled_raw_sums; FXC_X8192=0: off)
         const bool want_x8192 = N == 8192 && p->n_ant == 2 && T <= 4 && p->path == FXC_PATH_TILED && p->num_samp < (1ll << 28) &&
-                                env_int("FXC_X8192", 1) && env_int("FXC_F8192", 1);
+                                FXC_DEV_ENV_INT("FXC_X8192", 1) && FXC_DEV_ENV_INT("FXC_F8192", 1);
         p->split8192 = (N == 8192 && p->n_ant == 2 && T <= 16 && p->path == FXC_PATH_TILED && p->num_samp <= (1ll << 27) &&
                         !(split_env && std::atoi(split_env) == 0) && !want_x8192);
         if (p->split8192) {
@@ -609,7 +622,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         p->tiled_ring = ((T <= 4 || p->prefilter) && N <= 4096);
         // 8192 channels, up to four taps: the F stage alone has a ring kernel of its own (k_tiled.h::f8192_ring_kernel), fed with the
         // same window quads from L2.  FXC_F8192=0: the pair kernel (developer knob)
-        p->f8192 = N == 8192 && T <= 4 && !p->prefilter && env_int("FXC_F8192", 1);
+        p->f8192 = N == 8192 && T <= 4 && !p->prefilter && FXC_DEV_ENV_INT("FXC_F8192", 1);
         p->x8192 = want_x8192 && p->f8192;
         if ((p->tiled_ring || p->f8192) && (!p->d_win4 || p->prefilter)) {
             std::vector<f4> w4((size_t)N);
@@ -647,7 +660,7 @@ static int plan_build(fxc_plan* p, const double* window, int force_path) {
         }
         // more than 8 antennas: the matrix-core X-engine (k_xmfma.h) unless FXC_XENGINE=block (developer knob: the vector
         // kernel over blocks of 8 antennas it replaced)
-        const char* xe = std::getenv("FXC_XENGINE");
+        const char* xe = FXC_DEV_ENV("FXC_XENGINE");
         p->x_mfma = p->n_ant > kXB && !(FXC_DEV_KERNELS && xe && std::string(xe) == "block");
         if (p->x_mfma) {
             int per_cu = 0, threads = 0, lds = 0;
@@ -785,6 +798,8 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
     if (p->spec) {
         info->specialised |= 1;
         info->spec_vgprs = p->spec->vgprs;
+        info->spec_source = p->spec->source;
+        info->spec_seconds = (float)p->spec->seconds;
         info->grid = p->cu_count * p->spec->wgs_per_cu;
         info->block = p->spec->shape.threads();
         info->lds_bytes = (int)p->spec->shape.lds_bytes();
@@ -814,9 +829,10 @@ int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* re
         const SpecShape& sh = b.shape;
         std::snprintf(report, (size_t)report_bytes,
                       "nchan=%d ntaps=%d tpr=%d slots=%d frames_per_step=%d stages=%s lds_bytes=%zu code_bytes=%zu vgprs=%lld scratch=%lld resident=%d lean=%d rows=%d "
-                      "groups=%s pads=%s plane0=%d twfull=%d waves=%d",
+                      "groups=%s pads=%s plane0=%d twfull=%d waves=%d source=%s",
                       sh.n, sh.taps, sh.tpr, sh.slots, sh.u, sh.list(sh.radix).c_str(), sh.lds_bytes(), b.image.size(), b.vgprs, b.scratch, b.resident,
-                      (int)sh.lean, sh.rows, sh.list(sh.grp).c_str(), sh.list(sh.pad).c_str(), sh.plane0, sh.twfull, sh.waves);
+                      (int)sh.lean, sh.rows, sh.list(sh.grp).c_str(), sh.list(sh.pad).c_str(), sh.plane0, sh.twfull, sh.waves,
+                      b.source == kSpecPrebuilt ? "prebuilt" : b.source == kSpecCached ? "cache" : "built");
     }
     return FXC_OK;
 }
@@ -1058,7 +1074,7 @@ int pinned_rows_out(fxc_plan* p, void** out, int* mem_kind, int64_t n_chunks, in
     }
     const size_t ob = mode == FXC_MODE_SPECTRUM ? (size_t)n_chunks * p->n_base * p->nchan * sizeof(cf) : (size_t)n_chunks * p->n_base * sizeof(cd);
     void* d = pinned_device_ptr(*out, ob);
-    if (!d) return fail(p, FXC_ERR_ARG, "FXC_MEM_DEVICE_TO_PINNED: `out` (%zu bytes) is not inside memory from fxc_host_alloc", ob);
+    if (!d) return fail(p, FXC_ERR_ARG, "`out` of FXC_MEM_DEVICE_TO_PINNED (%zu bytes) is not inside memory from fxc_host_alloc", ob);
     *out = d;
     *mem_kind = FXC_MEM_DEVICE;
     return FXC_OK;
@@ -1301,7 +1317,7 @@ int fx_u8_dev(fxc_plan* p, const unsigned char* x8, void* out, int64_t n_chunks,
     // chunks per pass: at most 65535 streams (a grid dimension of the conditioning kernels), and plans without the
     // fused ingest convert a pass into a complex64 staging buffer that stays within the workspace target
     const bool fused_in = p->n_ant == 2 && !p->prefilter && (p->path == FXC_PATH_FUSED || (p->path == FXC_PATH_TILED && (p->tiled_ring || p->small || p->x8192)) ||
-                                                              (p->path == FXC_PATH_GENERIC && p->mixed_xf && env_int("FXC_MIXED_U8", 1)));
+                                                              (p->path == FXC_PATH_GENERIC && p->mixed_xf && FXC_DEV_ENV_INT("FXC_MIXED_U8", 1)));
     int64_t per_pass = std::min<int64_t>(16384, 65535 / p->n_ant);
     if (!fused_in) per_pass = std::min<int64_t>(per_pass, ws_target() / ((int64_t)p->n_ant * p->num_samp * (int64_t)sizeof(cf)));
     per_pass = std::max<int64_t>(1, per_pass);

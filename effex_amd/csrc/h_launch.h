@@ -16,7 +16,7 @@ int64_t spec_wg_splits(const fxc_plan* p, const SpecKernel* k, int64_t n_groups,
 // 7 - 16 % faster at 8 ... 250 channels, F only 5 - 7 % faster at 96 ... 250 but 17 % slower at 12 (slots of 4 threads) -- so F
 // only from 16 threads per slot.  Developer knob: FXC_MIXED_WAVELOCAL=0 keeps the barrier everywhere.
 int mixed_wave_local(const fxc_plan* p, bool fused_x) {
-    static const int v = env_int("FXC_MIXED_WAVELOCAL", 1);
+    static const int v = FXC_DEV_ENV_INT("FXC_MIXED_WAVELOCAL", 1);
     return v && (fused_x || p->mixed_tpr >= 16);
 }
 
@@ -79,7 +79,7 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
         const int threads = std::max(256, p->mixed_tpr);
         const int rpw = threads / p->mixed_tpr;
         const MixedExtras no_blu = {mixed_wave_local(p, false), ant, p->nchan, nullptr, nullptr, nullptr};
-        static const int tw_knob = env_int("FXC_MIXED_TWLDS", 1), u_knob = env_int("FXC_MIXED_U", 0);
+        static const int tw_knob = FXC_DEV_ENV_INT("FXC_MIXED_TWLDS", 1), u_knob = FXC_DEV_ENV_INT("FXC_MIXED_U", 0);
         // U = 2 frames per slot where the measurements favour it (tools/bench_channelize.py, r04 experiments.md §7): up to 1280
         // channels (three or more 256-thread workgroups still fit a CU's LDS) and, with 512 or 1024 threads per row, from 1321 to
         // 4096 (1440 ... 2000 channels: 10 - 25 % faster than one frame per slot on 256 threads)
@@ -94,7 +94,7 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
         const int64_t n_groups = n_streams * ((p->n_pts + fpg - 1) / fpg);
         // runs of up to 16 frame groups per workgroup (the FIR's re-reads of a frame stay in one L2), many more workgroups than
         // fit at once when there are rows for it (no second, part-filled round of resident workgroups)
-        static const int run_knob = env_int("FXC_MIXED_RUN", 16);
+        static const int run_knob = FXC_DEV_ENV_INT("FXC_MIXED_RUN", 16);
         const int64_t run = std::max<int64_t>(1, std::min<int64_t>(run_knob, n_groups / ((int64_t)p->cu_count * 8)));
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + run - 1) / run, 1 << 30));
 #define FXC_MIXED_LAUNCH(TWL, UU)                                                                                                     \
@@ -491,7 +491,7 @@ int launch_xengine(fxc_plan* p, const cf* spec, cf* raw, int64_t nc, int cg, int
         default: if (p->x_mfma && p->nchan % x_ch == 0) {       // (the matrix-core tiles take whole columns of x_ch bins)
             FXC_XMFMA_DISPATCH(p, hipLaunchKernelGGL(xengine_mfma_kernel<XT>, dim3((unsigned)(p->nchan / XMfmaGeo<XT>::kCH), grid.y),
                                                      dim3(XMfmaGeo<XT>::kThreads), XMfmaGeo<XT>::kLdsBytes, p->stream, spec, raw,
-                                                     p->n_pts, p->nchan, nc, cg, p->n_ant, xr, std::getenv("FXC_XMFMA_ABL") ? std::atoi(std::getenv("FXC_XMFMA_ABL")) : 0));
+                                                     p->n_pts, p->nchan, nc, cg, p->n_ant, xr, FXC_DEV_ENV_INT("FXC_XMFMA_ABL", 0)));
         } else {
             const unsigned gb = (unsigned)((p->n_ant + kXB - 1) / kXB);
             hipLaunchKernelGGL(xengine_block_kernel, dim3(grid.x, grid.y, gb * (gb + 1) / 2), dim3(kXThreads), 0, p->stream, spec,
@@ -690,7 +690,7 @@ int tiled_prefilter(fxc_plan* p, const cf* x, int64_t n_streams, const cf** y_ou
     // two adjacent positions per thread (16-byte accesses) for the 8-frame block (1024 channels / 8 taps: -6 %; the 16-frame
     // block would need 218 VGPRs: -2 % at 512 channels, +3 % at 2048; the 32-frame block has no registers to spare);
     // streams of odd length are not 16-byte aligned one after the other.  FXC_PRE_W=1: developer knob, 8-byte accesses
-    static const bool narrow = [] { const char* e = std::getenv("FXC_PRE_W"); return e && std::atoi(e) == 1; }();
+    static const bool narrow = FXC_DEV_ENV_INT("FXC_PRE_W", 0) == 1;
     const int w = (!narrow && tp == 8 && (p->num_samp % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0) ? 2 : 1;
     // channel counts below 256 w: several streams side by side in a workgroup, while their span fits a buffer descriptor
     const int64_t stream_bytes = p->num_samp * (int64_t)sizeof(cf);
@@ -832,7 +832,7 @@ int split_raw_sums(fxc_plan* p, const cf* x, int64_t nc, cf* raw) {
     cf* y = static_cast<cf*>(p->d_pre);
     const int tp = p->pre_tp;
     // two adjacent positions per thread (16-byte accesses) for the 4- and 8-frame blocks (the 16-frame one has no registers left)
-    static const bool narrow = [] { const char* e = std::getenv("FXC_PRE_W"); return e && std::atoi(e) == 1; }();
+    static const bool narrow = FXC_DEV_ENV_INT("FXC_PRE_W", 0) == 1;
     const int w = (!narrow && tp <= 8 && (p->num_samp % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0) ? 2 : 1;
     const int64_t blocks = (16 / w) * 2 * nc;
     int64_t fs = std::max<int64_t>(1, (2 * (int64_t)p->cu_count + blocks - 1) / blocks);

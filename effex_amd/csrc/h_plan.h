@@ -8,11 +8,6 @@ namespace {
 
 thread_local std::string g_lib_error;
 
-// developer knobs: an integer from the environment
-int env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? std::atoi(e) : dflt;
-}
 
 // Pinned host allocations handed out by fxc_host_alloc (process-wide).  with_host_staging looks a caller's pointer up
 // here: an output buffer inside one of them is written by the finishing kernel through `dev` (no copy back).

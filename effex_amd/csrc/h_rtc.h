@@ -27,7 +27,7 @@ extern const char fxc_src_fx_math_h[];
 namespace {
 
 // timing ablations of fx_spec.h (FXM_ABL: wrong results by design) exist in the developer library only
-int spec_ablation() { return FXC_DEV_KERNELS ? env_int("FXC_RTC_ABL", 0) : 0; }
+int spec_ablation() { return FXC_DEV_ENV_INT("FXC_RTC_ABL", 0); }
 
 // hiprtc's C API, the handful of calls used here (its header is not needed: plain C types)
 typedef struct _hiprtcProgram* rtc_program;
@@ -81,6 +81,9 @@ RtcApi* rtc_api() {
     return api;
 }
 
+// where a build came from (fxc_info.spec_source)
+enum SpecSource { kSpecNone = 0, kSpecBuilt = 1, kSpecCached = 2, kSpecPrebuilt = 3 };
+
 // how fx_spec.h is cut for one channel count: stage order, threads per slot, slots per workgroup
 enum SpecVariant { kSpecC64 = 0, kSpecU8 = 1, kSpecFOnly = 2 };      // F + X from complex64 / from the receivers' bytes, the F stage alone
 
@@ -89,9 +92,9 @@ constexpr int kSpecLeanAbove = 2048;
 
 // developer knobs of the search below exist in the developer library only (libfxcorr_dev.so): the shipped library's choices do not
 // depend on the process environment
-inline int dev_env_int(const char* name, int dflt) { return FXC_DEV_KERNELS ? env_int(name, dflt) : dflt; }
-inline int dev_env_list(const char* name, int* out, int cap) {      // "4,25,10" -> out[], the count (0: unset)
-    const char* e = FXC_DEV_KERNELS ? std::getenv(name) : nullptr;
+#define dev_env_int(name, dflt) FXC_DEV_ENV_INT(name, dflt)
+inline int dev_env_list_parse(const char* name, int* out, int cap) {      // "4,25,10" -> out[], the count (0: unset)
+    const char* e = name;
     int n = 0;
     while (e && *e && n < cap) {
         out[n++] = std::atoi(e);
@@ -100,6 +103,7 @@ inline int dev_env_list(const char* name, int* out, int cap) {      // "4,25,10"
     }
     return n;
 }
+#define dev_env_list(name, out, cap) dev_env_list_parse(FXC_DEV_ENV(name), out, cap)
 
 inline int spec_lean_above() { return dev_env_int("FXC_RTC_LEAN_ABOVE", kSpecLeanAbove); }
 
@@ -411,6 +415,8 @@ struct SpecKernel {
     SpecShape shape;
     int wgs_per_cu = 1;          // resident workgroups per CU (occupancy query)
     int vgprs = 0;
+    int source = kSpecNone;      // where the code object came from (SpecSource), and the seconds the whole search for it took
+    double seconds = 0;
     cf* d_tw1 = nullptr;         // lean builds: the first twiddles by stage, butterfly and thread (fx_spec.h, Args::tw1)
     std::string error;           // why there is none (fn == nullptr)
 };
@@ -483,6 +489,18 @@ std::string spec_cache_dir() {
     return (h && h[0]) ? std::string(h) + "/.cache/fxcorr" : std::string();
 }
 
+// Code objects that ship beside the library: <directory of libfxcorr>/rtc_prebuilt/<key>.co, made at build time (effex_amd/build.py) for a
+// stated list of channel counts.  Their key is the kernel's sources, the options and the architecture -- NOT the compiler, so that a
+// process with another hiprtc loaded (PyTorch ships clang 20, ROCm 7.2 clang 22) finds them too; they are looked up before hiprtc is
+// even bound.  Read-only for the shipped library; the developer library fills FXC_RTC_PREBUILD_DIR when that is set.
+std::string spec_prebuilt_dir() {
+    Dl_info where;
+    if (!dladdr(reinterpret_cast<const void*>(fxc_src_fx_spec_h), &where) || !where.dli_fname) return std::string();
+    std::string path = where.dli_fname;
+    const size_t slash = path.rfind('/');
+    return (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/rtc_prebuilt";
+}
+
 std::string spec_cache_key(const std::vector<std::string>& opts, RtcApi* api) {
     unsigned long long a = 1469598103934665603ull, b = 0x9E3779B97F4A7C15ull;      // two FNV-1a style sums over the same bytes
     auto eat = [&](const char* p, size_t n) {
@@ -494,12 +512,14 @@ std::string spec_cache_key(const std::vector<std::string>& opts, RtcApi* api) {
     };
     for (const char* src : {fxc_src_fx_spec_h, fxc_src_fx_mixed_h, fxc_src_fx_math_h}) eat(src, std::strlen(src) + 1);
     for (const std::string& o : opts) eat(o.c_str(), o.size() + 1);
-    int major = 0, minor = 0;
-    if (api->version) (void)api->version(&major, &minor);
-    const std::string v = "hiprtc " + std::to_string(major) + "." + std::to_string(minor);
-    eat(v.c_str(), v.size());
-    Dl_info where;                           // (two hiprtc builds of one version number: PyTorch's and ROCm's differ in path)
-    if (api->compile && dladdr(reinterpret_cast<void*>(api->compile), &where) && where.dli_fname) eat(where.dli_fname, std::strlen(where.dli_fname));
+    if (api) {                               // (nullptr: the key of a pre-built code object -- any compiler's)
+        int major = 0, minor = 0;
+        if (api->version) (void)api->version(&major, &minor);
+        const std::string v = "hiprtc " + std::to_string(major) + "." + std::to_string(minor);
+        eat(v.c_str(), v.size());
+        Dl_info where;                       // (two hiprtc builds of one version number: PyTorch's and ROCm's differ in path)
+        if (api->compile && dladdr(reinterpret_cast<void*>(api->compile), &where) && where.dli_fname) eat(where.dli_fname, std::strlen(where.dli_fname));
+    }
     char hex[40];
     std::snprintf(hex, sizeof hex, "%016llx%016llx", a, b);
     return hex;
@@ -546,12 +566,14 @@ std::string spec_arch(const char* gcn_arch_name) {
 }
 
 // fx_spec.h for one shape -> a code object for `arch` (e.g. "gfx950:sramecc+:xnack-"); needs no device
-bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::vector<char>& image, std::string& error) {
-    RtcApi* api = rtc_api();
-    if (!api->handle) {
-        error = api->error;
-        return false;
-    }
+bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::vector<char>& image, std::string& error, int* source = nullptr,
+                  double* seconds = nullptr) {
+    const auto t0 = std::chrono::steady_clock::now();
+    auto done = [&](int src) {
+        if (source) *source = src;
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return true;
+    };
     std::string radices;
     for (int i = 0; i < shape.n_stages; ++i) radices += (i ? "," : "") + std::to_string(shape.radix[i]);
     std::vector<std::string> opts = {std::string("--offload-arch=") + arch, "-O3", "-std=c++17", "-fno-slp-vectorize",
@@ -565,9 +587,19 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXC_STREAM_AUX=" + std::to_string((int)FXC_STREAM_AUX),
                                      "-DFXM_LD_AUX=" + std::to_string(dev_env_int("FXC_RTC_LD_AUX", kSpecLoadAux)),
                                      "-DFXM_ABL=" + std::to_string(spec_ablation())};      // (timing ablations: wrong results, developer library only)
+    const std::string pre_name = spec_cache_key(opts, nullptr) + ".co", pre_dir = spec_prebuilt_dir();
+    if (!pre_dir.empty() && !spec_ablation() && spec_cache_load(pre_dir + "/" + pre_name, image)) return done(kSpecPrebuilt);
+    RtcApi* api = rtc_api();
+    if (!api->handle) {
+        error = api->error;
+        return false;
+    }
     const std::string dir = spec_cache_dir();
     const std::string cached = dir.empty() ? std::string() : dir + "/" + spec_cache_key(opts, api) + ".co";
-    if (!cached.empty() && spec_cache_load(cached, image)) return true;
+    if (!cached.empty() && spec_cache_load(cached, image)) {
+        if (const char* fill = FXC_DEV_ENV("FXC_RTC_PREBUILD_DIR")) spec_cache_store(fill, std::string(fill) + "/" + pre_name, image);
+        return done(kSpecCached);
+    }
     std::vector<const char*> optv;
     for (const std::string& o : opts) optv.push_back(o.c_str());
     const char* headers[] = {fxc_src_fx_spec_h, fxc_src_fx_mixed_h, fxc_src_fx_math_h};
@@ -596,7 +628,8 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
     api->code(prog, image.data());
     api->destroy(&prog);
     if (!cached.empty()) spec_cache_store(dir, cached, image);
-    return true;
+    if (const char* fill = FXC_DEV_ENV("FXC_RTC_PREBUILD_DIR")) spec_cache_store(fill, std::string(fill) + "/" + pre_name, image);
+    return done(kSpecBuilt);
 }
 
 // workgroups of this build a CU holds: registers (512 per lane and SIMD, granule 8), LDS (160 KiB), 32 waves
@@ -615,12 +648,14 @@ struct SpecBuild {
     std::vector<char> image;
     long long vgprs = 0, scratch = 0;
     int resident = 0;
+    int source = kSpecNone;      // SpecSource of this build's code object
+    double seconds = 0;          // what getting it took (compiling, or reading the file)
     std::string error;
 };
 SpecBuild spec_build(const SpecShape& shape, int variant, const char* arch) {
     SpecBuild b;
     b.shape = shape;
-    if (!spec_compile(shape, variant, arch, b.image, b.error)) {
+    if (!spec_compile(shape, variant, arch, b.image, b.error, &b.source, &b.seconds)) {
         b.image.clear();
         return b;
     }
@@ -629,6 +664,8 @@ SpecBuild spec_build(const SpecShape& shape, int variant, const char* arch) {
     b.resident = b.scratch == 0 ? spec_resident(shape, b.vgprs) : 0;
     return b;
 }
+
+inline int spec_regs_est(SpecShape sh, bool fonly);
 
 // one candidate: its work items and layout chosen (spec_layout), built for two waves per SIMD first where the workgroup is small
 // enough for two of them on a CU (a build that spills there is built again for one)
@@ -646,12 +683,103 @@ SpecBuild spec_build_laid_out(SpecShape sh, int variant, const char* arch) {
         if (!b.image.empty() && b.scratch == 0) return b;
     }
     sh.waves = 1;
-    return spec_build(sh, variant, arch);
+    SpecBuild b = spec_build(sh, variant, arch);
+    if (env_int("FXC_RTC_VERBOSE", 0) > 1)
+        std::fprintf(stderr, "libfxcorr: built stages=%s u=%d lean=%d: vgprs=%lld (estimated %d) scratch=%lld resident=%d %s\n", sh.list(sh.radix).c_str(), sh.u,
+                     (int)sh.lean, b.vgprs, spec_regs_est(sh, variant == kSpecFOnly), b.scratch, b.resident, b.error.c_str());
+    return b;
 }
 
-// The stage lists worth building for n channels, best guess first: the prime-factor orders of spec_first_radices (fours, a two, the odd
-// primes ascending, one of them moved to the front).  FXC_RTC_RADICES (developer knob): exactly this list.
-std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows) {
+// Vector registers a build of this shape needs, roughly: what stays from step to step (the ring, the taps, the twiddles and offsets of the
+// thread's items, the sums) plus the busiest stage's butterfly in flight.  Checked against the compiler on the shapes of
+// profiles/r06/sweep_lists.md (within 10 %); a candidate estimated beyond the 256 a thread of two resident waves per SIMD has is not
+// built (the compiler would spill it, or halve the resident workgroups: [4,10,25] at 1000 channels: 348 registers, 2.33 ms against 1.52).
+inline int spec_regs_est(SpecShape sh, bool fonly) {
+    spec_layout(sh, fonly);
+    const int S = sh.n_stages, r0 = sh.radix[0];
+    const int j0 = (sh.nb_of(0) + sh.tpr - 1) / sh.tpr, pts = r0 * j0, ns_ring = sh.taps + sh.u - 1;
+    int keep = pts * sh.rows * ns_ring * 2 + (sh.lean ? 0 : sh.taps * pts) + 24;      // (+ addresses, loop state)
+    int busy = sh.u * sh.rows * (sh.lean ? r0 : pts) * 2 + 2 * r0 + 8;                  // the FIR's sums, one first butterfly
+    for (int s = 1; s < S; ++s) {
+        const int R = sh.radix[s], j = sh.j_of(s);
+        const bool whole = !sh.lean && R <= sh.twfull;
+        keep += j * ((whole ? 2 * (R - 1) : (sh.lean ? 0 : 2)) + (sh.lean ? 0 : 2));
+        int a = 0;
+        for (int c : {4, 2, 3, 5, 7})
+            if (!a && R % c == 0 && R > c && R != 4) a = c;
+        const int sub = a ? std::max(a, R / a) : R;
+        int t = 2 * R + 4 * sub + (whole ? 0 : 2 * (a ? a + R / a : R)) + 8;
+        if (s == S - 1 && !fonly) {
+            keep += j * 2 * R;                                                         // the sums
+            t += 2 * R;                                                                // the other antenna's outputs
+        }
+        busy = std::max(busy, t);
+    }
+    if (sh.lean && sh.u == 2) keep += 24;       // (measured: the lean build's two-frame steps need more than their rows' share)
+    if (sh.lean && r0 >= 8) keep += 32;         // (eight points through one butterfly beside the 128 registers of ring: 4000 channels spilled 52 - 100 B)
+    return keep + busy;
+}
+
+// What one step of a shape costs a CU, in cycles per frame, as far as a static count can tell: the vector instructions of the busiest
+// SIMD (a packed instruction about six cycles: tools/ubench/valu_rate.hip), the LDS's cycles for every wave's loads (two each) and
+// stores (six each: MI355X_MICROARCH.md), and a stall per trip through LDS (the barrier and the first load's latency).  It ranks the
+// candidates; the builds' registers decide (spec_search).
+inline double spec_cost(SpecShape sh, bool fonly) {
+    spec_layout(sh, fonly);
+    const int rows = sh.n_rows(), S = sh.n_stages;
+    auto rounds_of = [&](int items) {
+        long r = 0;
+        for (int i0 = 0; i0 < items; i0 += sh.tpr) r += ((std::min(items - i0, sh.tpr) + 63) / 64 + 3) / 4;
+        return r;
+    };
+    auto waves_of = [&](int items) { return (long)(items + 63) / 64; };
+    const int slots_per_wg = sh.slots;            // (several slots a workgroup: every slot its own frames, the same count per frame)
+    (void)slots_per_wg;
+    double valu = 0, lds = 0;
+    {   // the first stage: the FIR of a thread's points, their butterflies, the stores
+        const int nb0 = sh.nb_of(0), r0 = sh.radix[0];
+        const long rounds = rounds_of(nb0), waves = waves_of(nb0);
+        valu += (double)rounds * rows * (r0 * sh.taps + spec_bfly_cost(r0) - 2 * (r0 - 1));
+        if (S >= 2) lds += (double)waves * rows * r0 * 6;
+    }
+    for (int s = 1; s < S; ++s) {
+        const int R = sh.radix[s], G = sh.grp_of(s), items = sh.items_of(s);
+        const long rounds = rounds_of(items), waves = waves_of(items);
+        valu += (double)rounds * (G * spec_bfly_cost(R) + ((sh.lean || R > sh.twfull) ? 2 * (R - 2) : 0));
+        lds += (double)waves * G * R * 2;
+        if (s < S - 1) lds += (double)waves * G * R * 6;
+        else if (!fonly) valu += (double)rounds * (G / sh.rows) * 2 * R;
+    }
+    double cost = (6.0 * valu + lds + 700.0 * (S - 1)) / sh.u;
+    if (sh.threads() % 256 != 0 && sh.threads() > 64) cost *= 1.2;      // (a SIMD without a wave of its own: 720 channels on 192 threads 2.11 ms, on 256: 1.72)
+    return cost;
+}
+
+// The stage lists worth building for n channels, best guess first.  Candidates: every ordered way to write n as a product of radices
+// fx_spec.h has butterflies for -- primes, 4, and the composites that run in registers (6, 8, 9, 10, 16, 20, 25, 32) -- with at most
+// as many stages as the prime-factor order, a last radix of at most 10 (16 for the F stage alone: the last butterfly's outputs of
+// both antennas and the sums live in registers together) and at most one radix beyond 16; ranked by spec_cost.  The prime-factor order
+// of round 5 (spec_first_radices) follows as the fallback.  FXC_RTC_RADICES (developer knob): exactly this list; FXC_RTC_PICK: only the
+// k-th ranked candidate.
+inline void spec_enum_lists(int n_left, int max_stages, bool fonly, std::vector<int>& cur, std::vector<std::vector<int>>& out) {
+    if (out.size() >= 20000) return;
+    if (n_left == 1) {
+        if (!cur.empty() && cur.back() <= (fonly ? 16 : 10) ) out.push_back(cur);
+        return;
+    }
+    if ((int)cur.size() >= max_stages) return;
+    int n_big = 0;
+    for (int r : cur) n_big += r > 16;
+    for (int r : {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 16, 17, 19, 20, 23, 25, 32}) {
+        if (n_left % r || (r > 16 && n_big)) continue;
+        if (cur.empty() && (r > 8 || r == 2) && r != 11 && r != 13 && n_left != 2 * 2 && n_left > 2) continue;      // (the first radix: the ring holds eight points a thread; 2 first loses wherever there is a choice)
+        cur.push_back(r);
+        spec_enum_lists(n_left / r, max_stages, fonly, cur, out);
+        cur.pop_back();
+    }
+}
+
+std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows, bool fonly = false) {
     std::vector<std::vector<int>> out;
     int forced[fxc::kMixedMaxStages];
     const int nf = dev_env_list("FXC_RTC_RADICES", forced, fxc::kMixedMaxStages);
@@ -661,10 +789,39 @@ std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows) {
     }
     std::vector<int> firsts = spec_first_radices(n, taps, rows);
     if (const int want = dev_env_int("FXC_RTC_R0", 0)) firsts.assign(1, want);
+    std::vector<std::vector<int>> legacy;
     for (int r : firsts) {
         const SpecShape s = spec_shape(n, taps, r, 1, rows);
-        if (s.ok) out.emplace_back(s.radix, s.radix + s.n_stages);
+        if (s.ok) legacy.emplace_back(s.radix, s.radix + s.n_stages);
     }
+    if (legacy.empty()) return out;
+    if (dev_env_int("FXC_RTC_COMPOSITE", 1)) {
+        std::vector<std::vector<int>> all;
+        std::vector<int> cur;
+        spec_enum_lists(n, (int)legacy[0].size(), fonly, cur, all);
+        std::vector<std::pair<double, int>> ranked;
+        for (size_t i = 0; i < all.size(); ++i) {
+            const SpecShape one = spec_shape_of(n, taps, all[i].data(), (int)all[i].size(), 1, rows);
+            if (!one.ok || one.threads() > 512) continue;
+            bool big = false;
+            for (int r : all[i]) (void)spec_radix_ok(r, &big);
+            if (big && one.threads() > 256) continue;
+            const SpecShape two = spec_shape_of(n, taps, all[i].data(), (int)all[i].size(), 2, rows);
+            const int budget = one.threads() <= 256 ? 256 : 512 * 256 / one.threads();
+            if (spec_regs_est(one, fonly) > budget) continue;
+            const double c = std::min(spec_cost(one, fonly), two.ok && spec_regs_est(two, fonly) <= budget ? spec_cost(two, fonly) : 1e300);
+            ranked.emplace_back(c, (int)i);
+        }
+        std::sort(ranked.begin(), ranked.end());
+        const int pick = dev_env_int("FXC_RTC_PICK", -1);
+        if (pick >= 0) {
+            if (pick < (int)ranked.size()) out.push_back(all[ranked[pick].second]);
+            return out;
+        }
+        for (size_t k = 0; k < ranked.size() && k < 2; ++k) out.push_back(all[ranked[k].second]);
+    }
+    for (const std::vector<int>& l : legacy)
+        if (std::find(out.begin(), out.end(), l) == out.end()) out.push_back(l);
     return out;
 }
 
@@ -678,8 +835,8 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
     const int rows = spec_rows(n, variant);
     const int force_u = dev_env_int("FXC_RTC_U", 0);
     int tried = 0;
-    for (const std::vector<int>& list : spec_stage_lists(n, taps, rows)) {
-        if (tried == 2) break;                       // (a compile is about a second: two orders at most)
+    for (const std::vector<int>& list : spec_stage_lists(n, taps, rows, variant == kSpecFOnly)) {
+        if (tried == 3) break;                       // (a compile is a second or two: three lists at most)
         const SpecShape one = spec_shape_of(n, taps, list.data(), (int)list.size(), 1, rows);
         if (!one.ok) continue;
         ++tried;
@@ -704,13 +861,14 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
 // every developer knob that reaches a build, as part of the in-process cache's key (empty in the shipped library)
 std::string spec_knob_key() {
     std::string k;
-    if (!FXC_DEV_KERNELS) return k;
+#if FXC_DEV_KERNELS
     for (const char* name : {"FXC_RTC_ABL", "FXC_RTC_R0", "FXC_RTC_U", "FXC_RTC_LEAN_ABOVE", "FXC_RTC_TPR_MAX", "FXC_RTC_LD_AUX", "FXC_RTC_ROWS1_ABOVE",
                              "FXC_RTC_BIG_PRIMES", "FXC_RTC_RADICES", "FXC_RTC_GROUPS", "FXC_RTC_PADS", "FXC_RTC_PLANE0", "FXC_RTC_LAYOUT", "FXC_RTC_TWFULL",
-                             "FXC_RTC_WAVES"}) {
+                             "FXC_RTC_WAVES", "FXC_RTC_COMPOSITE", "FXC_RTC_PICK"}) {
         const char* e = std::getenv(name);
         k += std::string(e ? e : "") + ";";
     }
+#endif
     return k;
 }
 
@@ -728,13 +886,21 @@ const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
         k->error = "hipGetDeviceProperties failed";
         return k;
     }
+    const auto t0 = std::chrono::steady_clock::now();
     SpecBuild b = spec_search(n, taps, variant, spec_arch(prop.gcnArchName).c_str());
+    k->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    k->source = b.source;
     if (b.image.empty()) {
         k->error = b.error;
         return k;
     }
     k->shape = b.shape;
     k->vgprs = (int)b.vgprs;
+    if (env_int("FXC_RTC_VERBOSE", 0))
+        std::fprintf(stderr, "libfxcorr: %d channels, %d taps, build %d: stages=%s groups=%s pads=%s plane0=%d frames_per_step=%d threads=%d vgprs=%lld resident=%d lds=%zu source=%s (%.2f s)\n", n,
+                     taps, variant, b.shape.list(b.shape.radix).c_str(), b.shape.list(b.shape.grp).c_str(), b.shape.list(b.shape.pad).c_str(), b.shape.plane0,
+                     b.shape.u, b.shape.threads(), b.vgprs, b.resident, b.shape.lds_bytes(),
+                     b.source == kSpecPrebuilt ? "prebuilt" : b.source == kSpecCached ? "cache" : "built", k->seconds);
     DeviceGuard guard(device);
     hipError_t e = hipModuleLoadData(&k->module, b.image.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, "fxm_fx2_kernel");

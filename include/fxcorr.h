@@ -16,6 +16,17 @@
  *   - a plan is thread-compatible, not thread-safe (one caller thread per plan — the reference
  *     drives the path from one thread, effex/effex.py:326-417).
  *   - there is NO CPU backend: without a HIP device fxc_plan_create fails with FXC_ERR_NODEVICE.
+ *
+ * Environment.  The library reads FOUR variables and no others (`strings libfxcorr.so | grep '^FXC_'` lists exactly these):
+ *   FXC_RTC          0: plans keep the any-shape kernels for channel counts that are not a power of two instead of building the kernel
+ *                    for the channel count (fxc_info.specialised); read when a plan is made.  Default 1.
+ *   FXC_RTC_CACHE    directory of the code objects built at run time (default $XDG_CACHE_HOME/fxcorr, else ~/.cache/fxcorr; "0" or
+ *                    empty: no files).  The pre-built code objects that ship beside the library are looked up first.
+ *   FXC_RTC_VERBOSE  1: one line on stderr per kernel built or loaded for a channel count (stage list, registers, where it came from).
+ *   FXC_WS_MB        upper bound of the lazily grown device workspace in MiB (default 12288); calls over more chunks run in passes.
+ * Results do not depend on any of them beyond rounding (FXC_RTC chooses between two kernels of the same arithmetic family).  Route and
+ * tuning knobs for A/B measurements exist only in the developer build (libfxcorr_dev.so, fxc_dev_kernels() == 1), which tests and
+ * tools load explicitly.
  */
 #ifndef FXCORR_H
 #define FXCORR_H
@@ -26,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FXC_VERSION 105 /* 0.1.0 */
+#define FXC_VERSION 106 /* 0.1.1: fxc_info.spec_source, spec_seconds */
 
 typedef struct fxc_plan fxc_plan; /* opaque; one per (device, configuration) */
 typedef struct fxc_pipe fxc_pipe; /* opaque; host-fed double-buffered front end on a plan */
@@ -79,6 +90,10 @@ typedef struct fxc_info {
                                   (two antennas, a channel count that is not a power of two, up to four taps); bit 1: so was
                                   the F stage alone (built at the first fxc_channelize / multi-antenna call)            */
     int32_t spec_vgprs;        /* its vector registers per lane                                                          */
+    int32_t spec_source;       /* where its code object came from: 0 none, 1 built by hiprtc when the plan was made, 2 the cache of
+                                  earlier builds (FXC_RTC_CACHE), 3 pre-built beside the library (rtc_prebuilt/, made at build time
+                                  for a stated list of channel counts: effex_amd/build.py::PREBUILT)                     */
+    float   spec_seconds;      /* what getting it took when the plan was made (hiprtc: seconds; a file: milliseconds)      */
 } fxc_info;
 
 int         fxc_version(void);
@@ -106,8 +121,10 @@ int fxc_plan_get_info(const fxc_plan* plan, fxc_info* info);
  * antennas) -- for the device architecture `arch` ("gfx950"; NULL: the current
  * device's), without a device and without a plan: the library's embedded kernel source through hiprtc.  FXC_OK and a one-line
  * description in `report` (may be NULL: "nchan= ntaps= tpr= slots= frames_per_step= stages= lds_bytes= code_bytes= vgprs= scratch=
- * resident= lean= rows=" -- threads per frame, frames side by side in a workgroup, frames per step, the stage radices in order,
- * whether taps and twiddles come from tables (above 2048 channels), streams per workgroup); FXC_ERR_UNSUPPORTED when the shape has no such kernel (plans of that shape run the
+ * resident= lean= rows= groups= pads= plane0= twfull= waves=" -- threads per frame, frames side by side in a workgroup, frames per step,
+ * the stage radices in order, whether taps and twiddles come from tables (above 2048 channels), streams per workgroup, rows per work
+ * item of each stage, the LDS layout of the stage buffers, the largest radix whose twiddles all stay in registers, waves per SIMD the
+ * registers were held to); FXC_ERR_UNSUPPORTED when the shape has no such kernel (plans of that shape run the
  * any-shape kernel); FXC_ERR_HIP with the compiler's log in fxc_last_error(NULL) when the build fails.
  * (The reference takes any integer --resolution, effex.py:733-739; this is where the build meets that freedom.) */
 int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* report, int report_bytes);

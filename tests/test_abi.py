@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.fxc_version() == 105
+    assert lib.fxc_version() == 106
     assert lib.fxc_status_string(0) == b"ok"
     assert b"unsupported" in lib.fxc_status_string(_lib.FXC_ERR_UNSUPPORTED)
 
@@ -119,6 +119,85 @@ def test_header_and_library_from_plain_c(lib, tmp_path):
 def test_plan_from_plain_c_on_the_gpu(lib, tmp_path):
     """The same C program on a GPU box: creates a plan, reads its info, destroys it."""
     _run_c_program(tmp_path)
+
+
+def _hip_env():
+    env = dict(os.environ)
+    # the process needs a HIP runtime for libfxcorr's own dependency: torch's copy or ROCm's
+    try:
+        import torch
+        env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    except ImportError:
+        pass
+    return env
+
+
+def _c_array(name, ctype, values):
+    return "static const %s %s[] = {%s};\n" % (ctype, name, ", ".join(repr(float(v)) for v in values))
+
+
+def _build_compute_program(tmp_path):
+    """tests/cabi/compute_fxcorr.c against a header and a data file generated here from the committed reference goldens
+    (tests/golden/reference_outputs.npz) and the seeded inputs they were made from (oracle/golden_inputs.py)."""
+    import shutil
+    import subprocess
+    import sys
+    import numpy as np
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import golden_inputs as gi
+    from effex_amd.plan import rot_table
+    from effex_amd.window import design_window
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    arrays = np.load(os.path.join(ROOT, "tests", "golden", "reference_outputs.npz"))
+    x, h = gi.kat_input()
+    kat = arrays["kat_spec"]
+    x32 = x.astype(np.complex64)
+    with open(str(tmp_path / "golden_kat.h"), "w") as fh:
+        fh.write("/* generated by tests/test_abi.py from tests/golden/reference_outputs.npz (kat_spec) and oracle/golden_inputs.py::kat_input */\n")
+        fh.write("#define KAT_NCHAN 4\n#define KAT_NTAPS 2\n#define KAT_NUM_SAMP %d\n#define KAT_FRAMES %d\n" % (len(x), kat.shape[0]))
+        fh.write(_c_array("kat_window", "double", h))
+        fh.write(_c_array("kat_x", "float", x32.view(np.float32)))
+        fh.write(_c_array("kat_spec", "double", kat.astype(np.complex128).ravel().view(np.float64)))
+    nchan, ntaps, num_samp = 4096, 4, 2 ** 18
+    iq = np.ascontiguousarray(gi.xcorr_input(), dtype=np.complex64)
+    blob = str(tmp_path / "headline.bin")
+    with open(blob, "wb") as fh:
+        np.array([num_samp, nchan, ntaps], dtype=np.int64).tofile(fh)
+        np.ascontiguousarray(design_window(ntaps, nchan), dtype=np.float64).tofile(fh)
+        np.ascontiguousarray(rot_table(nchan, gi.BANDWIDTH, gi.FREQUENCY, 0.0), dtype=np.complex128).tofile(fh)
+        iq.tofile(fh)
+        np.ascontiguousarray(arrays["xcorr_SPECTRUM_0"], dtype=np.complex128).tofile(fh)
+    exe = str(tmp_path / "compute_fxcorr")
+    libdir = os.path.dirname(_lib.IN_TREE_LIB)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", str(tmp_path),
+                    os.path.join(ROOT, "tests", "cabi", "compute_fxcorr.c"), "-o", exe, "-L", libdir, "-lfxcorr", "-lm",
+                    "-Wl,-rpath," + libdir], check=True)
+    return exe, blob
+
+
+def test_computing_c_program_builds(lib, tmp_path):
+    """The computing C consumer compiles as C99 -pedantic against the generated golden header and links (it needs a GPU to run:
+    without one it says so and exits 77)."""
+    import subprocess
+    exe, blob = _build_compute_program(tmp_path)
+    proc = subprocess.run([exe, blob], env=_hip_env(), capture_output=True, text=True, timeout=120)
+    assert proc.returncode in (0, 77), (proc.returncode, proc.stdout, proc.stderr)
+
+
+@pytest.mark.gpu
+def test_c_program_computes_on_the_gpu(lib, tmp_path):
+    """From plain C, no Python in the process: fxc_channelize on the N = 4 / T = 2 known-answer case against the reference-executed
+    `kat_spec` (effex.py:530-555), and fxc_set_rot + fxc_fx_rows (FXC_MEM_HOST) on the headline shape against `xcorr_SPECTRUM_0`
+    (_run_task, effex.py:490-521); tolerance 1e-5 of max|expected|, stated in the C source."""
+    import subprocess
+    exe, blob = _build_compute_program(tmp_path)
+    proc = subprocess.run([exe, blob], env=_hip_env(), capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, (proc.returncode, proc.stdout, proc.stderr)
+    assert "c-abi compute ok" in proc.stdout and "kat_spec err" in proc.stdout and "xcorr_SPECTRUM_0 err" in proc.stdout
 
 
 def _run_c_program(tmp_path):

@@ -710,8 +710,8 @@ def test_8192_channels_in_two_passes(plan_mod, torch, monkeypatch, ntaps, n_chun
         assert rel_err(by[0, 0], ref) < TOL_VIS
         p.fx_accumulate_u8(u8, remove_dc=True)
         assert rel_err(p.finalize("SPECTRUM"), by.astype(np.complex128).mean(axis=0)) < 2e-6
-    monkeypatch.setenv("FXC_X8192", "0")
-    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as q:
+    monkeypatch.setenv("FXC_X8192", "0")      # (a route knob of the developer library: the shipped one reads none)
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window, dev=True) as q:
         assert q.info["block"] == 1024
         q.set_delay(gi.BANDWIDTH, gi.FREQUENCY, -2e-7)
         assert rel_err(q.fx_rows(xd, "SPECTRUM").cpu().numpy(), rows) < 2e-6
@@ -866,8 +866,8 @@ def test_channelize_at_8192_channels(plan_mod, torch, monkeypatch, n_ant, ntaps,
         if n_ant > 1:
             rows = p.fx_rows(xd).cpu().numpy()
             assert rel_err(rows[0], fx_oracle.fx_integrate(x[:1], nchan, window)) < TOL_VIS
-    monkeypatch.setenv("FXC_F8192", "0")
-    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window) as a:
+    monkeypatch.setenv("FXC_F8192", "0")      # (a route knob of the developer library: the shipped one reads none)
+    with plan_mod.FxPlan(n_ant, nchan, ntaps, num_samp, window=window, dev=True) as a:
         assert rel_err(a.channelize(flat).cpu().numpy(), spec) < 2e-6
         if n_ant > 1:
             assert rel_err(a.fx_rows(xd).cpu().numpy(), rows) < 2e-6
@@ -998,8 +998,8 @@ def test_mixed_radix_kernel_on_powers_of_two(plan_mod, torch, monkeypatch, nchan
     xd = torch.from_numpy(x).cuda()
     with plan_mod.FxPlan(2, nchan, 3, num_samp, path="generic") as g:
         ref = g.fx_rows(xd).cpu().numpy()
-    monkeypatch.setenv("FXC_GENERIC_FFT", "mixed")
-    with plan_mod.FxPlan(2, nchan, 3, num_samp, path="generic") as m:
+    monkeypatch.setenv("FXC_GENERIC_FFT", "mixed")      # (a route knob of the developer library: the shipped one reads none)
+    with plan_mod.FxPlan(2, nchan, 3, num_samp, path="generic", dev=True) as m:
         assert rel_err(m.fx_rows(xd).cpu().numpy(), ref) < 4e-6
 
 

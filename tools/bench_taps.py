@@ -23,7 +23,7 @@ def main():
     synth_fill(x, 1234)
     for case in args.cases.split(","):
         nchan, ntaps = (int(v) for v in case.split(":"))
-        with FxPlan(2, nchan, ntaps, num_samp) as plan:
+        with FxPlan(2, nchan, ntaps, num_samp, dev=bool(os.environ.get("FXC_PREFILTER"))) as plan:      # (route knobs: developer library only)
             plan.fx_accumulate(x)
             plan.finalize()
             ms = []

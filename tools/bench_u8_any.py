@@ -16,7 +16,7 @@ def main():
     num_samp, n_chunks = 2 ** 18, 1024
     u8 = torch.randint(0, 256, (n_chunks, 2, num_samp, 2), dtype=torch.uint8, device="cuda")
     for nchan in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1000").split(",")]:
-        with FxPlan(2, nchan, 4, num_samp) as plan:
+        with FxPlan(2, nchan, 4, num_samp, dev=bool(os.environ.get("FXC_MIXED_U8"))) as plan:      # (route knobs: developer library only)
             plan.fx_accumulate_u8(u8, remove_dc=True)
             plan.finalize()
             ms = []

@@ -26,7 +26,7 @@ def main():
             n_chunks = max(1, 2048 // n_ant)
             x = torch.empty((n_chunks, n_ant, num_samp), dtype=torch.complex64, device="cuda")
             synth_fill(x, 1234, delays=[a % 7 for a in range(n_ant)])
-            with FxPlan(n_ant, nchan, 4, num_samp) as plan:
+            with FxPlan(n_ant, nchan, 4, num_samp, dev=bool(os.environ.get("FXC_XENGINE"))) as plan:      # (route knobs: developer library only)
                 outs = [pinned_empty((plan.n_baselines, nchan), "complex128") for _ in range(2)]
 
                 def fn(k):
