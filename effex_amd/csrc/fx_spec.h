@@ -955,42 +955,71 @@ struct Body {
         }
     }
 
-    // LEAN: stage s reads rd and writes wr with the first twiddles w1; the next stage's are requested before, the last stage ends in X
+    // LEAN: the first twiddles of every item of every stage, [tw_base(s) + j], requested at the top of the step -- BEFORE the next frames'
+    // samples: vector-memory loads return in order, so a wait for a table entry requested behind the samples would wait for the samples
+    // (an HBM round trip in every step; FXM_LEAN_TW_EARLY 0: one stage ahead, as in round 5)
+#ifndef FXM_LEAN_TW_EARLY
+#define FXM_LEAN_TW_EARLY 1
+#endif
     template <int s>
-    FX_HD void lean_stages(cf* rd, cf* wr, const pk2 (&w1)[j_of(s)], long long f, long long f_end) {
+    FX_HD void load_tw1_all(pk2 (&all)[TW1C > 0 ? TW1C : 1]) {
+        if constexpr (s < S) {
+            pk2 w[j_of(s)];
+            load_tw1<s>(w);
+#pragma unroll
+            for (int j = 0; j < j_of(s); ++j) all[tw_base(s) + j] = w[j];
+            load_tw1_all<s + 1>(all);
+        }
+    }
+    // LEAN: stage s reads rd and writes wr with the first twiddles w1 (one stage ahead: the next stage's are requested before; early: all of
+    // them are there already); the last stage ends in X
+    template <int s>
+    FX_HD void lean_stages(cf* rd, cf* wr, const pk2* w1, long long f, long long f_end) {
         if constexpr (s < S - 1) {
-            pk2 nxt[j_of(s + 1)];
-            load_tw1<s + 1>(nxt);
-            mid_stage<s>(rd, wr, w1);
-            cx.sync();
-            lean_stages<s + 1>(wr, rd, nxt, f, f_end);
+            if constexpr (FXM_LEAN_TW_EARLY) {
+                mid_stage<s>(rd, wr, w1 + tw_base(s));
+                cx.sync();
+                lean_stages<s + 1>(wr, rd, w1, f, f_end);
+            } else {
+                pk2 nxt[j_of(s + 1)];
+                load_tw1<s + 1>(nxt);
+                mid_stage<s>(rd, wr, w1);
+                cx.sync();
+                lean_stages<s + 1>(wr, rd, nxt, f, f_end);
+            }
         } else {
-            last_stage(rd, f, f_end, w1);
+            last_stage(rd, f, f_end, FXM_LEAN_TW_EARLY ? w1 + tw_base(s) : w1);
         }
     }
 
-    // LEAN (S >= 2): one first-stage butterfly at a time -- its points' taps from L2, their FIR, the next frames' samples into the
-    // ring slots those points have just left, the butterfly into LDS -- so that only R0 points' taps and sums are live at once
+    // LEAN (S >= 2): one first-stage butterfly at a time -- its points' taps from L2, their FIR, the butterfly into LDS -- so that only R0
+    // points' taps and sums are live at once; then the next frames' samples into the ring slots the FIR has left
     template <int P>
     FX_HD void step_lean(long long f, long long f_end) {
         static_assert(!LEAN || S >= 2, "the lean build needs a first stage into LDS (h_rtc.h::spec_shape)");
-        pk2 w1[j_of(1)];
-        load_tw1<1>(w1);
+        pk2 w1[FXM_LEAN_TW_EARLY ? (TW1C > 0 ? TW1C : 1) : j_of(1)];
+        if constexpr (FXM_LEAN_TW_EARLY) {
+            load_tw1_all<1>(w1);
+        } else {
+            pk2 first[j_of(1)];
+            load_tw1<1>(first);
+#pragma unroll
+            for (int j = 0; j < j_of(1); ++j) w1[j] = first[j];
+        }
+        float hq[J0][R0][4];
 #pragma unroll
         for (int j = 0; j < J0; ++j) {
-            float hq[R0][4];
+            if constexpr (!FXM_LEAN_TW_EARLY) if (j > 0) continue;      // (one stage ahead: the taps are fetched inside the loop below)
 #pragma unroll
-            for (int r = 0; r < R0; ++r) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
-                const v4u32 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (unsigned)(lt + j * TPR) * 16u, (unsigned)(r * nb_of(0)) * 16u, 0);
+            for (int r = 0; r < R0; ++r) fetch_taps(hq[j][r], j, r);
+        }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) hq[r][t] = __uint_as_float(q[t]);      // (past the table: zeros, and so are those lanes' samples)
-#else
-                const int m = has_item(0, j, lt) ? lt + j * TPR + r * nb_of(0) : 0;
+        for (int j = 0; j < J0; ++j) {
+            if constexpr (!FXM_LEAN_TW_EARLY) {
+                if (j > 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) hq[r][t] = ar.h4[4 * m + t];
-#endif
+                    for (int r = 0; r < R0; ++r) fetch_taps(hq[j][r], j, r);
+                }
             }
             pk2 acc[U][NA][R0];
 #pragma unroll
@@ -1002,16 +1031,22 @@ struct Body {
 #pragma unroll
                         for (int r = 0; r < R0; ++r) {
                             const pk2 x = th.ring[a][j * R0 + r][(P + u - t + NS) % NS];
-                            acc[u][a][r] = t == 0 ? pk_splat(hq[r][t]) * x : pk_fma(pk_splat(hq[r][t]), x, acc[u][a][r]);
+                            acc[u][a][r] = t == 0 ? pk_splat(hq[j][r][t]) * x : pk_fma(pk_splat(hq[j][r][t]), x, acc[u][a][r]);
                         }
-            load_points<(P + U) % NS>(f + U, f + U < f_end, j);
-            if constexpr (U == 2) load_points<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end, j);
+            if constexpr (!FXM_LEAN_TW_EARLY) {
+                load_points<(P + U) % NS>(f + U, f + U < f_end, j);
+                if constexpr (U == 2) load_points<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end, j);
+            }
             if (has_item(0, j, lt)) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int a = 0; a < NA; ++a) first_to_lds(acc[u][a], u * NA + a, j);
             }
+        }
+        if constexpr (FXM_LEAN_TW_EARLY) {      // every table entry of the step has been requested: now the samples
+            load_frame<(P + U) % NS>(f + U, f + U < f_end);
+            if constexpr (U == 2) load_frame<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end);
         }
         cx.sync();
         lean_stages<1>(bx, by, w1, f, f_end);
@@ -1020,6 +1055,19 @@ struct Body {
             bx = by;
             by = t;
         }
+    }
+    // LEAN: the (up to four) taps of point (j, r) of the thread from the table of quads
+    FX_HD void fetch_taps(float (&q4)[4], int j, int r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+        const v4u32 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (unsigned)(lt + j * TPR) * 16u, (unsigned)(r * nb_of(0)) * 16u, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q4[t] = __uint_as_float(q[t]);      // (past the table: zeros, and so are those lanes' samples)
+#else
+        const int m = has_item(0, j, lt) ? lt + j * TPR + r * nb_of(0) : 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q4[t] = ar.h4[4 * m + t];
+#endif
     }
 
     // UNR steps per trip: step k of a trip starts at ring slot (k U) mod NS

@@ -24,6 +24,8 @@ extern const char fxc_src_fx_mixed_h[];
 extern const char fxc_src_fx_math_h[];
 }
 
+#include "spec_tuned.h"
+
 namespace {
 
 // timing ablations of fx_spec.h (FXM_ABL: wrong results by design) exist in the developer library only
@@ -795,6 +797,9 @@ std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows, bool f
         if (s.ok) legacy.emplace_back(s.radix, s.radix + s.n_stages);
     }
     if (legacy.empty()) return out;
+    if (dev_env_int("FXC_RTC_COMPOSITE", 1) && dev_env_int("FXC_RTC_TUNED", 1) && dev_env_int("FXC_RTC_PICK", -1) < 0 && !fonly && rows == 2)
+        for (const SpecTuned& t : kSpecTuned)           // a measured choice for this channel count (spec_tuned.h): first
+            if (t.n == n) out.emplace_back(t.radix, t.radix + t.n_stages);
     if (dev_env_int("FXC_RTC_COMPOSITE", 1)) {
         std::vector<std::vector<int>> all;
         std::vector<int> cur;
@@ -818,7 +823,8 @@ std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows, bool f
             if (pick < (int)ranked.size()) out.push_back(all[ranked[pick].second]);
             return out;
         }
-        for (size_t k = 0; k < ranked.size() && k < 2; ++k) out.push_back(all[ranked[k].second]);
+        for (size_t k = 0; k < ranked.size() && k < 2; ++k)
+            if (std::find(out.begin(), out.end(), all[ranked[k].second]) == out.end()) out.push_back(all[ranked[k].second]);
     }
     for (const std::vector<int>& l : legacy)
         if (std::find(out.begin(), out.end(), l) == out.end()) out.push_back(l);
@@ -833,7 +839,7 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
     SpecBuild best;
     best.error = "no specialised kernel for this channel count";
     const int rows = spec_rows(n, variant);
-    const int force_u = dev_env_int("FXC_RTC_U", 0);
+    const int knob_u = dev_env_int("FXC_RTC_U", 0);
     int tried = 0;
     for (const std::vector<int>& list : spec_stage_lists(n, taps, rows, variant == kSpecFOnly)) {
         if (tried == 3) break;                       // (a compile is a second or two: three lists at most)
@@ -841,6 +847,10 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
         if (!one.ok) continue;
         ++tried;
         const SpecShape two = spec_shape_of(n, taps, list.data(), (int)list.size(), 2, rows);
+        int force_u = knob_u;
+        if (!force_u && taps == 4 && variant != kSpecFOnly)      // a measured choice (spec_tuned.h) names its frames per step too
+            for (const SpecTuned& t : kSpecTuned)
+                if (t.n == n && t.n_stages == (int)list.size() && std::equal(list.begin(), list.end(), t.radix)) force_u = t.u;
         SpecBuild b = (force_u == 2 && two.ok) ? SpecBuild() : spec_build_laid_out(one, variant, arch);
         if (two.ok && force_u != 1) {
             SpecBuild b2 = spec_build_laid_out(two, variant, arch);
@@ -864,7 +874,7 @@ std::string spec_knob_key() {
 #if FXC_DEV_KERNELS
     for (const char* name : {"FXC_RTC_ABL", "FXC_RTC_R0", "FXC_RTC_U", "FXC_RTC_LEAN_ABOVE", "FXC_RTC_TPR_MAX", "FXC_RTC_LD_AUX", "FXC_RTC_ROWS1_ABOVE",
                              "FXC_RTC_BIG_PRIMES", "FXC_RTC_RADICES", "FXC_RTC_GROUPS", "FXC_RTC_PADS", "FXC_RTC_PLANE0", "FXC_RTC_LAYOUT", "FXC_RTC_TWFULL",
-                             "FXC_RTC_WAVES", "FXC_RTC_COMPOSITE", "FXC_RTC_PICK"}) {
+                             "FXC_RTC_WAVES", "FXC_RTC_COMPOSITE", "FXC_RTC_PICK", "FXC_RTC_TUNED"}) {
         const char* e = std::getenv(name);
         k += std::string(e ? e : "") + ";";
     }

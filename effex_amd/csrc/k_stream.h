@@ -64,21 +64,26 @@ __global__ __launch_bounds__(256) void stream1_kernel(const cf* __restrict__ x, 
 constexpr int kStream4Blocks = 16;   // workgroups per chunk
 typedef float v4f32 __attribute__((ext_vector_type(4)));
 
-// ntaps <= 4, even num_samp: a lane takes one sample pair of both streams with an aligned 16-byte load; the two
-// earlier pairs the FIR needs come from the neighbouring lanes (v_mov_b32_dpp wave_shr:1), so a wave covers 62 new
-// pairs plus 2 halo lanes and every pair is loaded exactly once per wave (the halo from L1 instead cost 5 %)
-__device__ __forceinline__ float lane_shr1(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false));
+// ntaps <= 4, even num_samp: a lane takes one sample pair of both streams with an aligned 16-byte load; the two earlier pairs the FIR
+// needs come from the neighbouring lanes (v_mov_b32_dpp wave_shr:1).  A wave walks a CONTIGUOUS run of its workgroup's pairs, 64 new
+// pairs a trip: what lanes 0 and 1 need from before the trip are lanes 62 and 63 of the wave's own previous trip (v_readlane, shifted in
+// through the DPP move's `old` operand), so every pair is loaded exactly once -- in round 5 a wave covered 62 new pairs plus two halo
+// lanes, and with nontemporal loads the halo's lines came from HBM a second time (FETCH_SIZE read 1.089 x the algorithmic bytes:
+// profiles/r05/summary_stream1.json; now profiles/r06/summary_stream1.json).
+__device__ __forceinline__ float lane_shr1(float v, float first) {      // lane l <- v of lane l - 1; lane 0 <- first
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xF, 0xF, false));
 }
-__device__ __forceinline__ v4f32 wave_shr1(v4f32 v) {
-    const float x = lane_shr1(v.x), y = lane_shr1(v.y), z = lane_shr1(v.z), w = lane_shr1(v.w);
+__device__ __forceinline__ v4f32 wave_shr1(v4f32 v, v4f32 first) {
+    const float x = lane_shr1(v.x, first.x), y = lane_shr1(v.y, first.y), z = lane_shr1(v.z, first.z), w = lane_shr1(v.w, first.w);
     v4f32 r = {x, y, z, w};
     return r;
 }
+__device__ __forceinline__ v4f32 wave_lane(v4f32 v, int lane) {            // lane `lane`'s value in every lane (a scalar register)
+    v4f32 r = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), lane)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), lane)),
+               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), lane)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.w), lane))};
+    return r;
+}
 
-#ifndef FXC_STREAM1_NT
-#define FXC_STREAM1_NT 1      // nontemporal sample loads in the continuum streaming kernel: 5.52 - 5.74 -> 5.39 - 5.58 ms (profiles/r05/experiments.md 10)
-#endif
 __global__ __launch_bounds__(256) void stream1_t4_kernel(const cf* __restrict__ x, cf* __restrict__ raw, int64_t num_samp,
                                                             float h0, float h1, float h2, float h3, int64_t n_chunks) {
     __shared__ cf red[256];
@@ -91,17 +96,24 @@ __global__ __launch_bounds__(256) void stream1_t4_kernel(const cf* __restrict__ 
     const v4f32* s1 = reinterpret_cast<const v4f32*>(x + (c * 2 + 1) * num_samp);
     const v4f32 zero = {0.f, 0.f, 0.f, 0.f};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave's run of the workgroup's pairs (wave-uniform bounds)
+    const int64_t per_wave = (((p1 > p0 ? p1 - p0 : 0) + 3) / 4 + 63) / 64 * 64;
+    const int64_t q0 = p0 + wave * per_wave < p1 ? p0 + wave * per_wave : p1;
+    const int64_t q1 = q0 + per_wave < p1 ? q0 + per_wave : p1;
+    // the two pairs in front of the run (zeros in front of the chunk): what lanes 62 and 63 of a trip before the first would have held
+    v4f32 a62 = q0 >= 2 && q0 < q1 ? s0[q0 - 2] : zero, a63 = q0 >= 1 && q0 < q1 ? s0[q0 - 1] : zero;
+    v4f32 b62 = q0 >= 2 && q0 < q1 ? s1[q0 - 2] : zero, b63 = q0 >= 1 && q0 < q1 ? s1[q0 - 1] : zero;
     float ar = 0.f, ai = 0.f;
-    for (int64_t base = p0 + wave * 62; base < p1; base += 4 * 62) {      // wave-uniform trip count
-        const int64_t m = base + lane - 2;
-        const bool in_range = m >= 0 && m < pairs;
-#if FXC_STREAM1_NT
+    for (int64_t base = q0; base < q1; base += 64) {      // wave-uniform trip count
+        const int64_t m = base + lane;
+        const bool in_range = m < q1;
         const v4f32 a2 = in_range ? __builtin_nontemporal_load(s0 + m) : zero, b2 = in_range ? __builtin_nontemporal_load(s1 + m) : zero;
-#else
-        const v4f32 a2 = in_range ? s0[m] : zero, b2 = in_range ? s1[m] : zero;
-#endif
-        const v4f32 a1 = wave_shr1(a2), b1 = wave_shr1(b2);
-        const v4f32 a0 = wave_shr1(a1), b0 = wave_shr1(b1);
+        const v4f32 a1 = wave_shr1(a2, a63), b1 = wave_shr1(b2, b63);
+        const v4f32 a0 = wave_shr1(a1, a62), b0 = wave_shr1(b1, b62);
+        a62 = wave_lane(a2, 62);
+        a63 = wave_lane(a2, 63);
+        b62 = wave_lane(b2, 62);
+        b63 = wave_lane(b2, 63);
         const float y0er = h0 * a2[0] + h1 * a1[2] + h2 * a1[0] + h3 * a0[2];
         const float y0ei = h0 * a2[1] + h1 * a1[3] + h2 * a1[1] + h3 * a0[3];
         const float y0or = h0 * a2[2] + h1 * a2[0] + h2 * a1[2] + h3 * a1[0];
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(256) void stream1_t4_kernel(const cf* __restrict__ 
         const float y1ei = h0 * b2[1] + h1 * b1[3] + h2 * b1[1] + h3 * b0[3];
         const float y1or = h0 * b2[2] + h1 * b2[0] + h2 * b1[2] + h3 * b1[0];
         const float y1oi = h0 * b2[3] + h1 * b2[1] + h2 * b1[3] + h3 * b1[1];
-        if (lane >= 2 && m < p1) {
+        if (in_range) {
             ar += y0er * y1er + y0ei * y1ei + y0or * y1or + y0oi * y1oi;
             ai += y0ei * y1er - y0er * y1ei + y0oi * y1or - y0or * y1oi;
         }

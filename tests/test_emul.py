@@ -271,9 +271,11 @@ def test_specialised_kernel_shapes():
     for nchan, ntaps in ((997, 4), (1000, 5), (2 * 29, 4), (16384, 4), (2 * 1700, 4)):      # (3400 = 8 x 25 x 17: a 17-point butterfly has room on 256 threads, 2048 channels at most)
         assert _spec_shape(nchan, ntaps)[0] == _lib.FXC_ERR_UNSUPPORTED, (nchan, ntaps)
     rc, (flags, tpr, slots) = _spec_shape(1000, 4)
-    assert rc == 0 and (tpr, slots) == (256, 1) and "-DFXM_RADICES=4,2,5,5,5" in flags
+    stages = [int(v) for v in [f for f in flags if f.startswith("-DFXM_RADICES=")][0].split("=")[1].split(",")]
+    # 1000 = 4 x 2 x 5 x 5 x 5 in prime factors: composite radices (10 = 2 x 5 in registers) take fewer trips through LDS
+    assert rc == 0 and (tpr, slots) == (256, 1) and int(np.prod(stages)) == 1000 and len(stages) < 5 and stages[0] in (4, 5), stages
     rc, (flags, tpr, slots) = _spec_shape(96, 4)
-    assert (tpr, slots) == (32, 8)
+    assert tpr * slots == 256 and tpr in (32, 64)
     rc, (flags, tpr, slots) = _spec_shape(2 * 17, 4)      # prime factors 17 ... 23: the lean build (registers for the butterfly)
     assert rc == 0 and "-DFXM_LEAN=1" in flags and "-DFXM_RADICES=2,17" in flags
 
@@ -381,22 +383,50 @@ def test_specialised_kernels_are_cached_on_disk(tmp_path, monkeypatch):
     import time
     from effex_amd import _lib
     lib = _lib.load()
-    buf = ctypes.create_string_buffer(512)
+    buf = ctypes.create_string_buffer(1024)
     cache = tmp_path / "rtc"
     monkeypatch.setenv("FXC_RTC_CACHE", str(cache))
+
+    def shape_of(report):          # everything but where the code object came from
+        return report.split(b" source=")[0]
+
     t0 = time.time()
     assert lib.fxc_spec_probe(360, 4, 0, b"gfx950", buf, len(buf)) == 0
     cold, first = time.time() - t0, buf.value
+    assert first.endswith(b"source=built")
     files = sorted(cache.glob("*.co"))
     assert files and all(f.read_bytes()[:4] == b"\x7fELF" for f in files)
     t0 = time.time()
-    assert lib.fxc_spec_probe(360, 4, 0, b"gfx950", buf, len(buf)) == 0 and buf.value == first
+    assert lib.fxc_spec_probe(360, 4, 0, b"gfx950", buf, len(buf)) == 0 and shape_of(buf.value) == shape_of(first)
+    assert buf.value.endswith(b"source=cache")
     warm = time.time() - t0
     assert warm < 0.5 * cold, (cold, warm)
-    files[0].write_bytes(b"not a code object")
-    assert lib.fxc_spec_probe(360, 4, 0, b"gfx950", buf, len(buf)) == 0 and buf.value == first
+    for f in files:
+        f.write_bytes(b"not a code object")
+    assert lib.fxc_spec_probe(360, 4, 0, b"gfx950", buf, len(buf)) == 0 and shape_of(buf.value) == shape_of(first)
     assert files[0].read_bytes()[:4] == b"\x7fELF"
     off = tmp_path / "off"
     monkeypatch.setenv("FXC_RTC_CACHE", "0")
     assert lib.fxc_spec_probe(360, 4, 2, b"gfx950", buf, len(buf)) == 0
     assert not off.exists() and len(sorted(cache.glob("*.co"))) == len(files)
+
+
+def test_prebuilt_code_objects_answer_before_hiprtc(monkeypatch):
+    """The stated list of channel counts of effex_amd/build.py (PREBUILT_CHANNELS) ships as code objects beside the library
+    (csrc/rtc_prebuilt/, keyed by source + options + architecture, not by compiler): the shipped library finds them with the
+    run-time cache switched off, for every variant the shape has, and says so (fxc_spec_probe's source=, fxc_info.spec_source);
+    a channel count outside the list is built by hiprtc."""
+    from effex_amd import _lib
+    from effex_amd import build as fx_build
+    fx_build.prebuild()
+    lib = _lib.load()
+    monkeypatch.setenv("FXC_RTC_CACHE", "0")
+    buf = ctypes.create_string_buffer(1024)
+    for nchan in fx_build.PREBUILT_CHANNELS:
+        for variant in (0, 1, 2):
+            rc = lib.fxc_spec_probe(nchan, 4, variant, b"gfx950", buf, len(buf))
+            if rc == _lib.FXC_ERR_UNSUPPORTED:
+                assert nchan > 4096 and variant < 2
+                continue
+            assert rc == 0 and buf.value.endswith(b"source=prebuilt") and b"scratch=0" in buf.value, (nchan, variant, buf.value)
+    assert lib.fxc_spec_probe(1080, 4, 0, b"gfx950", buf, len(buf)) == 0 and buf.value.endswith(b"source=built")

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -47,7 +49,51 @@ static double time_ms(F launch) {
     return ms[ms.size() / 2];
 }
 
-int main() {
+// `copy_rate three [bytes]`: what three passes over `bytes` (default 8 589 934 592 = BASELINE configs[4]'s samples: 512 chunks x 8 antennas x 2^18 x 8 B)
+// cost the memory system at its best -- a copy (read once, write once) and a read of what was written, with the cache policies of the
+// shipped route (nontemporal loads and stores) and with the default ones: the ceiling an F pass + X pass through HBM can reach, as a
+// fraction of 8 TB/s over the ALGORITHMIC bytes (the samples alone).
+static int three_pass(size_t bytes) {
+    const size_t n = bytes / sizeof(v4f);
+    v4f *src, *dst;
+    float* out;
+    if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&dst, bytes) != hipSuccess || hipMalloc(&out, 64) != hipSuccess) return 1;
+    hipMemset(src, 1, bytes);
+    hipMemset(dst, 0, bytes);
+    const int grid = 256 * 16;
+    const double gb = (double)bytes / 1e9;
+    const double c_nt = time_ms([&] { hipLaunchKernelGGL((copy_kernel<true, true>), dim3(grid), dim3(256), 0, 0, src, dst, n); });
+    const double r_nt = time_ms([&] { hipLaunchKernelGGL((read_kernel<true>), dim3(grid), dim3(256), 0, 0, dst, out, n); });
+    const double c_df = time_ms([&] { hipLaunchKernelGGL((copy_kernel<false, false>), dim3(grid), dim3(256), 0, 0, src, dst, n); });
+    const double r_df = time_ms([&] { hipLaunchKernelGGL((read_kernel<false>), dim3(grid), dim3(256), 0, 0, dst, out, n); });
+    // back to back, as the route runs them
+    const double both_nt = time_ms([&] {
+        hipLaunchKernelGGL((copy_kernel<true, true>), dim3(grid), dim3(256), 0, 0, src, dst, n);
+        hipLaunchKernelGGL((read_kernel<true>), dim3(grid), dim3(256), 0, 0, dst, out, n);
+    });
+    std::printf("{\"bytes\": %zu, \"copy_nt_ms\": %.3f, \"read_nt_ms\": %.3f, \"copy_default_ms\": %.3f, \"read_default_ms\": %.3f, \"copy_then_read_nt_ms\": %.3f, "
+                "\"three_pass_ceiling_of_8TBs_nt\": %.4f, \"three_pass_ceiling_of_8TBs_default\": %.4f}\n",
+                bytes, c_nt, r_nt, c_df, r_df, both_nt, gb / both_nt * 1e3 / 8000.0, gb / (c_df + r_df) * 1e3 / 8000.0);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "read16") {      // one read-only pass of 4 GiB with 16-byte loads, for `rocprofv3 --pmc FETCH_SIZE` (calibrates the gfx950 x 2)
+        const size_t bytes = (size_t)4 << 30, n = bytes / sizeof(v4f);
+        v4f* src;
+        float* out;
+        if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&out, 64) != hipSuccess) return 1;
+        hipMemset(src, 1, bytes);
+        const bool nt = argc > 2 && std::string(argv[2]) == "nt";
+        for (int r = 0; r < 5; ++r) {
+            if (nt) hipLaunchKernelGGL((read_kernel<true>), dim3(256 * 16), dim3(256), 0, 0, src, out, n);
+            else hipLaunchKernelGGL((read_kernel<false>), dim3(256 * 16), dim3(256), 0, 0, src, out, n);
+        }
+        hipDeviceSynchronize();
+        std::printf("read16 %s: 5 launches of %zu bytes\n", nt ? "nt" : "default", bytes);
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "three") return three_pass(argc > 2 ? (size_t)std::atoll(argv[2]) : (size_t)8589934592ull);
     const size_t bytes = (size_t)4 << 30;      // 4 GiB in, 4 GiB out
     const size_t n = bytes / sizeof(v4f);
     v4f *src, *dst;
