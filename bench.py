@@ -437,7 +437,8 @@ def other_configs(x, dev, reps=5):
             ms.sort()
             med = ms[len(ms) // 2]
             algo = need * 8
-            out.append({"config": name, "path": plan.path, "specialised_per_channel_count": bool(plan.info["specialised"]), "n_ant": n_ant, "nchan": nchan, "ntaps": ntaps, "num_samp": num_samp,
+            out.append({"config": name, "path": plan.path, "specialised_per_channel_count": bool(plan.info["specialised"]),
+                        "code_object": {0: None, 1: "built by hiprtc", 2: "run-time cache", 3: "pre-built (rtc_prebuilt/)"}.get(plan.info["spec_source"]), "n_ant": n_ant, "nchan": nchan, "ntaps": ntaps, "num_samp": num_samp,
                         "n_chunks": n_chunks, "mode": mode, "median_ms": round(med, 4),
                         "value": round(n_chunks * num_samp / med / 1e3, 1), "unit": "Msamples/s",
                         "algorithmic_GBps": round(algo / med / 1e6, 1), "frac_of_8TBs": round(algo / med / 1e6 / HBM_PEAK_GBS, 4)})

@@ -35,12 +35,6 @@ FX_HD int range_owner(int f, int n, int g) { return (int)((((long long)f + 1) * 
 
 FX_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
 
-// FXC_STREAM_AUX: cache policy of the streaming accesses outside the headline kernel (the samples on their way into a ring, spectra
-// on their way from an F pass to an X pass): 0 default policy, 2 nontemporal
-#ifndef FXC_STREAM_AUX
-#define FXC_STREAM_AUX 0
-#endif
-
 // Streaming accesses -- data a kernel touches once (spectra on their way from an F pass to an X pass): the nontemporal hint keeps
 // them from displacing what the caches are for.  Host build: plain accesses.
 FX_HD cf nt_load(const cf* p) {
@@ -56,11 +50,10 @@ FX_HD cf nt_load(const cf* p) {
 #endif
 }
 FX_HD void nt_store(cf* p, cf v);
-FX_HD cf st_load(const cf* p) { return FXC_STREAM_AUX ? nt_load(p) : *p; }
-FX_HD void st_store(cf* p, cf v) {
-    if (FXC_STREAM_AUX) nt_store(p, v);
-    else *p = v;
-}
+// (the spectra of the any-shape and per-channel-count F passes and the two-pass 8192 route keep the default policy: nontemporal there
+// measured neutral to 4 % slower, profiles/r05/experiments.md 10)
+FX_HD cf st_load(const cf* p) { return *p; }
+FX_HD void st_store(cf* p, cf v) { *p = v; }
 FX_HD void nt_store(cf* p, cf v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float nt_v2f __attribute__((ext_vector_type(2)));

@@ -62,10 +62,6 @@
 #ifndef FXM_ROWS
 #define FXM_ROWS 2
 #endif
-// FXM_LD_AUX: cache policy of the F + X builds' sample loads (h_rtc.h; 0 default, 2 nontemporal)
-#ifndef FXM_LD_AUX
-#define FXM_LD_AUX 0
-#endif
 #ifndef FXM_PLANE0
 #define FXM_PLANE0 0     // > 0: the first stage stores output q of butterfly b at q PLANE0 + b (consecutive lanes, consecutive addresses)
 #endif
@@ -604,7 +600,7 @@ struct Body {
     // thread (it carries the frame: slots inside one wave are at different frames), the point's place in the frame is an
     // immediate, the antenna a buffer descriptor of its own.
     static constexpr int kElem = U8 ? 2 : 8;                  // bytes per sample
-    static constexpr int kLoadAux = FONLY ? FXC_STREAM_AUX : FXM_LD_AUX;      // cache policy of the sample loads (2: nontemporal)
+    static constexpr int kLoadAux = 0;      // cache policy of the sample loads: default (nontemporal measured neutral to slower here: profiles/r05/experiments.md 10)
     template <int P>
     FX_HD void load_frame(long long f, bool valid) {
 #pragma unroll

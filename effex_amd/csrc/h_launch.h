@@ -155,6 +155,9 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
             FXC_HIP(p, hipModuleLaunchKernel(k->fn, (unsigned)grid, 1, 1, (unsigned)k->shape.threads(), 1, 1, 0, p->stream, params, nullptr));
             return FXC_OK;
         }
+        if (env_int("FXC_RTC_VERBOSE", 0))      // (results stay correct: the any-shape kernel below takes the call)
+            std::fprintf(stderr, "libfxcorr: %d channels: the %s build of the kernel per channel count does not take this call (%s), the any-shape kernel does\n",
+                         p->nchan, dc_u8 ? "byte-ingest" : "complex64", !k ? "no such build" : "its slots per workgroup do not divide the call's row splits");
     }
     const int threads = std::max(256, p->mixed_tpr);
     const int rpw = threads / p->mixed_tpr;

@@ -23,9 +23,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // CNT branches of a frame into ring registers; U8: the stream is byte pairs (uint8 I, Q), a pair goes into .x as it is
 // and convert_frame_u8 turns the slot into samples when its frame comes up (k_fused4096.h)
-#ifndef FXC_SMALL_NT
-#define FXC_SMALL_NT 100000      // nontemporal sample loads of the wave-local kernels from this many channels on (16 channels: 2.4 x SLOWER)
-#endif
+// (default cache policy on the sample loads: nontemporal measured 2.4 x SLOWER at 16 channels and no gain at 256, profiles/r05/experiments.md 10)
 template <class G, int CNT, bool U8>
 __device__ __forceinline__ void small_load(cf (&xr)[16], const cf* __restrict__ frame, int r0) {
     if (U8) {
@@ -34,7 +32,7 @@ __device__ __forceinline__ void small_load(cf (&xr)[16], const cf* __restrict__ 
         for (int r = r0; r < r0 + CNT; ++r) xr[r].x = __uint_as_float((unsigned)f8[G::P * (15 - r)]);
     } else {
 #pragma unroll
-        for (int r = r0; r < r0 + CNT; ++r) xr[r] = (G::N >= FXC_SMALL_NT) ? fxc::nt_load(frame + G::P * (15 - r)) : frame[G::P * (15 - r)];
+        for (int r = r0; r < r0 + CNT; ++r) xr[r] = frame[G::P * (15 - r)];
     }
 }
 

@@ -89,9 +89,6 @@ __device__ __forceinline__ void tiled_fir2(cf (&v0)[16], cf (&v1)[16], bool two,
 // bin_of(u, k2) in v[k2]; the exchange region serves as a transposition buffer (bin k at k + (k >> 4): the
 // 16 lanes of a group write 17 or R0 + 1/16 slots apart, conflict-free) and the rows go out 256 B per half-wave.
 // valid: this lane's stream exists (an odd stream count leaves the last pair half empty).
-#ifndef FXC_TILED_ST_NT
-#define FXC_TILED_ST_NT 0      // nontemporal stores of the F-only tiled kernels' spectra
-#endif
 template <class G>
 __device__ __forceinline__ void tiled_store_spectrum(const cf (&v)[16], cf* reg, int u, cf* out_row, bool valid) {
     __syncthreads();   // every wave holds its stage-C outputs in registers: the rows can be overwritten
@@ -108,8 +105,7 @@ __device__ __forceinline__ void tiled_store_spectrum(const cf (&v)[16], cf* reg,
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
             const cf o = fxc::fused::lds_load(rd + (G::P + G::P / 16) * n);
-            if (FXC_TILED_ST_NT) fxc::nt_store(dst + G::P * n, o);
-            else fxc::st_store(dst + G::P * n, o);
+            fxc::st_store(dst + G::P * n, o);
         }
     }
 }
@@ -446,13 +442,8 @@ using G8192 = fxc::tiled::Geo<2, true>;
 constexpr int kF8192Threads = G8192::P;                                          // 512
 // exchange rows of one stream + w256 table + the stage-A table + the window quads of the first kF8192WinLds branch groups (the
 // other 16 - kF8192WinLds groups -- the window is 128 KiB -- come from L2 every frame): 158 KiB
-// cache policy of the two-pass route's private spectra: pass 1's stores, pass 2's loads (0 default, 2 nontemporal)
-#ifndef FXC_X8192_ST_AUX
-#define FXC_X8192_ST_AUX FXC_STREAM_AUX
-#endif
-#ifndef FXC_X8192_LD_AUX
-#define FXC_X8192_LD_AUX FXC_STREAM_AUX
-#endif
+// (the two-pass route's private spectra -- pass 1's stores, pass 2's loads -- keep the default cache policy: nontemporal measured neutral
+// to slightly worse, profiles/r05/experiments.md 10)
 constexpr int kF8192WinLds = 7;
 
 constexpr int kF8192LdsCf = G8192::kRegion + 256 + 16 * 256 + kF8192WinLds * G8192::P * 2;
@@ -561,7 +552,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
         __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf*>(in0_row + i * (int64_t)G::N), 0, (int)(G::N * sizeof(cf)), 0x00020000);
 #pragma unroll
         for (int n = 0; n < kX8192Early; ++n) {
-            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_X8192_LD_AUX);
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
             s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
         }
         G::loadC(reg, u, v);
@@ -569,7 +560,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
         FXC_SCHED_FENCE();
 #pragma unroll
         for (int n = kX8192Early; n < 16; ++n) {
-            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_X8192_LD_AUX);
+            const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(r0, poff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
             s0[n] = fxc::mk(__uint_as_float(d[0]), __uint_as_float(d[1]));
         }
 #pragma unroll
@@ -584,7 +575,7 @@ __device__ __forceinline__ void f8192_step(cf (&h)[4][16], const f4* __restrict_
                 v2u32 d;
                 d[0] = __float_as_uint(v[n].x);
                 d[1] = __float_as_uint(v[n].y);
-                __builtin_amdgcn_raw_buffer_store_b64(d, rr, poff, (unsigned)(G::P * n * (int)sizeof(cf)), FXC_X8192_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(d, rr, poff, (unsigned)(G::P * n * (int)sizeof(cf)), 0);
             }
         } else {
             tiled_store_spectrum<G>(v, reg, u, out_row + i * out_step, true);

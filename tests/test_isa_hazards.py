@@ -116,14 +116,15 @@ def test_specialised_kernels_keep_their_registers(tmp_path, nchan, variant):
     barrier per LDS round trip (S - 1 per step)."""
     import ctypes
     from effex_amd import _lib
-    buf = ctypes.create_string_buffer(512)
+    buf = ctypes.create_string_buffer(1024)
     assert _lib.load().fxc_spec_probe(nchan, 4, variant, b"gfx950", buf, len(buf)) == 0
     rep = dict(kv.split("=") for kv in buf.value.decode().split())
     assert int(rep["scratch"]) == 0 and 0 < int(rep["vgprs"]) <= 512 // max(1, (int(rep["tpr"]) * int(rep["slots"]) // 64 + 3) // 4 * int(rep["resident"]))
     stages = rep["stages"].split(",")
     flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=4", "-DFXM_TPR=" + rep["tpr"], "-DFXM_SLOTS=" + rep["slots"], "-DFXM_NST=%d" % len(stages),
              "-DFXM_RADICES=" + rep["stages"], "-DFXM_U8=%d" % int(variant == 1), "-DFXM_FONLY=%d" % int(variant == 2), "-DFXM_U=" + rep["frames_per_step"],
-             "-DFXM_LEAN=" + rep["lean"], "-DFXM_ROWS=" + rep["rows"]]
+             "-DFXM_LEAN=" + rep["lean"], "-DFXM_ROWS=" + rep["rows"], "-DFXM_GROUPS=" + rep["groups"], "-DFXM_PADS=" + rep["pads"],
+             "-DFXM_PLANE0=" + rep["plane0"], "-DFXM_TWFULL=" + rep["twfull"], "-DFXM_WAVES=" + rep["waves"]]
     src = tmp_path / "spec.hip"
     src.write_text('#include "fx_spec.h"\n')
     asm = tmp_path / "spec.s"
@@ -138,4 +139,8 @@ def test_specialised_kernels_keep_their_registers(tmp_path, nchan, variant):
     if int(rep["tpr"]) > 64 and len(stages) >= 2:
         unrolled = (4 + int(rep["frames_per_step"]) - 1)
         unrolled //= __import__("math").gcd(unrolled, int(rep["frames_per_step"]))
-        assert ops.count("s_barrier") == unrolled * (len(stages) - 1), (ops.count("s_barrier"), unrolled, stages)
+        # (+ 2 once per launch where the last stage's items split a step's frames over threads: their sums meet in LDS at the end)
+        rows_per_step = int(rep["rows"]) * int(rep["frames_per_step"])
+        last_group = int(rep["groups"].split(",")[-1]) or rows_per_step
+        tail = 2 if (variant != 2 and last_group < rows_per_step) else 0
+        assert ops.count("s_barrier") == unrolled * (len(stages) - 1) + tail, (ops.count("s_barrier"), unrolled, stages, tail)

@@ -3,7 +3,7 @@
 # WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md: they do not fit one pass), GRBM_GUI_ACTIVE (effective clock) in a
 # third — for bench.py and the named
 # workloads of tools/prof_workload.py.  Raw output under gpurun_out/$1/raw; tools/summarize_profiles.py makes the summaries.
-#   gpurun -- 'bash tools/collect_profiles.sh r03'
+#   gpurun -- 'bash tools/collect_profiles.sh r03 ["8ant stream1 ..."]'
 set -u
 tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$PWD}
@@ -19,5 +19,5 @@ run() {   # name, program args...
 }
 # the driver's own command line (20 timed steps after 5 warm-up steps), minus the CPU leg and the untimed extras
 run bench "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-power --no-other-configs --no-verify
-for w in 8ant stream1 nfft2048 taps32 nfft256 nfft16 16ant 32ant res1000; do run $w "$root/tools/prof_workload.py" $w 10; done
+for w in ${2:-8ant stream1 nfft2048 taps32 nfft256 nfft16 16ant 32ant res1000}; do run $w "$root/tools/prof_workload.py" $w 10; done
 python3 "$root/tools/summarize_profiles.py" "$root/gpurun_out/$tag"
