@@ -885,16 +885,9 @@ struct Body {
             dft_to<R0>(v, bx + row * RS + b * (R0 + pad_of(0)), 1);      // ns = 1: o = b R0
     }
 
-    // ---- one step: the FIR of its U frames out of the ring, the first butterfly, the stages, X.  P = the ring slot of the
-    // step's first frame f.  Frame f + u exists for this slot while f + u < f_end (the slots of a workgroup take the same number of
-    // steps); frames from f_end on are not loaded
+    // the FIR of the step at ring slot P (frames f ...) into sums, and the next frames' samples requested into the slots it leaves
     template <int P>
-    FX_HD void step(long long f, long long f_end) {
-        if constexpr (LEAN) {
-            step_lean<P>(f, f_end);
-            return;
-        }
-        pk2 acc[U][NA][PTS];
+    FX_HD void fir_and_load(long long f, long long f_end, pk2 (&acc)[U][NA][PTS]) {
 #pragma unroll
         for (int t = 0; t < T; ++t)                     // (tap outside: consecutive instructions belong to different points)
 #pragma unroll
@@ -910,6 +903,18 @@ struct Body {
         // the U oldest slots are free now: the next step's frames go there, in flight through the stages below
         load_frame<(P + U) % NS>(f + U, f + U < f_end);
         if constexpr (U == 2) load_frame<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end);
+    }
+    // ---- one step: the FIR of its U frames out of the ring, the first butterfly, the stages, X.  P = the ring slot of the
+    // step's first frame f.  Frame f + u exists for this slot while f + u < f_end (the slots of a workgroup take the same number of
+    // steps); frames from f_end on are not loaded
+    template <int P>
+    FX_HD void step(long long f, long long f_end) {
+        if constexpr (LEAN) {
+            step_lean<P>(f, f_end);
+            return;
+        }
+        pk2 acc[U][NA][PTS];
+        fir_and_load<P>(f, f_end, acc);
         if constexpr (S == 1) {
 #pragma unroll
             for (int j = 0; j < J0; ++j)
@@ -957,6 +962,7 @@ struct Body {
 #ifndef FXM_LEAN_TW_EARLY
 #define FXM_LEAN_TW_EARLY 1
 #endif
+    static constexpr bool TW_EARLY = FXM_LEAN_TW_EARLY != 0 && TW1C <= 12;      // (3^8 channels: 35 entries -- 70 registers -- spilled; those keep one stage ahead)
     template <int s>
     FX_HD void load_tw1_all(pk2 (&all)[TW1C > 0 ? TW1C : 1]) {
         if constexpr (s < S) {
@@ -972,7 +978,7 @@ struct Body {
     template <int s>
     FX_HD void lean_stages(cf* rd, cf* wr, const pk2* w1, long long f, long long f_end) {
         if constexpr (s < S - 1) {
-            if constexpr (FXM_LEAN_TW_EARLY) {
+            if constexpr (TW_EARLY) {
                 mid_stage<s>(rd, wr, w1 + tw_base(s));
                 cx.sync();
                 lean_stages<s + 1>(wr, rd, w1, f, f_end);
@@ -984,17 +990,17 @@ struct Body {
                 lean_stages<s + 1>(wr, rd, nxt, f, f_end);
             }
         } else {
-            last_stage(rd, f, f_end, FXM_LEAN_TW_EARLY ? w1 + tw_base(s) : w1);
+            last_stage(rd, f, f_end, TW_EARLY ? w1 + tw_base(s) : w1);
         }
     }
 
     // LEAN (S >= 2): one first-stage butterfly at a time -- its points' taps from L2, their FIR, the butterfly into LDS -- so that only R0
-    // points' taps and sums are live at once; then the next frames' samples into the ring slots the FIR has left
+    // points' taps and sums are live at once; the next frames' samples go into the ring slots the FIR has left (early: behind all of them)
     template <int P>
     FX_HD void step_lean(long long f, long long f_end) {
         static_assert(!LEAN || S >= 2, "the lean build needs a first stage into LDS (h_rtc.h::spec_shape)");
-        pk2 w1[FXM_LEAN_TW_EARLY ? (TW1C > 0 ? TW1C : 1) : j_of(1)];
-        if constexpr (FXM_LEAN_TW_EARLY) {
+        pk2 w1[TW_EARLY ? (TW1C > 0 ? TW1C : 1) : j_of(1)];
+        if constexpr (TW_EARLY) {
             load_tw1_all<1>(w1);
         } else {
             pk2 first[j_of(1)];
@@ -1002,21 +1008,11 @@ struct Body {
 #pragma unroll
             for (int j = 0; j < j_of(1); ++j) w1[j] = first[j];
         }
-        float hq[J0][R0][4];
 #pragma unroll
         for (int j = 0; j < J0; ++j) {
-            if constexpr (!FXM_LEAN_TW_EARLY) if (j > 0) continue;      // (one stage ahead: the taps are fetched inside the loop below)
+            float hq[R0][4];
 #pragma unroll
-            for (int r = 0; r < R0; ++r) fetch_taps(hq[j][r], j, r);
-        }
-#pragma unroll
-        for (int j = 0; j < J0; ++j) {
-            if constexpr (!FXM_LEAN_TW_EARLY) {
-                if (j > 0) {
-#pragma unroll
-                    for (int r = 0; r < R0; ++r) fetch_taps(hq[j][r], j, r);
-                }
-            }
+            for (int r = 0; r < R0; ++r) fetch_taps(hq[r], j, r);
             pk2 acc[U][NA][R0];
 #pragma unroll
             for (int t = 0; t < T; ++t)
@@ -1027,9 +1023,9 @@ struct Body {
 #pragma unroll
                         for (int r = 0; r < R0; ++r) {
                             const pk2 x = th.ring[a][j * R0 + r][(P + u - t + NS) % NS];
-                            acc[u][a][r] = t == 0 ? pk_splat(hq[j][r][t]) * x : pk_fma(pk_splat(hq[j][r][t]), x, acc[u][a][r]);
+                            acc[u][a][r] = t == 0 ? pk_splat(hq[r][t]) * x : pk_fma(pk_splat(hq[r][t]), x, acc[u][a][r]);
                         }
-            if constexpr (!FXM_LEAN_TW_EARLY) {
+            if constexpr (!TW_EARLY || J0 > 2) {      // (many first butterflies a thread: the samples of each behind its FIR, as the ring frees)
                 load_points<(P + U) % NS>(f + U, f + U < f_end, j);
                 if constexpr (U == 2) load_points<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end, j);
             }
@@ -1040,7 +1036,7 @@ struct Body {
                     for (int a = 0; a < NA; ++a) first_to_lds(acc[u][a], u * NA + a, j);
             }
         }
-        if constexpr (FXM_LEAN_TW_EARLY) {      // every table entry of the step has been requested: now the samples
+        if constexpr (TW_EARLY && J0 <= 2) {      // every table entry of the step has been requested: now the samples
             load_frame<(P + U) % NS>(f + U, f + U < f_end);
             if constexpr (U == 2) load_frame<(P + U + 1) % NS>(f + U + 1, f + U + 1 < f_end);
         }

@@ -903,8 +903,10 @@ const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
     SpecKernel* k = new SpecKernel;
     g_spec_cache[key] = k;
     hipDeviceProp_t prop;
+    // (a failure that may not repeat -- the device query, the module load, device memory -- is not remembered: the next plan tries again)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
         k->error = "hipGetDeviceProperties failed";
+        g_spec_cache.erase(key);
         return k;
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -913,6 +915,7 @@ const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
     k->source = b.source;
     if (b.image.empty()) {
         k->error = b.error;
+        if (b.error.find("libhiprtc") != std::string::npos) g_spec_cache.erase(key);      // (no compiler in reach yet: not a property of the shape)
         return k;
     }
     k->shape = b.shape;
@@ -928,6 +931,7 @@ const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
     if (e != hipSuccess) {
         k->error = std::string("loading the compiled kernel: ") + hipGetErrorString(e);
         k->fn = nullptr;
+        g_spec_cache.erase(key);
         return k;
     }
     if (k->shape.lean) {
@@ -936,6 +940,7 @@ const SpecKernel* spec_kernel(int device, int n, int taps, int variant) {
             hipMemcpy(k->d_tw1, t.data(), t.size() * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess) {
             k->error = "the twiddle table of the lean build: out of device memory";
             k->fn = nullptr;
+            g_spec_cache.erase(key);
             return k;
         }
     }

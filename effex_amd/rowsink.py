@@ -27,6 +27,7 @@ Rows can be written one at a time, a batch at a time, or by filling a memory-map
 produced for the same rows, so ``post_process.py``-style readers keep working.
 """
 import os
+import threading
 import time
 import struct
 
@@ -105,6 +106,9 @@ class BinSink(object):
         self._fh.flush()
         self.rows = 0                 # rows committed
         self._published_at = 0.0
+        self._published_rows = 0
+        self._timer = None            # a pending late publication (write_rows)
+        self._lock = threading.RLock()
         self._map = None
         self._map_rows = 0            # rows the file is currently sized for beyond `rows`
         self.row_bytes = self.row_len * self.row_dtype.itemsize
@@ -114,6 +118,10 @@ class BinSink(object):
 
     def write_rows(self, rows):
         rows = np.ascontiguousarray(rows, dtype=self.row_dtype).reshape(-1, self.row_len)
+        with self._lock:
+            self._write_rows_locked(rows)
+
+    def _write_rows_locked(self, rows):
         self._drop_map()
         self._fh.seek(self.data_offset + self.rows * self.row_bytes)
         self._fh.write(rows.view(np.uint8).data)
@@ -123,12 +131,31 @@ class BinSink(object):
         now = time.monotonic()
         if len(rows) > 1 or now - self._published_at >= 0.1:
             self._publish()
+        elif self._timer is None:
+            # ... and a row whose publication was put off does not wait for the NEXT row to arrive (a source that stalls would leave
+            # it in this process's buffer, its count stale, for as long as the stall lasts): a one-shot timer publishes it 0.1 s on
+            self._timer = threading.Timer(0.1, self._publish_late)
+            self._timer.daemon = True
+            self._timer.start()
+
+    def _publish_late(self):
+        with self._lock:
+            self._timer = None
+            if self._fh is not None and self.rows > self._published_rows:
+                self._publish()
+
+    def flush(self):
+        """Publish every committed row now (the Correlator calls it when its source blocks)."""
+        with self._lock:
+            if self._fh is not None and self.rows > self._published_rows:
+                self._publish()
 
     def _publish(self):
         """The committed-row count goes into the preamble behind the rows it counts (same file object: ordered)."""
         self._fh.flush()
         os.pwrite(self._fh.fileno(), struct.pack("<Q", self.rows), self._count_at)
         self._published_at = time.monotonic()
+        self._published_rows = self.rows
 
     def reserve(self, n_rows):
         """A writable [n_rows, row_len] view of the file just behind the committed rows (the file grows to hold it);
@@ -159,6 +186,13 @@ class BinSink(object):
         self._map_rows = 0
 
     def close(self):
+        timer, self._timer = self._timer, None
+        if timer is not None:
+            timer.cancel()
+        with self._lock:
+            self._close_locked()
+
+    def _close_locked(self):
         if self._fh is not None:
             self._drop_map()
             self._fh.flush()

@@ -545,3 +545,24 @@ def test_binary_sidecar_rejects_other_files(tmp_path):
     p.write_text("run_time:1\n" + "x" * 100)
     with pytest.raises(ValueError):
         rowsink.RowFile(str(p))
+
+
+def test_bin_sink_publishes_a_lone_row_without_waiting_for_the_next(tmp_path):
+    """The per-row writer (one visibility per call, effex.py:689-693) puts publications off by up to 0.1 s; a row written just after a
+    publication must still reach a follower of the live file when the source then stalls: a one-shot timer publishes it, and
+    flush() does so at once."""
+    import time
+    from effex_amd import rowsink
+    path = str(tmp_path / "live.fxb")
+    sink = rowsink.BinSink(path, rowsink.header_line(1, 2.4e6, 1.4204e9, 4096, 8, 49.6, "SPECTRUM"), None, 8)
+    sink.write(np.full(8, 1, np.complex64))
+    sink.write(np.full(8, 2, np.complex64))          # within 0.1 s of the first: not published by the write itself
+    assert len(rowsink.RowFile(path).rows) == 1
+    time.sleep(0.35)                                 # the source stalls
+    rows = np.asarray(rowsink.RowFile(path).rows)
+    assert rows.shape[0] == 2 and rows[1, 0] == 2
+    sink.write(np.full(8, 3, np.complex64))
+    sink.flush()
+    assert len(rowsink.RowFile(path).rows) == 3
+    sink.close()
+    assert len(rowsink.RowFile(path).rows) == 3

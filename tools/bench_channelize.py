@@ -20,7 +20,7 @@ def main():
         x = torch.empty((n_streams // 2, 2, num_samp), dtype=torch.complex64, device="cuda")
         synth_fill(x, 1234)
         xs = x.view(n_streams, num_samp)
-        with FxPlan(1, nchan, ntaps, num_samp) as plan:
+        with FxPlan(1, nchan, ntaps, num_samp, dev=bool(os.environ.get("FXC_DEV"))) as plan:      # (FXC_DEV=1: the developer library and its knobs)
             out = plan.channelize(xs)
             plan.sync()
             ts = []
@@ -32,7 +32,7 @@ def main():
             ts.sort()
             ms = ts[len(ts) // 2]
             gb = n_streams * num_samp * 8 / 1e9
-            print(json.dumps({"nchan": nchan, "ntaps": ntaps, "streams": n_streams, "median_ms": round(ms, 3),
+            print(json.dumps({"tag": os.environ.get("FXC_TAG", ""), "nchan": nchan, "ntaps": ntaps, "streams": n_streams, "median_ms": round(ms, 3),
                               "Msamples_per_s": round(n_streams * num_samp / ms / 1e3, 1),
                               "in_plus_out_GBps": round(2 * gb / ms * 1e3, 1)}), flush=True)
             del out

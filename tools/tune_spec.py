@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-KNOBS = ("FXC_RTC_COMPOSITE", "FXC_RTC_PICK", "FXC_RTC_RADICES", "FXC_RTC_U")
+KNOBS = ("FXC_RTC_COMPOSITE", "FXC_RTC_PICK", "FXC_RTC_RADICES", "FXC_RTC_U", "FXC_RTC_TUNED", "FXC_RTC_LAYOUT", "FXC_RTC_WAVES", "FXC_RTC_GROUPS")
 
 
 def main():
@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--chunks", type=int, default=1024)
     ap.add_argument("--lists", default="", help="extra stage lists to time for every case that they multiply to, e.g. 4,25,10;5,20,10")
+    ap.add_argument("--env-arms", default="", help="instead of legacy / pick arms: one arm per ';'-separated group of NAME=VALUE assignments (',' between them), "
+                                                   "e.g. 'FXC_RTC_LAYOUT=0;FXC_RTC_LAYOUT=1' -- the library's own choice under each")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -41,6 +43,8 @@ def main():
     for nchan in (int(v) for v in args.cases.split(",")):
         arms = [("legacy", {"FXC_RTC_COMPOSITE": "0"})] + [("pick%d" % k, {"FXC_RTC_PICK": str(k)}) for k in range(args.picks)]
         arms += [("list", {"FXC_RTC_RADICES": ",".join(map(str, l))}) for l in extra if int(np.prod(l)) == nchan]
+        if args.env_arms:
+            arms = [(grp, dict(kv.split("=") for kv in grp.split(",") if kv)) for grp in args.env_arms.split(";")]
         ns, nc = nchan * 37 + 5, 3
         xs = synth.synth_iq(99 + nchan, nc, 2, ns)
         window = design_window(args.taps, nchan)
@@ -55,7 +59,7 @@ def main():
                 print(json.dumps({"nchan": nchan, "tag": tag, "error": (lib.fxc_last_error(None) or b"").decode()[:200]}), flush=True)
                 continue
             rep = dict(kv.split("=") for kv in buf.value.decode().split())
-            key = (rep["stages"], rep["frames_per_step"], rep["groups"])
+            key = (rep["stages"], rep["frames_per_step"], rep["groups"], tag if args.env_arms else "")
             if key in seen:
                 continue
             seen.add(key)
