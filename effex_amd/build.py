@@ -82,7 +82,7 @@ def prebuild(force=False, verbose=False):
     try:
         for nchan in PREBUILT_CHANNELS:
             for taps in PREBUILT_TAPS:
-                for variant in (0, 1, 2):
+                for variant in (0, 1, 2) + ((3,) if nchan > 4096 else ()):      # (3: the second pass of two antennas above 4096 channels)
                     report = ctypes.create_string_buffer(1024)
                     rc = lib.fxc_spec_probe(nchan, taps, variant, b"gfx950", report, len(report))
                     if verbose:

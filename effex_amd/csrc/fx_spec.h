@@ -35,6 +35,13 @@
 #define FXM_FONLY 0      // 1: the F stage alone -- a slot's two rows are two STREAMS (2 pair, 2 pair + 1) and the last butterfly's outputs are
                          // the spectra, stored in natural order; replaces cusignal's channelize_poly + .T (effex.py:553) at any channel count
 #endif
+// FXM_XM 1 (with FXM_FONLY 1, FXM_ROWS 1): the second pass of two antennas above 4096 channels (a thread cannot hold sixteen points of two
+// antennas): antenna 1 through the stages, and instead of storing its spectra the last butterfly loads antenna 0's values of the same bins
+// (written by an F-only launch before: Args::spec0, [stream][frame][N], natural order), multiplies and adds to the thread's sums -- the X stage
+// of effex.py:516-521 with antenna 0's spectra through HBM once (2 x the algorithmic bytes; spectra of both + xmul_kernel: 3 x)
+#ifndef FXM_XM
+#define FXM_XM 0
+#endif
 #ifndef FXM_U
 #define FXM_U 1          // frames a slot carries through every step together (2: half the barriers per frame, twice the work in flight)
 #endif
@@ -88,6 +95,7 @@ constexpr int kRadix[S] = {FXM_RADICES};
 constexpr bool U8 = FXM_U8 != 0;
 constexpr int U = FXM_U;
 constexpr bool FONLY = FXM_FONLY != 0;
+constexpr bool XM = FXM_XM != 0;                 // the F stage of ONE stream whose spectra are multiplied by another stream's (Args::spec0) and summed
 constexpr bool LEAN = FXM_LEAN != 0;
 constexpr int NA = FXM_ROWS;                     // streams a workgroup carries through a step: the two antennas, or (F only) one or two streams
 constexpr int THREADS = TPR * SLOTS;
@@ -174,6 +182,8 @@ static_assert(T >= 1 && T <= 4, "one to four taps (the ring lives in registers)"
 static_assert(U == 1 || U == 2, "one or two frames per step");
 static_assert(NA == 2 || (NA == 1 && FONLY), "one stream per workgroup: the F stage alone");
 static_assert(!(FONLY && U8), "the byte ingest is the two-antenna kernel's");
+static_assert(!XM || (FONLY && NA == 1), "the second pass carries one stream per workgroup");
+constexpr bool SUMS = !FONLY || XM;              // the thread keeps sums of products (else the last butterfly stores spectra)
 static_assert(SLOTS >= 1 && (SLOTS == 1 || TPR % 64 == 0 || 64 % TPR == 0), "slots do not straddle waves");
 static_assert(FONLY || S == 1 || grp(S - 1) % NA == 0, "the last stage's items hold both antennas of a frame");
 static_assert(P0 == 0 || (S >= 2 && P0 >= nb_of(0)), "planes hold the first stage's butterflies");
@@ -184,7 +194,7 @@ struct Thread {
     pk2 tw[TWC > 0 ? TWC : 1];       // twiddles of the thread's items in stages 1 .. S-1
     int ob[OBC > 0 ? OBC : 1];       // where the items of stages 1 .. S-2 put their outputs
     int ib[IBC > 0 ? IBC : 1];       // where the items of stages 1 .. S-1 find their inputs (kept only where it is not lt + j TPR)
-    pk2 xacc[FONLY ? 1 : JL * RL];               // sum over the run of s0 conj(s1) at the bins the thread's last items produce
+    pk2 xacc[SUMS ? JL * RL : 1];               // sum over the run of s0 conj(s1) at the bins the thread's last items produce
 };
 
 // Complex arithmetic on register pairs with the operand modifiers of the packed instructions (op_sel picks the half of a
@@ -478,6 +488,9 @@ struct Args {
     const float* h4;          // LEAN: the taps by point, [N][4] (zeros beyond T)
     const cf* tw1;            // LEAN: the first twiddle of butterfly j of stage s at thread lt: [tw_base(s) + j][TPR] = tw[(b mod ns) nb / ns],
                               // b = lt + j TPR (0 where the thread has no such butterfly)
+    long long stride;         // samples from one stream of this launch to the next (0: num_samp -- the streams stand back to back; 2 num_samp: one
+                              // antenna of every chunk pair)
+    const cf* spec0;          // XM: the other antenna's spectra, [stream][frame][N]
 };
 
 // The body of one GPU thread.  Ctx: tid(), bid(), lds() (the workgroup's LDS as cf*), sync() (all threads of the
@@ -496,6 +509,7 @@ struct Body {
     pk2 off8[2];
     bool row_ok[2];           // F only: the row's stream exists (the last pair of an odd number of streams has one)
     cf* row_out[2];           // F only: where the row's stream puts its first frame's spectrum
+    const cf* spec0_row;      // XM: the other antenna's spectrum of this stream's first frame
 #if defined(__HIP_DEVICE_COMPILE__)
     __amdgpu_buffer_rsrc_t rsrc[2], rsrc_h, rsrc_t;
 #endif
@@ -549,7 +563,7 @@ struct Body {
         }
         if constexpr (!LEAN) init_stage<1>();
 #pragma unroll
-        for (int i = 0; i < (FONLY ? 1 : JL * RL); ++i) th.xacc[i] = pk_splat(0.f);
+        for (int i = 0; i < (SUMS ? JL * RL : 1); ++i) th.xacc[i] = pk_splat(0.f);
     }
     template <int s>
     FX_HD void init_stage() {
@@ -851,7 +865,17 @@ struct Body {
     // butterfly b is bin b + q N/R there, so the lanes of a wave write R runs of consecutive bins
     template <int R>
     FX_HD void emit(pk2 (&o)[NA][R], int j, int bfly, long long frame) {
-        if constexpr (FONLY) {
+        if constexpr (XM) {
+            // antenna 0's values of the same bins (its F-only launch wrote them in natural order: a wave reads R runs of consecutive bins)
+            const cf* d = spec0_row + frame * (long long)N + bfly;
+            pk2 s0[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) s0[q] = pk(d[q * (N / R)]);
+#pragma unroll
+            for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_lo(th.xacc[j * R + q], s0[q], o[0][q]);
+#pragma unroll
+            for (int q = 0; q < R; ++q) th.xacc[j * R + q] = x_acc_hi(th.xacc[j * R + q], s0[q], o[0][q]);
+        } else if constexpr (FONLY) {
 #pragma unroll
             for (int a = 0; a < NA; ++a)
                 if (row_ok[a]) {
@@ -1095,12 +1119,14 @@ struct Body {
             const long long st = NA * chunk + a;                    // F only: the row's stream; `chunk` counts groups of NA streams
             row_ok[a] = !FONLY || st < ar.n_chunks;
             const long long oc = FONLY && row_ok[a] ? st / ar.ant : 0;
-            row_out[a] = FONLY && row_ok[a] ? ar.out + ((oc * ar.n_pts) * ar.ant + (st - oc * ar.ant)) * N : nullptr;
-            xs[a] = reinterpret_cast<const cf*>(ar.x) + st * ar.num_samp;
-            xb[a] = reinterpret_cast<const unsigned short*>(ar.x) + st * ar.num_samp;
+            row_out[a] = FONLY && !XM && row_ok[a] ? ar.out + ((oc * ar.n_pts) * ar.ant + (st - oc * ar.ant)) * N : nullptr;
+            if constexpr (XM) spec0_row = ar.spec0 + (row_ok[a] ? st : 0) * ar.n_pts * N;
+            const long long stride = ar.stride > 0 ? ar.stride : ar.num_samp;
+            xs[a] = reinterpret_cast<const cf*>(ar.x) + st * stride;
+            xb[a] = reinterpret_cast<const unsigned short*>(ar.x) + st * stride;
             off8[a] = U8 ? pk(ar.dc_u8[st]) : pk_splat(0.f);
 #if defined(__HIP_DEVICE_COMPILE__)
-            rsrc[a] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(ar.x)) + (row_ok[a] ? st : 0) * ar.num_samp * kElem, 0,
+            rsrc[a] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(ar.x)) + (row_ok[a] ? st : 0) * stride * kElem, 0,
                                                         (int)(ar.num_samp * kElem), 0x00020000);
 #endif
         }
@@ -1113,7 +1139,7 @@ struct Body {
         // zero history in front of the chunk; a run that starts inside it re-reads T - 1 frames
         preload<0>(f0, f1);
         for (long long i = 0; i < n_steps; i += UNR) steps<0>(f0 + i * U, f1, i, n_steps);
-        if constexpr (!FONLY) {
+        if constexpr (SUMS) {
             // the thread's bins: the last stage's butterfly b puts output q at b + q N/RL (k = b there: ns = N/RL)
             cf* o = ar.out + ((long long)e * ar.n_chunks + chunk) * N;
             constexpr int s = S - 1, nb = nb_of(S - 1);

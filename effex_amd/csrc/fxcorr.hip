@@ -795,6 +795,7 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
         info->lds_bytes = kF8192LdsCf * (int)sizeof(cf);
     }
     if (p->spec_f) info->specialised |= 2;
+    if (p->spec_xm) info->specialised |= 4;
     if (p->spec) {
         info->specialised |= 1;
         info->spec_vgprs = p->spec->vgprs;
@@ -811,7 +812,7 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
 }
 
 int fxc_spec_probe(int nchan, int ntaps, int variant, const char* arch, char* report, int report_bytes) {
-    if (variant < 0 || variant > 2) return fail(nullptr, FXC_ERR_ARG, "variant %d: 0 complex64 F+X, 1 bytes F+X, 2 F only", variant);
+    if (variant < 0 || variant > 3) return fail(nullptr, FXC_ERR_ARG, "variant %d: 0 complex64 F+X, 1 bytes F+X, 2 F only, 3 second pass (F x another stream's spectra)", variant);
     if (report && report_bytes > 0) report[0] = 0;
     if (spec_first_radices(nchan, ntaps, spec_rows(nchan, variant)).empty())
         return fail(nullptr, FXC_ERR_UNSUPPORTED, "no specialised kernel for %d channels, %d taps", nchan, ntaps);

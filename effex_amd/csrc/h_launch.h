@@ -58,7 +58,7 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
             const int64_t ws = spec_wg_splits(p, k, pairs, false);
             if (pairs * ws > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many streams for one launch");
             SpecArgs a = {x, p->d_win, spec, p->d_tw, nullptr, (long long)p->num_samp, (long long)p->n_pts, (long long)n_streams, (int)ws, ant,
-                          reinterpret_cast<const float*>(p->d_win4), k->d_tw1};
+                          reinterpret_cast<const float*>(p->d_win4), k->d_tw1, 0, nullptr};
             void* params[] = {&a};
             FXC_HIP(p, hipModuleLaunchKernel(k->fn, (unsigned)(pairs * ws), 1, 1, (unsigned)k->shape.threads(), 1, 1, 0, p->stream, params, nullptr));
             return FXC_OK;
@@ -131,6 +131,40 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
     return FXC_OK;
 }
 
+// Two antennas above 4096 channels off the powers of two (complex64 samples): two passes of the kernels built for the channel count --
+// antenna 0 of every chunk pair through the F stage into `spec` [chunk][frame][nchan], then antenna 1 through the same stages with the
+// last butterfly multiplying by antenna 0's values and adding to the thread's sums (fx_spec.h, FXM_XM): 2 x the algorithmic bytes, where
+// the spectra of both antennas + xmul_kernel move 3 x.  raw[split][chunk][nchan] out, as mixed_fx_raw_sums.
+bool two_pass_xm(fxc_plan* p, bool bytes_in) {
+    if (bytes_in || p->n_ant != 2 || !p->mixed || p->nchan <= 4096 || !p->spec_f || p->spec_f->shape.rows != 1 || p->mixed_xeng) return false;
+    if (!FXC_DEV_ENV_INT("FXC_XM", 1)) return false;
+    if (!p->spec_xm_tried) {
+        p->spec_xm_tried = true;
+        const SpecKernel* k = spec_kernel(p->device, p->nchan, p->ntaps, kSpecXM);
+        p->spec_xm = k->fn ? k : nullptr;
+        if (!k->fn && env_int("FXC_RTC_VERBOSE", 0))
+            std::fprintf(stderr, "libfxcorr: %d channels: no second-pass kernel (%s): both antennas' spectra + xmul_kernel\n", p->nchan, k->error.c_str());
+    }
+    return p->spec_xm != nullptr;
+}
+int two_pass_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, cf* spec, cf* raw) {
+    const SpecKernel* kf = p->spec_f;
+    const SpecKernel* kx = p->spec_xm;
+    if (n_splits % kx->shape.slots) return fail(p, FXC_ERR_STATE, "row splits and the second-pass kernel's slots disagree");
+    const int64_t wsf = spec_wg_splits(p, kf, n_chunks, false);
+    const int wsx = n_splits / kx->shape.slots;
+    if (n_chunks * std::max<int64_t>(wsf, wsx) > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
+    SpecArgs a0 = {x, p->d_win, spec, p->d_tw, nullptr, (long long)p->num_samp, (long long)p->n_pts, (long long)n_chunks, (int)wsf, 1,
+                   reinterpret_cast<const float*>(p->d_win4), kf->d_tw1, 2 * (long long)p->num_samp, nullptr};
+    void* params0[] = {&a0};
+    FXC_HIP(p, hipModuleLaunchKernel(kf->fn, (unsigned)(n_chunks * wsf), 1, 1, (unsigned)kf->shape.threads(), 1, 1, 0, p->stream, params0, nullptr));
+    SpecArgs a1 = {x + p->num_samp, p->d_win, raw, p->d_tw, nullptr, (long long)p->num_samp, (long long)p->n_pts, (long long)n_chunks, wsx, 1,
+                   reinterpret_cast<const float*>(p->d_win4), kx->d_tw1, 2 * (long long)p->num_samp, spec};
+    void* params1[] = {&a1};
+    FXC_HIP(p, hipModuleLaunchKernel(kx->fn, (unsigned)(n_chunks * wsx), 1, 1, (unsigned)kx->shape.threads(), 1, 1, 0, p->stream, params1, nullptr));
+    return FXC_OK;
+}
+
 // two antennas on the mixed-radix kernel: F and X in one pass, raw[split][chunk][nchan] out (xmul_kernel's layout)
 // (dc_u8 != nullptr: x is the uint8 I,Q stream of these chunks and dc_u8 its conversion offsets per stream)
 int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, cf* raw, const cf* dc_u8 = nullptr) {
@@ -150,7 +184,7 @@ int mixed_fx_raw_sums(fxc_plan* p, const cf* x, int64_t n_chunks, int n_splits, 
             const int64_t grid = n_chunks * wg_splits;
             if (grid > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many chunks for one launch");
             SpecArgs a = {x, p->d_win, raw, p->d_tw, dc_u8, (long long)p->num_samp, (long long)p->n_pts, (long long)n_chunks, wg_splits, 1,
-                          reinterpret_cast<const float*>(p->d_win4), k->d_tw1};
+                          reinterpret_cast<const float*>(p->d_win4), k->d_tw1, 0, nullptr};
             void* params[] = {&a};
             FXC_HIP(p, hipModuleLaunchKernel(k->fn, (unsigned)grid, 1, 1, (unsigned)k->shape.threads(), 1, 1, 0, p->stream, params, nullptr));
             return FXC_OK;
@@ -228,8 +262,13 @@ int64_t spec_wg_splits(const fxc_plan* p, const SpecKernel* k, int64_t n_groups,
 }
 
 // xf: this call takes the mixed-radix kernel that does F and X in one pass (mixed_xf plans; h_run.h::mixed_one_pass)
-XGeom x_geometry(const fxc_plan* p, int64_t n_chunks, bool xf) {
+XGeom x_geometry(const fxc_plan* p, int64_t n_chunks, bool xf, bool xm = false) {
     XGeom g;
+    if (xm) {      // two passes of the kernels built for the channel count (two_pass_raw_sums): the second one's rows
+        g.kx = 1;
+        g.n_splits = (int)(spec_wg_splits(p, p->spec_xm, n_chunks, true) * p->spec_xm->shape.slots);
+        return g;
+    }
     if (xf && p->spec) {
         g.kx = 1;
         g.n_splits = (int)(spec_wg_splits(p, p->spec, n_chunks, true) * p->spec->shape.slots);
@@ -265,8 +304,8 @@ bool mixed_one_pass(const fxc_plan* p, bool bytes_in) { return p->mixed_xf && (b
 
 // chunks per pass on the generic path so that spectra + raw sums fit the workspace target
 int64_t generic_chunks_per_pass(const fxc_plan* p, int64_t n_chunks, const XGeom& g, int64_t* spec_bytes,
-                                int64_t* raw_bytes, bool xf) {
-    const int64_t spec_per_chunk = xf ? 0 : (int64_t)p->n_ant * p->n_pts * p->nchan * (int64_t)sizeof(cf);
+                                int64_t* raw_bytes, bool xf, bool xm = false) {
+    const int64_t spec_per_chunk = xf ? 0 : (int64_t)(xm ? 1 : p->n_ant) * p->n_pts * p->nchan * (int64_t)sizeof(cf);      // (xm: antenna 0's spectra only)
     const int64_t raw_per_chunk = (int64_t)g.n_splits * p->n_base * p->nchan * (int64_t)sizeof(cf);
     int64_t cb = ws_target() / std::max<int64_t>(1, spec_per_chunk + raw_per_chunk);
     if (cb < 1) cb = 1;

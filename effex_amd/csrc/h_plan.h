@@ -74,6 +74,8 @@ struct fxc_plan {
     bool spec_u8_tried = false;
     const SpecKernel* spec_f = nullptr;      // the F stage alone (fxc_channelize, 3 + antennas), built on first use
     bool spec_f_tried = false;
+    const SpecKernel* spec_xm = nullptr;     // two antennas above 4096 channels: antenna 1's F stage multiplied into sums with antenna 0's spectra (built on first use)
+    bool spec_xm_tried = false;
     bool rtc = true;                         // FXC_RTC as it stood when the plan was made (developer knob: 0 keeps the any-shape kernels)
     hipStream_t stream = nullptr;
     bool own_stream = false;

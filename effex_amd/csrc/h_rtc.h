@@ -87,7 +87,9 @@ RtcApi* rtc_api() {
 enum SpecSource { kSpecNone = 0, kSpecBuilt = 1, kSpecCached = 2, kSpecPrebuilt = 3 };
 
 // how fx_spec.h is cut for one channel count: stage order, threads per slot, slots per workgroup
-enum SpecVariant { kSpecC64 = 0, kSpecU8 = 1, kSpecFOnly = 2 };      // F + X from complex64 / from the receivers' bytes, the F stage alone
+// F + X from complex64 / from the receivers' bytes, the F stage alone, the F stage of one stream multiplied into sums with another's spectra
+// (FXM_XM: the second pass of two antennas above 4096 channels)
+enum SpecVariant { kSpecC64 = 0, kSpecU8 = 1, kSpecFOnly = 2, kSpecXM = 3 };
 
 constexpr int kSpecLeanAbove = 2048;
 
@@ -222,9 +224,9 @@ SpecShape spec_shape(int n, int taps, int first = 0, int u = 1, int rows = 2) {
 
 // ---- fx_spec.h's work items and LDS layout for a shape (what FXM_GROUPS / FXM_PLANE0 / FXM_PADS say)
 //
-// LDS banking of the 8-byte accesses (MI355X_MICROARCH.md, LDS): a ds_write_b64 is served in four groups of 16 consecutive lanes, bank =
-// dword address mod 32; a ds_read_b64 in two groups of 32 lanes, bank = dword address mod 64; each further distinct dword on a busy
-// bank of a group costs a cycle.  Extra cycles of one wave instruction whose lane l touches element elem[l] (-1: lane idle):
+// LDS banking of the 8-byte accesses (MI355X_MICROARCH.md, LDS): a ds_write_b64 -- and each half of a ds_write2_b64 / ds_read2_b64 -- is
+// served in four groups of 16 consecutive lanes, bank = dword address mod 32; a ds_read_b64 in two groups of 32 lanes, bank = dword address
+// mod 64; each further distinct dword on a busy bank of a group costs a cycle.  Extra cycles of one wave instruction whose lane l touches element elem[l] (-1: lane idle):
 inline int spec_lds_extra(const int* elem, int group, int banks) {
     int extra = 0;
     for (int g0 = 0; g0 < 64; g0 += group) {
@@ -265,7 +267,7 @@ inline long spec_buffer_conflicts(const SpecShape& sh, int s, int plane0, int pa
                     elem[l] = s == 0 ? (plane0 > 0 ? q * plane0 + b : b * (R + pad) + q) : (b / ns) * (blk + pad) + b % ns + q * ns;
                     any = true;
                 }
-                if (any) extra += spec_lds_extra(elem, 16, 32);
+                if (any) extra += 4 * spec_lds_extra(elem, 16, 32);
             }
     const int s1 = s + 1, R1 = sh.radix[s1], nb1 = sh.nb_of(s1);
     const int rs = (s == 0 && plane0 > 0) ? nb1 / sh.radix[0] : nb1 + (nb1 / blk) * pad;
@@ -281,7 +283,9 @@ inline long spec_buffer_conflicts(const SpecShape& sh, int s, int plane0, int pa
                     elem[l] = ((s == 0 && plane0 > 0) ? (b % sh.radix[0]) * plane0 + b / sh.radix[0] : b + (b / blk) * pad) + r * rs;
                     any = true;
                 }
-                if (any) extra += spec_lds_extra(elem, 32, 64);
+                // (the compiler pairs most of a butterfly's loads into ds_read2_b64 -- served like the stores, 16 lanes over 32 banks -- and leaves
+                // about one in four a ds_read_b64: 32 lanes over 64 banks; profiles/r06/experiments.md 3)
+                if (any) extra += 3 * spec_lds_extra(elem, 16, 32) + spec_lds_extra(elem, 32, 64);
             }
     return extra;
 }
@@ -315,7 +319,7 @@ inline int spec_bfly_cost(int r) {
 // stage) that costs a SIMD the fewest issue slots -- whole rounds of four waves x the item's butterflies -- and, among equals, the most rows
 // (fewer twiddle and offset registers).  Then where the stages' outputs stand (spec_buffer_conflicts), kept within the LDS the
 // unpadded rows already allowed a CU's resident workgroups.
-inline void spec_layout(SpecShape& sh, bool fonly) {
+inline void spec_layout(SpecShape& sh, bool fonly, bool groups_only = false) {
     const int rows = sh.n_rows();
     int forced[fxc::kMixedMaxStages];
     const int nf = dev_env_list("FXC_RTC_GROUPS", forced, fxc::kMixedMaxStages);
@@ -339,7 +343,7 @@ inline void spec_layout(SpecShape& sh, bool fonly) {
         }
         if (s < nf && forced[s] > 0 && rows % forced[s] == 0) sh.grp[s] = forced[s];
     }
-    if (sh.n_stages < 2) return;
+    if (sh.n_stages < 2 || groups_only) return;      // (groups_only: ranking thousands of stage lists needs the items, not the bank patterns)
     const size_t base_lds = sh.lds_bytes();
     auto fits = [&](const SpecShape& t) {
         const size_t b = t.lds_bytes();
@@ -378,7 +382,9 @@ inline void spec_layout(SpecShape& sh, bool fonly) {
 // (N / 2 threads per frame leave the later stages a few butterflies each: 600 channels 3.4 ms against 1.75), then the fuller
 // first stage, then the smaller radix (fewer ring registers).
 // streams per workgroup of the build for (n, variant): F only above 4096 channels carries one (sixteen points a thread)
-inline int spec_rows(int n, int variant) { return (variant == kSpecFOnly && n > dev_env_int("FXC_RTC_ROWS1_ABOVE", 4096)) ? 1 : 2; }      // (developer knob)
+inline int spec_rows(int n, int variant) {
+    return variant == kSpecXM || (variant == kSpecFOnly && n > dev_env_int("FXC_RTC_ROWS1_ABOVE", 4096)) ? 1 : 2;      // (developer knob)
+}
 
 std::vector<int> spec_first_radices(int n, int taps, int rows = 2) {
     struct Cand {
@@ -434,6 +440,8 @@ struct SpecArgs {
     int ant;
     const float* h4;
     const cf* tw1;
+    long long stride;
+    const cf* spec0;
 };
 
 // Args::tw1 of a lean build: row tw_base(s) + j (stages 1 .. S-1, the thread's j-th butterfly) holds, at thread lt, the twiddle
@@ -581,10 +589,12 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXM_N=" + std::to_string(shape.n), "-DFXM_T=" + std::to_string(shape.taps),
                                      "-DFXM_TPR=" + std::to_string(shape.tpr), "-DFXM_SLOTS=" + std::to_string(shape.slots),
                                      "-DFXM_NST=" + std::to_string(shape.n_stages), "-DFXM_RADICES=" + radices,
-                                     "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)), "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly)),
+                                     "-DFXM_U8=" + std::to_string((int)(variant == kSpecU8)),
+                                     "-DFXM_FONLY=" + std::to_string((int)(variant == kSpecFOnly || variant == kSpecXM)), "-DFXM_XM=" + std::to_string((int)(variant == kSpecXM)),
                                      "-DFXM_U=" + std::to_string(shape.u), "-DFXM_LEAN=" + std::to_string((int)shape.lean), "-DFXM_ROWS=" + std::to_string(shape.rows),
                                      "-DFXM_GROUPS=" + shape.list(shape.grp), "-DFXM_PADS=" + shape.list(shape.pad), "-DFXM_PLANE0=" + std::to_string(shape.plane0),
                                      "-DFXM_TWFULL=" + std::to_string(shape.twfull), "-DFXM_WAVES=" + std::to_string(shape.waves),
+                                     "-DFXM_LEAN_TW_EARLY=" + std::to_string(dev_env_int("FXC_RTC_TW_EARLY", 1)),
                                      "-DFXM_ABL=" + std::to_string(spec_ablation())};      // (timing ablations: wrong results, developer library only)
     const std::string pre_name = spec_cache_key(opts, nullptr) + ".co", pre_dir = spec_prebuilt_dir();
     if (!pre_dir.empty() && !spec_ablation() && spec_cache_load(pre_dir + "/" + pre_name, image)) return done(kSpecPrebuilt);
@@ -694,7 +704,7 @@ SpecBuild spec_build_laid_out(SpecShape sh, int variant, const char* arch) {
 // profiles/r06/sweep_lists.md (within 10 %); a candidate estimated beyond the 256 a thread of two resident waves per SIMD has is not
 // built (the compiler would spill it, or halve the resident workgroups: [4,10,25] at 1000 channels: 348 registers, 2.33 ms against 1.52).
 inline int spec_regs_est(SpecShape sh, bool fonly) {
-    spec_layout(sh, fonly);
+    spec_layout(sh, fonly, true);
     const int S = sh.n_stages, r0 = sh.radix[0];
     const int j0 = (sh.nb_of(0) + sh.tpr - 1) / sh.tpr, pts = r0 * j0, ns_ring = sh.taps + sh.u - 1;
     int keep = pts * sh.rows * ns_ring * 2 + (sh.lean ? 0 : sh.taps * pts) + 24;      // (+ addresses, loop state)
@@ -724,7 +734,7 @@ inline int spec_regs_est(SpecShape sh, bool fonly) {
 // stores (six each: MI355X_MICROARCH.md), and a stall per trip through LDS (the barrier and the first load's latency).  It ranks the
 // candidates; the builds' registers decide (spec_search).
 inline double spec_cost(SpecShape sh, bool fonly) {
-    spec_layout(sh, fonly);
+    spec_layout(sh, fonly, true);
     const int rows = sh.n_rows(), S = sh.n_stages;
     auto rounds_of = [&](int items) {
         long r = 0;
@@ -798,7 +808,7 @@ std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows, bool f
     if (dev_env_int("FXC_RTC_COMPOSITE", 1) && dev_env_int("FXC_RTC_TUNED", 1) && dev_env_int("FXC_RTC_PICK", -1) < 0 && !fonly && rows == 2)
         for (const SpecTuned& t : kSpecTuned)           // a measured choice for this channel count (spec_tuned.h): first
             if (t.n == n) out.emplace_back(t.radix, t.radix + t.n_stages);
-    if (dev_env_int("FXC_RTC_COMPOSITE", 1)) {
+    if (dev_env_int("FXC_RTC_COMPOSITE", 1) && out.empty()) {      // (a measured choice needs no ranking behind it: the prime-factor orders are its fallback)
         std::vector<std::vector<int>> all;
         std::vector<int> cur;
         spec_enum_lists(n, (int)legacy[0].size(), fonly, cur, all);
@@ -854,7 +864,7 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
         const SpecShape two = spec_shape_of(n, taps, list.data(), (int)list.size(), 2, rows);
         int force_u = knob_u;
         bool tuned = false;
-        if (!force_u && taps == 4 && variant != kSpecFOnly)      // a measured choice (spec_tuned.h) names its frames per step too
+        if (!force_u && taps == 4 && variant <= kSpecU8)      // a measured choice (spec_tuned.h) names its frames per step too
             for (const SpecTuned& t : kSpecTuned)
                 if (t.n == n && t.n_stages == (int)list.size() && std::equal(list.begin(), list.end(), t.radix)) force_u = t.u, tuned = true;
         SpecBuild b = (force_u == 2 && two.ok) ? SpecBuild() : spec_build_laid_out(one, variant, arch);
@@ -872,6 +882,10 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
             if (aside.image.empty()) aside = std::move(b);
             continue;
         }
+        if (tuned) {                                                   // a measured choice: taken as it is
+            best = std::move(b);
+            break;
+        }
         if (best.image.empty() || b.resident * b.shape.threads() > best.resident * best.shape.threads()) best = std::move(b);
         if (best.resident * best.shape.threads() >= 512) break;       // two workgroups of 256 (or one of 512 and more): good enough
     }
@@ -885,7 +899,7 @@ std::string spec_knob_key() {
 #if FXC_DEV_KERNELS
     for (const char* name : {"FXC_RTC_ABL", "FXC_RTC_R0", "FXC_RTC_U", "FXC_RTC_LEAN_ABOVE", "FXC_RTC_TPR_MAX", "FXC_RTC_ROWS1_ABOVE",
                              "FXC_RTC_BIG_PRIMES", "FXC_RTC_RADICES", "FXC_RTC_GROUPS", "FXC_RTC_PADS", "FXC_RTC_PLANE0", "FXC_RTC_LAYOUT", "FXC_RTC_TWFULL",
-                             "FXC_RTC_WAVES", "FXC_RTC_COMPOSITE", "FXC_RTC_PICK", "FXC_RTC_TUNED"}) {
+                             "FXC_RTC_WAVES", "FXC_RTC_COMPOSITE", "FXC_RTC_PICK", "FXC_RTC_TUNED", "FXC_RTC_TW_EARLY"}) {
         const char* e = std::getenv(name);
         k += std::string(e ? e : "") + ";";
     }

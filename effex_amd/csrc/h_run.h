@@ -87,9 +87,10 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
         }
     } else {
         const bool xf = mixed_one_pass(p, dc_u8 != nullptr);
-        const XGeom g = x_geometry(p, n_chunks, xf);
+        const bool xm = !xf && two_pass_xm(p, dc_u8 != nullptr);
+        const XGeom g = x_geometry(p, n_chunks, xf, xm);
         int64_t spec_bytes, raw_bytes;
-        const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes, xf);
+        const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes, xf, xm);
         raw_bytes = (raw_bytes + 255) / 256 * 256;
         int rc = ensure_ws(p, spec_bytes + raw_bytes + fold_part_bytes(p));
         if (rc) return rc;
@@ -104,6 +105,9 @@ int fx_accumulate_dev(fxc_plan* p, const cf* x, int64_t n_chunks, const cf* dc_u
                 rc = dc_u8 ? mixed_fx_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * 2 * p->num_samp * 2),
                                                nc, g.n_splits, raw, dc_u8 + c0 * 2)
                            : mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
+                if (rc) return rc;
+            } else if (xm) {
+                rc = two_pass_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, spec, raw);
                 if (rc) return rc;
             } else if (p->mixed_xeng) {
                 // 3 .. 64 antennas off the powers of two: spectra antenna-interleaved, then the X-engines of the tiled paths
@@ -257,9 +261,10 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
         return FXC_OK;
     }
     const bool xf = mixed_one_pass(p, dc_u8 != nullptr);
-    const XGeom g = x_geometry(p, n_chunks, xf);
+    const bool xm = !xf && two_pass_xm(p, dc_u8 != nullptr);
+    const XGeom g = x_geometry(p, n_chunks, xf, xm);
     int64_t spec_bytes, raw_bytes;
-    const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes, xf);
+    const int64_t cb = generic_chunks_per_pass(p, n_chunks, g, &spec_bytes, &raw_bytes, xf, xm);
     int rc = ensure_ws(p, spec_bytes + raw_bytes);
     if (rc) return rc;
     cf* spec = reinterpret_cast<cf*>(p->d_ws);
@@ -271,6 +276,9 @@ int fx_rows_dev(fxc_plan* p, const cf* x, void* out, int64_t n_chunks, int mode,
             rc = dc_u8 ? mixed_fx_raw_sums(p, reinterpret_cast<const cf*>(reinterpret_cast<const char*>(x) + c0 * 2 * p->num_samp * 2),
                                            nc, g.n_splits, raw, dc_u8 + c0 * 2)
                        : mixed_fx_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, raw);
+            if (rc) return rc;
+        } else if (xm) {
+            rc = two_pass_raw_sums(p, x + c0 * p->n_ant * p->num_samp, nc, g.n_splits, spec, raw);
             if (rc) return rc;
         } else if (p->mixed_xeng) {
             rc = run_channelize(p, x + c0 * p->n_ant * p->num_samp, spec, nc * p->n_ant, p->n_ant);

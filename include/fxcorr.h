@@ -88,7 +88,8 @@ typedef struct fxc_info {
     int64_t workspace_bytes;
     int32_t specialised;       /* bit 0: the F+X kernel was compiled for exactly this channel count when the plan was made
                                   (two antennas, a channel count that is not a power of two, up to four taps); bit 1: so was
-                                  the F stage alone (built at the first fxc_channelize / multi-antenna call)            */
+                                  the F stage alone (built at the first fxc_channelize / multi-antenna call); bit 2: and the second
+                                  pass of two antennas above 4096 channels (antenna 1's F stage multiplied with antenna 0's spectra) */
     int32_t spec_vgprs;        /* its vector registers per lane                                                          */
     int32_t spec_source;       /* where its code object came from: 0 none, 1 built by hiprtc when the plan was made, 2 the cache of
                                   earlier builds (FXC_RTC_CACHE), 3 pre-built beside the library (rtc_prebuilt/, made at build time
@@ -118,7 +119,7 @@ int fxc_set_stream(fxc_plan* plan, void* stream);
 int fxc_plan_get_info(const fxc_plan* plan, fxc_info* info);
 /* Diagnostic: build the specialised kernel (fxc_info.specialised) for `nchan` channels and `ntaps` taps -- variant 0: F+X from
  * complex64 samples, 1: F+X from the receivers' bytes, 2: the F stage alone (fxc_channelize; the F pass of 3 and more
- * antennas) -- for the device architecture `arch` ("gfx950"; NULL: the current
+ * antennas), 3: the second pass of two antennas above 4096 channels -- for the device architecture `arch` ("gfx950"; NULL: the current
  * device's), without a device and without a plan: the library's embedded kernel source through hiprtc.  FXC_OK and a one-line
  * description in `report` (may be NULL: "nchan= ntaps= tpr= slots= frames_per_step= stages= lds_bytes= code_bytes= vgprs= scratch=
  * resident= lean= rows= groups= pads= plane0= twfull= waves=" -- threads per frame, frames side by side in a workgroup, frames per step,

@@ -34,8 +34,19 @@ int emul_spec_slots() { return fxm::SLOTS; }
 int emul_spec_fonly() { return fxm::FONLY ? 1 : 0; }
 
 // F only (FXM_FONLY): n_chunks = the number of streams, `out` = spec[stream / ant][frame][stream % ant][N]
+int emul_spec_xm() { return fxm::XM ? 1 : 0; }
+
+int emul_spec_run2(const void* x, const float* h, void* out, const void* tw, const void* dc_u8, long long num_samp, long long n_pts,
+                   long long n_chunks, int wg_splits, int ant, long long stride, const void* spec0);
+
 int emul_spec_run(const void* x, const float* h, void* out, const void* tw, const void* dc_u8, long long num_samp, long long n_pts,
                   long long n_chunks, int wg_splits, int ant) {
+    return emul_spec_run2(x, h, out, tw, dc_u8, num_samp, n_pts, n_chunks, wg_splits, ant, 0, nullptr);
+}
+
+// ... with the streams `stride` samples apart (0: back to back) and, for the XM build, the other antenna's spectra [stream][frame][N]
+int emul_spec_run2(const void* x, const float* h, void* out, const void* tw, const void* dc_u8, long long num_samp, long long n_pts,
+                   long long n_chunks, int wg_splits, int ant, long long stride, const void* spec0) {
     // the lean build's tables, from fx_spec.h's own definitions of them (the library builds them from the shape: h_rtc.h)
     std::vector<float> h4((size_t)fxm::N * 4, 0.f);
     for (int m = 0; m < fxm::N; ++m)
@@ -54,7 +65,7 @@ int emul_spec_run(const void* x, const float* h, void* out, const void* tw, cons
         }
     }
     const fxm::Args args = {x, h, static_cast<fxm::cf*>(out), static_cast<const fxm::cf*>(tw), static_cast<const fxm::cf*>(dc_u8),
-                            num_samp, n_pts, n_chunks, wg_splits, ant, h4.data(), tw1.data()};
+                            num_samp, n_pts, n_chunks, wg_splits, ant, h4.data(), tw1.data(), stride, static_cast<const fxm::cf*>(spec0)};
     const long long groups = fxm::FONLY ? (n_chunks + fxm::NA - 1) / fxm::NA : n_chunks;      // workgroups per split: chunk pairs, or groups of NA streams
     for (long long bid = 0; bid < groups * wg_splits; ++bid) {
         std::vector<fxm::cf> lds((size_t)fxm::SLOTS * fxm::LDS_PER_SLOT + 1);

@@ -244,22 +244,23 @@ print("sanitized emulation ok")
     assert "AddressSanitizer" not in proc.stderr and "runtime error" not in proc.stderr, proc.stderr[-3000:]
 
 
-def _spec_shape(nchan, ntaps, u8=False, fonly=False):
+def _spec_shape(nchan, ntaps, u8=False, fonly=False, xm=False):
     """The library's own cut of fx_spec.h for this shape (fxc_spec_probe compiles it through hiprtc -- no GPU needed -- and
     reports threads per slot, slots and stage order), as the -D options the host emulation is built with."""
     import re
     from effex_amd import _lib
     lib = _lib.load(dev=bool(os.environ.get("FXC_RTC_U")))      # (the knob that forces the frames per step exists in the developer library only)
     buf = ctypes.create_string_buffer(1024)
-    rc = lib.fxc_spec_probe(nchan, ntaps, 2 if fonly else int(u8), b"gfx950", buf, len(buf))
+    rc = lib.fxc_spec_probe(nchan, ntaps, 3 if xm else (2 if fonly else int(u8)), b"gfx950", buf, len(buf))
     if rc != 0:
         return rc, None
+    fonly = fonly or xm
     rep = dict(kv.split("=") for kv in buf.value.decode().split())
     stages = rep["stages"]
     flags = ["-DFXM_N=%d" % nchan, "-DFXM_T=%d" % ntaps, "-DFXM_TPR=%s" % rep["tpr"], "-DFXM_SLOTS=%s" % rep["slots"],
              "-DFXM_NST=%d" % len(stages.split(",")), "-DFXM_RADICES=%s" % stages, "-DFXM_U8=%d" % int(u8),
              "-DFXM_U=%s" % rep["frames_per_step"], "-DFXM_FONLY=%d" % int(fonly), "-DFXM_LEAN=%s" % rep["lean"], "-DFXM_ROWS=%s" % rep["rows"],
-             "-DFXM_GROUPS=%s" % rep["groups"], "-DFXM_PADS=%s" % rep["pads"], "-DFXM_PLANE0=%s" % rep["plane0"], "-DFXM_TWFULL=%s" % rep["twfull"]]
+             "-DFXM_GROUPS=%s" % rep["groups"], "-DFXM_PADS=%s" % rep["pads"], "-DFXM_PLANE0=%s" % rep["plane0"], "-DFXM_TWFULL=%s" % rep["twfull"], "-DFXM_XM=%d" % int(xm)]
     assert re.fullmatch(r"[0-9,]+", stages) and int(rep["code_bytes"]) > 1000
     return 0, (flags, int(rep["tpr"]), int(rep["slots"]))
 
@@ -430,3 +431,47 @@ def test_prebuilt_code_objects_answer_before_hiprtc(monkeypatch):
                 continue
             assert rc == 0 and buf.value.endswith(b"source=prebuilt") and b"scratch=0" in buf.value, (nchan, variant, buf.value)
     assert lib.fxc_spec_probe(1080, 4, 0, b"gfx950", buf, len(buf)) == 0 and buf.value.endswith(b"source=built")
+
+
+@pytest.mark.parametrize("nchan,ntaps,n_pts,wg_splits", [(6000, 4, 5, 2), (5000, 4, 6, 1), (4500, 2, 4, 1)])
+def test_second_pass_kernel_matches_oracle(tmp_path, nchan, ntaps, n_pts, wg_splits):
+    """Two antennas above 4096 channels off the powers of two, two passes (h_launch.h::two_pass_raw_sums) on the host emulation:
+    antenna 0 of every chunk pair through the F-only build (streams two chunks apart: Args::stride), then antenna 1 through the
+    second-pass build (FXM_XM) whose last butterfly multiplies with antenna 0's spectra -- the sums over the slots' runs are the
+    oracle's sum_i spec0[i] conj(spec1[i]) (effex.py:508-521 before the mean)."""
+    libs = []
+    for tag, xm in (("f", False), ("x", True)):
+        rc, shape = _spec_shape(nchan, ntaps, fonly=not xm, xm=xm)
+        assert rc == 0
+        flags, tpr, slots = shape
+        assert "-DFXM_ROWS=1" in flags and slots == 1
+        lib_path = str(tmp_path / ("libemul_spec_%s.so" % tag))
+        subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-pthread"] + flags +
+                       ["-o", lib_path, os.path.join(HERE, "emul", "emul_spec.cpp")], check=True)
+        lib = ctypes.CDLL(lib_path)
+        lib.emul_spec_run2.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_longlong] * 3 + [ctypes.c_int] * 2 + [ctypes.c_longlong, ctypes.c_void_p]
+        assert lib.emul_spec_xm() == int(xm)
+        libs.append(lib)
+    f_lib, x_lib = libs
+    n_chunks, num_samp = 3, nchan * n_pts + 11
+    window = design_window(ntaps, nchan)
+    x = synth.synth_iq(nchan + 1, n_chunks, 2, num_samp)
+    tw = np.exp(2j * np.pi * np.arange(nchan) / nchan).astype(np.complex64)
+    h32 = np.ascontiguousarray(window, dtype=np.float32)
+    spec0 = np.full((n_chunks, n_pts, nchan), np.nan + 0j, dtype=np.complex64)
+    assert f_lib.emul_spec_run2(x.ctypes.data, h32.ctypes.data, spec0.ctypes.data, tw.ctypes.data, None, num_samp, n_pts, n_chunks,
+                                wg_splits, 1, 2 * num_samp, None) == 0
+    for c in range(n_chunks):
+        ref = fx_oracle.spectrometer_poly(x[c, 0], ntaps, nchan, window)
+        assert np.abs(spec0[c] - ref).max() <= 1e-5 * np.abs(ref).max()
+    out = np.full((wg_splits, n_chunks, nchan), np.nan + 0j, dtype=np.complex64)
+    ant1 = x.reshape(-1)[num_samp:]
+    assert x_lib.emul_spec_run2(ant1.ctypes.data, h32.ctypes.data, out.ctypes.data, tw.ctypes.data, None, num_samp, n_pts, n_chunks,
+                                wg_splits, 1, 2 * num_samp, spec0.ctypes.data) == 0
+    assert np.isfinite(out).all()
+    got = out.astype(np.complex128).sum(axis=0)
+    for c in range(n_chunks):
+        s0 = fx_oracle.spectrometer_poly(x[c, 0], ntaps, nchan, window)
+        s1 = fx_oracle.spectrometer_poly(x[c, 1], ntaps, nchan, window)
+        ref = (s0 * np.conj(s1)).sum(axis=0)
+        assert np.abs(got[c] - ref).max() <= 1e-5 * np.abs(ref).max(), (nchan, c)

@@ -2100,3 +2100,37 @@ def test_sharded_rows_wait_for_the_plans_own_stream(tmp_path, torch, stream):
             assert rel_err(back[c], ref) < TOL_VIS, c
     finally:
         plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nchan,ntaps,n_chunks,frames,extra", [(6000, 4, 40, 9, 17), (5000, 4, 3, 70, 0), (4500, 2, 300, 2, 4499), (6561, 4, 5, 4, 0),
+                                                                (7000, 3, 2, 1100, 5)])
+def test_above_4096_channels_in_two_passes(plan_mod, torch, monkeypatch, nchan, ntaps, n_chunks, frames, extra):
+    """--resolution 4097 ... 8192 off the powers of two, two antennas (effex.py:733-739, :508-521): antenna 0 through the F-only kernel
+    built for the channel count, antenna 1 through its second-pass build whose last butterfly multiplies with antenna 0's spectra
+    (fx_spec.h, FXM_XM; 2 x the algorithmic bytes) -- rows against the oracle, the integration against the float64 mean of the rows,
+    runs longer than the float32 row limit, many chunks of few frames, a ragged tail, several workspace passes; and the route it
+    replaces (both antennas' spectra + xmul_kernel: FXC_XM=0, developer library) agrees."""
+    num_samp = nchan * frames + extra
+    x = synth.synth_iq(nchan + n_chunks, n_chunks, 2, num_samp)
+    xd = torch.from_numpy(x).cuda()
+    window = design_window(ntaps, nchan)
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as p:
+        p.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 3e-7)
+        rows = p.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        assert p.info["specialised"] & 4, p.info
+        for c in sorted({0, n_chunks // 2, n_chunks - 1}):
+            ref = fx_oracle.pfb_xcorr(x[c, 0], x[c, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 3e-7, "SPECTRUM")
+            assert rel_err(rows[c, 0], ref) < TOL_VIS, c
+        p.fx_accumulate(xd[: n_chunks // 2])
+        p.fx_accumulate(xd[n_chunks // 2:])
+        assert rel_err(p.finalize("SPECTRUM"), rows.astype(np.complex128).mean(axis=0)) < 2e-6
+        cont = p.fx_rows(xd[:1], "CONTINUUM", gi.BANDWIDTH).cpu().numpy()[0, 0]
+        ref_c = fx_oracle.pfb_xcorr(x[0, 0], x[0, 1], ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 3e-7, "CONTINUUM")
+        assert abs(cont - ref_c) < TOL_CONT * abs(ref_c) + 1e-8 * np.abs(rows[0, 0]).max() / gi.BANDWIDTH
+    monkeypatch.setenv("FXC_XM", "0")      # (a route knob of the developer library: the shipped one reads none)
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window, dev=True) as q:
+        q.set_delay(gi.BANDWIDTH, gi.FREQUENCY, 3e-7)
+        three = q.fx_rows(xd, "SPECTRUM").cpu().numpy()
+        assert not (q.info["specialised"] & 4)
+        assert rel_err(three, rows) < 2e-6
