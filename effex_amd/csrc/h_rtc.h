@@ -371,6 +371,9 @@ inline void spec_layout(SpecShape& sh, bool fonly, bool groups_only = false) {
                 const long c = spec_buffer_conflicts(sh, 0, pl, 0);
                 if (c < best) best = c, best_plane = pl, best_pad = 0;
             }
+        if (env_int("FXC_RTC_VERBOSE", 0) > 2)
+            std::fprintf(stderr, "libfxcorr: layout of the buffer behind stage %d of %s: %ld extra LDS cycles plain, %ld with pad %d / plane %d\n", s,
+                         sh.list(sh.radix).c_str(), spec_buffer_conflicts(sh, s, 0, 0), best, best_pad, best_plane);
         if (s == 0) sh.plane0 = fplane >= 0 ? fplane : best_plane;
         sh.pad[s] = s < npf ? fpads[s] : (s == 0 && sh.plane0 > 0 ? 0 : best_pad);
     }
