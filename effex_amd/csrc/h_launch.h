@@ -20,6 +20,19 @@ int mixed_wave_local(const fxc_plan* p, bool fused_x) {
     return v && (fused_x || p->mixed_tpr >= 16);
 }
 
+// the F stage built for exactly this channel count (fx_spec.h, FXM_FONLY), compiled (or found) on first use; nullptr: the shape has none
+const SpecKernel* spec_f_kernel(fxc_plan* p) {
+    if (!p->spec_f_tried) {
+        p->spec_f_tried = true;
+        if (p->mixed && p->ntaps <= 4 && p->num_samp < (1ll << 28) && p->rtc &&
+            !spec_first_radices(p->nchan, p->ntaps, spec_rows(p->nchan, kSpecFOnly)).empty()) {
+            const SpecKernel* k = spec_kernel(p->device, p->nchan, p->ntaps, kSpecFOnly);
+            p->spec_f = k->fn ? k : nullptr;
+        }
+    }
+    return p->spec_f;
+}
+
 int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int ant = 1) {
     if (n_streams == 0 || p->n_pts == 0) return FXC_OK;
     // the F-only tiled kernel writes natural-order spectra straight to `spec` (no workspace): any caller may use it
@@ -46,14 +59,7 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
     if (p->mixed && p->ntaps <= 4 && p->num_samp < (1ll << 28) && p->rtc) {
         // the F stage built for exactly this channel count (fx_spec.h, FXM_FONLY: a workgroup carries two streams through the
         // stages, the last butterfly stores the spectra); compiled on first use
-        if (!p->spec_f_tried) {
-            p->spec_f_tried = true;
-            if (!spec_first_radices(p->nchan, p->ntaps, spec_rows(p->nchan, kSpecFOnly)).empty()) {
-                const SpecKernel* k = spec_kernel(p->device, p->nchan, p->ntaps, kSpecFOnly);
-                p->spec_f = k->fn ? k : nullptr;
-            }
-        }
-        if (const SpecKernel* k = p->spec_f) {
+        if (const SpecKernel* k = spec_f_kernel(p)) {
             const int64_t pairs = (n_streams + k->shape.rows - 1) / k->shape.rows;      // (groups of streams: a workgroup's rows)
             const int64_t ws = spec_wg_splits(p, k, pairs, false);
             if (pairs * ws > (1ll << 30)) return fail(p, FXC_ERR_ARG, "too many streams for one launch");
@@ -136,7 +142,8 @@ int run_channelize(fxc_plan* p, const cf* x, cf* spec, int64_t n_streams, int an
 // last butterfly multiplying by antenna 0's values and adding to the thread's sums (fx_spec.h, FXM_XM): 2 x the algorithmic bytes, where
 // the spectra of both antennas + xmul_kernel move 3 x.  raw[split][chunk][nchan] out, as mixed_fx_raw_sums.
 bool two_pass_xm(fxc_plan* p, bool bytes_in) {
-    if (bytes_in || p->n_ant != 2 || !p->mixed || p->nchan <= 4096 || !p->spec_f || p->spec_f->shape.rows != 1 || p->mixed_xeng) return false;
+    if (bytes_in || p->n_ant != 2 || !p->mixed || p->mixed_blu || p->nchan <= 4096 || p->mixed_xeng) return false;
+    if (!spec_f_kernel(p) || p->spec_f->shape.rows != 1) return false;
     if (!FXC_DEV_ENV_INT("FXC_XM", 1)) return false;
     if (!p->spec_xm_tried) {
         p->spec_xm_tried = true;
