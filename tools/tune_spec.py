@@ -41,7 +41,8 @@ def main():
     synth_fill(x, 1234)
     extra = [tuple(int(v) for v in l.split(",")) for l in args.lists.split(";") if l]
     for nchan in (int(v) for v in args.cases.split(",")):
-        arms = [("legacy", {"FXC_RTC_COMPOSITE": "0"})] + [("pick%d" % k, {"FXC_RTC_PICK": str(k)}) for k in range(args.picks)]
+        # (legacy: round 5's prime-factor order; tuned: what the library chooses today -- spec_tuned.h or its ranking; pickK: the K-th ranked list)
+        arms = [("legacy", {"FXC_RTC_COMPOSITE": "0"}), ("tuned", {})] + [("pick%d" % k, {"FXC_RTC_PICK": str(k)}) for k in range(args.picks)]
         arms += [("list", {"FXC_RTC_RADICES": ",".join(map(str, l))}) for l in extra if int(np.prod(l)) == nchan]
         if args.env_arms:
             arms = [(grp, dict(kv.split("=") for kv in grp.split(",") if kv)) for grp in args.env_arms.split(";")]
