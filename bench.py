@@ -398,7 +398,7 @@ def other_configs(x, dev, reps=5):
     """Short, untimed-region runs of the other single-GPU BASELINE configs on the resident synthetic bytes (viewed with
     their own shapes): configs[2] continuum streaming limit (nchan = 1, num_samp = 2^20) and configs[4] (8 antennas,
     28 baselines, nchan 4096), plus a three-pass and a two-pass shape (32 taps; 8192 channels) and a channel count that is not a power
-    of two (1000, 3000).  HIP events around four calls back to
+    of two (1000, 3000, 6000).  HIP events around four calls back to
     back (results collected one call behind, as the headline loop does), per call, median of `reps`."""
     import numpy as np
     from effex_amd.plan import FxPlan, pinned_empty
@@ -460,6 +460,10 @@ def other_configs(x, dev, reps=5):
         "SPECTRUM", False)
     # ... and one above 2048 channels (the lean build of the same kernel: taps and first twiddles from L2 tables)
     run("--resolution 3000: 2 antennas, nchan=3000, ntaps=4, num_samp=262144, integrated", 2, 3000, NUM_SAMP, 1024, None,
+        "SPECTRUM", False)
+    # ... and one above 4096 channels: two passes of the kernels built for the channel count (antenna 0's spectra through HBM once:
+    # 2 x the algorithmic traffic by construction)
+    run("--resolution 6000: 2 antennas, nchan=6000, ntaps=4, num_samp=262144, integrated", 2, 6000, NUM_SAMP, 1024, None,
         "SPECTRUM", False)
     return out
 

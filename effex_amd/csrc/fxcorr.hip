@@ -804,6 +804,10 @@ int fxc_plan_get_info(const fxc_plan* p, fxc_info* info) {
         info->grid = p->cu_count * p->spec->wgs_per_cu;
         info->block = p->spec->shape.threads();
         info->lds_bytes = (int)p->spec->shape.lds_bytes();
+    } else if (p->spec_f) {      // (no one-pass build: where the F-only build -- and the second pass behind it -- came from, what both took)
+        info->spec_vgprs = p->spec_f->vgprs;
+        info->spec_source = p->spec_f->source;
+        info->spec_seconds = (float)(p->spec_f->seconds + (p->spec_xm ? p->spec_xm->seconds : 0.0));
     }
     info->device = p->device;
     info->cu_count = p->cu_count;
