@@ -2,8 +2,8 @@
 // integer in the reference, effex/effex.py:733-739), SPECIALISED for one channel count at run time: libfxcorr hands
 // this file to hiprtc with the shape as -D options (h_rtc.h), the way FFT libraries build their kernels.  Same
 // arithmetic as the any-shape kernel of k_generic.h (polyphase FIR of SURVEY.md 2.3, the Stockham autosort stages of
-// fx_mixed.h on the same float64-rounded twiddle table, s0 conj(s1) summed over the run of frames), but with every
-// stride, stage and trip count a compile-time constant:
+// fx_mixed.h with the inter-stage twiddles of the same float64-rounded table, s0 conj(s1) summed over the run of frames), but with every
+// stride, stage and trip count a compile-time constant, the roots of unity of the butterflies literals, and composite radices run in registers:
 //
 //   * every sample is fetched ONCE: a thread keeps the last T - 1 frames' samples of its own points in registers (the
 //     ring), frame f + 1 is in flight while frame f goes through its stages; the window taps of those points and the
@@ -58,8 +58,8 @@
 // FXM_LEAN 1: the build for frames of more than 2048 channels (a thread carries up to eight points of each antenna: 128
 // registers of ring) and for shapes with a prime factor of 17 ... 23 (the butterfly's registers) -- nothing but the ring and the sums stays in registers from step to step.  The window taps come from L2
 // every step (Args::h4: the four taps of a point in one 16-byte load); of a butterfly's twiddles only the first is fetched
-// (Args::tw1, a table by stage, butterfly and thread -- consecutive lanes read consecutive entries -- requested one stage ahead
-// of its use), the others are its powers (a few complex multiplies a stage, shared by the rows of the step); the output offsets
+// (Args::tw1, a table by stage, item and thread -- consecutive lanes read consecutive entries -- requested at the top of the
+// step, before the next frames' samples: Body::step_lean), the others are its powers (a few complex multiplies a stage, shared by the rows of the step); the output offsets
 // are recomputed.
 #ifndef FXM_LEAN
 #define FXM_LEAN 0
