@@ -745,8 +745,6 @@ inline double spec_cost(SpecShape sh, bool fonly) {
         return r;
     };
     auto waves_of = [&](int items) { return (long)(items + 63) / 64; };
-    const int slots_per_wg = sh.slots;            // (several slots a workgroup: every slot its own frames, the same count per frame)
-    (void)slots_per_wg;
     double valu = 0, lds = 0;
     {   // the first stage: the FIR of a thread's points, their butterflies, the stores
         const int nb0 = sh.nb_of(0), r0 = sh.radix[0];
