@@ -557,6 +557,8 @@ class Correlator(object):
                 raise ValueError("nbins = {} exceeds the {} taps of the window designed at construction "
                                  "(effex.py:126-127)".format(nb, len(self.window)))
             self._fx_plan = FxPlan(2, nb, ntaps_w, n, window=np.asarray(self.window)[:ntaps_w * nb], device=self.device)
+            if getattr(self.source, "fmt", None) == "u8":      # a byte source: its kernel build now (startup), not inside the first RUN task
+                self._fx_plan.warm_bytes()
             self._rot_key = None
         key = (self.bandwidth, self.frequency, self.calibrated_delay)
         if key != self._rot_key:      # rot only changes on calibration / TEST sweep

@@ -348,6 +348,15 @@ class FxPlan(object):
         self._queued.pop(0)
         return out
 
+    def warm_bytes(self):
+        """Have the byte-ingest build of the kernel for this channel count ready before the first byte call: a plan builds it
+        lazily, inside that call -- up to seconds of hiprtc in the middle of a live stream when the shape is neither pre-built nor
+        cached.  ``fxc_spec_probe`` runs the same search now and leaves the code object in the run-time cache (a file read later).
+        No effect on shapes without such a kernel; returns True if one is there."""
+        if not (self.info["specialised"] & 1):
+            return False
+        return self._lib.fxc_spec_probe(int(self.nchan), int(self.ntaps), 1, None, None, 0) == 0
+
     @property
     def finalize_pending(self):
         return int(self._lib.fxc_finalize_pending(self._h))

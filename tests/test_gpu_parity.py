@@ -6,6 +6,7 @@ Tolerances (float32 pipeline vs the float64 oracle on identical complex64 input)
   * integrations:         max|d| <= 1e-5 * max|vis|    (per-chunk float32 sums, float64 across chunks)
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -2134,3 +2135,24 @@ def test_above_4096_channels_in_two_passes(plan_mod, torch, monkeypatch, nchan, 
         three = q.fx_rows(xd, "SPECTRUM").cpu().numpy()
         assert not (q.info["specialised"] & 4)
         assert rel_err(three, rows) < 2e-6
+
+
+@pytest.mark.gpu
+def test_byte_ingest_build_is_warmed_at_plan_creation(plan_mod, torch, tmp_path, monkeypatch):
+    """A plan builds the byte-ingest twin of its kernel per channel count lazily, inside the first byte call (seconds of hiprtc in a
+    live stream when the shape is neither pre-built nor cached).  ``FxPlan.warm_bytes()`` -- which the drop-in calls at plan
+    creation for byte sources (pyrtlsdr's packed bytes, effex.py:652) -- runs the same search ahead of time: afterwards the code
+    object is in the run-time cache and the first byte call agrees with the oracle."""
+    monkeypatch.setenv("FXC_RTC_CACHE", str(tmp_path / "rtc"))
+    nchan, ntaps, num_samp = 1040, 4, 1040 * 9 + 3          # (a channel count outside the pre-built list)
+    window = design_window(ntaps, nchan)
+    u8 = np.random.default_rng(1040).integers(0, 256, size=(2, 2, num_samp, 2), dtype=np.uint8)
+    with plan_mod.FxPlan(2, nchan, ntaps, num_samp, window=window) as p:
+        assert p.info["specialised"] & 1
+        before = set(os.listdir(str(tmp_path / "rtc")))
+        assert p.warm_bytes()
+        assert set(os.listdir(str(tmp_path / "rtc"))) - before          # the byte-ingest build landed in the cache
+        rows = p.fx_rows_u8(torch.from_numpy(u8).cuda(), "SPECTRUM", remove_dc=True).cpu().numpy()
+    a = fx_oracle.u8_to_complex(u8[:1])[0]
+    ref = fx_oracle.pfb_xcorr(fx_oracle.remove_dc(a[0]), fx_oracle.remove_dc(a[1]), ntaps, nchan, window, gi.BANDWIDTH, gi.FREQUENCY, 0.0, "SPECTRUM")
+    assert rel_err(rows[0, 0], ref) < TOL_VIS
