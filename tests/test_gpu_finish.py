@@ -278,7 +278,8 @@ from effex_amd.plan import FxPlan
 for n_ant, nchan, num_samp, n_chunks, path in ((2, 4096, 4096 * 8, 700, "fused"), (8, 4096, 4096 * 4, 40, "fused"),
                                                (2, 1024, 1024 * 16, 300, "tiled"), (3, 8, 8 * 40, 200, "generic"),
                                                (3, 64, 64 * 40, 200, "tiled"), (2, 128, 128 * 40, 200, "tiled"),
-                                               (2, 8192, 8192 * 8 + 5, 100, "tiled")):      # (two passes per batch: antenna 0's spectra are the bound)
+                                               (2, 8192, 8192 * 8 + 5, 100, "tiled"),      # (two passes per batch: antenna 0's spectra are the bound)
+                                               (2, 6000, 6000 * 6 + 11, 120, "generic")):   # (two passes of the kernels built for 6000 channels: likewise)
     x = torch.from_numpy(synth.synth_iq(7, n_chunks, n_ant, num_samp)).cuda()
     with FxPlan(n_ant, nchan, 4, num_samp) as p:
         assert p.path == path, (p.path, path)
