@@ -789,7 +789,17 @@ inline void spec_enum_lists(int n_left, int max_stages, bool fonly, std::vector<
     }
 }
 
-std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows, bool fonly = false, int* n_chosen = nullptr) {
+// the measured choice for (n, variant) (spec_tuned.h; four taps), or nullptr
+inline const SpecTuned* spec_tuned_entry(int n, int taps, int variant) {
+    if (taps != 4 || !dev_env_int("FXC_RTC_TUNED", 1)) return nullptr;
+    const SpecTuned* table = variant == kSpecFOnly ? kSpecTunedF : (variant == kSpecXM ? kSpecTunedXM : kSpecTuned);
+    for (const SpecTuned* t = table; t->n > 0; ++t)
+        if (t->n == n) return t;
+    return nullptr;
+}
+
+std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows, int variant, int* n_chosen = nullptr) {
+    const bool fonly = variant == kSpecFOnly;
     std::vector<std::vector<int>> out;
     if (n_chosen) *n_chosen = 0;      // how many leading entries are measured / ranked choices (the prime-factor orders follow)
     int forced[fxc::kMixedMaxStages];
@@ -806,9 +816,11 @@ std::vector<std::vector<int>> spec_stage_lists(int n, int taps, int rows, bool f
         if (s.ok) legacy.emplace_back(s.radix, s.radix + s.n_stages);
     }
     if (legacy.empty()) return out;
-    if (dev_env_int("FXC_RTC_COMPOSITE", 1) && dev_env_int("FXC_RTC_TUNED", 1) && dev_env_int("FXC_RTC_PICK", -1) < 0 && !fonly && rows == 2)
-        for (const SpecTuned& t : kSpecTuned)           // a measured choice for this channel count (spec_tuned.h): first
-            if (t.n == n) out.emplace_back(t.radix, t.radix + t.n_stages);
+    if (dev_env_int("FXC_RTC_COMPOSITE", 1) && dev_env_int("FXC_RTC_PICK", -1) < 0)
+        if (const SpecTuned* t = spec_tuned_entry(n, taps, variant)) {      // a measured choice for this channel count (spec_tuned.h): first
+            const SpecShape probe = spec_shape_of(n, taps, t->radix, t->n_stages, 1, rows);
+            if (probe.ok) out.emplace_back(t->radix, t->radix + t->n_stages);
+        }
     if (dev_env_int("FXC_RTC_COMPOSITE", 1) && out.empty()) {      // (a measured choice needs no ranking behind it: the prime-factor orders are its fallback)
         std::vector<std::vector<int>> all;
         std::vector<int> cur;
@@ -851,7 +863,7 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
     const int rows = spec_rows(n, variant);
     const int knob_u = dev_env_int("FXC_RTC_U", 0);
     int tried = 0, n_chosen = 0, index = -1;
-    const std::vector<std::vector<int>> lists = spec_stage_lists(n, taps, rows, variant == kSpecFOnly, &n_chosen);
+    const std::vector<std::vector<int>> lists = spec_stage_lists(n, taps, rows, variant, &n_chosen);
     // Measured (profiles/r06/tune_spec.md): a ranked list that ends up with ONE frame per step where the prime-factor order carries TWO loses
     // to it (0.75 - 0.98 x over seven channel counts); with as many frames it wins (1.00 - 1.31 x).  Such a build is set aside until the
     // prime-factor order has shown what it gets.
@@ -865,9 +877,9 @@ SpecBuild spec_search(int n, int taps, int variant, const char* arch) {
         const SpecShape two = spec_shape_of(n, taps, list.data(), (int)list.size(), 2, rows);
         int force_u = knob_u;
         bool tuned = false;
-        if (!force_u && taps == 4 && variant <= kSpecU8)      // a measured choice (spec_tuned.h) names its frames per step too
-            for (const SpecTuned& t : kSpecTuned)
-                if (t.n == n && t.n_stages == (int)list.size() && std::equal(list.begin(), list.end(), t.radix)) force_u = t.u, tuned = true;
+        if (!force_u)      // a measured choice (spec_tuned.h) names its frames per step too
+            if (const SpecTuned* t = spec_tuned_entry(n, taps, variant))
+                if (t->n_stages == (int)list.size() && std::equal(list.begin(), list.end(), t->radix)) force_u = t->u, tuned = true;
         SpecBuild b = (force_u == 2 && two.ok) ? SpecBuild() : spec_build_laid_out(one, variant, arch);
         if (two.ok && force_u != 1) {
             SpecBuild b2 = spec_build_laid_out(two, variant, arch);
