@@ -53,7 +53,7 @@ def build(force=False, verbose=False, dev=False):
 # code objects keyed by source + options + architecture (not by compiler) that libfxcorr looks up before it touches hiprtc, so that a plan
 # for one of them costs a file read instead of 1 - 14 s of compiling (fxc_info.spec_source == 3).  Every variant that exists for the shape:
 # 0 F + X from complex64, 1 F + X from the receivers' bytes, 2 the F stage alone (fxc_channelize; 3+ antennas; above 4096 channels).
-PREBUILT_CHANNELS = (1000, 1200, 1500, 2000, 3000, 6000)
+PREBUILT_CHANNELS = (1000, 1200, 1250, 1280, 1440, 1500, 1536, 1600, 1800, 1920, 2000, 2400, 2500, 2560, 3000, 3072, 3600, 4000, 5000, 6000)
 PREBUILT_TAPS = (4,)
 PREBUILT_DIR = os.path.join(CSRC, "rtc_prebuilt")
 
