@@ -75,6 +75,9 @@
 #ifndef FXM_TWFULL
 #define FXM_TWFULL 13
 #endif
+#ifndef FXM_OOB_ZERO
+#define FXM_OOB_ZERO 1   // complex64 samples that do not exist are read as the zeros a buffer load returns beyond its records (0: a branch around the load)
+#endif
 
 namespace fxm {
 
@@ -639,6 +642,16 @@ struct Body {
                     const int m = lt + j * TPR + r * nb_of(0);
                     const bool ok = valid && has_item(0, j, lt) && !(FXM_ABL & 8) && (!FONLY || row_ok[a]);
                     pk2 v = pk_splat(0.f);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if constexpr (!U8 && FXM_OOB_ZERO) {
+                        // a sample that does not exist (a frame outside the run, a lane without the butterfly, a stream that is not there) is
+                        // asked for beyond the buffer's records: the hardware answers zero -- no branch, no zeroed register to fall back on
+                        const unsigned cst = (unsigned)((R0 - 1 - r) * nb_of(0)) * (unsigned)kElem;
+                        const v2u32 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc[a], ok ? voff : 0xC0000000u, cst, kLoadAux);
+                        th.ring[a][j * R0 + r][P] = pk2{__uint_as_float(d[0]), __uint_as_float(d[1])};
+                        continue;
+                    }
+#endif
                     if (ok) {
 #if defined(__HIP_DEVICE_COMPILE__)
                         const unsigned cst = (unsigned)((R0 - 1 - r) * nb_of(0)) * (unsigned)kElem;

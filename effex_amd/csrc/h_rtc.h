@@ -598,6 +598,7 @@ bool spec_compile(const SpecShape& shape, int variant, const char* arch, std::ve
                                      "-DFXM_GROUPS=" + shape.list(shape.grp), "-DFXM_PADS=" + shape.list(shape.pad), "-DFXM_PLANE0=" + std::to_string(shape.plane0),
                                      "-DFXM_TWFULL=" + std::to_string(shape.twfull), "-DFXM_WAVES=" + std::to_string(shape.waves),
                                      "-DFXM_LEAN_TW_EARLY=" + std::to_string(dev_env_int("FXC_RTC_TW_EARLY", 1)),
+                                     "-DFXM_OOB_ZERO=" + std::to_string(dev_env_int("FXC_RTC_OOB_ZERO", 1)),
                                      "-DFXM_ABL=" + std::to_string(spec_ablation())};      // (timing ablations: wrong results, developer library only)
     const std::string pre_name = spec_cache_key(opts, nullptr) + ".co", pre_dir = spec_prebuilt_dir();
     if (!pre_dir.empty() && !spec_ablation() && spec_cache_load(pre_dir + "/" + pre_name, image)) return done(kSpecPrebuilt);
@@ -912,7 +913,7 @@ std::string spec_knob_key() {
 #if FXC_DEV_KERNELS
     for (const char* name : {"FXC_RTC_ABL", "FXC_RTC_R0", "FXC_RTC_U", "FXC_RTC_LEAN_ABOVE", "FXC_RTC_TPR_MAX", "FXC_RTC_ROWS1_ABOVE",
                              "FXC_RTC_BIG_PRIMES", "FXC_RTC_RADICES", "FXC_RTC_GROUPS", "FXC_RTC_PADS", "FXC_RTC_PLANE0", "FXC_RTC_LAYOUT", "FXC_RTC_TWFULL",
-                             "FXC_RTC_WAVES", "FXC_RTC_COMPOSITE", "FXC_RTC_PICK", "FXC_RTC_TUNED", "FXC_RTC_TW_EARLY"}) {
+                             "FXC_RTC_WAVES", "FXC_RTC_COMPOSITE", "FXC_RTC_PICK", "FXC_RTC_TUNED", "FXC_RTC_TW_EARLY", "FXC_RTC_OOB_ZERO"}) {
         const char* e = std::getenv(name);
         k += std::string(e ? e : "") + ";";
     }

@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-KNOBS = ("FXC_RTC_COMPOSITE", "FXC_RTC_PICK", "FXC_RTC_RADICES", "FXC_RTC_U", "FXC_RTC_TW_EARLY", "FXC_RTC_TUNED", "FXC_RTC_LAYOUT", "FXC_RTC_WAVES", "FXC_RTC_GROUPS")
+KNOBS = ("FXC_RTC_COMPOSITE", "FXC_RTC_PICK", "FXC_RTC_RADICES", "FXC_RTC_U", "FXC_RTC_TW_EARLY", "FXC_RTC_OOB_ZERO", "FXC_RTC_TUNED", "FXC_RTC_LAYOUT", "FXC_RTC_WAVES", "FXC_RTC_GROUPS")
 
 
 def main():
